@@ -1,0 +1,584 @@
+"""Pin the oracle against the UNMODIFIED reference and emit golden vectors.
+
+TEST INFRASTRUCTURE.  Run in the build container only (needs /root/reference):
+
+    python oracle/gen_golden.py            # writes tests/golden/*.npz
+
+For every operator group G1..G10 it
+  1. builds seeded inputs (oracle/golden_inputs.py),
+  2. runs the reference implementation (imported through oracle/ref_import.py),
+  3. runs the oracle restatement (oracle/benerf_oracle.py) on the same inputs,
+  4. ASSERTS they agree (bit-identical where the same torch ops are used),
+  5. stores the REFERENCE outputs (plus inputs that are cheap to keep) as .npz.
+
+The .npz files are data only - no reference source or bytecode is written.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+import benerf_oracle as O  # noqa: E402
+import golden_inputs as GI  # noqa: E402
+from ref_import import load_reference, make_args  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+REPORT = []
+
+
+def npy(t):
+    if t is None:
+        return None
+    return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+
+
+def check(name, ref, ora, atol=0.0, rtol=0.0, equal_nan=True):
+    ref, ora = npy(ref), npy(ora)
+    assert ref.shape == ora.shape, (name, ref.shape, ora.shape)
+    bad = ~np.isclose(ora, ref, atol=atol, rtol=rtol, equal_nan=equal_nan)
+    err = float(np.nanmax(np.abs(ora.astype(np.float64) - ref.astype(np.float64)))) if ref.size else 0.0
+    REPORT.append("%-44s max|d|=%.3e  %s" % (name, err, "BITWISE" if np.array_equal(ref, ora, equal_nan=True) else "tol"))
+    assert not bad.any(), "%s: oracle != reference (max err %g, %d bad)" % (name, err, bad.sum())
+
+
+def save(fname, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, fname), **{k: npy(v) for k, v in arrs.items() if v is not None})
+
+
+class ReplayRNG:
+    """Replaces torch.rand / torch.randn by a queue of prepared tensors (reference draw
+    order) while a reference function runs."""
+
+    def __init__(self, queue):
+        self.queue = list(queue)
+
+    def __enter__(self):
+        self._rand, self._randn = torch.rand, torch.randn
+
+        def pop(*shape, **kw):
+            t = self.queue.pop(0)
+            shp = tuple(shape[0]) if len(shape) == 1 and not isinstance(shape[0], int) else tuple(shape)
+            assert tuple(t.shape) == shp, (t.shape, shp)
+            return t.clone()
+
+        torch.rand = pop
+        torch.randn = pop
+        return self
+
+    def __exit__(self, *a):
+        torch.rand, torch.randn = self._rand, self._randn
+        assert not self.queue, "unused draws"
+
+
+def ref_state_to_params(nerf_module):
+    return {k: v.detach().clone() for k, v in nerf_module.state_dict().items()}
+
+
+def load_params_into(nerf_module, p):
+    nerf_module.load_state_dict({k: v.clone() for k, v in p.items()})
+
+
+# ----------------------------------------------------------------------------------- G1
+def g1_spline(R):
+    out = {}
+    cases = []
+    rng = np.random.default_rng(101)
+    for kname, kfun in (("init", GI.knots_init), ("stress", GI.knots_stress)):
+        for tname in ("zero", "small"):
+            for P in (2, 19, 31):
+                for (t0, t1) in ((0.0, 1.0), (0.23, 0.33)):
+                    knots = kfun(rng)
+                    tr = torch.zeros(1, 6) if tname == "zero" else GI.transform_small(rng)
+                    G = GI.f32(rng.standard_normal((P, 3, 4)))
+                    cases.append((kname, tname, P, t0, t1, knots, tr, G))
+    for ci, (kname, tname, P, t0, t1, knots, tr, G) in enumerate(cases):
+        for traj in ("spline", "linear"):
+            tag = "c%02d_%s" % (ci, traj)
+            # reference
+            kr = knots.clone().requires_grad_(True)
+            trr = tr.clone().requires_grad_(True)
+            ts = torch.linspace(t0, t1, P)
+            kk = [(kr[i].reshape(1, 1, 6) + trr.reshape(1, 1, 6)) for i in range(4)]
+            if traj == "spline":
+                pr = R.spline.cubic_spline_pose_unit_time(kk[0], kk[1], kk[2], kk[3], ts.clone())
+            else:
+                pr = R.spline.linear_pose_unit_time(kk[0], kk[3], ts.clone())
+            (pr * G).sum().backward()
+            # oracle
+            ko = knots.clone().requires_grad_(True)
+            tro = tr.clone().requires_grad_(True)
+            po = O.trajectory_poses(ko, tro, (t0, t1), P, traj)
+            (po * G).sum().backward()
+            check("G1 poses " + tag, pr, po)
+            check("G1 dknots " + tag, kr.grad, ko.grad, atol=1e-6, rtol=1e-5)
+            check("G1 dtransform " + tag, trr.grad, tro.grad, atol=1e-6, rtol=1e-5)
+            out[tag + "_knots"] = knots
+            out[tag + "_transform"] = tr
+            out[tag + "_ts"] = np.array([t0, t1], np.float32)
+            out[tag + "_G"] = G
+            out[tag + "_poses"] = pr
+            out[tag + "_dknots"] = kr.grad
+            out[tag + "_dtransform"] = trr.grad
+    out["n_cases"] = np.array(len(cases))
+    save("g1_spline.npz", **out)
+
+
+# ----------------------------------------------------------------------------------- G2
+def g2_rays(R):
+    out = {}
+    rng = np.random.default_rng(202)
+    for cname, cam in GI.CAMERAS.items():
+        K = GI.cam_K(cam)
+        knots = GI.knots_stress(rng) * 0.2
+        poses = O.trajectory_poses(knots, None, (0.1, 0.9), 3, "spline").detach()
+        idx = GI.pixel_indices(rng, cam, 16)
+        # reference (training branch of Graph.render, model/nerf.py:241-254,272-279)
+        P, Rn = poses.shape[0], idx.shape[0]
+        idx_ = idx.repeat(P)
+        pp = poses.unsqueeze(1).repeat(1, Rn, 1, 1).reshape(-1, 3, 4)
+        j = idx_ // cam["W"]
+        i = idx_ % cam["W"]
+        ro, rd = R.helpers.get_specific_rays(i, j, K, pp)
+        vd = rd / torch.norm(rd, dim=-1, keepdim=True)
+        no, nd = R.helpers.ndc_rays(cam["H"], cam["W"], K[0][0], 1.0, ro, rd)
+        # inference branch (get_rays full grid then index, model/nerf.py:255-266)
+        args = types.SimpleNamespace(dataset="BeNeRF_Unreal")
+        fo, fd = R.helpers.get_rays(cam["H"], cam["W"], K, poses[1], args, torch.tensor([]))
+        fo = fo.reshape(-1, 3)[idx]
+        fd = fd.reshape(-1, 3)[idx]
+        # oracle
+        oo, od = O.pixel_rays(idx, cam["W"], K, poses)
+        o_ndc, d_ndc, o_vd = O.make_rays(poses, idx, cam["H"], cam["W"], K, True)
+        check("G2 rays_o " + cname, ro, oo)
+        check("G2 rays_d " + cname, rd, od)
+        check("G2 viewdirs " + cname, vd, o_vd)
+        check("G2 ndc_o " + cname, no, o_ndc)
+        check("G2 ndc_d " + cname, nd, d_ndc)
+        check("G2 get_rays==specific " + cname, fd, od[Rn:2 * Rn], atol=1e-6)
+        out.update({cname + "_poses": poses, cname + "_idx": idx, cname + "_rays_o": ro, cname + "_rays_d": rd,
+                    cname + "_viewdirs": vd, cname + "_ndc_o": no, cname + "_ndc_d": nd,
+                    cname + "_cam": np.array([cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"]], np.float64)})
+    save("g2_rays.npz", **out)
+
+
+# ----------------------------------------------------------------------------------- G3
+def g3_posenc(R):
+    rng = np.random.default_rng(303)
+    pts = GI.f32(rng.uniform(-1.5, 1.5, (256, 3)))
+    dirs = GI.f32(rng.standard_normal((256, 3)))
+    dirs = dirs / dirs.norm(dim=-1, keepdim=True)
+    args = make_args()
+    fn, dim = R.embedder.get_embedder(args, 10, 0)
+    fnd, dimd = R.embedder.get_embedder(args, 4, 0)
+    assert dim == 63 and dimd == 27
+    e, ed = fn(pts), fnd(dirs)
+    check("G3 posenc pts", e, O.posenc(pts, 10))
+    check("G3 posenc dirs", ed, O.posenc(dirs, 4))
+    save("g3_posenc.npz", pts=pts, dirs=dirs, pe=e, ped=ed)
+
+
+# ----------------------------------------------------------------------------------- G4
+def grad_summary(named_grads, rng):
+    """per-tensor Frobenius norm + 64 sampled entries (indices stored)."""
+    d = {}
+    for k, g in named_grads.items():
+        g = npy(g).reshape(-1)
+        idx = rng.integers(0, g.size, 64)
+        d[k + "__norm"] = np.array(np.linalg.norm(g.astype(np.float64)))
+        d[k + "__idx"] = idx
+        d[k + "__val"] = g[idx]
+    return d
+
+
+def g4_mlp(R):
+    out = {}
+    for C in (1, 3):
+        for variant in ("xavier", "trained"):
+            for S in (16, 64):
+                rng = np.random.default_rng(404 + C * 10 + S + (1000 if variant == "trained" else 0))
+                tag = "C%d_%s_S%d" % (C, variant, S)
+                p = O.xavier_params(rng, C)
+                if variant == "trained":
+                    p["alpha_linear.bias"] += 2.0
+                    for k in p:
+                        if k.endswith(".bias") and not k.startswith("alpha"):
+                            p[k] = GI.f32(rng.uniform(-0.1, 0.1, p[k].shape))
+                n_rays = 8 if S == 16 else 16
+                pts = GI.f32(rng.uniform(-1.2, 1.2, (n_rays, S, 3)))
+                vd = GI.f32(rng.standard_normal((n_rays, 3)))
+                vd = vd / vd.norm(dim=-1, keepdim=True)
+                G = GI.f32(rng.standard_normal((n_rays, S, C + 1)))
+                args = make_args(channels=C)
+                net = R.nerf.NeRF(8, 256, 63, 27, 4, [4], True, C)
+                load_params_into(net, p)
+                pts_r = pts.clone().requires_grad_(True)
+                vd_r = vd.clone().requires_grad_(True)
+                raw_r = net.forward(0, pts_r, vd_r, args)
+                (raw_r * G).sum().backward()
+                po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+                pts_o = pts.clone().requires_grad_(True)
+                vd_o = vd.clone().requires_grad_(True)
+                raw_o, acts = O.mlp_forward(po, pts_o, vd_o, want_acts=True)
+                (raw_o * G).sum().backward()
+                check("G4 raw " + tag, raw_r, raw_o)
+                check("G4 dpts " + tag, pts_r.grad, pts_o.grad, atol=1e-6, rtol=1e-5)
+                check("G4 dviewdirs " + tag, vd_r.grad, vd_o.grad, atol=1e-6, rtol=1e-5)
+                gr = {k: v.grad for k, v in net.named_parameters()}
+                for k in gr:
+                    check("G4 d%s %s" % (k, tag), gr[k], po[k].grad, atol=1e-6, rtol=1e-5)
+                out[tag + "_raw"] = raw_r
+                out[tag + "_dpts"] = pts_r.grad
+                out[tag + "_dviewdirs"] = vd_r.grad
+                if S == 16 and (C, variant) in ((1, "xavier"), (3, "trained")):
+                    out[tag + "_pe"] = acts["pe"]
+                    out[tag + "_h0"] = acts["h0"]
+                    out[tag + "_h4"] = acts["h4"]
+                    out[tag + "_h7"] = acts["h7"]
+                    out[tag + "_feat"] = acts["feat"]
+                    out[tag + "_hv"] = acts["hv"]
+                for k, v in grad_summary(gr, np.random.default_rng(7)).items():
+                    out[tag + "_g_" + k] = v
+    save("g4_mlp.npz", **out)
+
+
+# ----------------------------------------------------------------------------------- G5
+def g5_composite(R):
+    out = {}
+    for C in (1, 3):
+        rng = np.random.default_rng(505 + C)
+        N, S = 48, 64
+        raw = GI.f32(rng.standard_normal((N, S, C + 1)) * 2.0)
+        raw[4] = -50.0            # all-zero alpha row -> 0/0 in disp (NaN) (SURVEY hard part 6)
+        raw[5, :, C] = 60.0       # fully opaque ray
+        z = torch.sort(GI.f32(rng.random((N, S))), -1)[0]
+        rd = GI.f32(rng.standard_normal((N, 3)))
+        noise = GI.f32(rng.standard_normal((N, S)))
+        net = R.nerf.NeRF(8, 256, 63, 27, 4, [4], True, C)
+        for noisy in (True, False):
+            tag = "C%d_%s" % (C, "noise" if noisy else "clean")
+            raw_r = raw.clone().requires_grad_(True)
+            rd_r = rd.clone().requires_grad_(True)
+            if noisy:
+                with ReplayRNG([noise]):
+                    ref = net.raw2output(None, True, "rgb", raw_r, z, rd_r)
+            else:
+                ref = net.raw2output(None, True, "rgb", raw_r, z, rd_r, raw_noise_std=0.0)
+            raw_o = raw.clone().requires_grad_(True)
+            rd_o = rd.clone().requires_grad_(True)
+            ora = O.composite(raw_o, z, rd_o, noise if noisy else None, C)
+            names = ("rgb_map", "disp", "acc", "weights", "depth", "sigma")
+            for nm, a, b in zip(names, ref, ora):
+                check("G5 %s %s" % (nm, tag), a, b)
+                out[tag + "_" + nm] = a
+            Gm = GI.f32(np.random.default_rng(9).standard_normal((N, C)))
+            (ref[0] * Gm).sum().backward()
+            (ora[0] * Gm).sum().backward()
+            check("G5 draw " + tag, raw_r.grad, raw_o.grad, atol=1e-7, rtol=1e-5)
+            check("G5 drays_d " + tag, rd_r.grad, rd_o.grad, atol=1e-7, rtol=1e-5)
+            out[tag + "_draw"] = raw_r.grad
+            out[tag + "_drays_d"] = rd_r.grad
+            out[tag + "_Gmap"] = Gm
+        out["C%d_raw" % C] = raw
+        out["C%d_z" % C] = z
+        out["C%d_rays_d" % C] = rd
+        out["C%d_noise" % C] = noise
+    save("g5_composite.npz", **out)
+
+
+# ----------------------------------------------------------------------------------- G6
+def g6_sample_pdf(R):
+    out = {}
+    rng = np.random.default_rng(606)
+    for kind in ("flat", "peaky", "zero"):
+        for (S, Ni) in ((64, 64), (32, 32), (64, 128)):
+            N = 256
+            tag = "%s_S%d_N%d" % (kind, S, Ni)
+            t_rand = GI.f32(rng.random((N, S)))
+            z = O.stratified_z(N, S, t_rand)
+            bins = 0.5 * (z[..., 1:] + z[..., :-1])
+            if kind == "flat":
+                w = GI.f32(rng.random((N, S - 2)))
+            elif kind == "peaky":
+                w = GI.f32(rng.random((N, S - 2)) ** 8)
+            else:
+                w = torch.zeros(N, S - 2)
+                w[::2, 5] = 1.0
+            u = GI.f32(rng.random((N, Ni)))
+            u[0, 0] = 0.0
+            u[1, 1] = float(np.float32(1.0) - np.float32(2.0 ** -24))
+            with ReplayRNG([u]):
+                s_ref = R.helpers.sample_pdf(bins, w, Ni)
+            # indices the reference computes internally (run_nerf_helpers.py:76-80,101)
+            wr = w + 1e-5
+            cdf_r = torch.cumsum(wr / torch.sum(wr, -1, keepdim=True), -1)
+            cdf_r = torch.cat([torch.zeros_like(cdf_r[..., :1]), cdf_r], -1)
+            inds_ref = torch.searchsorted(cdf_r, u.contiguous(), right=True)
+            s_t, inds_t = O.sample_pdf_torch(bins, w, u)
+            check("G6 samples(torch) " + tag, s_ref, s_t)
+            check("G6 inds(torch) " + tag, inds_ref, inds_t)
+            s_e, inds_e, cdf_e = O.sample_pdf_exact(bins.numpy(), w.numpy(), u.numpy())
+            # exact restatement vs reference: indices may differ only where u sits within
+            # 2 ulp of a cdf knot (torch's float `sum` order is unspecified).
+            diff = np.nonzero(inds_e != inds_ref.numpy())
+            for r, c in zip(*diff):
+                k = min(int(inds_e[r, c]), int(inds_ref[r, c]))
+                gap = abs(float(u[r, c]) - float(cdf_e[r, k]))
+                assert gap <= 2 * np.spacing(np.float32(cdf_e[r, k])), ("G6 exact inds", tag, r, c, gap)
+            REPORT.append("%-44s index mismatches vs reference: %d of %d (tie-allowed)" %
+                          ("G6 inds(exact) " + tag, len(diff[0]), inds_e.size))
+            # value difference = the 1-ulp cdf difference amplified by (b1-b0)/denom; the
+            # `denom < 1e-5 -> 1` switch (run_nerf_helpers.py:110-111) is a genuine
+            # discontinuity, so samples whose denom sits within 4 ulp of 1e-5 are exempt.
+            below = np.maximum(inds_e - 1, 0)
+            above = np.minimum(inds_e, cdf_e.shape[-1] - 1)
+            den = np.take_along_axis(cdf_e, above, 1) - np.take_along_axis(cdf_e, below, 1)
+            bw = np.abs(np.take_along_axis(bins.numpy(), above, 1) - np.take_along_axis(bins.numpy(), below, 1))
+            tol = 1e-6 + 4 * 2.0 ** -23 * bw / np.where(den < 1e-5, 1.0, den)
+            exempt = (np.abs(den - 1e-5) < 5e-7) | (inds_e != inds_ref.numpy())
+            dv = np.abs(s_e - s_ref.numpy())
+            assert (dv <= tol)[~exempt].all(), ("G6 samples(exact)", tag, float(dv[~exempt].max()))
+            REPORT.append("%-44s max|d|=%.3e (conditioning-scaled tol), exempt %d" %
+                          ("G6 samples(exact) " + tag, float(dv[~exempt].max()), int(exempt.sum())))
+            # torch cumsum == float32(double running sum)?
+            pdf32 = (wr / torch.sum(wr, -1, keepdim=True)).numpy()
+            cs = np.cumsum(pdf32.astype(np.float64), -1).astype(np.float32)
+            check("G6 cumsum double-accumulate " + tag, cdf_r[:, 1:], cs)
+            out.update({tag + "_t_rand": t_rand, tag + "_w": w, tag + "_u": u, tag + "_samples": s_ref,
+                        tag + "_inds": inds_ref, tag + "_samples_exact": s_e, tag + "_inds_exact": inds_e})
+    save("g6_sample_pdf.npz", **out)
+
+
+# ----------------------------------------------------------------------------------- G7/G8
+def build_ref_graph(R, args, p_coarse, p_fine, knots, transform):
+    torch.manual_seed(0)
+    model = R.optimize.Model(args)
+    g = model.build_network(args)
+    load_params_into(g.nerf, p_coarse)
+    load_params_into(g.nerf_fine, p_fine)
+    g.evt_knot_pose_se3.params.weight.data = knots.clone()
+    g.transform.params.weight.data = transform.clone()
+    return model, g
+
+
+def g7_render(R):
+    out = {}
+    cam = GI.CAMERAS["unreal"]
+    K = GI.cam_K(cam)
+    ci = 0
+    for C in (1, 3):
+        for (P, Rn) in ((2, 32), (19, 4)):
+            for (S, Ni) in ((16, 16), (64, 64)):
+                rng = np.random.default_rng(707 + ci)
+                tag = "C%d_P%d_S%d" % (C, P, S)
+                ci += 1
+                pc, pf = O.xavier_params(rng, C), O.xavier_params(rng, C)
+                pc["alpha_linear.bias"] += 1.0
+                pf["alpha_linear.bias"] += 1.0
+                knots = GI.knots_init(rng) * 5
+                tr = GI.transform_small(rng) * 0.1
+                idx = GI.pixel_indices(rng, cam, Rn)
+                N = P * Rn
+                draws = GI.render_draws(rng, N, S, Ni)
+                args = make_args(channels=C, N_samples=S, N_importance=Ni, num_interpolated_pose=P)
+                _, g = build_ref_graph(R, args, pc, pf, knots, tr)
+                poses = g.get_pose_rgb(args, torch.tensor([0.0, 1.0]), seg_num=P).detach()
+                with ReplayRNG([draws["t_rand"], draws["noise0"], draws["u"], draws["noise1"]]):
+                    ref = g.render(0, poses, idx, cam["H"], cam["W"], K, args, True, "rgb", torch.tensor([]),
+                                   training=True)
+                with ReplayRNG([draws["t_rand"], draws["noise0"], draws["u"], draws["noise1"]]):
+                    ref_inf = g.render(0, poses, idx, cam["H"], cam["W"], K, args, True, "rgb", torch.tensor([]),
+                                       training=False)
+                ora = O.render(pc, pf, poses, idx, cam["H"], cam["W"], K, C, S, Ni, draws)
+                ora_x = O.render(pc, pf, poses, idx, cam["H"], cam["W"], K, C, S, Ni, draws, exact_pdf=True)
+                for k in ref:
+                    check("G7 %s %s" % (k, tag), ref[k], ora[k])
+                    # training=False builds rays through get_rays' float meshgrid: same numbers
+                    check("G7 %s %s (training=False)" % (k, tag), ref_inf[k], ref[k], atol=1e-6, rtol=1e-5)
+                    if k != "sigma" and "disp" not in k:
+                        check("G7 %s %s (exact-pdf oracle)" % (k, tag), ref[k], ora_x[k], atol=2e-5)
+                    out[tag + "_" + k] = ref[k]
+                out[tag + "_poses"] = poses
+    save("g7_render.npz", **out)
+
+
+def ref_losses(R, args, ret_event, ret_rgb, n_pix, target_acc, target_rgb):
+    """train.py:163-337 driven with the reference's own helper callables."""
+    mse = R.imgloss.MSELoss()
+    gray = R.img_utils.RGB2Gray()
+    bl = R.math_utils.rgb2brightlog
+
+    def diff(img):
+        a, b = img[:n_pix], img[n_pix:]
+        if args.channels == 3:
+            return bl(gray(b), args.dataset) - bl(gray(a), args.dataset)
+        return bl(b, args.dataset) - bl(a, args.dataset)
+
+    tgt = target_acc.clone()
+    if args.event_threshold > 0:
+        tgt *= torch.tensor(args.event_threshold)
+        ef = mse(diff(ret_event["rgb_map"]), tgt) * args.event_coeff_syn
+        ec = mse(diff(ret_event["rgb0"]), tgt) * args.event_coeff_syn
+    else:
+        def nrm(v):
+            return v / (torch.linalg.norm(v, dim=0, keepdim=True) + 1e-9)
+        ef = mse(nrm(diff(ret_event["rgb_map"])), nrm(tgt)) * args.event_coeff_real
+        ec = mse(nrm(diff(ret_event["rgb0"])), nrm(tgt)) * args.event_coeff_real
+    interval = target_rgb.shape[0]
+    sb, sb0 = 0, 0
+    for j in range(args.num_interpolated_pose):
+        sb = sb + ret_rgb["rgb_map"][j * interval:(j + 1) * interval]
+        sb0 = sb0 + ret_rgb["rgb0"][j * interval:(j + 1) * interval]
+    sb = sb / args.num_interpolated_pose
+    sb0 = sb0 / args.num_interpolated_pose
+    rf = mse(sb, target_rgb) * args.rgb_coeff
+    rc = mse(sb0, target_rgb) * args.rgb_coeff
+    return (ec + ef) + (rf + rc), ef, ec, rf, rc
+
+
+def g8_step(R):
+    out = {}
+    specs = [
+        ("unreal_C1", "unreal", 1, "BeNeRF_Unreal", 0.1, 19, 16, 16, 24, 3),
+        ("unreal_C3", "unreal", 3, "BeNeRF_Unreal", 0.1, 19, 16, 16, 24, 3),
+        ("e2syn_C3", "e2nerf_syn", 3, "E2NeRF_Synthetic", 0.2, 7, 32, 32, 16, 5),
+        ("e2real_C3", "e2nerf_real", 3, "E2NeRF_Real", -1.0, 31, 16, 32, 16, 2),
+    ]
+    for si, (tag, cname, C, dataset, thr, P, S, Ni, Re, Rr) in enumerate(specs):
+        rng = np.random.default_rng(808 + si)
+        cam = GI.CAMERAS[cname]
+        K = GI.cam_K(cam)
+        pc, pf = O.xavier_params(rng, C), O.xavier_params(rng, C)
+        pc["alpha_linear.bias"] += 1.0
+        pf["alpha_linear.bias"] += 1.0
+        knots = GI.knots_init(rng) * 3
+        tr = GI.transform_small(rng) * 0.1
+        idx_e = GI.pixel_indices(rng, cam, Re)
+        idx_r = GI.pixel_indices(rng, cam, Rr)
+        ev = GI.synthetic_events(rng, cam, 200000)
+        window = 0.1 if "unreal" in tag else 0.25
+        low_t = float(rng.random() * (1 - window))
+        sel, upper_t = O.event_window(ev["ts"], low_t, window)
+        acc = O.accumulate_events(cam["H"], cam["W"], ev["x"][sel], ev["y"][sel], ev["pol"][sel])
+        acc_ref = R.event_utils.accumulate_events_on_gpu(np.zeros((cam["H"], cam["W"])), ev["x"][sel], ev["y"][sel],
+                                                         ev["pol"][sel])
+        check("G8 events_accu " + tag, acc_ref, acc)
+        target_acc = acc.reshape(-1, 1)[idx_e]
+        img = torch.from_numpy(rng.random((1, cam["H"], cam["W"], C)))
+        target_rgb = torch.Tensor(img[0].numpy()).reshape(-1, cam["H"] * cam["W"], C)[:, idx_r].reshape(-1, C)
+        d_e = GI.render_draws(rng, 2 * Re, S, Ni)
+        d_r = GI.render_draws(rng, P * Rr, S, Ni)
+        args = make_args(channels=C, N_samples=S, N_importance=Ni, num_interpolated_pose=P, dataset=dataset,
+                         event_threshold=thr, event_height=cam["H"], event_width=cam["W"])
+        _, g = build_ref_graph(R, args, pc, pf, knots, tr)
+        evt_ts = torch.tensor(np.stack((low_t, upper_t)).reshape(2), dtype=torch.float32)
+        rgb_ts = torch.tensor([0.0, 1.0], dtype=torch.float32)
+        pe = g.get_pose_evt(args, evt_ts)
+        pr = g.get_pose_rgb(args, rgb_ts)
+        with ReplayRNG([d_e["t_rand"], d_e["noise0"], d_e["u"], d_e["noise1"]]):
+            ret_e = g.render(0, pe, idx_e, cam["H"], cam["W"], K, args, True, "event", torch.tensor([]), training=True)
+        with ReplayRNG([d_r["t_rand"], d_r["noise0"], d_r["u"], d_r["noise1"]]):
+            ret_r = g.render(0, pr, idx_r, cam["H"], cam["W"], K, args, True, "rgb", torch.tensor([]), training=True)
+        loss_r, ef, ec, rf, rc = ref_losses(R, args, ret_e, ret_r, Re, target_acc, target_rgb)
+        loss_r.backward()
+        # oracle
+        cfg = O.StepConfig(H=cam["H"], W=cam["W"], fx=cam["fx"], fy=cam["fy"], cx=cam["cx"], cy=cam["cy"], channels=C,
+                           n_samples=S, n_importance=Ni, n_poses=P, dataset=dataset, threshold=thr, window=window)
+        oc = {k: v.clone().requires_grad_(True) for k, v in pc.items()}
+        of = {k: v.clone().requires_grad_(True) for k, v in pf.items()}
+        ko = knots.clone().requires_grad_(True)
+        to = tr.clone().requires_grad_(True)
+        loss_o, parts = O.step_loss(cfg, oc, of, ko, to, evt_ts, rgb_ts, idx_e, idx_r, target_acc, target_rgb, d_e, d_r)
+        loss_o.backward()
+        check("G8 loss " + tag, loss_r, loss_o)
+        check("G8 event_fine " + tag, ef, parts["event_fine"])
+        check("G8 rgb_fine " + tag, rf, parts["rgb_fine"])
+        check("G8 dknots " + tag, g.evt_knot_pose_se3.params.weight.grad, ko.grad, atol=1e-7, rtol=1e-4)
+        check("G8 dtransform " + tag, g.transform.params.weight.grad, to.grad, atol=1e-7, rtol=1e-4)
+        gr = {}
+        for net_name, net, op in (("nerf", g.nerf, oc), ("nerf_fine", g.nerf_fine, of)):
+            for k, v in net.named_parameters():
+                gr[net_name + "." + k] = v.grad
+                check("G8 d%s.%s %s" % (net_name, k, tag), v.grad, op[k].grad, atol=1e-7, rtol=1e-4)
+        out.update({tag + "_loss": loss_r, tag + "_event_fine": ef, tag + "_event_coarse": ec,
+                    tag + "_rgb_fine": rf, tag + "_rgb_coarse": rc,
+                    tag + "_dknots": g.evt_knot_pose_se3.params.weight.grad,
+                    tag + "_dtransform": g.transform.params.weight.grad,
+                    tag + "_rgb_map_evt": ret_e["rgb_map"], tag + "_rgb_map_rgb": ret_r["rgb_map"],
+                    tag + "_rgb0_evt": ret_e["rgb0"], tag + "_rgb0_rgb": ret_r["rgb0"],
+                    tag + "_low_t": np.array(low_t)})
+        for k, v in grad_summary(gr, np.random.default_rng(8)).items():
+            out[tag + "_g_" + k] = v
+        out[tag + "_spec"] = np.array([C, thr, P, S, Ni, Re, Rr, window], np.float64)
+    save("g8_step.npz", **out)
+
+
+# ----------------------------------------------------------------------------------- G9
+def g9_events(R):
+    out = {}
+    rng = np.random.default_rng(909)
+    cam = GI.CAMERAS["e2nerf_real"]
+    ev = GI.synthetic_events(rng, cam, 100000)
+    ev["x"][:5000] = ev["x"][0]      # heavy duplicates
+    ev["y"][:5000] = ev["y"][0]
+    ref = R.event_utils.accumulate_events_on_gpu(np.zeros((cam["H"], cam["W"])), ev["x"], ev["y"], ev["pol"])
+    ora = O.accumulate_events(cam["H"], cam["W"], ev["x"], ev["y"], ev["pol"])
+    check("G9 accumulate", ref, ora)
+    assert ref.dtype == torch.float64
+    save("g9_events.npz", accu=ref.numpy().astype(np.int16))
+
+
+# ----------------------------------------------------------------------------------- G10
+def g10_adam(R):
+    out = {}
+    rng = np.random.default_rng(1010)
+    p0 = GI.f32(rng.standard_normal(4096))
+    grads = [GI.f32(rng.standard_normal(4096) * (10.0 ** rng.integers(-6, 2))) for _ in range(5)]
+    pr = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([pr], lr=5e-4)
+    po = p0.clone()
+    m, v = torch.zeros_like(po), torch.zeros_like(po)
+    lr = 5e-4
+    for step, gtensor in enumerate(grads):
+        pr.grad = gtensor.clone()
+        opt.step()
+        O.adam_update(po, gtensor, m, v, step + 1, lr)
+        # reference LR schedule (train.py:355-362) applied AFTER the step
+        lr = 5e-4 * (0.1 ** (step / (200 * 1000)))
+        for gq in opt.param_groups:
+            gq["lr"] = lr
+        assert lr == O.decayed_lr(5e-4, 0.1, step)
+        check("G10 adam step %d" % step, pr.data, po, atol=1e-7, rtol=1e-6)
+        out["p_after_%d" % step] = pr.data.clone()
+        out["g_%d" % step] = gtensor
+    out["p0"] = p0
+    for s in (0, 1, 1000, 80000):
+        out["lr_%d" % s] = np.array(5e-4 * (0.1 ** (s / (200 * 1000))))
+        assert out["lr_%d" % s] == O.decayed_lr(5e-4, 0.1, s)
+    save("g10_adam.npz", **out)
+
+
+def main():
+    torch.set_num_threads(8)
+    R = load_reference()
+    only = sys.argv[1:]
+    for fn in (g1_spline, g2_rays, g3_posenc, g4_mlp, g5_composite, g6_sample_pdf, g7_render, g8_step, g9_events,
+               g10_adam):
+        if only and fn.__name__.split("_")[0] not in only:
+            continue
+        fn(R)
+        print("ok", fn.__name__, flush=True)
+    with open(os.path.join(OUT, "PINNING_REPORT.txt"), "a" if only else "w") as f:
+        f.write("oracle vs unmodified reference (torch %s, CPU) - generated by oracle/gen_golden.py\n" % torch.__version__)
+        f.write("\n".join(REPORT) + "\n")
+    print("\n".join(REPORT[-12:]))
+    print("wrote", OUT)
+
+
+if __name__ == "__main__":
+    main()
