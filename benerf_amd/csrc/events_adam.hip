@@ -1,0 +1,125 @@
+// K7: event accumulation (polarity histogram), row gather; K8: fused Adam.
+//
+// K7 follows utils/event_utils.py:246-259 (sparse COO -> dense scatter-add: duplicates
+// summed) and the window selection of model/nerf.py:162-178.  Polarities are +-1 so float
+// atomic adds are exact and order independent.
+// K8 follows torch.optim.Adam with default hyper-parameters (model/optimize.py:36-55,
+// train.py:343-352).
+#include "common.h"
+
+namespace {
+
+__global__ void event_accumulate_kernel(const int32_t* __restrict__ xs, const int32_t* __restrict__ ys,
+                                        const float* __restrict__ ps, int64_t begin, int64_t end, int H, int W,
+                                        float* __restrict__ out) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < end; e += stride) {
+        int x = xs[e], y = ys[e];
+        if (x >= 0 && x < W && y >= 0 && y < H) atomicAdd(out + (int64_t)y * W + x, ps[e]);
+    }
+}
+
+// first index with ts[idx] >= v (lower) / first index with ts[idx] > v (upper)
+__device__ int64_t bound(const double* ts, int64_t n, double v, bool upper) {
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) >> 1;
+        bool go = upper ? (ts[mid] <= v) : (ts[mid] < v);
+        if (go) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void event_window_accumulate_kernel(const int32_t* __restrict__ xs, const int32_t* __restrict__ ys,
+                                               const float* __restrict__ ps, const double* __restrict__ ts, int64_t n,
+                                               double low_t, double upper_t, int H, int W, float* __restrict__ out) {
+    // low_t <= ts <= upper_t (both inclusive, model/nerf.py:170-172)
+    int64_t begin = bound(ts, n, low_t, false);
+    int64_t end = bound(ts, n, upper_t, true);
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < end; e += stride) {
+        int x = xs[e], y = ys[e];
+        if (x >= 0 && x < W && y >= 0 && y < H) atomicAdd(out + (int64_t)y * W + x, ps[e]);
+    }
+}
+
+__global__ void gather_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ idx, int64_t n_idx,
+                                   int width, float* __restrict__ out) {
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_idx * width) return;
+    int64_t r = e / width;
+    int c = (int)(e % width);
+    out[e] = src[idx[r] * width + c];
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, int64_t n, float step_size, float omb1, float beta2, float omb2,
+                            float eps, float bc2_sqrt, float grad_scale) {
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float gi = g[i] * grad_scale;
+        float mi = m[i] + (gi - m[i]) * omb1;                    // exp_avg.lerp_(grad, 1-beta1)
+        float vi = v[i] * beta2 + (gi * gi) * omb2;               // mul_(beta2).addcmul_(g, g, 1-beta2)
+        float denom = sqrtf(vi) / bc2_sqrt + eps;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = p[i] - step_size * (mi / denom);                    // addcdiv_(m, denom, -step_size)
+    }
+}
+
+}  // namespace
+
+extern "C" int benerf_event_accumulate(const int32_t* xs, const int32_t* ys, const float* ps, int64_t n, int H, int W,
+                                       float* out, benerf_stream_t stream) {
+    BENERF_REQUIRE(out && H > 0 && W > 0 && n >= 0, "event_accumulate: bad args");
+    if (n == 0) return BENERF_OK;
+    BENERF_REQUIRE(xs && ys && ps, "event_accumulate: null event arrays");
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(event_accumulate_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), xs, ys, ps, (int64_t)0, n,
+                       H, W, out);
+    BENERF_LAUNCH_CHECK("event_accumulate");
+    return BENERF_OK;
+}
+
+extern "C" int benerf_event_window_accumulate(const int32_t* xs, const int32_t* ys, const float* ps, const double* ts,
+                                              int64_t n, double low_t, double upper_t, int H, int W, float* out,
+                                              benerf_stream_t stream) {
+    BENERF_REQUIRE(out && H > 0 && W > 0 && n >= 0, "event_window_accumulate: bad args");
+    if (n == 0) return BENERF_OK;
+    BENERF_REQUIRE(xs && ys && ps && ts, "event_window_accumulate: null event arrays");
+    hipLaunchKernelGGL(event_window_accumulate_kernel, dim3(1024), dim3(256), 0, as_stream(stream), xs, ys, ps, ts, n,
+                       low_t, upper_t, H, W, out);
+    BENERF_LAUNCH_CHECK("event_window_accumulate");
+    return BENERF_OK;
+}
+
+extern "C" int benerf_gather_rows(const float* src, const int64_t* idx, int64_t n_idx, int width, float* out,
+                                  benerf_stream_t stream) {
+    BENERF_REQUIRE(src && idx && out && width > 0 && n_idx >= 0, "gather_rows: bad args");
+    if (n_idx == 0) return BENERF_OK;
+    int64_t total = n_idx * width;
+    int blocks = (int)((total + 255) / 256);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), src, idx, n_idx, width, out);
+    BENERF_LAUNCH_CHECK("gather_rows");
+    return BENERF_OK;
+}
+
+extern "C" int benerf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr,
+                                double beta1, double beta2, double eps, int step, double grad_scale,
+                                benerf_stream_t stream) {
+    BENERF_REQUIRE(param && grad && exp_avg && exp_avg_sq && n >= 0 && step >= 1, "adam_step: bad args");
+    if (n == 0) return BENERF_OK;
+    double bc1 = 1.0 - pow(beta1, (double)step);
+    double bc2 = 1.0 - pow(beta2, (double)step);
+    float step_size = (float)(lr / bc1);
+    float bc2_sqrt = (float)sqrt(bc2);
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq, n,
+                       step_size, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, bc2_sqrt,
+                       (float)grad_scale);
+    BENERF_LAUNCH_CHECK("adam_step");
+    return BENERF_OK;
+}

@@ -1,0 +1,376 @@
+// K3 backward, part 1: activation-gradient chain for one tile of 64 sample points per
+// workgroup, exact-f32 MFMA.  Walks NeRF.forward (model/nerf.py:67-116) in reverse:
+//
+//   d_raw -> rgb layer (VALU) -> dYv = dHV * [hv>0]                       -> DYV
+//   VIEWS^T : dYv (128)  x Wv[:, :256]   -> dFeat ; dYv x Wv[:,256:283] (VALU) -> dPE(dir)
+//   FEAT^T  : dFeat      x Wf  + d_sigma * w_alpha, * [h7>0]              -> DYH[7]
+//   L7..L1  : dY_l       x W_l (h part), * [h_{l-1}>0]                    -> DYH[l-1]
+//             (L5 additionally emits dPE = dY_5 x W5[:, :63])
+//   L0^T    : dY_0       x W_0                                            -> dPE +=
+//   dPE -> d_pts, dPE(dir) -> d_viewdirs (per point) through the sin/cos derivatives, using
+//   the PE values saved by the forward pass (no sincos recomputation).
+//
+// The dY tiles are streamed to HBM for part 2 (mlp_dw.hip: dW = dY^T X).  Same tiling as the
+// forward kernel: the gradient tile lives in the LDS tile Hs, each wave owns 64 columns, B
+// operands (transposed-packed weights) stream from L2.  ReLU masks come from the saved
+// activations, prefetched into registers ahead of each stage's k-loop.
+#include "mlp_common.h"
+
+namespace {
+using namespace mlp;
+
+struct BwdArgs {
+    const float* d_raw;
+    const float* acts;
+    float* dacts;
+    const float* packed;
+    const float* w_views;   // [128][283]
+    const float* w_alpha;   // [256]
+    const float* w_rgb;     // [C][128]
+    float* d_pts;           // [M][3]
+    float* d_vdir;          // [M][3]
+    int64_t M;
+};
+
+constexpr int WVD_LD = 28;
+constexpr int OFF_DRAW = TM * LD;               // [64][4]
+constexpr int OFF_WVD = OFF_DRAW + TM * 4;      // [128][28]
+constexpr int OFF_DPED = OFF_WVD + 128 * WVD_LD;   // [64][28]
+constexpr int OFF_RED = OFF_DPED + TM * WVD_LD;    // [4][64][3]
+constexpr int BWD_SMEM_FLOATS = OFF_RED + 4 * TM * 3;
+
+template <int KB, int NCT>
+__device__ __forceinline__ void gemm_stage(const float* __restrict__ Hs, int kcol0, const float* __restrict__ wp,
+                                           int ct0, int lane, f32x16 (&acc)[2][NCT]) {
+    const float* a0p = Hs + (lane & 31) * LD + kcol0 + 4 * (lane >> 5);
+    const float* a1p = a0p + 32 * LD;
+    const float4* bp[NCT];
+    float4 bn[NCT];
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) {
+        bp[c] = reinterpret_cast<const float4*>(wp) + (int64_t)(ct0 + c) * KB * 64 + lane;
+        bn[c] = bp[c][0];
+    }
+#pragma unroll 2
+    for (int kb = 0; kb < KB; ++kb) {
+        float4 b[NCT];
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) b[c] = bn[c];
+        if (kb + 1 < KB) {
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) bn[c] = bp[c][(kb + 1) * 64];
+        }
+        const float4 a0 = *reinterpret_cast<const float4*>(a0p + kb * 8);
+        const float4 a1 = *reinterpret_cast<const float4*>(a1p + kb * 8);
+        const float a0v[4] = {a0.x, a0.y, a0.z, a0.w};
+        const float a1v[4] = {a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                const float bv = i == 0 ? b[c].x : i == 1 ? b[c].y : i == 2 ? b[c].z : b[c].w;
+                acc[0][c] = mfma32(a0v[i], bv, acc[0][c]);
+                acc[1][c] = mfma32(a1v[i], bv, acc[1][c]);
+            }
+        }
+    }
+}
+
+// one 32x32 output tile: rows rt*32.., column tile `tile` of the packed block
+template <int KB>
+__device__ __forceinline__ void gemm_one(const float* __restrict__ Hs, int kcol0, const float* __restrict__ wp, int tile,
+                                         int rt, int lane, f32x16& acc) {
+    const float* ap = Hs + (rt * 32 + (lane & 31)) * LD + kcol0 + 4 * (lane >> 5);
+    const float4* bp = reinterpret_cast<const float4*>(wp) + (int64_t)tile * KB * 64 + lane;
+    float4 bn = bp[0];
+#pragma unroll 4
+    for (int kb = 0; kb < KB; ++kb) {
+        const float4 b = bn;
+        if (kb + 1 < KB) bn = bp[(kb + 1) * 64];
+        const float4 a = *reinterpret_cast<const float4*>(ap + kb * 8);
+        acc = mfma32(a.x, b.x, acc);
+        acc = mfma32(a.y, b.y, acc);
+        acc = mfma32(a.z, b.z, acc);
+        acc = mfma32(a.w, b.w, acc);
+    }
+}
+
+template <int NCT>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][NCT]) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[r][c][e] = 0.f;
+}
+
+// saved activation values in accumulator layout (for the ReLU mask of the stage's output)
+__device__ __forceinline__ void load_mask(float (&hm)[2][2][16], const float* __restrict__ h, int ct0, int lane,
+                                          int64_t m0, int64_t M) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int k = (ct0 + c) * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t mm = m0 + r * 32 + acc_row(e, lane);
+                hm[r][c][e] = mm < M ? h[mm * 256 + k] : 0.f;
+            }
+    }
+}
+
+// dY = acc (+ extra) masked by hm > 0  -> LDS tile + DY array
+template <bool MASK>
+__device__ __forceinline__ void epilogue(f32x16 (&acc)[2][2], const float (&hm)[2][2][16], float* __restrict__ Hs,
+                                         int ct0, int lane, float* __restrict__ dy, int64_t m0, int64_t M) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int k = (ct0 + c) * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int pt = r * 32 + acc_row(e, lane);
+                float v = acc[r][c][e];
+                if (MASK) v = hm[r][c][e] > 0.f ? v : 0.f;
+                Hs[pt * LD + k] = v;
+                if (m0 + pt < M) dy[(m0 + pt) * 256 + k] = v;
+            }
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(NTHREADS, 1) void mlp_bwd_kernel(BwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Hs = smem;
+    float* draw = smem + OFF_DRAW;
+    float* wvd = smem + OFF_WVD;
+    float* dped = smem + OFF_DPED;
+    float* red = smem + OFF_RED;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int64_t m0 = (int64_t)blockIdx.x * TM;
+    const int64_t M = a.M;
+    const int pt = tid & 63;
+    const int grp = tid >> 6;
+    const int64_t m = m0 + pt;
+    const float* acts = a.acts;
+    float* dacts = a.dacts;
+    const int ct0 = wave * 2;
+
+    // ---- P0: d_raw tile, PE(dir) slice of the views weights --------------------------------------
+    if (tid < 64) {
+#pragma unroll
+        for (int c = 0; c <= C; ++c) draw[tid * 4 + c] = m < M ? a.d_raw[m * (C + 1) + c] : 0.f;
+    }
+    for (int e = tid; e < 128 * 27; e += NTHREADS) {
+        const int n = e / 27, j = e - n * 27;
+        wvd[n * WVD_LD + j] = a.w_views[n * 283 + 256 + j];
+    }
+    __syncthreads();
+
+    // ---- P1: rgb layer backward + ReLU mask of the views layer -> dYv in Hs[:,0:128) ------------------
+    {
+        const int j = tid & 127, half = tid >> 7;
+        float wr[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) wr[c] = a.w_rgb[c * 128 + j];
+        const float* hv = acts + act_hv(M);
+        float* dyv = dacts + dact_hv(M);
+#pragma unroll 4
+        for (int p = half * 32; p < half * 32 + 32; ++p) {
+            const int64_t mm = m0 + p;
+            float g = 0.f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) g += draw[p * 4 + c] * wr[c];
+            const float h = mm < M ? hv[mm * ACT_HV_W + j] : 0.f;
+            const float v = h > 0.f ? g : 0.f;
+            Hs[p * LD + j] = v;
+            if (mm < M) dyv[mm * ACT_HV_W + j] = v;
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc[2][2];
+    float hm[2][2][16];
+
+    // ---- P2: VIEWS^T: dFeat = dYv x Wv[:, :256]; dPE(dir) = dYv x Wv[:, 256:283] (VALU) ------------------
+    zero_acc(acc);
+    gemm_stage<16, 2>(Hs, 0, a.packed + pack_offset(PB_VIEWS), ct0, lane, acc);
+    {
+        float s[7];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) s[q] = 0.f;
+        const float* hrow = Hs + pt * LD;
+#pragma unroll 2
+        for (int n = 0; n < 128; n += 4) {
+            const float4 h4 = *reinterpret_cast<const float4*>(hrow + n);
+            const float hv4[4] = {h4.x, h4.y, h4.z, h4.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int q = 0; q < 7; ++q) {
+                    const int j = grp + 4 * q;
+                    if (j < 27) s[q] += hv4[i] * wvd[(n + i) * WVD_LD + j];
+                }
+        }
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            const int j = grp + 4 * q;
+            if (j < 27) dped[pt * WVD_LD + j] = s[q];
+        }
+    }
+    __syncthreads();   // dYv fully consumed
+    epilogue<false>(acc, hm, Hs, ct0, lane, dacts + dact_feat(M), m0, M);
+    if (grp == 0 && m < M) {   // d viewdirs (per point) through PE(dir)
+        const float* ped = acts + act_ped(M) + m * ACT_PED_W;
+        const float* g = dped + pt * WVD_LD;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            float s = g[d];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const float sn = ped[3 + f * 6 + d], cs = ped[3 + f * 6 + 3 + d];
+                s += (float)(1 << f) * (cs * g[3 + f * 6 + d] - sn * g[3 + f * 6 + 3 + d]);
+            }
+            a.d_vdir[m * 3 + d] = s;
+        }
+    }
+    load_mask(hm, acts + act_h(M, 7), ct0, lane, m0, M);
+    __syncthreads();
+
+    // ---- P3: FEAT^T (+ alpha head), mask h7 -> dY7 ----------------------------------------------------
+    zero_acc(acc);
+    gemm_stage<32, 2>(Hs, 0, a.packed + pack_offset(PB_FEAT), ct0, lane, acc);
+    {
+        const float wa0 = a.w_alpha[ct0 * 32 + (lane & 31)];
+        const float wa1 = a.w_alpha[(ct0 + 1) * 32 + (lane & 31)];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float ds = draw[(r * 32 + acc_row(e, lane)) * 4 + C];
+                acc[r][0][e] += ds * wa0;
+                acc[r][1][e] += ds * wa1;
+            }
+    }
+    __syncthreads();
+    epilogue<true>(acc, hm, Hs, ct0, lane, dacts + dact_h(M, 7), m0, M);
+    __syncthreads();
+
+    // ---- P4: L7 .. L1: dY_l x W_l, mask h_{l-1} -> dY_{l-1} ----------------------------------------------
+#pragma unroll 1
+    for (int l = 7; l >= 1; --l) {
+        load_mask(hm, acts + act_h(M, l - 1), ct0, lane, m0, M);
+        zero_acc(acc);
+        const int pid = PB_L7 + (7 - l);
+        gemm_stage<32, 2>(Hs, 0, a.packed + pack_offset(pid), ct0, lane, acc);
+        if (l == 5) {   // skip connection: dPE = dY5 x W5[:, PE part] (tiles 8, 9 of the block)
+            f32x16 ap;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) ap[e] = 0.f;
+            gemm_one<32>(Hs, 0, a.packed + pack_offset(PB_L5), 8 + (wave & 1), wave >> 1, lane, ap);
+            const int col = COL_PE + (wave & 1) * 32 + (lane & 31);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) Hs[((wave >> 1) * 32 + acc_row(e, lane)) * LD + col] = ap[e];
+        }
+        __syncthreads();
+        epilogue<true>(acc, hm, Hs, ct0, lane, dacts + dact_h(M, l - 1), m0, M);
+        __syncthreads();
+    }
+
+    // ---- P5: L0^T: dPE += dY0 x W0 -----------------------------------------------------------------------
+    {
+        f32x16 ap;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ap[e] = 0.f;
+        gemm_one<32>(Hs, 0, a.packed + pack_offset(PB_L0), wave & 1, wave >> 1, lane, ap);
+        const int col = COL_PE + (wave & 1) * 32 + (lane & 31);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) Hs[((wave >> 1) * 32 + acc_row(e, lane)) * LD + col] += ap[e];
+    }
+    __syncthreads();
+
+    // ---- P6: dPE -> d_pts through the saved PE values ------------------------------------------------------
+    {
+        float s[3] = {0.f, 0.f, 0.f};
+        const float* g = Hs + pt * LD + COL_PE;
+        const int64_t mc = m < M ? m : M - 1;
+        const float* pe = acts + act_pe(M) + mc * ACT_PE_W;
+        if (grp == 0) {
+            s[0] = g[0];
+            s[1] = g[1];
+            s[2] = g[2];
+        }
+        for (int f = grp; f < 10; f += 4) {
+            const float sc = (float)(1 << f);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const float sn = pe[3 + f * 6 + d], cs = pe[3 + f * 6 + 3 + d];
+                s[d] += sc * (cs * g[3 + f * 6 + d] - sn * g[3 + f * 6 + 3 + d]);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) red[(grp * TM + pt) * 3 + d] = s[d];
+    }
+    __syncthreads();
+    if (tid < 64 && m < M) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+            a.d_pts[m * 3 + d] = (red[(0 * TM + tid) * 3 + d] + red[(1 * TM + tid) * 3 + d]) +
+                                 (red[(2 * TM + tid) * 3 + d] + red[(3 * TM + tid) * 3 + d]);
+    }
+}
+
+constexpr size_t BWD_SMEM = (size_t)BWD_SMEM_FLOATS * sizeof(float);
+
+}  // namespace
+
+// part 2 (mlp_dw.hip)
+int benerf_mlp_dw_launch(const BenerfMlpParams* params, int channels, int64_t M, const float* d_raw, const float* acts,
+                         const float* dacts, float* dw_ws, const BenerfMlpGrads* grads, int accumulate,
+                         hipStream_t stream);
+
+extern "C" int benerf_mlp_bwd(const BenerfMlpParams* params, const float* packed, int channels, int n_rays,
+                              int n_samples, const float* d_raw, const float* acts, float* dacts, float* dw_ws,
+                              size_t dw_ws_floats, const BenerfMlpGrads* grads, int accumulate, float* d_pts,
+                              float* d_vdir_pts, benerf_stream_t stream) {
+    BENERF_REQUIRE(params && packed && d_raw && acts && dacts && dw_ws && grads && d_pts && d_vdir_pts,
+                   "mlp_bwd: null pointer");
+    BENERF_REQUIRE(channels == 1 || channels == 3, "mlp_bwd: channels must be 1 or 3");
+    BENERF_REQUIRE(n_rays > 0 && n_samples > 0, "mlp_bwd: bad sizes");
+    if (dw_ws_floats < (size_t)mlp::DW_WS_FLOATS) {
+        benerf_set_error("mlp_bwd: dw workspace too small (%zu < %lld floats)", dw_ws_floats, (long long)mlp::DW_WS_FLOATS);
+        return BENERF_EWORKSPACE;
+    }
+    for (int l = 0; l < BENERF_NLAYERS; ++l)
+        BENERF_REQUIRE(params->w[l] && params->b[l] && grads->w[l] && grads->b[l], "mlp_bwd: null parameter/grad %d", l);
+    BwdArgs a;
+    a.d_raw = d_raw;
+    a.acts = acts;
+    a.dacts = dacts;
+    a.packed = packed;
+    a.w_views = params->w[BENERF_L_VIEWS];
+    a.w_alpha = params->w[BENERF_L_ALPHA];
+    a.w_rgb = params->w[BENERF_L_RGB];
+    a.d_pts = d_pts;
+    a.d_vdir = d_vdir_pts;
+    a.M = (int64_t)n_rays * n_samples;
+    const int64_t tiles = (a.M + mlp::TM - 1) / mlp::TM;
+    BENERF_REQUIRE(tiles < (1ll << 31), "mlp_bwd: too many points");
+    dim3 grid((unsigned)tiles), block(mlp::NTHREADS);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)mlp_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_SMEM);
+        (void)hipFuncSetAttribute((const void*)mlp_bwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_SMEM);
+        attr_done = true;
+    }
+    if (channels == 1) hipLaunchKernelGGL((mlp_bwd_kernel<1>), grid, block, BWD_SMEM, as_stream(stream), a);
+    else hipLaunchKernelGGL((mlp_bwd_kernel<3>), grid, block, BWD_SMEM, as_stream(stream), a);
+    BENERF_LAUNCH_CHECK("mlp_bwd(dx)");
+    return benerf_mlp_dw_launch(params, channels, a.M, d_raw, acts, dacts, dw_ws, grads, accumulate, as_stream(stream));
+}

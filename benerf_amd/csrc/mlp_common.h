@@ -1,0 +1,119 @@
+// Shared layout definitions for the fused NeRF MLP kernels (K3).
+//
+// Network (model/nerf.py:41-64,67-116): PE(63) -> 8 x 256 ReLU (layer 5 consumes
+// cat[PE, h4]) -> { alpha: 256->1 ; feature: 256->256 (linear) } ->
+// views: cat[feature, PE_dir(27)] -> 128 ReLU -> rgb: 128 -> C.
+//
+// Arithmetic: exact-f32 MFMA (v_mfma_f32_32x32x2_f32), f32 accumulate.  A point tile is
+// TM = 64 sample points; its activations live in ONE LDS tile Hs[64][LD] for the whole
+// network:  columns [0,256) hidden state, [256,320) PE(pts) (63 + 1 zero pad; later reused
+// for PE(dir), 27 + 5 zero pad).  Weights never touch LDS: every wave streams its own
+// MFMA-shaped slices straight from L2 (pre-packed so that one global_load_dwordx4 per lane
+// = the B operand of four consecutive MFMA k-steps).
+#pragma once
+#include "common.h"
+
+namespace mlp {
+
+constexpr int TM = 64;        // sample points per workgroup tile
+constexpr int LD = 324;       // LDS row stride in floats (16 B aligned rows, 4-bank skew)
+constexpr int COL_PE = 256;   // first PE column of the LDS tile
+constexpr int NTHREADS = 256; // 4 wavefronts
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// ---- saved activations (floats per point) ------------------------------------------------
+constexpr int ACT_PE_W = 64, ACT_HV_W = 128, ACT_PED_W = 32;
+constexpr int ACT_PER_POINT = ACT_PE_W + 8 * 256 + 256 + ACT_HV_W + ACT_PED_W;   // 2528
+constexpr int DACT_PER_POINT = 8 * 256 + 256 + 128;                               // 2432
+__host__ __device__ inline int64_t act_pe(int64_t M) { (void)M; return 0; }
+__host__ __device__ inline int64_t act_h(int64_t M, int l) { return M * ACT_PE_W + (int64_t)l * M * 256; }
+__host__ __device__ inline int64_t act_feat(int64_t M) { return M * ACT_PE_W + 8 * M * 256; }
+__host__ __device__ inline int64_t act_hv(int64_t M) { return act_feat(M) + M * 256; }
+__host__ __device__ inline int64_t act_ped(int64_t M) { return act_hv(M) + M * ACT_HV_W; }
+__host__ __device__ inline int64_t dact_h(int64_t M, int l) { return (int64_t)l * M * 256; }
+__host__ __device__ inline int64_t dact_feat(int64_t M) { return 8 * M * 256; }
+__host__ __device__ inline int64_t dact_hv(int64_t M) { return 9 * M * 256; }
+
+// ---- packed weights ----------------------------------------------------------------------
+// A packed block is [n_tiles][k_blocks][64 lanes][4 floats]: lane l of tile t, block kb holds
+// element (col = t*32 + (l&31), k = kb*8 + 4*(l>>5) + i), i = 0..3.  MFMA step i of block
+// kb contracts k-pair (kb*8+i, kb*8+4+i); the LDS A operand uses the same pairing.
+enum PackId {
+    PF_L0 = 0, PF_L1, PF_L2, PF_L3, PF_L4, PF_L5, PF_L6, PF_L7, PF_FEAT, PF_VIEWS,   // forward: col = output feature
+    PB_VIEWS, PB_FEAT, PB_L7, PB_L6, PB_L5, PB_L4, PB_L3, PB_L2, PB_L1, PB_L0,       // backward: col = input feature
+    PACK_COUNT
+};
+struct PackShape { int tiles, kblocks; };
+__host__ __device__ constexpr PackShape pack_shape(int id) {
+    switch (id) {
+        case PF_L0: return {8, 8};        // K 63 -> 64
+        case PF_L5: return {8, 40};       // K [h4 256 | PE 63 -> 64]
+        case PF_VIEWS: return {4, 36};    // N 128, K [feature 256 | PE_dir 27 -> 32]
+        case PB_VIEWS: return {8, 16};    // out 256 feature cols, contraction n = 128
+        case PB_L5: return {10, 32};      // out [h4 256 | PE 64]
+        case PB_L0: return {2, 32};       // out PE 64
+        default: return {8, 32};
+    }
+}
+__host__ __device__ constexpr int64_t pack_floats(int id) {
+    return (int64_t)pack_shape(id).tiles * pack_shape(id).kblocks * 256;
+}
+__host__ __device__ constexpr int64_t pack_offset(int id) {
+    int64_t o = 0;
+    for (int i = 0; i < id; ++i) o += pack_floats(i);
+    return o;
+}
+constexpr int64_t PACKED_FLOATS = pack_offset(PACK_COUNT);
+
+// nn.Linear source of every packed block (index into BenerfMlpParams.w)
+__host__ __device__ constexpr int pack_layer(int id) {
+    switch (id) {
+        case PF_FEAT: case PB_FEAT: return BENERF_L_FEAT;
+        case PF_VIEWS: case PB_VIEWS: return BENERF_L_VIEWS;
+        case PB_L7: return 7; case PB_L6: return 6; case PB_L5: return 5; case PB_L4: return 4;
+        case PB_L3: return 3; case PB_L2: return 2; case PB_L1: return 1; case PB_L0: return 0;
+        default: return id;   // PF_L0..PF_L7
+    }
+}
+__host__ __device__ constexpr int layer_in(int l) {
+    return l == 0 ? 63 : l == 5 ? 319 : l == BENERF_L_VIEWS ? 283 : l == BENERF_L_RGB ? 128 : 256;
+}
+__host__ __device__ constexpr int layer_out(int l, int C) {
+    return l == BENERF_L_VIEWS ? 128 : l == BENERF_L_ALPHA ? 1 : l == BENERF_L_RGB ? C : 256;
+}
+
+// ---- weight-gradient workspace -------------------------------------------------------------
+// GEMM instances of the dW kernel (dW = dY^T X over all points), each split DW_SPLITS ways
+// along the point dimension; partials are summed in fixed order by the reduce kernel.
+constexpr int DW_SPLITS = 64;
+enum DwInst { DW_L1 = 0, DW_L2, DW_L3, DW_L4, DW_L5H, DW_L6, DW_L7, DW_FEAT, DW_VIEWSF, DW_L0, DW_L5P, DW_VIEWSP, DW_RGB, DW_COUNT };
+struct DwShape { int n, k; };   // output rows (layer outputs) x cols (layer inputs of this instance)
+__host__ __device__ constexpr DwShape dw_shape(int inst) {
+    switch (inst) {
+        case DW_VIEWSF: return {128, 256};
+        case DW_L0: return {256, 64};
+        case DW_L5P: return {256, 64};
+        case DW_VIEWSP: return {128, 32};
+        case DW_RGB: return {4, 128};      // up to 3 channels + 1 spare row
+        default: return {256, 256};
+    }
+}
+// per split: weight partial [n*k] + bias partial [n] (+ alpha row [256+1] riding on DW_FEAT)
+__host__ __device__ constexpr int64_t dw_inst_floats(int inst) {
+    return (int64_t)dw_shape(inst).n * dw_shape(inst).k + dw_shape(inst).n + (inst == DW_FEAT ? 257 : 0);
+}
+__host__ __device__ constexpr int64_t dw_inst_offset(int inst) {
+    int64_t o = 0;
+    for (int i = 0; i < inst; ++i) o += dw_inst_floats(i) * DW_SPLITS;
+    return o;
+}
+constexpr int64_t DW_WS_FLOATS = dw_inst_offset(DW_COUNT);
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+// accumulator register r of a 32x32 tile holds row (r&3) + 8*(r>>2) + 4*(lane>>5), col lane&31
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+}  // namespace mlp

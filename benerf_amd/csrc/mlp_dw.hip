@@ -1,0 +1,311 @@
+// K3 backward, part 2: weight gradients dW_l = dY_l^T X_l summed over ALL sample points,
+// exact-f32 MFMA, + bias gradients (column sums) and the two tiny heads (alpha, rgb) on the
+// VALU.  The reduction dimension is the point index (hundreds of thousands), so every GEMM
+// instance is split DW_SPLITS ways along it; each workgroup keeps its whole output block
+// (up to 256x256 = 256 accumulator registers per lane across 4 waves) in registers while it
+// streams 32-point chunks of dY and X through LDS (register-staged prefetch of the next
+// chunk during the MFMAs).  Partials are then summed in a fixed order by dw_reduce_kernel,
+// which also scatters into nn.Linear layout ([out,in], model/nerf.py:53-64) -> deterministic.
+#include "mlp_common.h"
+
+namespace {
+using namespace mlp;
+
+constexpr int CH = 32;   // points per chunk
+
+struct DwArgs {
+    const float* d_raw;
+    const float* acts;
+    const float* dacts;
+    float* ws;
+    int64_t M;
+    int C;
+};
+
+struct InstSrc {
+    const float* dy;   // [M][n]
+    const float* x;    // [M][k]
+    bool bias;
+};
+
+__device__ __forceinline__ InstSrc inst_src(const DwArgs& a, int inst) {
+    const int64_t M = a.M;
+    switch (inst) {
+        case DW_L1: return {a.dacts + dact_h(M, 1), a.acts + act_h(M, 0), true};
+        case DW_L2: return {a.dacts + dact_h(M, 2), a.acts + act_h(M, 1), true};
+        case DW_L3: return {a.dacts + dact_h(M, 3), a.acts + act_h(M, 2), true};
+        case DW_L4: return {a.dacts + dact_h(M, 4), a.acts + act_h(M, 3), true};
+        case DW_L5H: return {a.dacts + dact_h(M, 5), a.acts + act_h(M, 4), true};
+        case DW_L6: return {a.dacts + dact_h(M, 6), a.acts + act_h(M, 5), true};
+        case DW_L7: return {a.dacts + dact_h(M, 7), a.acts + act_h(M, 6), true};
+        case DW_FEAT: return {a.dacts + dact_feat(M), a.acts + act_h(M, 7), true};
+        case DW_VIEWSF: return {a.dacts + dact_hv(M), a.acts + act_feat(M), true};
+        case DW_L0: return {a.dacts + dact_h(M, 0), a.acts + act_pe(M), true};
+        case DW_L5P: return {a.dacts + dact_h(M, 5), a.acts + act_pe(M), false};
+        default: return {a.dacts + dact_hv(M), a.acts + act_ped(M), false};   // DW_VIEWSP
+    }
+}
+
+// Output block (4*NRT*32) x (NCT*32); wave w owns rows [w*NRT*32, (w+1)*NRT*32).
+template <int NRT, int NCT, bool ALPHA>
+__device__ __forceinline__ void dw_gemm(const DwArgs& a, const InstSrc src, int64_t chunk_begin, int64_t chunk_end,
+                                        float* __restrict__ part, float* __restrict__ smem) {
+    constexpr int N = 4 * NRT * 32, K = NCT * 32;
+    constexpr int NY4 = N / 32, NX4 = K / 32;   // float4 loads per thread per chunk
+    float* Ys = smem;                 // [CH][N]
+    float* Xs = smem + CH * N;        // [CH][K]
+    float* da = Xs + CH * K;          // [CH] d_sigma of the chunk (ALPHA only)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int64_t M = a.M;
+
+    f32x16 acc[NRT][NCT];
+#pragma unroll
+    for (int r = 0; r < NRT; ++r)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[r][c][e] = 0.f;
+    float bsum = 0.f, asum = 0.f, absum = 0.f;
+
+    float4 ry[NY4], rx[NX4];
+    float rda = 0.f;
+    auto prefetch = [&](int64_t chunk) {
+        const int64_t row0 = chunk * CH;
+#pragma unroll
+        for (int j = 0; j < NY4; ++j) {
+            const int q = tid + j * NTHREADS;
+            const int64_t row = row0 + (q * 4) / N;
+            ry[j] = row < M ? *reinterpret_cast<const float4*>(src.dy + row0 * N + (int64_t)q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < NX4; ++j) {
+            const int q = tid + j * NTHREADS;
+            const int64_t row = row0 + (q * 4) / K;
+            rx[j] = row < M ? *reinterpret_cast<const float4*>(src.x + row0 * K + (int64_t)q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (ALPHA && tid < CH) rda = row0 + tid < M ? a.d_raw[(row0 + tid) * (a.C + 1) + a.C] : 0.f;
+    };
+
+    if (chunk_begin < chunk_end) prefetch(chunk_begin);
+    for (int64_t chunk = chunk_begin; chunk < chunk_end; ++chunk) {
+        __syncthreads();   // previous chunk fully consumed
+#pragma unroll
+        for (int j = 0; j < NY4; ++j) *reinterpret_cast<float4*>(Ys + (tid + j * NTHREADS) * 4) = ry[j];
+#pragma unroll
+        for (int j = 0; j < NX4; ++j) *reinterpret_cast<float4*>(Xs + (tid + j * NTHREADS) * 4) = rx[j];
+        if (ALPHA && tid < CH) da[tid] = rda;
+        __syncthreads();
+        if (chunk + 1 < chunk_end) prefetch(chunk + 1);
+
+        const float* yp = Ys + lh * N + wave * NRT * 32 + lr;
+        const float* xp = Xs + lh * K + lr;
+#pragma unroll 4
+        for (int pp = 0; pp < CH; pp += 2) {
+            float av[NRT], bv[NCT];
+#pragma unroll
+            for (int r = 0; r < NRT; ++r) av[r] = yp[pp * N + r * 32];
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) bv[c] = xp[pp * K + c * 32];
+#pragma unroll
+            for (int r = 0; r < NRT; ++r)
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) acc[r][c] = mfma32(av[r], bv[c], acc[r][c]);
+        }
+        if (src.bias && tid < N) {
+            float s = 0.f;
+#pragma unroll 8
+            for (int p = 0; p < CH; ++p) s += Ys[p * N + tid];
+            bsum += s;
+        }
+        if (ALPHA) {   // K == 256 == NTHREADS
+            float s = 0.f, sb = 0.f;
+#pragma unroll 8
+            for (int p = 0; p < CH; ++p) {
+                s += da[p] * Xs[p * K + tid];
+                sb += da[p];
+            }
+            asum += s;
+            absum += sb;
+        }
+    }
+
+    // partial block -> workspace: [N][K] then bias [N] (then alpha row [256] + alpha bias)
+#pragma unroll
+    for (int r = 0; r < NRT; ++r)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = wave * NRT * 32 + r * 32 + acc_row(e, lane);
+                part[(int64_t)row * K + c * 32 + lr] = acc[r][c][e];
+            }
+    if (tid < N) part[(int64_t)N * K + tid] = src.bias ? bsum : 0.f;
+    if (ALPHA) {
+        part[(int64_t)N * K + N + tid] = asum;
+        if (tid == 0) part[(int64_t)N * K + N + 256] = absum;
+    }
+}
+
+// rgb head: dW_rgb[c][j] = sum_pt d_rgb[pt][c] * hv[pt][j], db_rgb[c] = sum_pt d_rgb[pt][c]
+__device__ __forceinline__ void dw_rgb(const DwArgs& a, int64_t row_begin, int64_t row_end, float* __restrict__ part,
+                                       float* __restrict__ smem) {
+    const int tid = threadIdx.x, j = tid & 127, half = tid >> 7;
+    const float* hv = a.acts + act_hv(a.M);
+    const int C = a.C;
+    float s[3] = {0.f, 0.f, 0.f}, sb[3] = {0.f, 0.f, 0.f};
+    for (int64_t mrow = row_begin + half; mrow < row_end; mrow += 2) {
+        const float h = hv[mrow * ACT_HV_W + j];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            if (c < C) {
+                const float g = a.d_raw[mrow * (C + 1) + c];
+                s[c] += g * h;
+                sb[c] += g;
+            }
+    }
+    if (half == 1) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            smem[c * 128 + j] = s[c];
+            smem[384 + c * 128 + j] = sb[c];
+        }
+    }
+    __syncthreads();
+    if (half == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float v = 0.f;
+            if (c < 3 && c < C) v = s[c] + smem[c * 128 + j];
+            part[c * 128 + j] = v;
+        }
+        if (j < 4) {
+            float v = 0.f;
+            if (j < 3 && j < C) v = (j == 0 ? sb[0] : j == 1 ? sb[1] : sb[2]) + smem[384 + j * 128 + j];
+            part[4 * 128 + j] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(NTHREADS, 1) void mlp_dw_kernel(DwArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int inst = blockIdx.y;
+    const int split = blockIdx.x;
+    const int64_t nchunks = (a.M + CH - 1) / CH;
+    const int64_t per = (nchunks + DW_SPLITS - 1) / DW_SPLITS;
+    int64_t cb = (int64_t)split * per, ce = cb + per;
+    if (cb > nchunks) cb = nchunks;
+    if (ce > nchunks) ce = nchunks;
+    float* part = a.ws + dw_inst_offset(inst) + (int64_t)split * dw_inst_floats(inst);
+    if (inst == DW_RGB) {
+        int64_t rb = cb * CH, re = ce * CH;
+        if (re > a.M) re = a.M;
+        if (rb > a.M) rb = a.M;
+        dw_rgb(a, rb, re, part, smem);
+        return;
+    }
+    const InstSrc src = inst_src(a, inst);
+    if (inst == DW_FEAT) dw_gemm<2, 8, true>(a, src, cb, ce, part, smem);
+    else if (inst <= DW_L7) dw_gemm<2, 8, false>(a, src, cb, ce, part, smem);
+    else if (inst == DW_VIEWSF) dw_gemm<1, 8, false>(a, src, cb, ce, part, smem);
+    else if (inst == DW_VIEWSP) dw_gemm<1, 1, false>(a, src, cb, ce, part, smem);
+    else dw_gemm<2, 2, false>(a, src, cb, ce, part, smem);   // DW_L0, DW_L5P
+}
+
+constexpr size_t DW_SMEM = (size_t)(CH * 256 + CH * 256 + CH) * sizeof(float);
+
+// ---- fixed-order reduction over the splits + scatter into nn.Linear layout --------------------------
+struct ReduceArgs {
+    const float* ws;
+    float* gw[BENERF_NLAYERS];
+    float* gb[BENERF_NLAYERS];
+    int C;
+    int accumulate;
+};
+
+__device__ __forceinline__ float sum_splits(const float* ws, int inst, int64_t elem) {
+    const float* p = ws + dw_inst_offset(inst) + elem;
+    const int64_t stride = dw_inst_floats(inst);
+    float s = 0.f;
+#pragma unroll 8
+    for (int sp = 0; sp < DW_SPLITS; ++sp) s += p[sp * stride];
+    return s;
+}
+
+__device__ __forceinline__ int layer_inst(int l) {   // instance holding the bias / main block of layer l
+    switch (l) {
+        case 0: return DW_L0;
+        case 5: return DW_L5H;
+        case 6: return DW_L6;
+        case 7: return DW_L7;
+        case BENERF_L_VIEWS: return DW_VIEWSF;
+        case BENERF_L_FEAT: return DW_FEAT;
+        case BENERF_L_ALPHA: return DW_FEAT;
+        case BENERF_L_RGB: return DW_RGB;
+        default: return DW_L1 + (l - 1);
+    }
+}
+
+__global__ void dw_reduce_kernel(ReduceArgs a) {
+    const int l = blockIdx.y;
+    const int C = a.C;
+    const int in = layer_in(l), out = layer_out(l, C);
+    const int64_t nw = (int64_t)in * out;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nw + out; e += (int64_t)gridDim.x * blockDim.x) {
+        float v;
+        float* dst;
+        if (e < nw) {
+            const int n = (int)(e / in), j = (int)(e % in);
+            dst = a.gw[l] + e;
+            if (l == 0) v = sum_splits(a.ws, DW_L0, (int64_t)n * 64 + j);
+            else if (l == 5) v = j < 63 ? sum_splits(a.ws, DW_L5P, (int64_t)n * 64 + j) : sum_splits(a.ws, DW_L5H, (int64_t)n * 256 + (j - 63));
+            else if (l == BENERF_L_VIEWS) v = j < 256 ? sum_splits(a.ws, DW_VIEWSF, (int64_t)n * 256 + j) : sum_splits(a.ws, DW_VIEWSP, (int64_t)n * 32 + (j - 256));
+            else if (l == BENERF_L_ALPHA) v = sum_splits(a.ws, DW_FEAT, (int64_t)256 * 256 + 256 + j);
+            else if (l == BENERF_L_RGB) v = sum_splits(a.ws, DW_RGB, (int64_t)n * 128 + j);
+            else v = sum_splits(a.ws, layer_inst(l), (int64_t)n * 256 + j);
+        } else {
+            const int n = (int)(e - nw);
+            dst = a.gb[l] + n;
+            if (l == BENERF_L_ALPHA) v = sum_splits(a.ws, DW_FEAT, (int64_t)256 * 256 + 256 + 256);
+            else if (l == BENERF_L_RGB) v = sum_splits(a.ws, DW_RGB, (int64_t)4 * 128 + n);
+            else {
+                const int inst = layer_inst(l);
+                v = sum_splits(a.ws, inst, (int64_t)dw_shape(inst).n * dw_shape(inst).k + n);
+            }
+        }
+        *dst = a.accumulate ? *dst + v : v;
+    }
+}
+
+}  // namespace
+
+int benerf_mlp_dw_launch(const BenerfMlpParams* params, int channels, int64_t M, const float* d_raw, const float* acts,
+                         const float* dacts, float* dw_ws, const BenerfMlpGrads* grads, int accumulate,
+                         hipStream_t stream) {
+    (void)params;
+    DwArgs a;
+    a.d_raw = d_raw;
+    a.acts = acts;
+    a.dacts = dacts;
+    a.ws = dw_ws;
+    a.M = M;
+    a.C = channels;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)mlp_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DW_SMEM);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(mlp_dw_kernel, dim3(mlp::DW_SPLITS, mlp::DW_COUNT), dim3(mlp::NTHREADS), DW_SMEM, stream, a);
+    BENERF_LAUNCH_CHECK("mlp_bwd(dw)");
+    ReduceArgs r;
+    r.ws = dw_ws;
+    for (int l = 0; l < BENERF_NLAYERS; ++l) {
+        r.gw[l] = grads->w[l];
+        r.gb[l] = grads->b[l];
+    }
+    r.C = channels;
+    r.accumulate = accumulate;
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3(64, BENERF_NLAYERS), dim3(256), 0, stream, r);
+    BENERF_LAUNCH_CHECK("mlp_bwd(reduce)");
+    return BENERF_OK;
+}

@@ -1,0 +1,327 @@
+// K3 forward: fused positional encoding + NeRF MLP for one tile of 64 sample points per
+// workgroup (4 wavefronts), exact-f32 MFMA.  Replaces Embedder.embed (model/embedder.py:9-34)
+// + NeRF.forward (model/nerf.py:67-116) + pts = o + d*z (model/nerf.py:308,327).
+//
+// Data flow per tile (see mlp_common.h for the LDS tile layout):
+//   prologue : pts, PE(pts) -> Hs[:,256:320)
+//   L0       : Hs[:,256:320) x W0^T            -> relu -> Hs[:,0:256)
+//   L1..L4   : Hs[:,0:256)   x Wl^T            -> relu -> Hs[:,0:256)
+//   L5       : Hs[:,0:320)   x [W5h|W5pe]^T    -> relu -> Hs[:,0:256)   (skip connection)
+//   L6,L7    : as L1
+//   alpha    : VALU dot(Hs[:,0:256), w_alpha)  ; PE(dir) -> Hs[:,256:288)
+//   FEAT     : Hs[:,0:256)   x Wf^T   (linear) -> Hs[:,0:256)
+//   VIEWS    : Hs[:,0:288)   x Wv^T            -> relu -> Hs[:,0:128)
+//   rgb      : VALU dot(Hs[:,0:128), w_rgb[c])
+// Each wave owns 64 output features (2 MFMA column tiles) x all 64 points (2 row tiles):
+// per 8-deep k-block it issues 2 ds_read_b128 (A, points) + 2 global_load_dwordx4 (B,
+// weights, L2-resident) for 16 MFMAs (1024 cycles) - operand traffic is negligible, the
+// kernel is bound by the f32 matrix pipe.  In training mode every layer output is also
+// streamed to HBM (full 128-B lines per store instruction) for the backward pass.
+#include "mlp_common.h"
+
+namespace {
+using namespace mlp;
+
+struct FwdArgs {
+    const float* rays_o;
+    const float* rays_d;
+    const float* viewdirs;
+    const float* z;
+    const float* packed;
+    const float* bias[10];   // L0..L7, views, feat  (index by BENERF layer id for 8, 9)
+    const float* w_alpha;
+    const float* b_alpha;
+    const float* w_rgb;
+    const float* b_rgb;
+    float* raw;
+    float* acts;
+    int64_t M;
+    int S;
+};
+
+// acc[r][c] += Hs[rows r*32.., kcol0 + 0..KB*8) x Wp(tile ct0+c)
+template <int KB, int NCT>
+__device__ __forceinline__ void gemm_stage(const float* __restrict__ Hs, int kcol0, const float* __restrict__ wp,
+                                           int ct0, int lane, f32x16 (&acc)[2][NCT]) {
+    const float* a0p = Hs + (lane & 31) * LD + kcol0 + 4 * (lane >> 5);
+    const float* a1p = a0p + 32 * LD;
+    const float4* bp[NCT];
+    float4 bn[NCT];
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) {
+        bp[c] = reinterpret_cast<const float4*>(wp) + (int64_t)(ct0 + c) * KB * 64 + lane;
+        bn[c] = bp[c][0];
+    }
+#pragma unroll 2
+    for (int kb = 0; kb < KB; ++kb) {
+        float4 b[NCT];
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) b[c] = bn[c];
+        if (kb + 1 < KB) {
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) bn[c] = bp[c][(kb + 1) * 64];
+        }
+        const float4 a0 = *reinterpret_cast<const float4*>(a0p + kb * 8);
+        const float4 a1 = *reinterpret_cast<const float4*>(a1p + kb * 8);
+        const float a0v[4] = {a0.x, a0.y, a0.z, a0.w};
+        const float a1v[4] = {a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                const float bv = i == 0 ? b[c].x : i == 1 ? b[c].y : i == 2 ? b[c].z : b[c].w;
+                acc[0][c] = mfma32(a0v[i], bv, acc[0][c]);
+                acc[1][c] = mfma32(a1v[i], bv, acc[1][c]);
+            }
+        }
+    }
+}
+
+template <int NCT>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][NCT]) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[r][c][e] = 0.f;
+}
+
+// bias (+ReLU) -> LDS tile columns [ct*32..) and, when `save` != nullptr, to the [M][ldo]
+// activation array (row m0+pt).  Every store instruction writes two full 128-B rows.
+template <int NCT, bool RELU>
+__device__ __forceinline__ void epilogue(f32x16 (&acc)[2][NCT], float* __restrict__ Hs, int ct0, int lane,
+                                         const float* __restrict__ bias, float* __restrict__ save, int ldo,
+                                         int64_t m0, int64_t M) {
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) {
+        const int n = (ct0 + c) * 32 + (lane & 31);
+        const float bv = bias[n];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int pt = r * 32 + acc_row(e, lane);
+                float v = acc[r][c][e] + bv;
+                if (RELU) v = fmaxf(v, 0.f);
+                Hs[pt * LD + n] = v;
+                if (save != nullptr && m0 + pt < M) save[(m0 + pt) * ldo + n] = v;
+            }
+        }
+    }
+}
+
+template <int C, bool SAVE>
+__global__ __launch_bounds__(NTHREADS, 1) void mlp_fwd_kernel(FwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Hs = smem;                  // [TM][LD]
+    float* red = smem + TM * LD;       // [3][4][64] partial dot products
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int64_t m0 = (int64_t)blockIdx.x * TM;
+    const int64_t M = a.M;
+    const int pt = tid & 63;           // this thread's point in prologue / VALU phases
+    const int grp = tid >> 6;
+    const int64_t m = m0 + pt;
+    const int64_t mc = m < M ? m : M - 1;
+    const int64_t ray = mc / a.S;
+    float* acts = a.acts;
+
+    // ---- prologue: pts = o + d*z (separately rounded like torch), PE(pts) ----------------------
+    {
+        const float zz = a.z[mc];
+        float x[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) x[c] = __fadd_rn(a.rays_o[ray * 3 + c], __fmul_rn(a.rays_d[ray * 3 + c], zz));
+        float* row = Hs + pt * LD + COL_PE;
+        if (grp == 0) {
+            row[0] = x[0];
+            row[1] = x[1];
+            row[2] = x[2];
+            row[63] = 0.f;
+        }
+        // 30 (freq, dim) pairs, strided over the 4 thread groups        model/embedder.py:13-28
+        for (int p = grp; p < 30; p += 4) {
+            const int f = p / 3, d = p - 3 * f;
+            const float v = x[d] * (float)(1 << f);
+            float s, c;
+            sincosf(v, &s, &c);
+            row[3 + f * 6 + d] = s;
+            row[3 + f * 6 + 3 + d] = c;
+        }
+    }
+    __syncthreads();
+    if (SAVE) {   // PE tile -> acts (256 B per point, 4 threads per row)
+        const int r = tid >> 2, q = tid & 3;
+        if (m0 + r < M) {
+            float4* dst = reinterpret_cast<float4*>(acts + act_pe(M) + (m0 + r) * ACT_PE_W + q * 16);
+            const float4* src = reinterpret_cast<const float4*>(Hs + r * LD + COL_PE + q * 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dst[j] = src[j];
+        }
+    }
+
+    f32x16 acc[2][2];
+    const int ct0 = wave * 2;
+
+    // ---- L0 ---------------------------------------------------------------------------------
+    zero_acc(acc);
+    gemm_stage<8, 2>(Hs, COL_PE, a.packed + pack_offset(PF_L0), ct0, lane, acc);
+    // L0 reads columns >= 256 and writes columns < 256: no barrier needed before the epilogue
+    epilogue<2, true>(acc, Hs, ct0, lane, a.bias[0], SAVE ? acts + act_h(M, 0) : nullptr, 256, m0, M);
+    __syncthreads();
+
+    // ---- L1..L7 -------------------------------------------------------------------------------
+#pragma unroll 1
+    for (int l = 1; l < 8; ++l) {
+        zero_acc(acc);
+        if (l == 5) gemm_stage<40, 2>(Hs, 0, a.packed + pack_offset(PF_L5), ct0, lane, acc);
+        else gemm_stage<32, 2>(Hs, 0, a.packed + pack_offset(PF_L0 + l), ct0, lane, acc);
+        __syncthreads();   // every wave finished reading the previous hidden state
+        epilogue<2, true>(acc, Hs, ct0, lane, a.bias[l], SAVE ? acts + act_h(M, l) : nullptr, 256, m0, M);
+        __syncthreads();
+    }
+
+    // ---- alpha partials (reads h7) + PE(viewdir) into columns [256,288) ---------------------------
+    {
+        const float* hrow = Hs + pt * LD + grp * 64;
+        const float* wa = a.w_alpha + grp * 64;
+        float s = 0.f;
+#pragma unroll 4
+        for (int k = 0; k < 64; k += 4) {
+            const float4 h = *reinterpret_cast<const float4*>(hrow + k);
+            const float4 w = *reinterpret_cast<const float4*>(wa + k);
+            s += h.x * w.x + h.y * w.y + h.z * w.z + h.w * w.w;
+        }
+        red[grp * 64 + pt] = s;
+        float vd[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) vd[c] = a.viewdirs[ray * 3 + c];
+        float* row = Hs + pt * LD + COL_PE;
+        if (grp == 0) {
+            row[0] = vd[0];
+            row[1] = vd[1];
+            row[2] = vd[2];
+        }
+        if (grp == 1) {
+#pragma unroll
+            for (int k = 27; k < 32; ++k) row[k] = 0.f;
+        }
+        for (int p = grp; p < 12; p += 4) {
+            const int f = p / 3, d = p - 3 * f;
+            const float v = vd[d] * (float)(1 << f);
+            float sn, cs;
+            sincosf(v, &sn, &cs);
+            row[3 + f * 6 + d] = sn;
+            row[3 + f * 6 + 3 + d] = cs;
+        }
+    }
+
+    // ---- FEAT (linear) ----------------------------------------------------------------------------
+    zero_acc(acc);
+    gemm_stage<32, 2>(Hs, 0, a.packed + pack_offset(PF_FEAT), ct0, lane, acc);
+    __syncthreads();   // h7 fully consumed (GEMM + alpha partials); PE(dir) + red[] visible
+    epilogue<2, false>(acc, Hs, ct0, lane, a.bias[BENERF_L_FEAT], SAVE ? acts + act_feat(M) : nullptr, 256, m0, M);
+    if (tid < 64 && m < M) {
+        a.raw[m * (C + 1) + C] = ((red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid])) + a.b_alpha[0];
+    }
+    if (SAVE) {   // PE(dir) tile -> acts (128 B per point)
+        const int r = tid >> 2, q = tid & 3;
+        if (m0 + r < M) {
+            float4* dst = reinterpret_cast<float4*>(acts + act_ped(M) + (m0 + r) * ACT_PED_W + q * 8);
+            const float4* src = reinterpret_cast<const float4*>(Hs + r * LD + COL_PE + q * 8);
+            dst[0] = src[0];
+            dst[1] = src[1];
+        }
+    }
+    __syncthreads();
+
+    // ---- VIEWS: [feature | PE(dir)] (288) -> 128, one column tile per wave ----------------------------
+    {
+        f32x16 av[2][1];
+        zero_acc(av);
+        gemm_stage<36, 1>(Hs, 0, a.packed + pack_offset(PF_VIEWS), wave, lane, av);
+        __syncthreads();
+        epilogue<1, true>(av, Hs, wave, lane, a.bias[BENERF_L_VIEWS], SAVE ? acts + act_hv(M) : nullptr, ACT_HV_W, m0, M);
+    }
+    __syncthreads();
+
+    // ---- rgb: 128 -> C on the VALU -----------------------------------------------------------------------
+    {
+        const float* hrow = Hs + pt * LD + grp * 32;
+        float s[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) s[c] = 0.f;
+#pragma unroll 2
+        for (int k = 0; k < 32; k += 4) {
+            const float4 h = *reinterpret_cast<const float4*>(hrow + k);
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float4 w = *reinterpret_cast<const float4*>(a.w_rgb + c * 128 + grp * 32 + k);
+                s[c] += h.x * w.x + h.y * w.y + h.z * w.z + h.w * w.w;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) red[(c * 4 + grp) * 64 + pt] = s[c];
+    }
+    __syncthreads();
+    if (tid < 64 && m < M) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float* rc = red + c * 256;
+            a.raw[m * (C + 1) + c] = ((rc[tid] + rc[64 + tid]) + (rc[128 + tid] + rc[192 + tid])) + a.b_rgb[c];
+        }
+    }
+}
+
+constexpr size_t FWD_SMEM = (size_t)(TM * LD + 3 * 4 * 64) * sizeof(float);
+
+}  // namespace
+
+extern "C" int benerf_mlp_fwd(const BenerfMlpParams* params, const float* packed, int channels, int n_rays,
+                              int n_samples, const float* rays_o, const float* rays_d, const float* viewdirs,
+                              const float* z, float* raw, float* acts, benerf_stream_t stream) {
+    BENERF_REQUIRE(params && packed && rays_o && rays_d && viewdirs && z && raw, "mlp_fwd: null pointer");
+    BENERF_REQUIRE(channels == 1 || channels == 3, "mlp_fwd: channels must be 1 or 3");
+    BENERF_REQUIRE(n_rays > 0 && n_samples > 0, "mlp_fwd: bad sizes");
+    FwdArgs a;
+    a.rays_o = rays_o;
+    a.rays_d = rays_d;
+    a.viewdirs = viewdirs;
+    a.z = z;
+    a.packed = packed;
+    for (int l = 0; l < 8; ++l) a.bias[l] = params->b[l];
+    a.bias[BENERF_L_VIEWS] = params->b[BENERF_L_VIEWS];
+    a.bias[BENERF_L_FEAT] = params->b[BENERF_L_FEAT];
+    a.w_alpha = params->w[BENERF_L_ALPHA];
+    a.b_alpha = params->b[BENERF_L_ALPHA];
+    a.w_rgb = params->w[BENERF_L_RGB];
+    a.b_rgb = params->b[BENERF_L_RGB];
+    for (int l = 0; l < BENERF_NLAYERS; ++l) BENERF_REQUIRE(params->b[l] && params->w[l], "mlp_fwd: null parameter %d", l);
+    a.raw = raw;
+    a.acts = acts;
+    a.M = (int64_t)n_rays * n_samples;
+    a.S = n_samples;
+    const int64_t tiles = (a.M + mlp::TM - 1) / mlp::TM;
+    BENERF_REQUIRE(tiles < (1ll << 31), "mlp_fwd: too many points");
+    dim3 grid((unsigned)tiles), block(mlp::NTHREADS);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute((const void*)mlp_fwd_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD_SMEM);
+        hipFuncSetAttribute((const void*)mlp_fwd_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD_SMEM);
+        hipFuncSetAttribute((const void*)mlp_fwd_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD_SMEM);
+        hipFuncSetAttribute((const void*)mlp_fwd_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD_SMEM);
+        attr_done = true;
+    }
+    if (channels == 1) {
+        if (acts) hipLaunchKernelGGL((mlp_fwd_kernel<1, true>), grid, block, FWD_SMEM, as_stream(stream), a);
+        else hipLaunchKernelGGL((mlp_fwd_kernel<1, false>), grid, block, FWD_SMEM, as_stream(stream), a);
+    } else {
+        if (acts) hipLaunchKernelGGL((mlp_fwd_kernel<3, true>), grid, block, FWD_SMEM, as_stream(stream), a);
+        else hipLaunchKernelGGL((mlp_fwd_kernel<3, false>), grid, block, FWD_SMEM, as_stream(stream), a);
+    }
+    BENERF_LAUNCH_CHECK("mlp_fwd");
+    return BENERF_OK;
+}

@@ -1,0 +1,99 @@
+// K3 helper: re-pack one network's nn.Linear weights ([out,in] row-major, model/nerf.py:53-64)
+// into the MFMA-operand-shaped blocks described in mlp_common.h.  One launch per network
+// per optimiser step (2.4 M floats read, 4.9 M written).
+#include "mlp_common.h"
+
+namespace {
+using namespace mlp;
+
+struct PackArgs {
+    const float* w[BENERF_NLAYERS];
+    float* packed;
+};
+
+// source element for packed block `id`, column index `col` (tile*32 + lane&31) and
+// contraction index `kk` (kblock*8 + 4*(lane>>5) + i); returns 0 for padding.
+__device__ __forceinline__ float pack_source(const PackArgs& a, int id, int col, int kk) {
+    const int layer = pack_layer(id);
+    const float* W = a.w[layer];
+    const int in = layer_in(layer);
+    if (id <= PF_VIEWS) {
+        // forward: col = output feature n, kk = packed input index
+        const int n = col;
+        int k;
+        if (id == PF_L0) {
+            if (kk >= 63) return 0.f;
+            k = kk;
+        } else if (id == PF_L5) {          // packed order [h4 (256) | PE (63)], nn.Linear order [PE | h4]
+            if (kk < 256) k = 63 + kk;
+            else if (kk < 319) k = kk - 256;
+            else return 0.f;
+        } else if (id == PF_VIEWS) {       // [feature (256) | PE_dir (27)] = nn.Linear order
+            if (kk >= 283) return 0.f;
+            k = kk;
+        } else {
+            k = kk;
+        }
+        return W[(int64_t)n * in + k];
+    }
+    // backward: col = input feature (packed order), kk = output feature n (contraction)
+    const int n = kk;
+    int k;
+    if (id == PB_L5) {
+        if (col < 256) k = 63 + col;
+        else if (col < 319) k = col - 256;
+        else return 0.f;
+    } else if (id == PB_L0) {
+        if (col >= 63) return 0.f;
+        k = col;
+    } else {
+        k = col;                           // PB_VIEWS: feature columns 0..255 only
+    }
+    return W[(int64_t)n * in + k];
+}
+
+__global__ void pack_kernel(PackArgs a) {
+    const int id = blockIdx.y;
+    const PackShape sh = pack_shape(id);
+    const int64_t n4 = (int64_t)sh.tiles * sh.kblocks * 64;   // float4 slots
+    float4* dst = reinterpret_cast<float4*>(a.packed + pack_offset(id));
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
+        int lane = (int)(e & 63);
+        int64_t tb = e >> 6;
+        int kb = (int)(tb % sh.kblocks);
+        int tile = (int)(tb / sh.kblocks);
+        int col = tile * 32 + (lane & 31);
+        int k0 = kb * 8 + 4 * (lane >> 5);
+        float4 v;
+        v.x = pack_source(a, id, col, k0 + 0);
+        v.y = pack_source(a, id, col, k0 + 1);
+        v.z = pack_source(a, id, col, k0 + 2);
+        v.w = pack_source(a, id, col, k0 + 3);
+        dst[e] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" size_t benerf_mlp_packed_floats(void) { return (size_t)mlp::PACKED_FLOATS; }
+extern "C" size_t benerf_mlp_act_floats_per_point(void) { return (size_t)mlp::ACT_PER_POINT; }
+extern "C" size_t benerf_mlp_dact_floats_per_point(void) { return (size_t)mlp::DACT_PER_POINT; }
+extern "C" size_t benerf_mlp_dw_workspace_floats(int64_t n_points) {
+    (void)n_points;
+    return (size_t)mlp::DW_WS_FLOATS;
+}
+
+extern "C" int benerf_mlp_pack_weights(const BenerfMlpParams* params, int channels, float* packed,
+                                       benerf_stream_t stream) {
+    BENERF_REQUIRE(params && packed, "mlp_pack_weights: null pointer");
+    BENERF_REQUIRE(channels >= 1 && channels <= 3, "mlp_pack_weights: channels must be 1..3");
+    PackArgs a;
+    for (int l = 0; l < BENERF_NLAYERS; ++l) {
+        BENERF_REQUIRE(params->w[l], "mlp_pack_weights: null weight %d", l);
+        a.w[l] = params->w[l];
+    }
+    a.packed = packed;
+    hipLaunchKernelGGL(pack_kernel, dim3(40, mlp::PACK_COUNT), dim3(256), 0, as_stream(stream), a);
+    BENERF_LAUNCH_CHECK("mlp_pack_weights");
+    return BENERF_OK;
+}

@@ -1,0 +1,334 @@
+// K1: SE(3) trajectory interpolation (cubic B-spline / linear), forward + backward.
+//
+// Follows spline.py:16-26 (se3 -> q,t with 11-term Taylor B,C), :79-100 (exp), :167-192
+// (log, plain arctan), :130-148 (quaternion product matrix / conjugate), :111-118 (q -> R),
+// :247-303 (cumulative cubic B-spline), :305-331 (linear) and model/optimize.py:58-111
+// (knots + transform in se(3), torch.linspace of the query times).
+//
+// One thread per pose, everything in registers.  The backward runs the SAME templated
+// code on forward-mode dual numbers (one tangent per knot coefficient): 24 tangents x P
+// poses, then a fixed-order reduction, so results are run-to-run deterministic.
+#include "common.h"
+
+namespace {
+
+struct Dual {
+    float v, d;
+};
+__device__ __forceinline__ Dual mk(float v, float d = 0.f) { return Dual{v, d}; }
+__device__ __forceinline__ Dual operator+(Dual a, Dual b) { return {a.v + b.v, a.d + b.d}; }
+__device__ __forceinline__ Dual operator-(Dual a, Dual b) { return {a.v - b.v, a.d - b.d}; }
+__device__ __forceinline__ Dual operator-(Dual a) { return {-a.v, -a.d}; }
+__device__ __forceinline__ Dual operator*(Dual a, Dual b) { return {a.v * b.v, a.d * b.v + a.v * b.d}; }
+__device__ __forceinline__ Dual operator/(Dual a, Dual b) {
+    float q = a.v / b.v;
+    return {q, (a.d - q * b.d) / b.v};
+}
+__device__ __forceinline__ Dual operator+(Dual a, float b) { return {a.v + b, a.d}; }
+__device__ __forceinline__ Dual operator+(float a, Dual b) { return {a + b.v, b.d}; }
+__device__ __forceinline__ Dual operator-(Dual a, float b) { return {a.v - b, a.d}; }
+__device__ __forceinline__ Dual operator-(float a, Dual b) { return {a - b.v, -b.d}; }
+__device__ __forceinline__ Dual operator*(Dual a, float b) { return {a.v * b, a.d * b}; }
+__device__ __forceinline__ Dual operator*(float a, Dual b) { return {a * b.v, a * b.d}; }
+__device__ __forceinline__ Dual operator/(Dual a, float b) { return {a.v / b, a.d / b}; }
+__device__ __forceinline__ Dual operator/(float a, Dual b) {
+    float q = a / b.v;
+    return {q, -q * b.d / b.v};
+}
+
+__device__ __forceinline__ float val(float x) { return x; }
+__device__ __forceinline__ float val(Dual x) { return x.v; }
+__device__ __forceinline__ float t_sqrt(float x) { return sqrtf(x); }
+// torch's norm/sqrt backward at 0 yields 0 for the cases on this path (masked_fill in
+// norm_backward); keep the tangent finite.
+__device__ __forceinline__ Dual t_sqrt(Dual x) {
+    float s = sqrtf(x.v);
+    return {s, s > 0.f ? 0.5f * x.d / s : 0.f};
+}
+__device__ __forceinline__ float t_sin(float x) { return sinf(x); }
+__device__ __forceinline__ Dual t_sin(Dual x) { return {sinf(x.v), cosf(x.v) * x.d}; }
+__device__ __forceinline__ float t_cos(float x) { return cosf(x); }
+__device__ __forceinline__ Dual t_cos(Dual x) { return {cosf(x.v), -sinf(x.v) * x.d}; }
+__device__ __forceinline__ float t_atan(float x) { return atanf(x); }
+__device__ __forceinline__ Dual t_atan(Dual x) { return {atanf(x.v), x.d / (1.f + x.v * x.v)}; }
+// x ** n for integer n >= 0 as torch.pow does it (n==0 -> 1 with zero gradient)
+__device__ __forceinline__ float t_powi(float x, int n) {
+    if (n == 0) return 1.f;
+    if (n == 2) return x * x;
+    return powf(x, (float)n);
+}
+__device__ __forceinline__ Dual t_powi(Dual x, int n) {
+    if (n == 0) return {1.f, 0.f};
+    if (n == 2) return {x.v * x.v, 2.f * x.v * x.d};
+    return {powf(x.v, (float)n), (float)n * powf(x.v, (float)(n - 1)) * x.d};
+}
+template <class T>
+__device__ __forceinline__ T lift(float x);
+template <>
+__device__ __forceinline__ float lift<float>(float x) { return x; }
+template <>
+__device__ __forceinline__ Dual lift<Dual>(float x) { return {x, 0.f}; }
+
+// sum_i (-1)^i th^(2i) / prod (2j+a)(2j+a+1)            spline.py:46-62
+template <class T>
+__device__ T taylor_series(T th, int a) {
+    T acc = lift<T>(0.f);
+    double denom = 1.0;
+#pragma unroll
+    for (int i = 0; i <= 10; ++i) {
+        denom *= (double)((2 * i + a) * (2 * i + a + 1));
+        T term = t_powi(th, 2 * i) / (float)denom;
+        acc = (i & 1) ? acc - term : acc + term;
+    }
+    return acc;
+}
+
+// rotation vector -> quaternion xyzw; th = half angle        spline.py:79-100
+template <class T>
+__device__ void rotvec_to_quat(const T r[3], T q[4]) {
+    T th = 0.5f * t_sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    if (val(th) < 1e-9f) {
+        T th2 = th * th, th4 = th2 * th2;
+        T s = 0.5f - (1.0f / 12.0f) * th2 - (1.0f / 240.0f) * th4;
+        q[0] = s * r[0];
+        q[1] = s * r[1];
+        q[2] = s * r[2];
+        q[3] = 1.0f - 0.5f * th2 + (1.0f / 24.0f) * th4;
+    } else {
+        T lam = t_sin(th) / (2.0f * th);
+        q[0] = lam * r[0];
+        q[1] = lam * r[1];
+        q[2] = lam * r[2];
+        q[3] = t_cos(th);
+    }
+}
+
+// quaternion -> rotation vector, plain arctan              spline.py:167-192
+template <class T>
+__device__ void quat_to_rotvec(const T q[4], T r[3]) {
+    const float PI = 3.14159265358979323846f;
+    T th = t_sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+    T w = q[3];
+    T lam;
+    if (fabsf(val(w)) < 1e-10f) {
+        lam = (val(w) < 0.f) ? (-PI) / th : PI / th;
+    } else if (val(th) < 1e-20f) {
+        lam = 2.0f / w - (2.0f / 3.0f) * (th * th) / (w * w * w);
+    } else {
+        lam = 2.0f * t_atan(th / w) / th;
+    }
+    r[0] = lam * q[0];
+    r[1] = lam * q[1];
+    r[2] = lam * q[2];
+}
+
+// a (x) b with the left-product matrix of spline.py:130-138
+template <class T>
+__device__ void quat_mul(const T a[4], const T b[4], T o[4]) {
+    T x = a[0], y = a[1], z = a[2], w = a[3];
+    o[0] = w * b[0] - z * b[1] + y * b[2] + x * b[3];
+    o[1] = z * b[0] + w * b[1] - x * b[2] + y * b[3];
+    o[2] = -y * b[0] + x * b[1] + w * b[2] + z * b[3];
+    o[3] = -x * b[0] - y * b[1] - z * b[2] + w * b[3];
+}
+template <class T>
+__device__ void quat_conj(const T q[4], T o[4]) {
+    o[0] = -q[0];
+    o[1] = -q[1];
+    o[2] = -q[2];
+    o[3] = q[3];
+}
+
+// se(3) [w,u] -> q, t = V u, V = I + B wx + (C wx) wx       spline.py:16-26
+template <class T>
+__device__ void se3_to_qt(const T wu[6], T q[4], T t[3]) {
+    T w0 = wu[0], w1 = wu[1], w2 = wu[2];
+    T th = t_sqrt(w0 * w0 + w1 * w1 + w2 * w2);
+    T B = taylor_series(th, 1);
+    T C = taylor_series(th, 2);
+    T z = lift<T>(0.f);
+    T wx[3][3] = {{z, -w2, w1}, {w2, z, -w0}, {-w1, w0, z}};
+    T V[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            T s = (C * wx[i][0]) * wx[0][j] + (C * wx[i][1]) * wx[1][j] + (C * wx[i][2]) * wx[2][j];
+            V[i][j] = ((i == j ? 1.0f : 0.0f) + B * wx[i][j]) + s;
+        }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t[i] = V[i][0] * wu[3] + V[i][1] * wu[4] + V[i][2] * wu[5];
+    T r[3] = {w0, w1, w2};
+    rotvec_to_quat(r, q);
+}
+
+template <class T>
+__device__ void quat_to_pose(const T q[4], const T t[3], T out[12]) {
+    T b = q[0], c = q[1], d = q[2], a = q[3];   // spline.py:111-118
+    out[0] = 1.0f - 2.0f * (c * c + d * d);
+    out[1] = 2.0f * (b * c - a * d);
+    out[2] = 2.0f * (a * c + b * d);
+    out[3] = t[0];
+    out[4] = 2.0f * (b * c + a * d);
+    out[5] = 1.0f - 2.0f * (b * b + d * d);
+    out[6] = 2.0f * (c * d - a * b);
+    out[7] = t[1];
+    out[8] = 2.0f * (b * d - a * c);
+    out[9] = 2.0f * (a * b + c * d);
+    out[10] = 1.0f - 2.0f * (b * b + c * c);
+    out[11] = t[2];
+}
+
+// torch.linspace(t0, t1, n)[i] (float kernel: symmetric two-sided formula)
+__device__ __forceinline__ float linspace_at(float t0, float t1, int n, int i) {
+    if (n <= 1) return t0;
+    float step = (t1 - t0) / (float)(n - 1);
+    return (i < n / 2) ? t0 + step * (float)i : t1 - step * (float)(n - 1 - i);
+}
+__device__ __forceinline__ float nudge(float u) {   // spline.py:249-252
+    if (u == 0.f) u = u + 0.000001f;
+    if (u == 1.f) u = u - 0.000001f;
+    return u;
+}
+
+template <class T>
+__device__ void cubic_pose(const T k[4][6], float u, T out[12]) {   // spline.py:247-303
+    T q[4][4], t[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) se3_to_qt(k[i], q[i], t[i]);
+    float uu = u * u, uuu = u * u * u;
+    const float sixth = 1.0f / 6.0f, half = 0.5f;
+    float c0 = sixth - half * u + half * uu - sixth * uuu;
+    float c1 = 4 * sixth - uu + half * uuu;
+    float c2 = sixth + half * u + half * uu - half * uuu;
+    float c3 = sixth * uuu;
+    T tr[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tr[i] = c0 * t[0][i] + c1 * t[1][i] + c2 * t[2][i] + c3 * t[3][i];
+    float r1 = 5 * sixth + half * u - half * uu + sixth * uuu;
+    float r2 = sixth + half * u + half * uu - 2 * sixth * uuu;
+    float r3 = sixth * uuu;
+    T cj[4], d01[4], d12[4], d23[4], rv[3], e0[4], e1[4], e2[4];
+    quat_conj(q[0], cj);
+    quat_mul(cj, q[1], d01);
+    quat_conj(q[1], cj);
+    quat_mul(cj, q[2], d12);
+    quat_conj(q[2], cj);
+    quat_mul(cj, q[3], d23);
+    quat_to_rotvec(d01, rv);
+    rv[0] = rv[0] * r1; rv[1] = rv[1] * r1; rv[2] = rv[2] * r1;
+    rotvec_to_quat(rv, e0);
+    quat_to_rotvec(d12, rv);
+    rv[0] = rv[0] * r2; rv[1] = rv[1] * r2; rv[2] = rv[2] * r2;
+    rotvec_to_quat(rv, e1);
+    quat_to_rotvec(d23, rv);
+    rv[0] = rv[0] * r3; rv[1] = rv[1] * r3; rv[2] = rv[2] * r3;
+    rotvec_to_quat(rv, e2);
+    T p1[4], p2[4], qt[4];
+    quat_mul(e1, e2, p1);
+    quat_mul(e0, p1, p2);
+    quat_mul(q[0], p2, qt);
+    quat_to_pose(qt, tr, out);
+}
+
+template <class T>
+__device__ void linear_pose(const T k0[6], const T k3[6], float u, T out[12]) {   // spline.py:305-331
+    T qs[4], ts[3], qe[4], te[3];
+    se3_to_qt(k0, qs, ts);
+    se3_to_qt(k3, qe, te);
+    T tr[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) tr[i] = (1.0f - u) * ts[i] + u * te[i];
+    T cj[4], rel[4], rv[3], st[4], qt[4];
+    quat_conj(qs, cj);
+    quat_mul(cj, qe, rel);
+    quat_to_rotvec(rel, rv);
+    rv[0] = u * rv[0]; rv[1] = u * rv[1]; rv[2] = u * rv[2];
+    rotvec_to_quat(rv, st);
+    quat_mul(qs, st, qt);
+    quat_to_pose(qt, tr, out);
+}
+
+__global__ void spline_fwd_kernel(const float* __restrict__ knots, const float* __restrict__ transform,
+                                  const float* __restrict__ ts2, int n_poses, int traj, float* __restrict__ poses) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_poses) return;
+    float k[4][6];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) k[i][j] = knots[i * 6 + j] + (transform ? transform[j] : 0.f);
+    float u = nudge(linspace_at(ts2[0], ts2[1], n_poses, p));
+    float out[12];
+    if (traj == 1)
+        linear_pose(k[0], k[3], u, out);
+    else
+        cubic_pose(k, u, out);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) poses[p * 12 + i] = out[i];
+}
+
+// one block; thread (p, j): tangent of pose p w.r.t. effective-knot coefficient j (0..23);
+// contrib[p][j] = <d_poses[p], tangent>; then j-threads sum over p in index order.
+__global__ void spline_bwd_kernel(const float* __restrict__ knots, const float* __restrict__ transform,
+                                  const float* __restrict__ ts2, int n_poses, int traj,
+                                  const float* __restrict__ d_poses, float* __restrict__ d_knots,
+                                  float* __restrict__ d_transform) {
+    extern __shared__ float contrib[];   // [n_poses][24]
+    for (int w = threadIdx.x; w < n_poses * 24; w += blockDim.x) {
+        int p = w / 24, j = w % 24;
+        Dual k[4][6];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+                k[i][c] = Dual{knots[i * 6 + c] + (transform ? transform[c] : 0.f), (i * 6 + c == j) ? 1.f : 0.f};
+        float u = nudge(linspace_at(ts2[0], ts2[1], n_poses, p));
+        Dual out[12];
+        if (traj == 1)
+            linear_pose(k[0], k[3], u, out);
+        else
+            cubic_pose(k, u, out);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) s += d_poses[p * 12 + i] * out[i].d;
+        contrib[w] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 24) {
+        float s = 0.f;
+        for (int p = 0; p < n_poses; ++p) s += contrib[p * 24 + threadIdx.x];
+        contrib[threadIdx.x] = s;   // row 0 reused: safe, every reader of row 0 is this thread's column
+        d_knots[threadIdx.x] = s;
+    }
+    __syncthreads();
+    if (d_transform && threadIdx.x < 6) {
+        d_transform[threadIdx.x] = contrib[threadIdx.x] + contrib[6 + threadIdx.x] + contrib[12 + threadIdx.x] +
+                                   contrib[18 + threadIdx.x];
+    }
+}
+
+}  // namespace
+
+extern "C" int benerf_spline_poses_fwd(const float* knots, const float* transform, const float* ts2, int n_poses,
+                                       int traj, float* poses, benerf_stream_t stream) {
+    BENERF_REQUIRE(knots && ts2 && poses, "spline_poses_fwd: null pointer");
+    BENERF_REQUIRE(n_poses > 0 && (traj == 0 || traj == 1), "spline_poses_fwd: bad n_poses/traj");
+    int threads = 64, blocks = (n_poses + threads - 1) / threads;
+    hipLaunchKernelGGL(spline_fwd_kernel, dim3(blocks), dim3(threads), 0, as_stream(stream), knots, transform, ts2,
+                       n_poses, traj, poses);
+    BENERF_LAUNCH_CHECK("spline_poses_fwd");
+    return BENERF_OK;
+}
+
+extern "C" int benerf_spline_poses_bwd(const float* knots, const float* transform, const float* ts2, int n_poses,
+                                       int traj, const float* d_poses, float* d_knots, float* d_transform,
+                                       benerf_stream_t stream) {
+    BENERF_REQUIRE(knots && ts2 && d_poses && d_knots, "spline_poses_bwd: null pointer");
+    BENERF_REQUIRE(n_poses > 0 && n_poses <= 512 && (traj == 0 || traj == 1), "spline_poses_bwd: n_poses must be in [1,512]");
+    size_t smem = (size_t)n_poses * 24 * sizeof(float);
+    hipLaunchKernelGGL(spline_bwd_kernel, dim3(1), dim3(256), smem, as_stream(stream), knots, transform, ts2, n_poses,
+                       traj, d_poses, d_knots, d_transform);
+    BENERF_LAUNCH_CHECK("spline_poses_bwd");
+    return BENERF_OK;
+}

@@ -1,0 +1,294 @@
+"""Tensor-level wrappers over the C ABI (one function per entry point of
+include/benerf_hip.h).  PyTorch is plumbing only: device memory, streams, autograd glue.
+Every wrapper validates dtype / device / contiguity and raises on any non-zero return code.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import LossCfg, MlpGrads, MlpParams
+
+LAYER_NAMES = tuple(["pts_linears.%d" % i for i in range(8)] + ["views_linears.0", "feature_linear", "alpha_linear",
+                                                               "rgb_linear"])
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, dtype=torch.float32, name="tensor"):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.BenerfHipError("%s must live on the GPU (got %s); there is no CPU path" % (name, t.device))
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    return t.data_ptr()
+
+
+def _new(shape, like, dtype=torch.float32):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+_scratch = {}
+
+
+def scratch(key, n_floats, device, dtype=torch.float32):
+    """Grow-only cached scratch buffers (activation-gradient tiles, dW partial sums)."""
+    k = (key, str(device), dtype)
+    buf = _scratch.get(k)
+    if buf is None or buf.numel() < n_floats:
+        buf = torch.empty(int(n_floats), dtype=dtype, device=device)
+        _scratch[k] = buf
+    return buf
+
+
+# ----------------------------------------------------------------------------- K1 trajectory
+def spline_poses_fwd(knots, transform, ts2, n_poses, traj=0):
+    lib = _lib.load()
+    poses = _new((n_poses, 3, 4), knots)
+    _lib.check(lib.benerf_spline_poses_fwd(_chk(knots, name="knots"), _chk(transform, name="transform"),
+                                           _chk(ts2, name="ts2"), n_poses, traj, poses.data_ptr(), _stream()),
+               "spline_poses_fwd")
+    return poses
+
+
+def spline_poses_bwd(knots, transform, ts2, n_poses, traj, d_poses):
+    lib = _lib.load()
+    d_knots = _new((4, 6), knots)
+    d_tr = _new((1, 6), knots) if transform is not None else None
+    _lib.check(lib.benerf_spline_poses_bwd(_chk(knots), _chk(transform), _chk(ts2), n_poses, traj,
+                                           _chk(d_poses, name="d_poses"), d_knots.data_ptr(),
+                                           None if d_tr is None else d_tr.data_ptr(), _stream()), "spline_poses_bwd")
+    return d_knots, d_tr
+
+
+# ----------------------------------------------------------------------------- K2 rays
+def rays_fwd(poses, ray_idx, H, W, fx, fy, cx, cy, ndc=True, out=None):
+    lib = _lib.load()
+    n = poses.shape[0] * ray_idx.shape[0]
+    if out is None:
+        out = (_new((n, 3), poses), _new((n, 3), poses), _new((n, 3), poses))
+    ro, rd, vd = out
+    _lib.check(lib.benerf_rays_fwd(_chk(poses, name="poses"), _chk(ray_idx, torch.int64, "ray_idx"), poses.shape[0],
+                                   ray_idx.shape[0], H, W, fx, fy, cx, cy, int(bool(ndc)), _chk(ro), _chk(rd), _chk(vd),
+                                   _stream()), "rays_fwd")
+    return ro, rd, vd
+
+
+def rays_bwd(poses, ray_idx, H, W, fx, fy, cx, cy, ndc, d_rays_o, d_rays_d, d_viewdirs):
+    lib = _lib.load()
+    d_poses = _new((poses.shape[0], 3, 4), poses)
+    _lib.check(lib.benerf_rays_bwd(_chk(poses), _chk(ray_idx, torch.int64), poses.shape[0], ray_idx.shape[0], H, W, fx,
+                                   fy, cx, cy, int(bool(ndc)), _chk(d_rays_o), _chk(d_rays_d), _chk(d_viewdirs),
+                                   d_poses.data_ptr(), _stream()), "rays_bwd")
+    return d_poses
+
+
+def stratified_z(n_rays, n_samples, device, t_rand=None, seed=0, offset=0, near=0.0, far=1.0):
+    lib = _lib.load()
+    z = torch.empty((n_rays, n_samples), dtype=torch.float32, device=device)
+    _lib.check(lib.benerf_stratified_z(n_rays, n_samples, near, far, _chk(t_rand, name="t_rand"), seed, offset,
+                                       z.data_ptr(), _stream()), "stratified_z")
+    return z
+
+
+def ray_grad_reduce(z, d_pts, d_vdir_pts, d_rays_o, d_rays_d, d_viewdirs, accumulate):
+    lib = _lib.load()
+    _lib.check(lib.benerf_ray_grad_reduce(z.shape[0], z.shape[1], _chk(z), _chk(d_pts), _chk(d_vdir_pts),
+                                          int(bool(accumulate)), _chk(d_rays_o), _chk(d_rays_d), _chk(d_viewdirs),
+                                          _stream()), "ray_grad_reduce")
+
+
+# ----------------------------------------------------------------------------- K3 fused MLP
+def _param_struct(cls, tensors_w, tensors_b):
+    s = cls()
+    for i in range(_lib.NLAYERS):
+        s.w[i] = _chk(tensors_w[i], name="weight %d" % i)
+        s.b[i] = _chk(tensors_b[i], name="bias %d" % i)
+    return s
+
+
+class PackedMlp:
+    """MFMA-shaped copy of one NeRF's weights; `pack()` after every optimiser step."""
+
+    def __init__(self, weights, biases, channels):
+        self.weights = list(weights)   # 12 tensors, nn.Linear layout [out,in]
+        self.biases = list(biases)
+        self.channels = channels
+        lib = _lib.load()
+        self.packed = torch.empty(lib.benerf_mlp_packed_floats(), dtype=torch.float32, device=self.weights[0].device)
+        self.version = None
+
+    def struct(self):
+        return _param_struct(MlpParams, self.weights, self.biases)
+
+    def pack(self):
+        lib = _lib.load()
+        s = self.struct()
+        _lib.check(lib.benerf_mlp_pack_weights(ctypes.byref(s), self.channels, self.packed.data_ptr(), _stream()),
+                   "mlp_pack_weights")
+
+    def pack_if_stale(self):
+        v = tuple(w._version for w in self.weights)
+        if v != self.version:
+            self.pack()
+            self.version = v
+
+
+def mlp_fwd(net, rays_o, rays_d, viewdirs, z, save_acts):
+    lib = _lib.load()
+    n_rays, n_samples = z.shape
+    C = net.channels
+    raw = _new((n_rays, n_samples, C + 1), z)
+    acts = None
+    if save_acts:
+        acts = torch.empty(n_rays * n_samples * lib.benerf_mlp_act_floats_per_point(), dtype=torch.float32,
+                           device=z.device)
+    s = net.struct()
+    _lib.check(lib.benerf_mlp_fwd(ctypes.byref(s), net.packed.data_ptr(), C, n_rays, n_samples, _chk(rays_o),
+                                  _chk(rays_d), _chk(viewdirs), _chk(z), raw.data_ptr(), _chk(acts), _stream()),
+               "mlp_fwd")
+    return raw, acts
+
+
+def mlp_bwd(net, d_raw, acts, n_rays, n_samples, grad_w, grad_b, accumulate):
+    """Returns per-point (d_pts [M,3], d_vdir [M,3]); writes/accumulates weight grads."""
+    lib = _lib.load()
+    M = n_rays * n_samples
+    dev = d_raw.device
+    dacts = scratch("dacts", M * lib.benerf_mlp_dact_floats_per_point(), dev)
+    ws_floats = lib.benerf_mlp_dw_workspace_floats(M)
+    ws = scratch("dw_ws", ws_floats, dev)
+    d_pts = torch.empty((M, 3), dtype=torch.float32, device=dev)
+    d_vd = torch.empty((M, 3), dtype=torch.float32, device=dev)
+    s = net.struct()
+    g = _param_struct(MlpGrads, grad_w, grad_b)
+    _lib.check(lib.benerf_mlp_bwd(ctypes.byref(s), net.packed.data_ptr(), net.channels, n_rays, n_samples,
+                                  _chk(d_raw, name="d_raw"), _chk(acts), dacts.data_ptr(), ws.data_ptr(), ws_floats,
+                                  ctypes.byref(g), int(bool(accumulate)), d_pts.data_ptr(), d_vd.data_ptr(), _stream()),
+               "mlp_bwd")
+    return d_pts, d_vd
+
+
+# ----------------------------------------------------------------------------- K4 compositing
+def composite_fwd(raw, z, rays_d, noise=None, noise_std=0.0, seed=0, offset=0, want=("rgb_map", "disp", "acc", "weights",
+                                                                                    "depth", "sigma")):
+    lib = _lib.load()
+    n_rays, n_samples, c1 = raw.shape
+    C = c1 - 1
+    out = {}
+    shapes = {"rgb_map": (n_rays, C), "disp": (n_rays,), "acc": (n_rays,), "weights": (n_rays, n_samples),
+              "depth": (n_rays,), "sigma": (n_rays, n_samples)}
+    for k in want:
+        out[k] = _new(shapes[k], raw)
+    p = lambda k: out[k].data_ptr() if k in out else None  # noqa: E731
+    _lib.check(lib.benerf_composite_fwd(_chk(raw), _chk(z), _chk(rays_d), _chk(noise), noise_std, seed, offset, C, n_rays,
+                                        n_samples, p("rgb_map"), p("disp"), p("acc"), p("weights"), p("depth"),
+                                        p("sigma"), _stream()), "composite_fwd")
+    return out
+
+
+def composite_bwd(raw, z, rays_d, noise, noise_std, seed, offset, d_rgb_map, d_acc=None, d_depth=None, d_disp=None,
+                  d_rays_d=None, accumulate=False):
+    lib = _lib.load()
+    n_rays, n_samples, c1 = raw.shape
+    d_raw = torch.empty_like(raw)
+    if d_rays_d is None:
+        d_rays_d = _new((n_rays, 3), raw)
+        accumulate = False
+    _lib.check(lib.benerf_composite_bwd(_chk(raw), _chk(z), _chk(rays_d), _chk(noise), noise_std, seed, offset, c1 - 1,
+                                        n_rays, n_samples, _chk(d_rgb_map), _chk(d_acc), _chk(d_depth), _chk(d_disp),
+                                        d_raw.data_ptr(), d_rays_d.data_ptr(), int(bool(accumulate)), _stream()),
+               "composite_bwd")
+    return d_raw, d_rays_d
+
+
+# ----------------------------------------------------------------------------- K5 sample_pdf
+def sample_pdf_merge(z_coarse, weights, n_importance, u=None, seed=0, offset=0, want_debug=False):
+    lib = _lib.load()
+    n_rays, n_samples = z_coarse.shape
+    z_fine = _new((n_rays, n_samples + n_importance), z_coarse)
+    zs = inds = None
+    if want_debug:
+        zs = _new((n_rays, n_importance), z_coarse)
+        inds = _new((n_rays, n_importance), z_coarse, torch.int64)
+    _lib.check(lib.benerf_sample_pdf_merge(_chk(z_coarse), _chk(weights), _chk(u, name="u"), seed, offset, n_rays,
+                                           n_samples, n_importance, z_fine.data_ptr(), _chk(zs),
+                                           _chk(inds, torch.int64), _stream()), "sample_pdf_merge")
+    if want_debug:
+        return z_fine, zs, inds
+    return z_fine
+
+
+# ----------------------------------------------------------------------------- K6 losses
+def make_loss_cfg(channels, linlog, n_evt_pix, n_rgb_pix, n_poses, threshold, event_coeff, rgb_coeff,
+                  n_evt_pix_global=None, n_rgb_pix_global=None):
+    c = LossCfg()
+    c.channels, c.linlog = channels, int(bool(linlog))
+    c.n_evt_pix, c.n_rgb_pix, c.n_poses = n_evt_pix, n_rgb_pix, n_poses
+    c.n_evt_pix_global = n_evt_pix if n_evt_pix_global is None else n_evt_pix_global
+    c.n_rgb_pix_global = n_rgb_pix if n_rgb_pix_global is None else n_rgb_pix_global
+    c.event_threshold, c.event_coeff, c.rgb_coeff = threshold, event_coeff, rgb_coeff
+    return c
+
+
+def loss_stats(cfg, rgb_evt, rgb0_evt, target_acc, rgb_rgb, rgb0_rgb, target_rgb):
+    lib = _lib.load()
+    ref = rgb_evt if rgb_evt is not None else rgb_rgb
+    stats = torch.empty(_lib.LOSS_NSTATS, dtype=torch.float64, device=ref.device)
+    _lib.check(lib.benerf_loss_stats(ctypes.byref(cfg), _chk(rgb_evt), _chk(rgb0_evt), _chk(target_acc), _chk(rgb_rgb),
+                                     _chk(rgb0_rgb), _chk(target_rgb), stats.data_ptr(), _stream()), "loss_stats")
+    return stats
+
+
+def loss_grads(cfg, stats, rgb_evt, rgb0_evt, target_acc, rgb_rgb, rgb0_rgb, target_rgb):
+    lib = _lib.load()
+    ref = rgb_evt if rgb_evt is not None else rgb_rgb
+    losses = torch.empty(8, dtype=torch.float32, device=ref.device)
+    g = [None if t is None else torch.empty_like(t) for t in (rgb_evt, rgb0_evt, rgb_rgb, rgb0_rgb)]
+    _lib.check(lib.benerf_loss_grads(ctypes.byref(cfg), _chk(stats, torch.float64), _chk(rgb_evt), _chk(rgb0_evt),
+                                     _chk(target_acc), _chk(rgb_rgb), _chk(rgb0_rgb), _chk(target_rgb),
+                                     losses.data_ptr(), _chk(g[0]), _chk(g[1]), _chk(g[2]), _chk(g[3]), _stream()),
+               "loss_grads")
+    return losses, g
+
+
+# ----------------------------------------------------------------------------- K7 events
+def event_accumulate(xs, ys, ps, H, W, out=None):
+    lib = _lib.load()
+    if out is None:
+        out = torch.zeros((H, W), dtype=torch.float32, device=xs.device)
+    _lib.check(lib.benerf_event_accumulate(_chk(xs, torch.int32, "xs"), _chk(ys, torch.int32, "ys"), _chk(ps, name="ps"),
+                                           xs.numel(), H, W, out.data_ptr(), _stream()), "event_accumulate")
+    return out
+
+
+def event_window_accumulate(xs, ys, ps, ts, low_t, upper_t, H, W, out=None):
+    lib = _lib.load()
+    if out is None:
+        out = torch.zeros((H, W), dtype=torch.float32, device=xs.device)
+    _lib.check(lib.benerf_event_window_accumulate(_chk(xs, torch.int32), _chk(ys, torch.int32), _chk(ps),
+                                                  _chk(ts, torch.float64, "ts"), xs.numel(), float(low_t),
+                                                  float(upper_t), H, W, out.data_ptr(), _stream()),
+               "event_window_accumulate")
+    return out
+
+
+def gather_rows(src, idx):
+    lib = _lib.load()
+    width = src.shape[-1] if src.dim() > 1 else 1
+    out = torch.empty((idx.numel(), width), dtype=torch.float32, device=src.device)
+    _lib.check(lib.benerf_gather_rows(_chk(src), _chk(idx, torch.int64), idx.numel(), width, out.data_ptr(), _stream()),
+               "gather_rows")
+    return out
+
+
+# ----------------------------------------------------------------------------- K8 optimiser
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    lib = _lib.load()
+    _lib.check(lib.benerf_adam_step(_chk(param), _chk(grad), _chk(exp_avg), _chk(exp_avg_sq), param.numel(), lr, beta1,
+                                    beta2, eps, step, grad_scale, _stream()), "adam_step")

@@ -1,0 +1,218 @@
+/*
+ * benerf_hip.h - C ABI of libbenerf_hip.so (MI355X / gfx950 kernels for the BeNeRF
+ * training + rendering hot path).
+ *
+ * The reference (WU-CVGL/BeNeRF) is pure Python/PyTorch and has no FFI; each entry
+ * point below replaces the chain of ATen dispatches issued by the cited reference
+ * lines (paths relative to the reference root).  The Python host side
+ * (benerf_amd/) binds these with ctypes; see INTEGRATION.md for the stub.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless the
+ *     name ends in _host; arrays are dense row-major, float32 / int64 / int32 exactly
+ *     as the torch tensors on the reference side;
+ *   - the caller owns every buffer and the stream (pass
+ *     torch.cuda.current_stream().cuda_stream); no allocation, no implicit
+ *     synchronisation, nothing is thrown across the ABI;
+ *   - return 0 on success, BENERF_EBADARG (-1) bad argument, BENERF_EWORKSPACE (-2)
+ *     workspace too small, BENERF_EHIP (-3) HIP error; text via benerf_last_error();
+ *   - thread-compatible: no global mutable state except the thread-local last error.
+ */
+#ifndef BENERF_HIP_H
+#define BENERF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BENERF_OK 0
+#define BENERF_EBADARG (-1)
+#define BENERF_EWORKSPACE (-2)
+#define BENERF_EHIP (-3)
+
+typedef void* benerf_stream_t; /* hipStream_t */
+
+int benerf_version(void);
+const char* benerf_last_error(void);
+
+/* ---------------------------------------------------------------- K1: trajectory --- */
+/* Cubic B-spline / linear pose interpolation in SE(3).
+ * Replaces spline.cubic_spline_pose_unit_time (spline.py:247-303),
+ * spline.linear_pose_unit_time (spline.py:305-331) and the knot/transform/linspace
+ * plumbing of Graph.get_pose_evt / get_pose_rgb (model/optimize.py:58-111).
+ *   knots [4,6] se(3); transform [6] added to every knot in se(3) or NULL;
+ *   ts2 [2] device floats = (t_start, t_end); pose p uses torch.linspace(t0,t1,n)[p];
+ *   traj 0 = cubic spline, 1 = linear (knots 0 and 3); poses out [n_poses,3,4]. */
+int benerf_spline_poses_fwd(const float* knots, const float* transform, const float* ts2,
+                            int n_poses, int traj, float* poses, benerf_stream_t stream);
+/* d_poses [n_poses,3,4] -> d_knots [4,6] (overwritten), d_transform [6] (overwritten, may
+ * be NULL).  Forward-mode duals over the same float code; deterministic reduction. */
+int benerf_spline_poses_bwd(const float* knots, const float* transform, const float* ts2,
+                            int n_poses, int traj, const float* d_poses, float* d_knots,
+                            float* d_transform, benerf_stream_t stream);
+
+/* ---------------------------------------------------------------- K2: rays --------- */
+/* Pinhole ray generation (pose-major, N = n_poses*n_pix), view directions and LLFF NDC.
+ * Replaces run_nerf_helpers.get_specific_rays / get_rays (run_nerf_helpers.py:13-44),
+ * ndc_rays (run_nerf_helpers.py:46-71) and Graph.render's ray plumbing
+ * (model/nerf.py:241-286).  ray_idx [n_pix] int64 pixel indices (row-major, idx = j*W+i).
+ * Outputs rays_o, rays_d (NDC'd when ndc != 0), viewdirs: [N,3] each. */
+int benerf_rays_fwd(const float* poses, const int64_t* ray_idx, int n_poses, int n_pix,
+                    int H, int W, float fx, float fy, float cx, float cy, int ndc,
+                    float* rays_o, float* rays_d, float* viewdirs, benerf_stream_t stream);
+/* (d_rays_o, d_rays_d, d_viewdirs) [N,3] -> d_poses [n_poses,3,4] (overwritten). */
+int benerf_rays_bwd(const float* poses, const int64_t* ray_idx, int n_poses, int n_pix,
+                    int H, int W, float fx, float fy, float cx, float cy, int ndc,
+                    const float* d_rays_o, const float* d_rays_d, const float* d_viewdirs,
+                    float* d_poses, benerf_stream_t stream);
+/* Stratified coarse depths: z = lower + (upper-lower)*t_rand (model/nerf.py:297-307).
+ * t_rand [n_rays,n_samples] uniform draws, or NULL for in-kernel Philox(seed, offset). */
+int benerf_stratified_z(int n_rays, int n_samples, float near, float far, const float* t_rand,
+                        uint64_t seed, uint64_t offset, float* z, benerf_stream_t stream);
+/* Sums per-sample point gradients into ray gradients: pts = o + d*z (model/nerf.py:308,327)
+ *   d_o = sum_s d_pts, d_d = sum_s z*d_pts, d_viewdirs = sum_s d_vdir_pts.
+ * accumulate != 0 adds into the outputs instead of overwriting. */
+int benerf_ray_grad_reduce(int n_rays, int n_samples, const float* z, const float* d_pts,
+                           const float* d_vdir_pts, int accumulate, float* d_rays_o,
+                           float* d_rays_d, float* d_viewdirs, benerf_stream_t stream);
+
+/* ---------------------------------------------------------------- K3: fused MLP ---- */
+/* NeRF parameter block in nn.Linear layout ([out,in] row-major), reference state-dict
+ * order (model/nerf.py:53-64): pts_linears.0..7, views_linears.0, feature_linear,
+ * alpha_linear, rgb_linear. */
+enum { BENERF_NLAYERS = 12, BENERF_L_VIEWS = 8, BENERF_L_FEAT = 9, BENERF_L_ALPHA = 10, BENERF_L_RGB = 11 };
+typedef struct BenerfMlpParams {
+    const float* w[BENERF_NLAYERS];
+    const float* b[BENERF_NLAYERS];
+} BenerfMlpParams;
+typedef struct BenerfMlpGrads {
+    float* w[BENERF_NLAYERS];
+    float* b[BENERF_NLAYERS];
+} BenerfMlpGrads;
+
+/* floats needed for the MFMA-packed copies of one network's weights */
+size_t benerf_mlp_packed_floats(void);
+/* Re-pack one network (call after every optimiser step). packed [benerf_mlp_packed_floats()] */
+int benerf_mlp_pack_weights(const BenerfMlpParams* params, int channels, float* packed,
+                            benerf_stream_t stream);
+/* floats per sample point of the saved-activation / activation-gradient buffers */
+size_t benerf_mlp_act_floats_per_point(void);
+size_t benerf_mlp_dact_floats_per_point(void);
+/* floats of the weight-gradient partial-sum workspace for n_points */
+size_t benerf_mlp_dw_workspace_floats(int64_t n_points);
+
+/* Fused positional encoding + 8x256 MLP + view branch, forward.
+ * Replaces Embedder.embed (model/embedder.py:9-34) and NeRF.forward
+ * (model/nerf.py:67-116) incl. pts = o + d*z (model/nerf.py:308,327).
+ *   rays_o, rays_d, viewdirs [n_rays,3]; z [n_rays,n_samples]; raw out
+ *   [n_rays,n_samples,channels+1] = [rgb..., sigma] pre-activation.
+ *   acts: NULL (inference) or [n_points * act_floats_per_point] saved for backward. */
+int benerf_mlp_fwd(const BenerfMlpParams* params, const float* packed, int channels,
+                   int n_rays, int n_samples, const float* rays_o, const float* rays_d,
+                   const float* viewdirs, const float* z, float* raw, float* acts,
+                   benerf_stream_t stream);
+/* Backward of the above.  d_raw [n_points,channels+1].
+ *   dacts scratch [n_points * dact_floats_per_point]; dw_ws scratch
+ *   [benerf_mlp_dw_workspace_floats(n_points)]; grads: overwritten when accumulate == 0,
+ *   added to otherwise; d_pts [n_points,3], d_vdir_pts [n_points,3] out (per point; reduce
+ *   with benerf_ray_grad_reduce). */
+int benerf_mlp_bwd(const BenerfMlpParams* params, const float* packed, int channels,
+                   int n_rays, int n_samples, const float* d_raw, const float* acts,
+                   float* dacts, float* dw_ws, size_t dw_ws_floats,
+                   const BenerfMlpGrads* grads, int accumulate, float* d_pts,
+                   float* d_vdir_pts, benerf_stream_t stream);
+
+/* ---------------------------------------------------------------- K4: compositing -- */
+/* Alpha compositing, one wavefront per ray.  Replaces NeRF.raw2output
+ * (model/nerf.py:118-148).  noise [n_rays,n_samples] = randn*raw_noise_std, or NULL with
+ * noise_std > 0 for in-kernel Philox normals, or NULL with noise_std == 0 for none.
+ * Any output pointer may be NULL. n_samples <= 512. */
+int benerf_composite_fwd(const float* raw, const float* z, const float* rays_d,
+                         const float* noise, float noise_std, uint64_t seed, uint64_t offset,
+                         int channels, int n_rays, int n_samples, float* rgb_map, float* disp,
+                         float* acc, float* weights, float* depth, float* sigma,
+                         benerf_stream_t stream);
+/* d_rgb_map [n_rays,C] (required); d_acc, d_depth, d_disp [n_rays] optional (NULL = 0).
+ * Out: d_raw [n_rays,n_samples,C+1]; d_rays_d [n_rays,3] through ||rays_d|| in dists
+ * (overwritten, or added to when accumulate != 0; may be NULL). */
+int benerf_composite_bwd(const float* raw, const float* z, const float* rays_d,
+                         const float* noise, float noise_std, uint64_t seed, uint64_t offset,
+                         int channels, int n_rays, int n_samples, const float* d_rgb_map,
+                         const float* d_acc, const float* d_depth, const float* d_disp,
+                         float* d_raw, float* d_rays_d, int accumulate, benerf_stream_t stream);
+
+/* ---------------------------------------------------------------- K5: sample_pdf --- */
+/* Inverse-CDF importance sampling + sorted merge with the coarse depths.
+ * Replaces run_nerf_helpers.sample_pdf (run_nerf_helpers.py:74-115) and
+ * model/nerf.py:322-326 (z_mid, weights[1:-1], detach, cat, sort).
+ *   z_coarse, weights [n_rays,n_samples]; u [n_rays,n_importance] uniforms or NULL for
+ *   Philox; z_fine out [n_rays,n_samples+n_importance] ascending.
+ *   Optional test outputs: z_samples [n_rays,n_importance], inds int64 same shape.
+ * Arithmetic is fully specified (see oracle sample_pdf_exact): bit-exact vs the oracle. */
+int benerf_sample_pdf_merge(const float* z_coarse, const float* weights, const float* u,
+                            uint64_t seed, uint64_t offset, int n_rays, int n_samples,
+                            int n_importance, float* z_fine, float* z_samples, int64_t* inds,
+                            benerf_stream_t stream);
+
+/* ---------------------------------------------------------------- K6: losses ------- */
+typedef struct BenerfLossCfg {
+    int32_t channels;        /* 1 or 3 */
+    int32_t linlog;          /* 0 safelog (BeNeRF_*), 1 linlog (E2NeRF_*): utils/math_utils.py:4-23 */
+    int32_t n_evt_pix;       /* local event pixels R_e (rgb_evt has 2*R_e rows) */
+    int32_t n_rgb_pix;       /* local blur pixels R_r */
+    int32_t n_poses;         /* virtual poses n (rgb_rgb has n*R_r rows) */
+    int32_t n_evt_pix_global;/* global batch sizes (== local on one GPU) */
+    int32_t n_rgb_pix_global;
+    float event_threshold;   /* > 0 synthetic branch (train.py:207-236), else L2-normalised (train.py:238-292) */
+    float event_coeff;       /* event_coeff_syn or event_coeff_real */
+    float rgb_coeff;
+} BenerfLossCfg;
+enum { BENERF_LOSS_NSTATS = 16 };
+/* Pass 1: partial sums over the local batch -> stats[BENERF_LOSS_NSTATS] doubles (sum over
+ * ranks with an all-reduce when data-parallel).
+ *   rgb_evt/rgb0_evt [2*R_e,C]; target_acc [R_e] accumulated events at the sampled pixels;
+ *   rgb_rgb/rgb0_rgb [n*R_r,C] pose-major; target_rgb [R_r,C]. */
+int benerf_loss_stats(const BenerfLossCfg* cfg, const float* rgb_evt, const float* rgb0_evt,
+                      const float* target_acc, const float* rgb_rgb, const float* rgb0_rgb,
+                      const float* target_rgb, double* stats, benerf_stream_t stream);
+/* Pass 2: loss values (losses[8] floats: total, event, event_fine, event_coarse, rgb,
+ * rgb_fine, rgb_coarse, 0) and gradients w.r.t. the four rendered colour arrays.
+ * Replaces train.py:163-337 + loss/imgloss.py:3-5 + utils/img_utils.py:7-16. */
+int benerf_loss_grads(const BenerfLossCfg* cfg, const double* stats, const float* rgb_evt,
+                      const float* rgb0_evt, const float* target_acc, const float* rgb_rgb,
+                      const float* rgb0_rgb, const float* target_rgb, float* losses,
+                      float* d_rgb_evt, float* d_rgb0_evt, float* d_rgb_rgb, float* d_rgb0_rgb,
+                      benerf_stream_t stream);
+
+/* ---------------------------------------------------------------- K7: events ------- */
+/* out[y,x] += p for every event (duplicates summed; +-1 values => order independent,
+ * exact).  Replaces utils/event_utils.accumulate_events_on_gpu (utils/event_utils.py:246-259).
+ * out [H,W] float32 must be zeroed (or hold the running image) by the caller. */
+int benerf_event_accumulate(const int32_t* xs, const int32_t* ys, const float* ps, int64_t n,
+                            int H, int W, float* out, benerf_stream_t stream);
+/* Time-window variant over events kept sorted by ts on the device (model/nerf.py:162-197):
+ * accumulates every event with low_t <= ts <= upper_t; window bounds found by binary
+ * search in-kernel.  ts [n] float64 ascending. */
+int benerf_event_window_accumulate(const int32_t* xs, const int32_t* ys, const float* ps,
+                                   const double* ts, int64_t n, double low_t, double upper_t,
+                                   int H, int W, float* out, benerf_stream_t stream);
+/* out[i] = src[idx[i]] (target gather: train.py:177,301-302). src float32 [n_src,width] */
+int benerf_gather_rows(const float* src, const int64_t* idx, int64_t n_idx, int width,
+                       float* out, benerf_stream_t stream);
+
+/* ---------------------------------------------------------------- K8: optimiser ---- */
+/* torch.optim.Adam (defaults beta 0.9/0.999, eps 1e-8) on a flat fp32 buffer; step counts
+ * from 1.  Replaces train.py:343-352 (+ model/optimize.py:36-55); the caller applies the
+ * exponential LR decay of train.py:355-394 to `lr`.  grad_scale multiplies g first
+ * (1/world_size after a sum all-reduce). */
+int benerf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                     int64_t n, double lr, double beta1, double beta2, double eps, int step,
+                     double grad_scale, benerf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BENERF_HIP_H */

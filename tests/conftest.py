@@ -1,0 +1,63 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+REPORT = []
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    cache = {}
+
+    def load(name):
+        if name not in cache:
+            cache[name] = np.load(os.path.join(GOLDEN, name + ".npz"))
+        return cache[name]
+
+    return load
+
+
+def report(name, got, ref, atol=0.0, rtol=0.0):
+    """Record max abs / rel error, then assert allclose.  Accepts torch or numpy."""
+    import torch
+    g = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    r = ref.detach().cpu().numpy() if isinstance(ref, torch.Tensor) else np.asarray(ref)
+    assert g.shape == r.shape, (name, g.shape, r.shape)
+    d = np.abs(g.astype(np.float64) - r.astype(np.float64))
+    nan_mismatch = np.isnan(g) != np.isnan(r)
+    d = np.where(np.isnan(g) & np.isnan(r), 0.0, d)
+    mx = float(np.nanmax(d)) if d.size else 0.0
+    scale = float(np.nanmax(np.abs(r))) if r.size and not np.isnan(r).all() else 0.0
+    both_nan = np.isnan(g) & np.isnan(r)
+    with np.errstate(invalid="ignore"):
+        within = (d <= atol + rtol * np.abs(r)) | both_nan
+    ok = (not nan_mismatch.any()) and bool(np.all(within))
+    line = "%-58s max|d|=%.3e  max|ref|=%.3e  atol=%g rtol=%g  %s" % (name, mx, scale, atol, rtol, "ok" if ok else "FAIL")
+    REPORT.append(line)
+    print(line)
+    assert ok, line
+    return mx
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not REPORT:
+        return
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_report.txt"), "w") as f:
+            f.write("\n".join(REPORT) + "\n")
+    except OSError:
+        pass

@@ -1,0 +1,47 @@
+"""CPU: the C-ABI shared library builds, loads and exports every symbol include/benerf_hip.h
+declares (no compute calls without a GPU), and the product path refuses to run on CPU."""
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from benerf_amd import _lib, build
+    if not os.path.exists(_lib.LIB_PATH):
+        build.build()
+    return _lib.load()
+
+
+def test_header_symbols_exported(lib):
+    from benerf_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "benerf_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(benerf_[a-z0-9_]+)\s*\(", hdr)))
+    assert declared == list(_lib.EXPORTED_SYMBOLS), "ctypes table and header disagree"
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_size_queries(lib):
+    assert lib.benerf_version() >= 100
+    assert lib.benerf_mlp_act_floats_per_point() == 64 + 8 * 256 + 256 + 128 + 32
+    assert lib.benerf_mlp_dact_floats_per_point() == 8 * 256 + 256 + 128
+    assert lib.benerf_mlp_packed_floats() > 2 * 593920 - 200000
+    assert lib.benerf_mlp_dw_workspace_floats(1000) > 0
+
+
+def test_bad_arguments_are_reported(lib):
+    rc = lib.benerf_spline_poses_fwd(None, None, None, 2, 0, None, None)
+    assert rc == -1 and b"null" in lib.benerf_last_error()
+    rc = lib.benerf_composite_fwd(None, None, None, None, 0.0, 0, 0, 5, 1, 1, None, None, None, None, None, None, None)
+    assert rc == -1
+
+
+def test_no_cpu_fallback():
+    from benerf_amd import _lib, kernels
+    with pytest.raises(_lib.BenerfHipError):
+        kernels.spline_poses_fwd(torch.zeros(4, 6), None, torch.zeros(2), 2, 0)

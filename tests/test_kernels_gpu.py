@@ -1,0 +1,404 @@
+"""GPU parity tests, kernel by kernel: HIP path (through the C ABI) vs the committed golden
+vectors of the unmodified reference and vs the oracle on seeded inputs.
+
+Tolerances: poses / rays / PE 1e-6 abs; MLP raw 1e-5 rel;
+rgb_map 1e-4 abs (north-star); sample_pdf indices and values BIT-EXACT vs the oracle's fully
+specified restatement; gradients 1e-4 rel on norms, 1e-3 on entries.
+"""
+import numpy as np
+import pytest
+import torch
+
+import benerf_oracle as O
+import golden_inputs as GI
+from conftest import report
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def dev(x, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(x)) if isinstance(x, np.ndarray) else x
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV).contiguous()
+
+
+@pytest.fixture(scope="module")
+def K():
+    from benerf_amd import kernels
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return kernels
+
+
+# ------------------------------------------------------------------------------------ K1
+def test_spline_fwd_bwd_golden(K, golden):
+    g = golden("g1_spline")
+    n = int(g["n_cases"])
+    worst = 0.0
+    for ci in range(n):
+        for ti, traj in enumerate(("spline", "linear")):
+            tag = "c%02d_%s" % (ci, traj)
+            knots, tr, ts, G = (dev(g[tag + "_" + k]) for k in ("knots", "transform", "ts", "G"))
+            P = g[tag + "_poses"].shape[0]
+            poses = K.spline_poses_fwd(knots, tr.reshape(6), ts, P, ti)
+            worst = max(worst, float((poses.cpu() - torch.from_numpy(g[tag + "_poses"])).abs().max()))
+            report("K1 poses " + tag, poses, g[tag + "_poses"], atol=2e-6)
+            dk, dt = K.spline_poses_bwd(knots, tr.reshape(6), ts, P, ti, G)
+            sc = float(np.abs(g[tag + "_dknots"]).max())
+            report("K1 dknots " + tag, dk, g[tag + "_dknots"], atol=2e-5 * max(sc, 1.0), rtol=1e-3)
+            report("K1 dtransform " + tag, dt, g[tag + "_dtransform"], atol=2e-5 * max(sc, 1.0), rtol=1e-3)
+    print("K1 worst pose error", worst)
+
+
+def test_spline_no_transform(K):
+    rng = np.random.default_rng(5)
+    knots = GI.knots_init(rng)
+    ts = torch.tensor([0.2, 0.7])
+    ref = O.trajectory_poses(knots, None, (0.2, 0.7), 2, "spline")
+    got = K.spline_poses_fwd(dev(knots), None, dev(ts), 2, 0)
+    report("K1 poses (no transform, P=2)", got, ref, atol=2e-6)
+
+
+# ------------------------------------------------------------------------------------ K2
+def test_rays_fwd_golden(K, golden):
+    g = golden("g2_rays")
+    for cname in GI.CAMERAS:
+        H, W, fx, fy, cx, cy = g[cname + "_cam"]
+        poses, idx = dev(g[cname + "_poses"]), dev(g[cname + "_idx"])
+        ro, rd, vd = K.rays_fwd(poses, idx, int(H), int(W), fx, fy, cx, cy, ndc=True)
+        report("K2 ndc rays_o " + cname, ro, g[cname + "_ndc_o"], atol=2e-6, rtol=2e-6)
+        report("K2 ndc rays_d " + cname, rd, g[cname + "_ndc_d"], atol=2e-6, rtol=2e-6)
+        report("K2 viewdirs " + cname, vd, g[cname + "_viewdirs"], atol=1e-6)
+        ro, rd, vd = K.rays_fwd(poses, idx, int(H), int(W), fx, fy, cx, cy, ndc=False)
+        report("K2 rays_o " + cname, ro, g[cname + "_rays_o"], atol=1e-6)
+        report("K2 rays_d " + cname, rd, g[cname + "_rays_d"], atol=1e-6)
+
+
+def test_rays_bwd_vs_oracle(K):
+    rng = np.random.default_rng(21)
+    cam = GI.CAMERAS["unreal"]
+    Kmat = GI.cam_K(cam)
+    for ndc in (True, False):
+        poses = O.trajectory_poses(GI.knots_stress(rng) * 0.2, None, (0.0, 1.0), 5, "spline").detach()
+        idx = GI.pixel_indices(rng, cam, 300)
+        N = 5 * 300
+        go, gd, gv = (GI.f32(rng.standard_normal((N, 3))) for _ in range(3))
+        p = poses.clone().requires_grad_(True)
+        ro, rd, vd = O.make_rays(p, idx, cam["H"], cam["W"], Kmat, ndc)
+        ((ro * go).sum() + (rd * gd).sum() + (vd * gv).sum()).backward()
+        got = K.rays_bwd(dev(poses), dev(idx), cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"], ndc,
+                         dev(go), dev(gd), dev(gv))
+        sc = float(p.grad.abs().max())
+        report("K2 d_poses ndc=%d" % ndc, got, p.grad, atol=2e-5 * sc, rtol=1e-4)
+
+
+def test_stratified_z(K):
+    rng = np.random.default_rng(3)
+    for S in (16, 32, 64, 128):
+        t = GI.f32(rng.random((77, S)))
+        ref = O.stratified_z(77, S, t)
+        got = K.stratified_z(77, S, DEV, t_rand=dev(t))
+        report("K2 stratified_z S=%d" % S, got, ref, atol=1e-7)
+    z = K.stratified_z(1000, 64, DEV, seed=7, offset=1)
+    z2 = K.stratified_z(1000, 64, DEV, seed=7, offset=1)
+    assert torch.equal(z, z2), "Philox stream must be reproducible"
+    zc = z.cpu()
+    assert bool((zc[:, 1:] >= zc[:, :-1]).all()) and float(zc.min()) >= 0 and float(zc.max()) <= 1
+
+
+# ------------------------------------------------------------------------------------ K3
+def _params_for(rng, C, variant):
+    p = O.xavier_params(rng, C)
+    if variant == "trained":
+        p["alpha_linear.bias"] += 2.0
+        for k in p:
+            if k.endswith(".bias") and not k.startswith("alpha"):
+                p[k] = GI.f32(rng.uniform(-0.1, 0.1, p[k].shape))
+    return p
+
+
+def _packed(K, p, C):
+    ws = [dev(p[n + ".weight"]) for n in K.LAYER_NAMES]
+    bs = [dev(p[n + ".bias"]) for n in K.LAYER_NAMES]
+    net = K.PackedMlp(ws, bs, C)
+    net.pack()
+    return net
+
+
+def _g4_case(C, variant, S):
+    """Regenerates the inputs of gen_golden.g4_mlp (same rng stream)."""
+    rng = np.random.default_rng(404 + C * 10 + S + (1000 if variant == "trained" else 0))
+    p = _params_for(rng, C, variant)
+    n_rays = 8 if S == 16 else 16
+    pts = GI.f32(rng.uniform(-1.2, 1.2, (n_rays, S, 3)))
+    vd = GI.f32(rng.standard_normal((n_rays, 3)))
+    vd = vd / vd.norm(dim=-1, keepdim=True)
+    G = GI.f32(rng.standard_normal((n_rays, S, C + 1)))
+    return p, pts, vd, G
+
+
+def _run_mlp_on_points(K, net, pts, vd, save):
+    """pts [N,S,3] arbitrary: feed as rays with o = 0, per-point d via S=1 rays."""
+    N, S = pts.shape[:2]
+    M = N * S
+    rays_o = torch.zeros(M, 3)
+    rays_d = pts.reshape(M, 3)
+    z = torch.ones(M, 1)
+    vdp = vd[:, None].expand(N, S, 3).reshape(M, 3)
+    raw, acts = K.mlp_fwd(net, dev(rays_o), dev(rays_d), dev(vdp), dev(z), save)
+    return raw.reshape(N, S, -1), acts, M
+
+
+def _act_views(acts, M):
+    a = acts.cpu()
+    off = 0
+    out = {}
+    out["pe"] = a[off:off + M * 64].reshape(M, 64)
+    off += M * 64
+    for l in range(8):
+        out["h%d" % l] = a[off:off + M * 256].reshape(M, 256)
+        off += M * 256
+    out["feat"] = a[off:off + M * 256].reshape(M, 256)
+    off += M * 256
+    out["hv"] = a[off:off + M * 128].reshape(M, 128)
+    off += M * 128
+    out["ped"] = a[off:off + M * 32].reshape(M, 32)
+    return out
+
+
+@pytest.mark.parametrize("C,variant,S", [(1, "xavier", 16), (3, "trained", 16), (1, "trained", 64), (3, "xavier", 64)])
+def test_mlp_fwd_golden(K, golden, C, variant, S):
+    g = golden("g4_mlp")
+    tag = "C%d_%s_S%d" % (C, variant, S)
+    p, pts, vd, G = _g4_case(C, variant, S)
+    net = _packed(K, p, C)
+    raw, acts, M = _run_mlp_on_points(K, net, pts, vd, True)
+    ref = g[tag + "_raw"]
+    sc = float(np.abs(ref).max())
+    if tag + "_h0" in g:
+        av = _act_views(acts, M)
+        report("K3 PE " + tag, av["pe"][:, :63], g[tag + "_pe"], atol=2e-6)
+        assert float(av["pe"][:, 63].abs().max()) == 0.0
+        for name in ("h0", "h4", "h7", "feat", "hv"):
+            r = g[tag + "_" + name]
+            report("K3 act %s %s" % (name, tag), av[name], r, atol=2e-5 * float(np.abs(r).max()), rtol=1e-4)
+    report("K3 raw " + tag, raw, ref, atol=1e-5 * max(sc, 1.0), rtol=1e-5)
+    raw2, _, _ = _run_mlp_on_points(K, net, pts, vd, False)
+    assert torch.equal(raw2, raw), "inference and training forward must agree bit for bit"
+
+
+def test_mlp_fwd_rays_and_tail(K):
+    """pts = o + d*z inside the kernel, ragged tile tail (M not a multiple of 64)."""
+    rng = np.random.default_rng(77)
+    C = 3
+    p = _params_for(rng, C, "trained")
+    net = _packed(K, p, C)
+    N, S = 37, 48        # M = 1776 = 27.75 tiles
+    ro = GI.f32(rng.uniform(-0.5, 0.5, (N, 3)))
+    rd = GI.f32(rng.uniform(-1, 1, (N, 3)))
+    vd = GI.f32(rng.standard_normal((N, 3)))
+    vd = vd / vd.norm(dim=-1, keepdim=True)
+    z = GI.f32(np.sort(rng.random((N, S)), -1))
+    pts = ro[:, None, :] + rd[:, None, :] * z[:, :, None]
+    ref = O.mlp_forward(p, pts, vd)
+    raw, _ = K.mlp_fwd(net, dev(ro), dev(rd), dev(vd), dev(z), False)
+    report("K3 raw rays+tail", raw, ref, atol=1e-5 * float(ref.abs().max()), rtol=1e-5)
+
+
+@pytest.mark.parametrize("C,variant,S", [(1, "xavier", 16), (3, "trained", 16), (1, "trained", 64), (3, "xavier", 64)])
+def test_mlp_bwd_golden(K, golden, C, variant, S):
+    g = golden("g4_mlp")
+    tag = "C%d_%s_S%d" % (C, variant, S)
+    p, pts, vd, G = _g4_case(C, variant, S)
+    net = _packed(K, p, C)
+    raw, acts, M = _run_mlp_on_points(K, net, pts, vd, True)
+    gw = [torch.zeros_like(w) for w in net.weights]
+    gb = [torch.zeros_like(b) for b in net.biases]
+    d_pts, d_vd = K.mlp_bwd(net, dev(G.reshape(M, C + 1)), acts, M, 1, gw, gb, False)
+    # with o = 0, z = 1: pts = d  =>  d_pts is the reference's d(pts)
+    ref_dpts = g[tag + "_dpts"].reshape(M, 3)
+    report("K3 d_pts " + tag, d_pts, ref_dpts, atol=2e-5 * float(np.abs(ref_dpts).max()), rtol=1e-3)
+    N = pts.shape[0]
+    ref_dvd = g[tag + "_dviewdirs"]
+    got_dvd = d_vd.reshape(N, S, 3).sum(1)
+    report("K3 d_viewdirs " + tag, got_dvd, ref_dvd, atol=2e-5 * float(np.abs(ref_dvd).max()), rtol=1e-3)
+    for i, name in enumerate(K.LAYER_NAMES):
+        for kind, got in (("weight", gw[i]), ("bias", gb[i])):
+            key = "%s_g_%s.%s" % (tag, name, kind)
+            flat = got.reshape(-1).cpu().numpy()
+            nrm = float(np.linalg.norm(flat.astype(np.float64)))
+            ref_n = float(g[key + "__norm"])
+            report("K3 |d%s.%s| %s" % (name, kind, tag), np.array(nrm), np.array(ref_n), atol=1e-9, rtol=1e-4)
+            idx = g[key + "__idx"]
+            ref_v = g[key + "__val"]
+            report("K3 d%s.%s[64] %s" % (name, kind, tag), flat[idx], ref_v, atol=1e-3 * float(np.abs(ref_v).max()) + 1e-9,
+                   rtol=1e-3)
+    # accumulate=True adds on top
+    gw2 = [x.clone() for x in gw]
+    gb2 = [x.clone() for x in gb]
+    K.mlp_bwd(net, dev(G.reshape(M, C + 1)), acts, M, 1, gw2, gb2, True)
+    report("K3 accumulate doubles grads", gw2[3], 2 * gw[3], atol=1e-6 * float(gw[3].abs().max()), rtol=1e-6)
+
+
+def test_mlp_bwd_vs_oracle_tail_and_determinism(K):
+    rng = np.random.default_rng(78)
+    C = 1
+    p = _params_for(rng, C, "trained")
+    net = _packed(K, p, C)
+    N, S = 21, 40       # M = 840: 13.125 tiles, 26.25 chunks
+    ro = GI.f32(rng.uniform(-0.5, 0.5, (N, 3)))
+    rd = GI.f32(rng.uniform(-1, 1, (N, 3)))
+    vd = GI.f32(rng.standard_normal((N, 3)))
+    vd = vd / vd.norm(dim=-1, keepdim=True)
+    z = GI.f32(np.sort(rng.random((N, S)), -1))
+    G = GI.f32(rng.standard_normal((N, S, C + 1)))
+    po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    ro_o, rd_o, vd_o = (t.clone().requires_grad_(True) for t in (ro, rd, vd))
+    pts = ro_o[:, None, :] + rd_o[:, None, :] * z[:, :, None]
+    (O.mlp_forward(po, pts, vd_o) * G).sum().backward()
+    raw, acts = K.mlp_fwd(net, dev(ro), dev(rd), dev(vd), dev(z), True)
+    gw = [torch.zeros_like(w) for w in net.weights]
+    gb = [torch.zeros_like(b) for b in net.biases]
+    d_pts, d_vd = K.mlp_bwd(net, dev(G.reshape(-1, C + 1)), acts, N, S, gw, gb, False)
+    d_o = torch.zeros(N, 3, device=DEV)
+    d_d = torch.zeros(N, 3, device=DEV)
+    d_v = torch.zeros(N, 3, device=DEV)
+    K.ray_grad_reduce(dev(z), d_pts, d_vd, d_o, d_d, d_v, False)
+    for nm, got, ref in (("d_rays_o", d_o, ro_o.grad), ("d_rays_d", d_d, rd_o.grad), ("d_viewdirs", d_v, vd_o.grad)):
+        report("K3 %s (tail)" % nm, got, ref, atol=2e-5 * float(ref.abs().max()), rtol=1e-3)
+    for i, name in enumerate(K.LAYER_NAMES):
+        r = po[name + ".weight"].grad
+        report("K3 d%s.weight (tail)" % name, gw[i], r, atol=2e-5 * float(r.abs().max()), rtol=1e-3)
+        r = po[name + ".bias"].grad
+        report("K3 d%s.bias (tail)" % name, gb[i], r, atol=2e-5 * float(r.abs().max()), rtol=1e-3)
+    gw2 = [torch.zeros_like(w) for w in net.weights]
+    gb2 = [torch.zeros_like(b) for b in net.biases]
+    K.mlp_bwd(net, dev(G.reshape(-1, C + 1)), acts, N, S, gw2, gb2, False)
+    assert all(torch.equal(a, b) for a, b in zip(gw, gw2)), "weight gradients must be run-to-run deterministic"
+
+
+# ------------------------------------------------------------------------------------ K4
+@pytest.mark.parametrize("C", [1, 3])
+def test_composite_golden(K, golden, C):
+    g = golden("g5_composite")
+    raw, z, rd, noise = (dev(g["C%d_%s" % (C, k)]) for k in ("raw", "z", "rays_d", "noise"))
+    for noisy in (True, False):
+        tag = "C%d_%s" % (C, "noise" if noisy else "clean")
+        out = K.composite_fwd(raw, z, rd, noise if noisy else None)
+        for nm in ("rgb_map", "disp", "acc", "weights", "depth", "sigma"):
+            ref = g[tag + "_" + nm]
+            fin = np.isfinite(ref)
+            sc = float(np.abs(ref[fin]).max()) if fin.any() else 1.0
+            # disp of a near-empty ray is 1/(tiny): relative tolerance only
+            report("K4 %s %s" % (nm, tag), out[nm], ref, atol=(0.0 if nm == "disp" else 2e-6 * max(sc, 1.0)), rtol=2e-5)
+        d_raw, d_rd = K.composite_bwd(raw, z, rd, noise if noisy else None, 0.0, 0, 0, dev(g[tag + "_Gmap"]))
+        ref = g[tag + "_draw"]
+        report("K4 d_raw " + tag, d_raw, ref, atol=2e-5 * float(np.abs(ref).max()), rtol=1e-3)
+        ref = g[tag + "_drays_d"]
+        report("K4 d_rays_d " + tag, d_rd, ref, atol=2e-5 * float(np.abs(ref).max()), rtol=1e-3)
+
+
+def test_composite_bwd_all_heads_and_sizes(K):
+    rng = np.random.default_rng(55)
+    for S in (24, 64, 128, 192, 256):
+        C, N = 3, 19
+        raw = GI.f32(rng.standard_normal((N, S, C + 1)))
+        z = GI.f32(np.sort(rng.random((N, S)), -1))
+        rd = GI.f32(rng.standard_normal((N, 3)))
+        noise = GI.f32(rng.standard_normal((N, S)))
+        g_rgb, g_acc, g_dep, g_dsp = (GI.f32(rng.standard_normal(s)) for s in ((N, C), (N,), (N,), (N,)))
+        raw_o, rd_o = raw.clone().requires_grad_(True), rd.clone().requires_grad_(True)
+        rgb, disp, acc, w, depth, sig = O.composite(raw_o, z, rd_o, noise, C)
+        ((rgb * g_rgb).sum() + (acc * g_acc).sum() + (depth * g_dep).sum() + (disp * g_dsp).sum()).backward()
+        out = K.composite_fwd(dev(raw), dev(z), dev(rd), dev(noise))
+        report("K4 rgb_map S=%d" % S, out["rgb_map"], rgb, atol=2e-6, rtol=2e-5)
+        report("K4 weights S=%d" % S, out["weights"], w, atol=2e-6, rtol=2e-5)
+        d_raw, d_rd = K.composite_bwd(dev(raw), dev(z), dev(rd), dev(noise), 0.0, 0, 0, dev(g_rgb), dev(g_acc),
+                                      dev(g_dep), dev(g_dsp))
+        report("K4 d_raw (all heads) S=%d" % S, d_raw, raw_o.grad, atol=3e-5 * float(raw_o.grad.abs().max()), rtol=1e-3)
+        report("K4 d_rays_d (all heads) S=%d" % S, d_rd, rd_o.grad, atol=3e-5 * float(rd_o.grad.abs().max()), rtol=1e-3)
+
+
+# ------------------------------------------------------------------------------------ K5
+def test_sample_pdf_bit_exact(K, golden):
+    g = golden("g6_sample_pdf")
+    for kind in ("flat", "peaky", "zero"):
+        for (S, Ni) in ((64, 64), (32, 32), (64, 128)):
+            tag = "%s_S%d_N%d" % (kind, S, Ni)
+            t_rand = torch.from_numpy(g[tag + "_t_rand"])
+            N = t_rand.shape[0]
+            z = O.stratified_z(N, S, t_rand)
+            w_mid = torch.from_numpy(g[tag + "_w"])
+            weights = torch.cat([torch.zeros(N, 1), w_mid, torch.zeros(N, 1)], -1)   # kernel uses weights[1:-1]
+            u = torch.from_numpy(g[tag + "_u"])
+            z_fine, zs, inds = K.sample_pdf_merge(dev(z), dev(weights), Ni, u=dev(u), want_debug=True)
+            assert np.array_equal(inds.cpu().numpy(), g[tag + "_inds_exact"]), "K5 inds not bit-exact " + tag
+            assert np.array_equal(zs.cpu().numpy(), g[tag + "_samples_exact"]), "K5 samples not bit-exact " + tag
+            ref_sorted, _ = torch.sort(torch.cat([z, torch.from_numpy(g[tag + "_samples_exact"])], -1), -1)
+            assert torch.equal(z_fine.cpu(), ref_sorted), "K5 merged depths not bit-exact " + tag
+            # vs the reference itself: identical indices except at 1-ulp cdf ties
+            mism = int((inds.cpu().numpy() != g[tag + "_inds"]).sum())
+            report("K5 index mismatches vs reference (of %d) %s" % (inds.numel(), tag), np.array(float(mism)),
+                   np.array(0.0), atol=2.0)
+
+
+# ------------------------------------------------------------------------------------ K6
+@pytest.mark.parametrize("spec", [(1, "BeNeRF_Unreal", 0.1, 0.1), (3, "BeNeRF_Unreal", 0.1, 0.1),
+                                  (3, "E2NeRF_Synthetic", 0.2, 0.1), (3, "E2NeRF_Real", -1.0, 2.0),
+                                  (1, "E2NeRF_Real", -1.0, 2.0)])
+def test_losses_vs_oracle(K, spec):
+    C, dataset, thr, coeff = spec
+    rng = np.random.default_rng(66)
+    Re, Rr, P = 200, 37, 19
+    rgb_e, rgb0_e = (GI.f32(rng.uniform(0.02, 0.98, (2 * Re, C))) for _ in range(2))
+    rgb_r, rgb0_r = (GI.f32(rng.uniform(0.02, 0.98, (P * Rr, C))) for _ in range(2))
+    acc = torch.from_numpy(rng.integers(-4, 5, (Re, 1)).astype(np.float64))
+    tgt_rgb = GI.f32(rng.random((Rr, C)))
+    leaves = [t.clone().requires_grad_(True) for t in (rgb_e, rgb0_e, rgb_r, rgb0_r)]
+    le, lef, lec = O.event_loss(leaves[0], leaves[1], Re, acc, C, dataset, thr, 0.1, 2.0)
+    lr, lrf, lrc = O.blur_loss(leaves[2], leaves[3], tgt_rgb, P, 1.0)
+    (le + lr).backward()
+    cfg = K.make_loss_cfg(C, dataset.startswith("E2NeRF"), Re, Rr, P, thr, coeff, 1.0)
+    args = (dev(rgb_e), dev(rgb0_e), dev(acc.float().reshape(-1)), dev(rgb_r), dev(rgb0_r), dev(tgt_rgb))
+    stats = K.loss_stats(cfg, *args)
+    losses, grads = K.loss_grads(cfg, stats, *args)
+    ref_l = torch.tensor([float(le + lr), float(le), float(lef), float(lec), float(lr), float(lrf), float(lrc), 0.0])
+    report("K6 losses %s C=%d" % (dataset, C), losses, ref_l, atol=1e-7, rtol=2e-5)
+    for nm, got, leaf in zip(("d_rgb_evt", "d_rgb0_evt", "d_rgb_rgb", "d_rgb0_rgb"), grads, leaves):
+        report("K6 %s %s C=%d" % (nm, dataset, C), got, leaf.grad, atol=2e-5 * float(leaf.grad.abs().max()), rtol=1e-3)
+
+
+# ------------------------------------------------------------------------------------ K7
+def test_event_accumulate_golden(K, golden):
+    g = golden("g9_events")
+    rng = np.random.default_rng(909)
+    cam = GI.CAMERAS["e2nerf_real"]
+    ev = GI.synthetic_events(rng, cam, 100000)
+    ev["x"][:5000] = ev["x"][0]
+    ev["y"][:5000] = ev["y"][0]
+    out = K.event_accumulate(dev(ev["x"], torch.int32), dev(ev["y"], torch.int32), dev(ev["pol"]), cam["H"], cam["W"])
+    assert np.array_equal(out.cpu().numpy().astype(np.int16), g["accu"]), "K7 accumulate must be exact"
+    # sorted-on-device window variant == host mask of the reference (inclusive bounds)
+    low, up = 0.3123, 0.5623
+    sel, _ = O.event_window(ev["ts"], low, up - low)
+    ref = O.accumulate_events(cam["H"], cam["W"], ev["x"][sel], ev["y"][sel], ev["pol"][sel])
+    got = K.event_window_accumulate(dev(ev["x"], torch.int32), dev(ev["y"], torch.int32), dev(ev["pol"]), dev(ev["ts"]),
+                                    low, low + (up - low), cam["H"], cam["W"])
+    assert np.array_equal(got.cpu().numpy(), ref.numpy().astype(np.float32)), "K7 window accumulate must be exact"
+    idx = torch.from_numpy(rng.permutation(cam["H"] * cam["W"])[:500])
+    gat = K.gather_rows(out.reshape(-1, 1), dev(idx))
+    assert torch.equal(gat.cpu(), out.cpu().reshape(-1, 1)[idx])
+
+
+# ------------------------------------------------------------------------------------ K8
+def test_adam_golden(K, golden):
+    g = golden("g10_adam")
+    p = dev(g["p0"].copy())
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    lr = 5e-4
+    for step in range(5):
+        K.adam_step(p, dev(g["g_%d" % step]), m, v, lr, step + 1)
+        lr = O.decayed_lr(5e-4, 0.1, step)
+        report("K8 adam step %d" % step, p, g["p_after_%d" % step], atol=2e-7, rtol=2e-6)

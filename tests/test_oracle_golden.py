@@ -1,0 +1,117 @@
+"""CPU: the oracle (oracle/benerf_oracle.py) re-checked against the committed golden vectors
+of the unmodified reference (tests/golden/*.npz, written by oracle/gen_golden.py)."""
+import numpy as np
+import torch
+
+import benerf_oracle as O
+import golden_inputs as GI
+from conftest import report
+
+T = torch.from_numpy
+
+
+def test_g1_spline(golden):
+    g = golden("g1_spline")
+    for ci in range(int(g["n_cases"])):
+        for traj in ("spline", "linear"):
+            tag = "c%02d_%s" % (ci, traj)
+            k = T(g[tag + "_knots"]).requires_grad_(True)
+            tr = T(g[tag + "_transform"]).requires_grad_(True)
+            P = g[tag + "_poses"].shape[0]
+            poses = O.trajectory_poses(k, tr, tuple(g[tag + "_ts"]), P, traj)
+            (poses * T(g[tag + "_G"])).sum().backward()
+            report("G1 poses " + tag, poses, g[tag + "_poses"], atol=1e-7)
+            report("G1 dknots " + tag, k.grad, g[tag + "_dknots"], atol=1e-5, rtol=1e-4)
+            report("G1 dtransform " + tag, tr.grad, g[tag + "_dtransform"], atol=1e-5, rtol=1e-4)
+
+
+def test_g2_rays(golden):
+    g = golden("g2_rays")
+    for cname, cam in GI.CAMERAS.items():
+        poses, idx = T(g[cname + "_poses"]), T(g[cname + "_idx"])
+        K = GI.cam_K(cam)
+        o, d, v = O.make_rays(poses, idx, cam["H"], cam["W"], K, True)
+        report("G2 ndc_o " + cname, o, g[cname + "_ndc_o"], atol=1e-7)
+        report("G2 ndc_d " + cname, d, g[cname + "_ndc_d"], atol=1e-7)
+        report("G2 viewdirs " + cname, v, g[cname + "_viewdirs"], atol=1e-7)
+
+
+def test_g3_posenc(golden):
+    g = golden("g3_posenc")
+    report("G3 pe", O.posenc(T(g["pts"]), 10), g["pe"], atol=1e-7)
+    report("G3 ped", O.posenc(T(g["dirs"]), 4), g["ped"], atol=1e-7)
+
+
+def test_g5_composite(golden):
+    g = golden("g5_composite")
+    for C in (1, 3):
+        raw, z, rd, noise = (T(g["C%d_%s" % (C, k)]) for k in ("raw", "z", "rays_d", "noise"))
+        for noisy in (True, False):
+            tag = "C%d_%s" % (C, "noise" if noisy else "clean")
+            out = O.composite(raw, z, rd, noise if noisy else None, C)
+            for nm, v in zip(("rgb_map", "disp", "acc", "weights", "depth", "sigma"), out):
+                report("G5 %s %s" % (nm, tag), v, g[tag + "_" + nm], atol=1e-7, rtol=1e-6)
+    assert np.isnan(g["C1_noise_disp"][4]), "all-zero-alpha ray must give disp = NaN like the reference"
+
+
+def test_g6_sample_pdf(golden):
+    g = golden("g6_sample_pdf")
+    for kind in ("flat", "peaky", "zero"):
+        for (S, Ni) in ((64, 64), (32, 32), (64, 128)):
+            tag = "%s_S%d_N%d" % (kind, S, Ni)
+            t_rand = T(g[tag + "_t_rand"])
+            z = O.stratified_z(t_rand.shape[0], S, t_rand)
+            bins = 0.5 * (z[..., 1:] + z[..., :-1])
+            s, inds = O.sample_pdf_torch(bins, T(g[tag + "_w"]), T(g[tag + "_u"]))
+            assert np.array_equal(inds.numpy(), g[tag + "_inds"]), tag
+            report("G6 samples " + tag, s, g[tag + "_samples"], atol=1e-7)
+            se, ie, _ = O.sample_pdf_exact(bins.numpy(), g[tag + "_w"], g[tag + "_u"])
+            assert np.array_equal(ie, g[tag + "_inds_exact"]) and np.array_equal(se, g[tag + "_samples_exact"]), tag
+            assert int((ie != g[tag + "_inds"]).sum()) <= 2, "exact restatement may differ from torch only at cdf ties"
+
+
+def test_g7_render(golden):
+    g = golden("g7_render")
+    cam = GI.CAMERAS["unreal"]
+    K = GI.cam_K(cam)
+    ci = 0
+    for C in (1, 3):
+        for (P, Rn) in ((2, 32), (19, 4)):
+            for (S, Ni) in ((16, 16), (64, 64)):
+                rng = np.random.default_rng(707 + ci)
+                tag = "C%d_P%d_S%d" % (C, P, S)
+                ci += 1
+                pc, pf = O.xavier_params(rng, C), O.xavier_params(rng, C)
+                pc["alpha_linear.bias"] += 1.0
+                pf["alpha_linear.bias"] += 1.0
+                GI.knots_init(rng)
+                GI.transform_small(rng)
+                idx = GI.pixel_indices(rng, cam, Rn)
+                draws = GI.render_draws(rng, P * Rn, S, Ni)
+                ret = O.render(pc, pf, T(g[tag + "_poses"]), idx, cam["H"], cam["W"], K, C, S, Ni, draws)
+                for k in ("rgb_map", "rgb0", "acc_map", "sigma"):
+                    report("G7 %s %s" % (k, tag), ret[k], g[tag + "_" + k], atol=2e-6, rtol=1e-5)
+
+
+def test_g9_events(golden):
+    g = golden("g9_events")
+    rng = np.random.default_rng(909)
+    cam = GI.CAMERAS["e2nerf_real"]
+    ev = GI.synthetic_events(rng, cam, 100000)
+    ev["x"][:5000] = ev["x"][0]
+    ev["y"][:5000] = ev["y"][0]
+    acc = O.accumulate_events(cam["H"], cam["W"], ev["x"], ev["y"], ev["pol"])
+    assert np.array_equal(acc.numpy().astype(np.int16), g["accu"])
+
+
+def test_g10_adam(golden):
+    g = golden("g10_adam")
+    p = T(g["p0"].copy())
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    lr = 5e-4
+    for step in range(5):
+        O.adam_update(p, T(g["g_%d" % step]), m, v, step + 1, lr)
+        lr = O.decayed_lr(5e-4, 0.1, step)
+        report("G10 adam %d" % step, p, g["p_after_%d" % step], atol=1e-7, rtol=1e-6)
+    for s in (0, 1, 1000, 80000):
+        assert float(g["lr_%d" % s]) == O.decayed_lr(5e-4, 0.1, s)
