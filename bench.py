@@ -1,0 +1,235 @@
+#!/usr/bin/env python
+"""Training-throughput bench of the BeNeRF hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one full training iteration (train.py:153-394 semantics) on a synthetic batch
+of the BASELINE.json workload (default C2: benerf_unreal/livingroom_gray camera, gray,
+2 x 1024 event rays + 19 x 107 blur rays = 4081 rays, 64 coarse + 128 fine samples):
+trajectory spline -> rays -> PE + coarse MLP -> compositing -> sample_pdf -> PE + fine MLP ->
+compositing -> event + blur loss -> full backward (both MLPs, rays, spline) -> gradient
+all-reduce (N > 1) -> Adam with LR decay -> weight re-pack.  Inputs are resident in HBM when
+the timed region starts.  Data-parallel = weak scaling: every rank renders its own 4081 rays.
+
+Prints ONE JSON line (rank 0) with the metric, the roofline of the dominant kernel (HIP-event
+timed inside the run) and a CPU baseline (the oracle's op-for-op torch-CPU step on a bounded
+sample of the same workload, host cores stated).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X f32 matrix peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="C2")
+    ap.add_argument("--n-events", type=int, default=2_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=0)
+    return ap.parse_args()
+
+
+def build_graph(args_ns, device, seed):
+    """Reference-shaped graph with Xavier-uniform weights drawn from numpy."""
+    from benerf_amd.model import optimize
+    from benerf_amd import kernels as K
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import benerf_oracle as O   # parameter initialiser only (xavier_params); not on the timed path
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    model = optimize.Model(args_ns)
+    model.graph.to(device)
+    g = model.build_network(args_ns)
+    for net in (g.nerf, g.nerf_fine):
+        p = O.xavier_params(rng, args_ns.channels)
+        with torch.no_grad():
+            for name in K.LAYER_NAMES:
+                lin = net
+                for part in name.split("."):
+                    lin = lin[int(part)] if part.isdigit() else getattr(lin, part)
+                lin.weight.copy_(p[name + ".weight"])
+                lin.bias.copy_(p[name + ".bias"])
+    with torch.no_grad():
+        g.evt_knot_pose_se3.params.weight.copy_(torch.from_numpy(rng.uniform(0, 0.01, (4, 6)).astype(np.float32)))
+    return g
+
+
+def cpu_baseline(wl, seed):
+    """Oracle training step (torch CPU, all host cores) on a bounded 1/8 sample of the workload."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import benerf_oracle as O
+    import golden_inputs as GI
+    from benerf_amd import workloads as WL
+    w = WL.WORKLOADS[wl]
+    cam = WL.CAMERAS[w["cam"]]
+    Re, Rr = max(w["Re"] // 8, 8), max(w["Rr"] // 8, 1)
+    C, S, Ni, P = w["channels"], w["S"], w["Ni"], w["n"]
+    rng = np.random.default_rng(seed)
+    cfg = O.StepConfig(H=cam["H"], W=cam["W"], fx=cam["fx"], fy=cam["fy"], cx=cam["cx"], cy=cam["cy"], channels=C,
+                       n_samples=S, n_importance=Ni, n_poses=P, dataset=w["dataset"], threshold=w["threshold"],
+                       window=w["window"])
+    pc = {k: v.requires_grad_(True) for k, v in O.xavier_params(rng, C).items()}
+    pf = {k: v.requires_grad_(True) for k, v in O.xavier_params(rng, C).items()}
+    knots = GI.knots_init(rng).requires_grad_(True)
+    tr = torch.zeros(1, 6, requires_grad=True)
+    params = list(pc.values()) + list(pf.values()) + [knots]
+    state = [(torch.zeros_like(p), torch.zeros_like(p)) for p in params]
+    ev = GI.synthetic_events(rng, cam, 200000)
+    img = torch.from_numpy(rng.random((cam["H"] * cam["W"], C)).astype(np.float32))
+    times = []
+    n_steps = 3
+    for it in range(n_steps + 1):
+        t0 = time.perf_counter()
+        low_t = float(rng.random() * (1 - w["window"]))
+        sel, up = O.event_window(ev["ts"], low_t, w["window"])
+        acc = O.accumulate_events(cam["H"], cam["W"], ev["x"][sel], ev["y"][sel], ev["pol"][sel])
+        idx_e, idx_r = GI.pixel_indices(rng, cam, Re), GI.pixel_indices(rng, cam, Rr)
+        d_e = GI.render_draws(rng, 2 * Re, S, Ni)
+        d_r = GI.render_draws(rng, P * Rr, S, Ni)
+        loss, _ = O.step_loss(cfg, pc, pf, knots, tr, torch.tensor([low_t, up], dtype=torch.float32),
+                              torch.tensor([0.0, 1.0]), idx_e, idx_r, acc.reshape(-1, 1)[idx_e], img[idx_r], d_e, d_r)
+        for p in params:
+            p.grad = None
+        loss.backward()
+        with torch.no_grad():
+            for p, (m, v) in zip(params, state):
+                O.adam_update(p, p.grad, m, v, it + 1, 5e-4)
+        if it > 0:
+            times.append(time.perf_counter() - t0)
+    rays = 2 * Re + P * Rr
+    return {"value": round(rays / (sum(times) / len(times)), 1), "unit": "rays/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": "%d steps of 1/8 of %s (%d rays/step, %d+%d samples), oracle torch-CPU step incl. backward + Adam"
+                      % (n_steps, wl, rays, S, S + Ni)}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    pg = None
+    if world > 1:
+        torch.distributed.init_process_group("nccl", device_id=device)   # RCCL over xGMI
+        pg = torch.distributed.group.WORLD
+
+    from benerf_amd import engine, workloads as WL, kernels as K
+    wl = WL.WORKLOADS[a.workload]
+    cam = WL.CAMERAS[wl["cam"]]
+    args_ns = WL.make_args(a.workload)
+    g = build_graph(args_ns, device, a.seed)     # identical on every rank (same seed)
+    cam_o = engine.Camera(cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+    # weak scaling: every rank renders a full per-GPU batch; the global batch is world x that
+    glob = WL.make_args(a.workload)
+    step = engine.TrainStep(g, glob, cam_o, cam_o, device, world_size=world, rank=rank, process_group=pg, seed=a.seed)
+
+    # ---- synthetic inputs, resident in HBM ------------------------------------------------------------
+    rng = np.random.default_rng(a.seed)
+    HW = cam["H"] * cam["W"]
+    ev_x = torch.from_numpy(rng.integers(0, cam["W"], a.n_events).astype(np.int32)).to(device)
+    ev_y = torch.from_numpy(rng.integers(0, cam["H"], a.n_events).astype(np.int32)).to(device)
+    ev_t = torch.from_numpy(np.sort(rng.random(a.n_events))).to(device)
+    ev_p = torch.from_numpy((rng.integers(0, 2, a.n_events) * 2 - 1).astype(np.float32)).to(device)
+    image = torch.from_numpy(rng.random((HW, wl["channels"])).astype(np.float32)).to(device)
+    rgb_ts = torch.tensor([0.0, 1.0], device=device)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(a.seed + 1234)               # same pixel draws on every rank, sharded by TrainStep
+    accu = torch.zeros((cam["H"], cam["W"]), dtype=torch.float32, device=device)
+    Re_g, Rr_g = wl["Re"] * world, wl["Rr"] * world
+
+    def one_step():
+        low_t = float(rng.random() * (1 - wl["window"]))
+        up_t = low_t + wl["window"]
+        accu.zero_()
+        K.event_window_accumulate(ev_x, ev_y, ev_p, ev_t, low_t, up_t, cam["H"], cam["W"], out=accu)
+        evt_ts = torch.tensor([low_t, up_t], dtype=torch.float32).to(device, non_blocking=True)
+        idx_e = torch.randperm(HW, device=device, generator=gen)[:Re_g]
+        idx_r = torch.randperm(HW, device=device, generator=gen)[:Rr_g]
+        return step.step(evt_ts, rgb_ts, idx_e, idx_r, accu.view(-1), image)
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        one_step()
+    K.TIMERS.enabled = True
+    K.TIMERS.records.clear()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        losses = one_step()
+    sync()
+    dt = time.perf_counter() - t0
+    K.TIMERS.enabled = False
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    rays_step = WL.rays_per_step(a.workload) * world
+    ms_step = dt / a.steps * 1e3
+    value = rays_step / (dt / a.steps)
+
+    # ---- roofline of the dominant kernel, from the HIP-event brackets of the timed region ---------------------
+    fpp = WL.mlp_flops_per_point(wl["channels"])
+    summ = K.TIMERS.summary()
+    roof = None
+    kern = {}
+    for name, (n, ms, pts) in summ.items():
+        # algorithmic flops: fwd = fpp/point; dx chain = fpp/point; dW = fpp/point (training = 3 x fwd)
+        tf = pts * fpp / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        kern[name] = {"launches": n, "avg_ms": round(ms / n, 4), "tflops": round(tf, 2)}
+    if kern:
+        dom = max(summ.items(), key=lambda kv: kv[1][1])[0]
+        ach = kern[dom]["tflops"]
+        roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "avg_launch_ms": kern[dom]["avg_ms"], "per_kernel": kern}
+    mlp_ms = sum(v[1] for v in summ.values()) / a.steps if summ else None
+
+    out = {
+        "metric": "training rays/s", "value": round(value, 1), "unit": "rays/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s: %s" % (a.workload, wl["name"]), "rays_per_step_per_gpu": WL.rays_per_step(a.workload),
+                   "samples": "%d+%d" % (wl["S"], wl["S"] + wl["Ni"]), "channels": wl["channels"],
+                   "parallelism": "dp%d" % world, "mlp_ms_per_step": None if mlp_ms is None else round(mlp_ms, 3),
+                   "step_tflops_algorithmic": round(rays_step / world * (wl["S"] + wl["S"] + wl["Ni"]) * fpp * 3 /
+                                                    (dt / a.steps) / 1e12, 2),
+                   "final_loss": float(losses[0])},
+        "roofline": roof,
+    }
+    if rank == 0:
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.workload, a.seed)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

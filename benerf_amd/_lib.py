@@ -33,8 +33,8 @@ P = c_void_p
 _SIGNATURES = {
     "benerf_version": (c_int, []),
     "benerf_last_error": (c_char_p, []),
-    "benerf_spline_poses_fwd": (c_int, [P, P, P, c_int, c_int, P, P]),
-    "benerf_spline_poses_bwd": (c_int, [P, P, P, c_int, c_int, P, P, P, P]),
+    "benerf_spline_poses_fwd": (c_int, [P, P, P, c_int, c_int, c_int, P, P]),
+    "benerf_spline_poses_bwd": (c_int, [P, P, P, c_int, c_int, c_int, P, P, P, P]),
     "benerf_rays_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_int, P, P, P, P]),
     "benerf_rays_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_int, P, P, P, P, P]),
     "benerf_stratified_z": (c_int, [c_int, c_int, c_float, c_float, P, c_uint64, c_uint64, P, P]),
@@ -47,10 +47,18 @@ _SIGNATURES = {
     "benerf_mlp_fwd": (c_int, [POINTER(MlpParams), P, c_int, c_int, c_int, P, P, P, P, P, P, P]),
     "benerf_mlp_bwd": (c_int, [POINTER(MlpParams), P, c_int, c_int, c_int, P, P, P, P, c_size_t, POINTER(MlpGrads),
                                c_int, P, P, P]),
+    "benerf_mlp_bwd_dx": (c_int, [POINTER(MlpParams), P, c_int, c_int, c_int, P, P, P, P, P, P]),
+    "benerf_mlp_bwd_dw": (c_int, [c_int, c_int, c_int, P, P, P, P, c_size_t, POINTER(MlpGrads), c_int, P]),
     "benerf_composite_fwd": (c_int, [P, P, P, P, c_float, c_uint64, c_uint64, c_int, c_int, c_int, P, P, P, P, P, P, P]),
     "benerf_composite_bwd": (c_int, [P, P, P, P, c_float, c_uint64, c_uint64, c_int, c_int, c_int, P, P, P, P, P, P,
                                      c_int, P]),
     "benerf_sample_pdf_merge": (c_int, [P, P, P, c_uint64, c_uint64, c_int, c_int, c_int, P, P, P, P]),
+    "benerf_sample_pdf": (c_int, [P, P, P, c_uint64, c_uint64, c_int, c_int, c_int, P, P, P]),
+    "benerf_pixel_rays": (c_int, [P, c_int, P, P, c_int64, c_float, c_float, c_float, c_float, P, P, P]),
+    "benerf_ndc_rays": (c_int, [c_int, c_int, c_float, c_float, P, P, c_int64, P, P, P]),
+    "benerf_posenc": (c_int, [P, c_int64, c_int, c_int, c_int, P, P]),
+    "benerf_mse_fwd": (c_int, [P, P, c_int64, P, P]),
+    "benerf_mse_bwd": (c_int, [P, P, c_int64, P, P, P, P]),
     "benerf_loss_stats": (c_int, [POINTER(LossCfg), P, P, P, P, P, P, P, P]),
     "benerf_loss_grads": (c_int, [POINTER(LossCfg), P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "benerf_event_accumulate": (c_int, [P, P, P, c_int64, c_int, c_int, P, P]),

@@ -335,20 +335,8 @@ int benerf_mlp_dw_launch(const BenerfMlpParams* params, int channels, int64_t M,
                          const float* dacts, float* dw_ws, const BenerfMlpGrads* grads, int accumulate,
                          hipStream_t stream);
 
-extern "C" int benerf_mlp_bwd(const BenerfMlpParams* params, const float* packed, int channels, int n_rays,
-                              int n_samples, const float* d_raw, const float* acts, float* dacts, float* dw_ws,
-                              size_t dw_ws_floats, const BenerfMlpGrads* grads, int accumulate, float* d_pts,
-                              float* d_vdir_pts, benerf_stream_t stream) {
-    BENERF_REQUIRE(params && packed && d_raw && acts && dacts && dw_ws && grads && d_pts && d_vdir_pts,
-                   "mlp_bwd: null pointer");
-    BENERF_REQUIRE(channels == 1 || channels == 3, "mlp_bwd: channels must be 1 or 3");
-    BENERF_REQUIRE(n_rays > 0 && n_samples > 0, "mlp_bwd: bad sizes");
-    if (dw_ws_floats < (size_t)mlp::DW_WS_FLOATS) {
-        benerf_set_error("mlp_bwd: dw workspace too small (%zu < %lld floats)", dw_ws_floats, (long long)mlp::DW_WS_FLOATS);
-        return BENERF_EWORKSPACE;
-    }
-    for (int l = 0; l < BENERF_NLAYERS; ++l)
-        BENERF_REQUIRE(params->w[l] && params->b[l] && grads->w[l] && grads->b[l], "mlp_bwd: null parameter/grad %d", l);
+static int launch_dx(const BenerfMlpParams* params, const float* packed, int channels, int64_t M, const float* d_raw,
+                     const float* acts, float* dacts, float* d_pts, float* d_vdir_pts, hipStream_t stream) {
     BwdArgs a;
     a.d_raw = d_raw;
     a.acts = acts;
@@ -359,8 +347,8 @@ extern "C" int benerf_mlp_bwd(const BenerfMlpParams* params, const float* packed
     a.w_rgb = params->w[BENERF_L_RGB];
     a.d_pts = d_pts;
     a.d_vdir = d_vdir_pts;
-    a.M = (int64_t)n_rays * n_samples;
-    const int64_t tiles = (a.M + mlp::TM - 1) / mlp::TM;
+    a.M = M;
+    const int64_t tiles = (M + mlp::TM - 1) / mlp::TM;
     BENERF_REQUIRE(tiles < (1ll << 31), "mlp_bwd: too many points");
     dim3 grid((unsigned)tiles), block(mlp::NTHREADS);
     static bool attr_done = false;
@@ -369,8 +357,43 @@ extern "C" int benerf_mlp_bwd(const BenerfMlpParams* params, const float* packed
         (void)hipFuncSetAttribute((const void*)mlp_bwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_SMEM);
         attr_done = true;
     }
-    if (channels == 1) hipLaunchKernelGGL((mlp_bwd_kernel<1>), grid, block, BWD_SMEM, as_stream(stream), a);
-    else hipLaunchKernelGGL((mlp_bwd_kernel<3>), grid, block, BWD_SMEM, as_stream(stream), a);
+    if (channels == 1) hipLaunchKernelGGL((mlp_bwd_kernel<1>), grid, block, BWD_SMEM, stream, a);
+    else hipLaunchKernelGGL((mlp_bwd_kernel<3>), grid, block, BWD_SMEM, stream, a);
     BENERF_LAUNCH_CHECK("mlp_bwd(dx)");
-    return benerf_mlp_dw_launch(params, channels, a.M, d_raw, acts, dacts, dw_ws, grads, accumulate, as_stream(stream));
+    return BENERF_OK;
+}
+
+extern "C" int benerf_mlp_bwd_dx(const BenerfMlpParams* params, const float* packed, int channels, int n_rays,
+                                 int n_samples, const float* d_raw, const float* acts, float* dacts, float* d_pts,
+                                 float* d_vdir_pts, benerf_stream_t stream) {
+    BENERF_REQUIRE(params && packed && d_raw && acts && dacts && d_pts && d_vdir_pts, "mlp_bwd_dx: null pointer");
+    BENERF_REQUIRE(channels == 1 || channels == 3, "mlp_bwd_dx: channels must be 1 or 3");
+    BENERF_REQUIRE(n_rays > 0 && n_samples > 0, "mlp_bwd_dx: bad sizes");
+    for (int l = 0; l < BENERF_NLAYERS; ++l) BENERF_REQUIRE(params->w[l], "mlp_bwd_dx: null parameter %d", l);
+    return launch_dx(params, packed, channels, (int64_t)n_rays * n_samples, d_raw, acts, dacts, d_pts, d_vdir_pts,
+                     as_stream(stream));
+}
+
+extern "C" int benerf_mlp_bwd_dw(int channels, int n_rays, int n_samples, const float* d_raw, const float* acts,
+                                 const float* dacts, float* dw_ws, size_t dw_ws_floats, const BenerfMlpGrads* grads,
+                                 int accumulate, benerf_stream_t stream) {
+    BENERF_REQUIRE(d_raw && acts && dacts && dw_ws && grads, "mlp_bwd_dw: null pointer");
+    BENERF_REQUIRE(channels == 1 || channels == 3, "mlp_bwd_dw: channels must be 1 or 3");
+    BENERF_REQUIRE(n_rays > 0 && n_samples > 0, "mlp_bwd_dw: bad sizes");
+    if (dw_ws_floats < (size_t)mlp::DW_WS_FLOATS) {
+        benerf_set_error("mlp_bwd_dw: dw workspace too small (%zu < %lld floats)", dw_ws_floats, (long long)mlp::DW_WS_FLOATS);
+        return BENERF_EWORKSPACE;
+    }
+    for (int l = 0; l < BENERF_NLAYERS; ++l) BENERF_REQUIRE(grads->w[l] && grads->b[l], "mlp_bwd_dw: null grad %d", l);
+    return benerf_mlp_dw_launch(nullptr, channels, (int64_t)n_rays * n_samples, d_raw, acts, dacts, dw_ws, grads, accumulate,
+                                as_stream(stream));
+}
+
+extern "C" int benerf_mlp_bwd(const BenerfMlpParams* params, const float* packed, int channels, int n_rays,
+                              int n_samples, const float* d_raw, const float* acts, float* dacts, float* dw_ws,
+                              size_t dw_ws_floats, const BenerfMlpGrads* grads, int accumulate, float* d_pts,
+                              float* d_vdir_pts, benerf_stream_t stream) {
+    int rc = benerf_mlp_bwd_dx(params, packed, channels, n_rays, n_samples, d_raw, acts, dacts, d_pts, d_vdir_pts, stream);
+    if (rc != BENERF_OK) return rc;
+    return benerf_mlp_bwd_dw(channels, n_rays, n_samples, d_raw, acts, dacts, dw_ws, dw_ws_floats, grads, accumulate, stream);
 }

@@ -309,10 +309,10 @@ extern "C" int benerf_mlp_fwd(const BenerfMlpParams* params, const float* packed
     dim3 grid((unsigned)tiles), block(mlp::NTHREADS);
     static bool attr_done = false;
     if (!attr_done) {
-        hipFuncSetAttribute((const void*)mlp_fwd_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD_SMEM);
-        hipFuncSetAttribute((const void*)mlp_fwd_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD_SMEM);
-        hipFuncSetAttribute((const void*)mlp_fwd_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD_SMEM);
-        hipFuncSetAttribute((const void*)mlp_fwd_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD_SMEM);
+        (void)hipFuncSetAttribute((const void*)mlp_fwd_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD_SMEM);
+        (void)hipFuncSetAttribute((const void*)mlp_fwd_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD_SMEM);
+        (void)hipFuncSetAttribute((const void*)mlp_fwd_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD_SMEM);
+        (void)hipFuncSetAttribute((const void*)mlp_fwd_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD_SMEM);
         attr_done = true;
     }
     if (channels == 1) {

@@ -250,7 +250,8 @@ __device__ void linear_pose(const T k0[6], const T k3[6], float u, T out[12]) { 
 }
 
 __global__ void spline_fwd_kernel(const float* __restrict__ knots, const float* __restrict__ transform,
-                                  const float* __restrict__ ts2, int n_poses, int traj, float* __restrict__ poses) {
+                                  const float* __restrict__ ts2, int n_poses, int traj, int explicit_ts,
+                                  float* __restrict__ poses) {
     int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_poses) return;
     float k[4][6];
@@ -258,7 +259,7 @@ __global__ void spline_fwd_kernel(const float* __restrict__ knots, const float* 
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 6; ++j) k[i][j] = knots[i * 6 + j] + (transform ? transform[j] : 0.f);
-    float u = nudge(linspace_at(ts2[0], ts2[1], n_poses, p));
+    float u = nudge(explicit_ts ? ts2[p] : linspace_at(ts2[0], ts2[1], n_poses, p));
     float out[12];
     if (traj == 1)
         linear_pose(k[0], k[3], u, out);
@@ -271,7 +272,7 @@ __global__ void spline_fwd_kernel(const float* __restrict__ knots, const float* 
 // one block; thread (p, j): tangent of pose p w.r.t. effective-knot coefficient j (0..23);
 // contrib[p][j] = <d_poses[p], tangent>; then j-threads sum over p in index order.
 __global__ void spline_bwd_kernel(const float* __restrict__ knots, const float* __restrict__ transform,
-                                  const float* __restrict__ ts2, int n_poses, int traj,
+                                  const float* __restrict__ ts2, int n_poses, int traj, int explicit_ts,
                                   const float* __restrict__ d_poses, float* __restrict__ d_knots,
                                   float* __restrict__ d_transform) {
     extern __shared__ float contrib[];   // [n_poses][24]
@@ -283,7 +284,7 @@ __global__ void spline_bwd_kernel(const float* __restrict__ knots, const float* 
 #pragma unroll
             for (int c = 0; c < 6; ++c)
                 k[i][c] = Dual{knots[i * 6 + c] + (transform ? transform[c] : 0.f), (i * 6 + c == j) ? 1.f : 0.f};
-        float u = nudge(linspace_at(ts2[0], ts2[1], n_poses, p));
+        float u = nudge(explicit_ts ? ts2[p] : linspace_at(ts2[0], ts2[1], n_poses, p));
         Dual out[12];
         if (traj == 1)
             linear_pose(k[0], k[3], u, out);
@@ -311,24 +312,24 @@ __global__ void spline_bwd_kernel(const float* __restrict__ knots, const float* 
 }  // namespace
 
 extern "C" int benerf_spline_poses_fwd(const float* knots, const float* transform, const float* ts2, int n_poses,
-                                       int traj, float* poses, benerf_stream_t stream) {
+                                       int traj, int explicit_ts, float* poses, benerf_stream_t stream) {
     BENERF_REQUIRE(knots && ts2 && poses, "spline_poses_fwd: null pointer");
     BENERF_REQUIRE(n_poses > 0 && (traj == 0 || traj == 1), "spline_poses_fwd: bad n_poses/traj");
     int threads = 64, blocks = (n_poses + threads - 1) / threads;
     hipLaunchKernelGGL(spline_fwd_kernel, dim3(blocks), dim3(threads), 0, as_stream(stream), knots, transform, ts2,
-                       n_poses, traj, poses);
+                       n_poses, traj, explicit_ts, poses);
     BENERF_LAUNCH_CHECK("spline_poses_fwd");
     return BENERF_OK;
 }
 
 extern "C" int benerf_spline_poses_bwd(const float* knots, const float* transform, const float* ts2, int n_poses,
-                                       int traj, const float* d_poses, float* d_knots, float* d_transform,
-                                       benerf_stream_t stream) {
+                                       int traj, int explicit_ts, const float* d_poses, float* d_knots,
+                                       float* d_transform, benerf_stream_t stream) {
     BENERF_REQUIRE(knots && ts2 && d_poses && d_knots, "spline_poses_bwd: null pointer");
     BENERF_REQUIRE(n_poses > 0 && n_poses <= 512 && (traj == 0 || traj == 1), "spline_poses_bwd: n_poses must be in [1,512]");
     size_t smem = (size_t)n_poses * 24 * sizeof(float);
     hipLaunchKernelGGL(spline_bwd_kernel, dim3(1), dim3(256), smem, as_stream(stream), knots, transform, ts2, n_poses,
-                       traj, d_poses, d_knots, d_transform);
+                       traj, explicit_ts, d_poses, d_knots, d_transform);
     BENERF_LAUNCH_CHECK("spline_poses_bwd");
     return BENERF_OK;
 }

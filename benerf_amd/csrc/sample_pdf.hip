@@ -20,8 +20,10 @@ constexpr int WAVES = 4;
 
 __global__ void sample_pdf_merge_kernel(const float* __restrict__ z_coarse, const float* __restrict__ weights,
                                         const float* __restrict__ u_in, uint64_t seed, uint64_t offset, int n_rays,
-                                        int S, int Ni, float* __restrict__ z_fine, float* __restrict__ z_samples,
-                                        int64_t* __restrict__ inds_out) {
+                                        int S, int Ni, int bins_mode, float* __restrict__ z_fine,
+                                        float* __restrict__ z_samples, int64_t* __restrict__ inds_out) {
+    // bins_mode: z_coarse is `bins` [n_rays,S-1... given as B = S-1 columns], weights is [n_rays,B-1]
+    // (already sliced, run_nerf_helpers.sample_pdf's own signature); no merge, samples only.
     extern __shared__ float smem[];
     const int B = S - 1, F = S + Ni;
     const int per_wave = 2 * B + F;
@@ -32,13 +34,19 @@ __global__ void sample_pdf_merge_kernel(const float* __restrict__ z_coarse, cons
     float* cdf = smem + wave * per_wave;
     float* bins = cdf + B;
     float* vals = bins + B;
-    const float* zr = z_coarse + ray * S;
-    const float* wr = weights + ray * S;
-
-    for (int k = lane; k < B; k += 64) bins[k] = 0.5f * (zr[k + 1] + zr[k]);
-    for (int k = lane; k < S; k += 64) vals[k] = zr[k];
-    // stage w' = weights[1:-1] + 1e-5 in cdf[1..B-1] (B-1 = S-2 values)
-    for (int k = lane; k < B - 1; k += 64) cdf[k + 1] = wr[k + 1] + 1e-5f;
+    if (bins_mode) {
+        const float* br = z_coarse + ray * B;
+        const float* wr = weights + ray * (B - 1);
+        for (int k = lane; k < B; k += 64) bins[k] = br[k];
+        for (int k = lane; k < B - 1; k += 64) cdf[k + 1] = wr[k] + 1e-5f;
+    } else {
+        const float* zr = z_coarse + ray * S;
+        const float* wr = weights + ray * S;
+        for (int k = lane; k < B; k += 64) bins[k] = 0.5f * (zr[k + 1] + zr[k]);
+        for (int k = lane; k < S; k += 64) vals[k] = zr[k];
+        // stage w' = weights[1:-1] + 1e-5 in cdf[1..B-1] (B-1 = S-2 values)
+        for (int k = lane; k < B - 1; k += 64) cdf[k + 1] = wr[k + 1] + 1e-5f;
+    }
     __syncthreads();
     if (lane == 0) {
         double tot = 0.0;
@@ -77,7 +85,7 @@ __global__ void sample_pdf_merge_kernel(const float* __restrict__ z_coarse, cons
         if (active && inds_out) inds_out[ray * Ni + q] = ind;
     }
     __syncthreads();
-    if (!active) return;
+    if (!active || bins_mode) return;
 
     // rank sort (values only): rank = #less + #equal-with-lower-index
     float* out = z_fine + ray * F;
@@ -105,7 +113,23 @@ extern "C" int benerf_sample_pdf_merge(const float* z_coarse, const float* weigh
     BENERF_REQUIRE(smem <= 64 * 1024, "sample_pdf_merge: sample counts too large for LDS scratch");
     dim3 grid((n_rays + WAVES - 1) / WAVES), block(64 * WAVES);
     hipLaunchKernelGGL(sample_pdf_merge_kernel, grid, block, smem, as_stream(stream), z_coarse, weights, u, seed, offset,
-                       n_rays, n_samples, n_importance, z_fine, z_samples, inds);
+                       n_rays, n_samples, n_importance, 0, z_fine, z_samples, inds);
     BENERF_LAUNCH_CHECK("sample_pdf_merge");
+    return BENERF_OK;
+}
+
+extern "C" int benerf_sample_pdf(const float* bins, const float* weights, const float* u, uint64_t seed, uint64_t offset,
+                                 int n_rays, int n_bins, int n_draws, float* samples, int64_t* inds,
+                                 benerf_stream_t stream) {
+    BENERF_REQUIRE(bins && weights && samples, "sample_pdf: null pointer");
+    BENERF_REQUIRE(n_rays > 0 && n_bins >= 2 && n_bins <= 1024 && n_draws > 0 && n_draws <= 1024,
+                   "sample_pdf: need 2 <= n_bins <= 1024, 0 < n_draws <= 1024");
+    int S = n_bins + 1, F = S + n_draws;
+    size_t smem = (size_t)WAVES * (2 * n_bins + F) * sizeof(float);
+    BENERF_REQUIRE(smem <= 64 * 1024, "sample_pdf: sizes too large for LDS scratch");
+    dim3 grid((n_rays + WAVES - 1) / WAVES), block(64 * WAVES);
+    hipLaunchKernelGGL(sample_pdf_merge_kernel, grid, block, smem, as_stream(stream), bins, weights, u, seed, offset,
+                       n_rays, S, n_draws, 1, (float*)nullptr, samples, inds);
+    BENERF_LAUNCH_CHECK("sample_pdf");
     return BENERF_OK;
 }

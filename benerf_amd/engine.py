@@ -1,0 +1,387 @@
+"""Kernel sequencing for the BeNeRF hot path on one MI355X.
+
+Two entry styles over the SAME HIP kernels (benerf_amd.kernels -> C ABI):
+
+  * autograd Functions (`SplinePoses`, `RenderRays`): make the reference's
+    `graph.render(...)` / `graph.get_pose_*` + `loss.backward()` + torch.optim flow work
+    unchanged (model/nerf.py:236-343, model/optimize.py:58-111, train.py:340-352);
+  * `TrainStep`: the lean fixed-shape training iteration (no autograd graph, flat parameter
+    / gradient / Adam buffers, event + blur rays batched into one launch sequence, in-kernel
+    Philox draws).  This is what bench.py measures and what data-parallel training uses
+    (one process per GPU, one RCCL all-reduce of the flat gradient buffer per step).
+
+Random draws follow the reference order per render: stratified jitter,
+sigma noise (coarse), importance u, sigma noise (fine).
+"""
+import math
+
+import torch
+
+from . import dist
+from . import kernels as K
+
+NOISE_STD_DEFAULT = 1.0   # NeRF.raw2output default, never overridden by the reference (model/nerf.py:118)
+
+
+class Camera:
+    __slots__ = ("H", "W", "fx", "fy", "cx", "cy")
+
+    def __init__(self, H, W, fx, fy, cx, cy):
+        self.H, self.W = int(H), int(W)
+        self.fx, self.fy, self.cx, self.cy = float(fx), float(fy), float(cx), float(cy)
+
+    @staticmethod
+    def from_K(H, W, Kmat):
+        return Camera(H, W, float(Kmat[0][0]), float(Kmat[1][1]), float(Kmat[0][2]), float(Kmat[1][2]))
+
+
+class Draws:
+    """Random inputs of one render: explicit tensors (parity mode) or Philox (seed, offsets)."""
+
+    def __init__(self, t_rand=None, noise0=None, u=None, noise1=None, seed=0, offset=0, noise_std=NOISE_STD_DEFAULT):
+        self.t_rand, self.noise0, self.u, self.noise1 = t_rand, noise0, u, noise1
+        self.seed, self.offset, self.noise_std = int(seed), int(offset), float(noise_std)
+
+    def noise_args(self, which):
+        t = self.noise0 if which == 0 else self.noise1
+        if t is not None:
+            return t, 0.0, 0, 0
+        return None, self.noise_std, self.seed, self.offset * 4 + (1 if which == 0 else 3)
+
+    def jitter_args(self):
+        return self.t_rand, self.seed, self.offset * 4 + 0
+
+    def u_args(self):
+        return self.u, self.seed, self.offset * 4 + 2
+
+
+# ------------------------------------------------------------------------------------------
+# autograd glue
+# ------------------------------------------------------------------------------------------
+class SplinePoses(torch.autograd.Function):
+    """(knots [4,6], transform [1,6] | None, ts) -> poses [P,3,4]   (K1)"""
+
+    @staticmethod
+    def forward(ctx, knots, transform, ts, n_poses, traj, explicit_ts):
+        knots_c = knots.detach().contiguous()
+        tr_c = None if transform is None else transform.detach().reshape(6).contiguous()
+        ts_c = ts.detach().to(device=knots.device, dtype=torch.float32).contiguous()
+        ctx.save_for_backward(knots_c, tr_c, ts_c)
+        ctx.cfg = (n_poses, traj, explicit_ts, None if transform is None else transform.shape)
+        return K.spline_poses_fwd(knots_c, tr_c, ts_c, n_poses, traj, explicit_ts)
+
+    @staticmethod
+    def backward(ctx, d_poses):
+        knots, tr, ts = ctx.saved_tensors
+        n_poses, traj, explicit_ts, tr_shape = ctx.cfg
+        d_knots, d_tr = K.spline_poses_bwd(knots, tr, ts, n_poses, traj, d_poses.contiguous(), explicit_ts)
+        if d_tr is not None:
+            d_tr = d_tr.reshape(tr_shape)
+        return d_knots, d_tr, None, None, None, None
+
+
+def _render_forward(cam, ndc, n_samples, n_importance, draws, poses, ray_idx, net_c, net_f, save):
+    """Shared forward kernel sequence of Graph.render.  Returns (outputs dict, saved dict)."""
+    ro, rd, vd = K.rays_fwd(poses, ray_idx, cam.H, cam.W, cam.fx, cam.fy, cam.cx, cam.cy, ndc)
+    n_rays = ro.shape[0]
+    t_rand, seed, off = draws.jitter_args()
+    z = K.stratified_z(n_rays, n_samples, ro.device, t_rand, seed, off)
+    raw0, acts0 = K.mlp_fwd(net_c, ro, rd, vd, z, save)
+    nz0 = draws.noise_args(0)
+    want0 = ("rgb_map", "disp", "acc", "weights") if n_importance > 0 else ("rgb_map", "disp", "acc", "sigma")
+    c0 = K.composite_fwd(raw0, z, rd, nz0[0], nz0[1], nz0[2], nz0[3], want=want0)
+    out = {"rgb_map": c0["rgb_map"], "disp_map": c0["disp"], "acc_map": c0["acc"]}
+    saved = {"ro": ro, "rd": rd, "vd": vd, "z": z, "raw0": raw0, "acts0": acts0}
+    if n_importance > 0:
+        u, useed, uoff = draws.u_args()
+        z_fine = K.sample_pdf_merge(z, c0["weights"], n_importance, u, useed, uoff)
+        raw1, acts1 = K.mlp_fwd(net_f, ro, rd, vd, z_fine, save)
+        nz1 = draws.noise_args(1)
+        c1 = K.composite_fwd(raw1, z_fine, rd, nz1[0], nz1[1], nz1[2], nz1[3], want=("rgb_map", "disp", "acc", "sigma"))
+        out = {"rgb_map": c1["rgb_map"], "disp_map": c1["disp"], "acc_map": c1["acc"], "rgb0": c0["rgb_map"],
+               "disp0": c0["disp"], "acc0": c0["acc"], "sigma": c1["sigma"]}
+        saved.update({"z_fine": z_fine, "raw1": raw1, "acts1": acts1})
+    else:
+        out["sigma"] = c0["sigma"]
+    return out, saved
+
+
+def _render_backward(cam, ndc, draws, poses, ray_idx, net_c, net_f, saved, g, grads_c, grads_f, accumulate):
+    """Backward kernel sequence.  g: dict of upstream grads (rgb_map, acc_map, disp_map, rgb0, acc0,
+    disp0; missing = zero).  grads_c/f: (list_w, list_b) written (or accumulated into).
+    Returns d_poses [P,3,4]."""
+    ro, rd, vd, z = saved["ro"], saved["rd"], saved["vd"], saved["z"]
+    n_rays = ro.shape[0]
+    dev = ro.device
+    d_o = torch.zeros((n_rays, 3), dtype=torch.float32, device=dev)
+    d_d = torch.empty((n_rays, 3), dtype=torch.float32, device=dev)   # first written by composite_bwd
+    d_v = torch.zeros((n_rays, 3), dtype=torch.float32, device=dev)
+    fine = "raw1" in saved
+
+    def zeros_like_rgb(t):
+        return torch.zeros_like(t)
+
+    first = True
+    if fine:
+        nz1 = draws.noise_args(1)
+        g_rgb = g.get("rgb_map")
+        if g_rgb is None:
+            g_rgb = zeros_like_rgb(saved["raw1"][:, 0, :-1]).contiguous()
+        d_raw1, _ = K.composite_bwd(saved["raw1"], saved["z_fine"], rd, nz1[0], nz1[1], nz1[2], nz1[3], g_rgb,
+                                    g.get("acc_map"), None, g.get("disp_map"), d_rays_d=d_d, accumulate=False)
+        d_pts, d_vp = K.mlp_bwd(net_f, d_raw1.reshape(-1, d_raw1.shape[-1]), saved["acts1"], n_rays,
+                                saved["z_fine"].shape[1], grads_f[0], grads_f[1], accumulate)
+        # d_d already holds the ||rays_d|| term of the fine compositing: accumulate on top of it
+        K.ray_grad_reduce(saved["z_fine"], d_pts, d_vp, d_o, d_d, d_v, True)
+        first = False
+        g_rgb0, g_acc0, g_disp0 = g.get("rgb0"), g.get("acc0"), g.get("disp0")
+    else:
+        g_rgb0, g_acc0, g_disp0 = g.get("rgb_map"), g.get("acc_map"), g.get("disp_map")
+    nz0 = draws.noise_args(0)
+    if g_rgb0 is None:
+        g_rgb0 = zeros_like_rgb(saved["raw0"][:, 0, :-1]).contiguous()
+    d_raw0, _ = K.composite_bwd(saved["raw0"], z, rd, nz0[0], nz0[1], nz0[2], nz0[3], g_rgb0, g_acc0, None, g_disp0,
+                                d_rays_d=d_d, accumulate=not first)
+    d_pts, d_vp = K.mlp_bwd(net_c, d_raw0.reshape(-1, d_raw0.shape[-1]), saved["acts0"], n_rays, z.shape[1],
+                            grads_c[0], grads_c[1], accumulate)
+    K.ray_grad_reduce(z, d_pts, d_vp, d_o, d_d, d_v, True)
+    return K.rays_bwd(poses, ray_idx, cam.H, cam.W, cam.fx, cam.fy, cam.cx, cam.cy, ndc, d_o, d_d, d_v)
+
+
+class RenderRays(torch.autograd.Function):
+    """Graph.render as ONE autograd node (model/nerf.py:236-343).
+
+    inputs: poses [P,3,4], then the 24 coarse and 24 fine parameter tensors (weights then
+    biases, reference state-dict order).  outputs: rgb_map, disp_map, acc_map, rgb0, disp0,
+    acc0, sigma (sigma is not differentiable here - it is never used in a loss)."""
+
+    @staticmethod
+    def forward(ctx, poses, ray_idx, cam, ndc, n_samples, n_importance, draws, net_c, net_f, *params):
+        poses_c = poses.detach().contiguous()
+        need_grad = any(ctx.needs_input_grad)
+        net_c.pack_if_stale()
+        if net_f is not None:
+            net_f.pack_if_stale()
+        out, saved = _render_forward(cam, ndc, n_samples, n_importance, draws, poses_c, ray_idx, net_c, net_f, need_grad)
+        ctx.cam, ctx.ndc, ctx.draws, ctx.net_c, ctx.net_f = cam, ndc, draws, net_c, net_f
+        ctx.poses, ctx.ray_idx, ctx.saved_k = poses_c, ray_idx, saved if need_grad else None
+        ctx.fine = n_importance > 0
+        ctx.mark_non_differentiable(out["sigma"])
+        if ctx.fine:
+            return (out["rgb_map"], out["disp_map"], out["acc_map"], out["rgb0"], out["disp0"], out["acc0"], out["sigma"])
+        return (out["rgb_map"], out["disp_map"], out["acc_map"], out["sigma"])
+
+    @staticmethod
+    def backward(ctx, *gs):
+        def c(t):
+            return None if t is None else t.contiguous()
+
+        if ctx.fine:
+            g = {"rgb_map": c(gs[0]), "disp_map": c(gs[1]), "acc_map": c(gs[2]), "rgb0": c(gs[3]), "disp0": c(gs[4]),
+                 "acc0": c(gs[5])}
+        else:
+            g = {"rgb_map": c(gs[0]), "disp_map": c(gs[1]), "acc_map": c(gs[2])}
+        net_c, net_f = ctx.net_c, ctx.net_f
+        gc = ([torch.empty_like(w) for w in net_c.weights], [torch.empty_like(b) for b in net_c.biases])
+        gf = (None, None)
+        if net_f is not None:
+            gf = ([torch.empty_like(w) for w in net_f.weights], [torch.empty_like(b) for b in net_f.biases])
+        d_poses = _render_backward(ctx.cam, ctx.ndc, ctx.draws, ctx.poses, ctx.ray_idx, net_c, net_f, ctx.saved_k, g,
+                                   gc, gf, False)
+        ctx.saved_k = None
+        grads = list(gc[0]) + list(gc[1])
+        if net_f is not None:
+            grads += list(gf[0]) + list(gf[1])
+        return (d_poses, None, None, None, None, None, None, None, None) + tuple(grads)
+
+
+# ------------------------------------------------------------------------------------------
+# lean fixed-shape training step
+# ------------------------------------------------------------------------------------------
+class FlatNet:
+    """One NeRF's 24 parameter tensors re-homed into flat fp32 buffers (param, grad, Adam m/v).
+    The nn.Parameters keep their names/shapes (checkpoint compatible) but alias the flat
+    storage, so the fused Adam (K8) and the gradient all-reduce see one contiguous range."""
+
+    def __init__(self, weights, biases, channels, flat_param, flat_grad, offset):
+        self.views_w, self.views_b, self.gviews_w, self.gviews_b = [], [], [], []
+        o = offset
+        for lst, vl, gl in ((weights, self.views_w, self.gviews_w), (biases, self.views_b, self.gviews_b)):
+            for t in lst:
+                n = t.numel()
+                v = flat_param[o:o + n].view(t.shape)
+                v.copy_(t.detach())
+                if isinstance(t, torch.nn.Parameter) or t.requires_grad:
+                    t.data = v
+                vl.append(v)
+                gl.append(flat_grad[o:o + n].view(t.shape))
+                o += n
+        self.end = o
+        self.packed = K.PackedMlp(self.views_w, self.views_b, channels)
+
+
+def nerf_param_lists(module):
+    """(weights, biases) of a NeRF module in C-ABI order."""
+    ws = [getattr_path(module, n).weight for n in K.LAYER_NAMES]
+    bs = [getattr_path(module, n).bias for n in K.LAYER_NAMES]
+    return ws, bs
+
+
+def getattr_path(obj, dotted):
+    for part in dotted.split("."):
+        obj = obj[int(part)] if part.isdigit() else getattr(obj, part)
+    return obj
+
+
+class TrainStep:
+    """One full training iteration (train.py:153-394 semantics) as a fixed kernel sequence.
+
+    Per rank it renders its shard of the event pixels (2 poses) and blur pixels (n poses) in one
+    batched launch sequence, computes loss + gradients (K6), backpropagates through both MLPs,
+    rays and the trajectory, all-reduces the flat gradient buffer (when world_size > 1) and
+    applies Adam with the exponential LR schedule.
+    """
+
+    def __init__(self, graph, cfg, cam_rgb, cam_evt, device, world_size=1, rank=0, process_group=None, seed=0):
+        self.g, self.cfg, self.cam_rgb, self.cam_evt = graph, cfg, cam_rgb, cam_evt
+        self.dev, self.world, self.rank, self.pg = device, world_size, rank, process_group
+        self.seed = seed
+        self.C = cfg.channels
+        wc, bc = nerf_param_lists(graph.nerf)
+        wf, bf = nerf_param_lists(graph.nerf_fine)
+        n_net = sum(t.numel() for t in wc + bc)
+        self.n_net = n_net
+        n_total = 2 * n_net + 24 + 6
+        self.flat_p = torch.zeros(n_total, dtype=torch.float32, device=device)
+        self.flat_g = torch.zeros(n_total, dtype=torch.float32, device=device)
+        self.flat_m = torch.zeros(n_total, dtype=torch.float32, device=device)
+        self.flat_v = torch.zeros(n_total, dtype=torch.float32, device=device)
+        self.net_c = FlatNet(wc, bc, self.C, self.flat_p, self.flat_g, 0)
+        self.net_f = FlatNet(wf, bf, self.C, self.flat_p, self.flat_g, n_net)
+        o = 2 * n_net
+        kn = graph.evt_knot_pose_se3.params.weight
+        tr = graph.transform.params.weight
+        self.knots = self.flat_p[o:o + 24].view(4, 6)
+        self.knots.copy_(kn.detach())
+        kn.data = self.knots
+        self.transform = self.flat_p[o + 24:o + 30].view(1, 6)
+        self.transform.copy_(tr.detach())
+        tr.data = self.transform
+        self.g_knots = self.flat_g[o:o + 24].view(4, 6)
+        self.g_transform = self.flat_g[o + 24:o + 30].view(1, 6)
+        self.off_pose = o
+        self.global_step = 0
+        self.net_c.packed.pack()
+        self.net_f.packed.pack()
+        self.last_losses = None
+
+    # -- schedule (train.py:355-394) ------------------------------------------------------------
+    def _lr(self, lr0, decay):
+        # the reference recomputes lr AFTER optimizer.step() of iteration i from global_step = i
+        # (train.py:355-394), so iteration k >= 1 runs with lr0 * decay^((k-1)/steps), iteration 0 with lr0
+        k = max(self.global_step, 1) - 1
+        return lr0 * (decay ** (k / (self.cfg.lrate_decay * 1000)))
+
+    def shard(self, idx):
+        """Contiguous slice of a global pixel-index vector for this rank."""
+        return dist.shard_indices(idx, self.rank, self.world)
+
+    def step(self, evt_ts2, rgb_ts2, idx_evt_global, idx_rgb_global, events_accu, image, draws_evt=None,
+             draws_rgb=None):
+        """evt_ts2/rgb_ts2: [2] device floats; idx_*_global: int64 device pixel indices (global batch,
+        identical on every rank); events_accu [H_e*W_e] float32 device; image [H*W, C] float32 device."""
+        cfg, C, dev = self.cfg, self.C, self.dev
+        P = cfg.num_interpolated_pose
+        S, Ni = cfg.N_samples, cfg.N_importance
+        idx_e, idx_r = self.shard(idx_evt_global), self.shard(idx_rgb_global)
+        Re, Rr = idx_e.shape[0], idx_r.shape[0]
+        Ne, Nr = 2 * Re, P * Rr
+        N = Ne + Nr
+        traj = 1 if cfg.traj == "linear" else 0
+        step_id = self.global_step
+
+        # ---- forward ---------------------------------------------------------------------------
+        poses_e = K.spline_poses_fwd(self.knots, None, evt_ts2, 2, traj)
+        poses_r = K.spline_poses_fwd(self.knots, self.transform.view(6), rgb_ts2, P, traj)
+        ro = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        rd = torch.empty_like(ro)
+        vd = torch.empty_like(ro)
+        ce, cr = self.cam_evt, self.cam_rgb
+        K.rays_fwd(poses_e, idx_e, ce.H, ce.W, ce.fx, ce.fy, ce.cx, ce.cy, cfg.ndc, out=(ro[:Ne], rd[:Ne], vd[:Ne]))
+        K.rays_fwd(poses_r, idx_r, cr.H, cr.W, cr.fx, cr.fy, cr.cx, cr.cy, cfg.ndc, out=(ro[Ne:], rd[Ne:], vd[Ne:]))
+        if draws_evt is not None:   # parity mode: explicit draws for both renders, concatenated
+            d = Draws(torch.cat([draws_evt.t_rand, draws_rgb.t_rand]), torch.cat([draws_evt.noise0, draws_rgb.noise0]),
+                      torch.cat([draws_evt.u, draws_rgb.u]), torch.cat([draws_evt.noise1, draws_rgb.noise1]))
+        else:
+            d = Draws(seed=self.seed + self.rank * 7919, offset=step_id)
+        t_rand, sd, off = d.jitter_args()
+        z = K.stratified_z(N, S, dev, t_rand, sd, off)
+        raw0, acts0 = K.mlp_fwd(self.net_c.packed, ro, rd, vd, z, True)
+        nz0 = d.noise_args(0)
+        c0 = K.composite_fwd(raw0, z, rd, nz0[0], nz0[1], nz0[2], nz0[3], want=("rgb_map", "weights"))
+        u, usd, uoff = d.u_args()
+        z_fine = K.sample_pdf_merge(z, c0["weights"], Ni, u, usd, uoff)
+        raw1, acts1 = K.mlp_fwd(self.net_f.packed, ro, rd, vd, z_fine, True)
+        nz1 = d.noise_args(1)
+        c1 = K.composite_fwd(raw1, z_fine, rd, nz1[0], nz1[1], nz1[2], nz1[3], want=("rgb_map",))
+        rgb_map, rgb0 = c1["rgb_map"], c0["rgb_map"]
+
+        # ---- loss + gradient w.r.t. rendered colours (K6) ------------------------------------------
+        target_acc = K.gather_rows(events_accu.view(-1, 1), idx_e).view(-1)
+        target_rgb = K.gather_rows(image, idx_r)
+        syn = cfg.event_threshold > 0
+        lcfg = K.make_loss_cfg(C, cfg.dataset.startswith("E2NeRF"), Re, Rr, P, cfg.event_threshold,
+                               cfg.event_coeff_syn if syn else cfg.event_coeff_real, cfg.rgb_coeff,
+                               Re * self.world, Rr * self.world)
+        largs = (rgb_map[:Ne], rgb0[:Ne], target_acc, rgb_map[Ne:], rgb0[Ne:], target_rgb)
+        stats = K.loss_stats(lcfg, *largs)
+        dist.allreduce_sum_(stats, self.world, self.pg)
+        g_rgb = torch.empty_like(rgb_map)
+        g_rgb0 = torch.empty_like(rgb0)
+        losses, _ = K.loss_grads(lcfg, stats, *largs, out=(g_rgb[:Ne], g_rgb0[:Ne], g_rgb[Ne:], g_rgb0[Ne:]))
+
+        # ---- backward -------------------------------------------------------------------------------
+        d_o = torch.zeros_like(ro)
+        d_d = torch.empty_like(ro)
+        d_v = torch.zeros_like(ro)
+        d_raw1, _ = K.composite_bwd(raw1, z_fine, rd, nz1[0], nz1[1], nz1[2], nz1[3], g_rgb, d_rays_d=d_d)
+        d_pts, d_vp = K.mlp_bwd(self.net_f.packed, d_raw1.view(-1, C + 1), acts1, N, S + Ni, self.net_f.gviews_w,
+                                self.net_f.gviews_b, False)
+        K.ray_grad_reduce(z_fine, d_pts, d_vp, d_o, d_d, d_v, True)
+        d_raw0, _ = K.composite_bwd(raw0, z, rd, nz0[0], nz0[1], nz0[2], nz0[3], g_rgb0, d_rays_d=d_d, accumulate=True)
+        d_pts, d_vp = K.mlp_bwd(self.net_c.packed, d_raw0.view(-1, C + 1), acts0, N, S, self.net_c.gviews_w,
+                                self.net_c.gviews_b, False)
+        K.ray_grad_reduce(z, d_pts, d_vp, d_o, d_d, d_v, True)
+        dp_e = K.rays_bwd(poses_e, idx_e, ce.H, ce.W, ce.fx, ce.fy, ce.cx, ce.cy, cfg.ndc, d_o[:Ne], d_d[:Ne], d_v[:Ne])
+        dp_r = K.rays_bwd(poses_r, idx_r, cr.H, cr.W, cr.fx, cr.fy, cr.cx, cr.cy, cfg.ndc, d_o[Ne:], d_d[Ne:], d_v[Ne:])
+        dk_e, _ = K.spline_poses_bwd(self.knots, None, evt_ts2, 2, traj, dp_e)
+        dk_r, dt_r = K.spline_poses_bwd(self.knots, self.transform.view(6), rgb_ts2, P, traj, dp_r)
+        torch.add(dk_e, dk_r, out=self.g_knots)
+        self.g_transform.copy_(dt_r)
+
+        # ---- gradient exchange: one all-reduce of the flat buffer over RCCL/xGMI ------------------------------
+        dist.allreduce_sum_(self.flat_g, self.world, self.pg)
+
+        # ---- Adam (K8) with the reference's per-group switches and LR schedule ---------------------------------
+        t = self.global_step + 1
+        if cfg.optimize_nerf:
+            K.adam_step(self.flat_p[:2 * self.n_net], self.flat_g[:2 * self.n_net], self.flat_m[:2 * self.n_net],
+                        self.flat_v[:2 * self.n_net], self._lr(cfg.lrate, cfg.decay_rate), t)
+        o = self.off_pose
+        if cfg.optimize_pose:
+            K.adam_step(self.flat_p[o:o + 24], self.flat_g[o:o + 24], self.flat_m[o:o + 24], self.flat_v[o:o + 24],
+                        self._lr(cfg.pose_lrate, cfg.decay_rate_pose), t)
+        if cfg.optimize_trans:
+            K.adam_step(self.flat_p[o + 24:o + 30], self.flat_g[o + 24:o + 30], self.flat_m[o + 24:o + 30],
+                        self.flat_v[o + 24:o + 30],
+                        self._lr(cfg.transform_lrate, cfg.decay_rate_transform), t)
+        self.net_c.packed.pack()
+        self.net_f.packed.pack()
+        self.global_step += 1
+        self.last_losses = losses
+        return losses
+
+
+def psnr(img, gt):
+    """-10 log10(MSE) on [0,1] images (metrics.py:34,51-52,79-81)."""
+    return float(-10.0 * math.log10(float(torch.mean((img - gt) ** 2))))

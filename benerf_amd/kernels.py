@@ -47,21 +47,23 @@ def scratch(key, n_floats, device, dtype=torch.float32):
 
 
 # ----------------------------------------------------------------------------- K1 trajectory
-def spline_poses_fwd(knots, transform, ts2, n_poses, traj=0):
+def spline_poses_fwd(knots, transform, ts, n_poses, traj=0, explicit_ts=False, out=None):
+    """ts: [2] range (linspace applied in-kernel) or, with explicit_ts, [n_poses] sample times."""
     lib = _lib.load()
-    poses = _new((n_poses, 3, 4), knots)
+    poses = _new((n_poses, 3, 4), knots) if out is None else out
+    assert ts.numel() == (n_poses if explicit_ts else 2)
     _lib.check(lib.benerf_spline_poses_fwd(_chk(knots, name="knots"), _chk(transform, name="transform"),
-                                           _chk(ts2, name="ts2"), n_poses, traj, poses.data_ptr(), _stream()),
-               "spline_poses_fwd")
+                                           _chk(ts, name="ts"), n_poses, traj, int(bool(explicit_ts)),
+                                           _chk(poses), _stream()), "spline_poses_fwd")
     return poses
 
 
-def spline_poses_bwd(knots, transform, ts2, n_poses, traj, d_poses):
+def spline_poses_bwd(knots, transform, ts, n_poses, traj, d_poses, explicit_ts=False):
     lib = _lib.load()
     d_knots = _new((4, 6), knots)
     d_tr = _new((1, 6), knots) if transform is not None else None
-    _lib.check(lib.benerf_spline_poses_bwd(_chk(knots), _chk(transform), _chk(ts2), n_poses, traj,
-                                           _chk(d_poses, name="d_poses"), d_knots.data_ptr(),
+    _lib.check(lib.benerf_spline_poses_bwd(_chk(knots), _chk(transform), _chk(ts), n_poses, traj,
+                                           int(bool(explicit_ts)), _chk(d_poses, name="d_poses"), d_knots.data_ptr(),
                                            None if d_tr is None else d_tr.data_ptr(), _stream()), "spline_poses_bwd")
     return d_knots, d_tr
 
@@ -104,6 +106,40 @@ def ray_grad_reduce(z, d_pts, d_vdir_pts, d_rays_o, d_rays_d, d_viewdirs, accumu
 
 
 # ----------------------------------------------------------------------------- K3 fused MLP
+class KernelTimers:
+    """Optional HIP-event brackets around the three MLP launches (same stream the kernels run
+    on).  bench.py enables them to report per-kernel launch durations for the roofline."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []      # (name, n_points, start_event, end_event)
+        self._open = None
+
+    def mark(self, name, n_points):
+        if not self.enabled:
+            return
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        if self._open is not None:
+            self.records.append(self._open + (ev,))
+        self._open = (name, n_points, ev) if name is not None else None
+
+    def summary(self):
+        """{name: (launches, total_ms, total_points)} - call after a device synchronize."""
+        out = {}
+        for name, npts, a, b in self.records:
+            n, ms, pts = out.get(name, (0, 0.0, 0))
+            out[name] = (n + 1, ms + a.elapsed_time(b), pts + npts)
+        return out
+
+
+TIMERS = KernelTimers()
+
+
+def _timer(name, n_points):
+    TIMERS.mark(name, n_points)
+
+
 def _param_struct(cls, tensors_w, tensors_b):
     s = cls()
     for i in range(_lib.NLAYERS):
@@ -133,7 +169,7 @@ class PackedMlp:
                    "mlp_pack_weights")
 
     def pack_if_stale(self):
-        v = tuple(w._version for w in self.weights)
+        v = tuple((w._version, w.data_ptr()) for w in self.weights)
         if v != self.version:
             self.pack()
             self.version = v
@@ -149,9 +185,11 @@ def mlp_fwd(net, rays_o, rays_d, viewdirs, z, save_acts):
         acts = torch.empty(n_rays * n_samples * lib.benerf_mlp_act_floats_per_point(), dtype=torch.float32,
                            device=z.device)
     s = net.struct()
+    _timer("mlp_fwd", n_rays * n_samples)
     _lib.check(lib.benerf_mlp_fwd(ctypes.byref(s), net.packed.data_ptr(), C, n_rays, n_samples, _chk(rays_o),
                                   _chk(rays_d), _chk(viewdirs), _chk(z), raw.data_ptr(), _chk(acts), _stream()),
                "mlp_fwd")
+    _timer(None, 0)
     return raw, acts
 
 
@@ -167,10 +205,15 @@ def mlp_bwd(net, d_raw, acts, n_rays, n_samples, grad_w, grad_b, accumulate):
     d_vd = torch.empty((M, 3), dtype=torch.float32, device=dev)
     s = net.struct()
     g = _param_struct(MlpGrads, grad_w, grad_b)
-    _lib.check(lib.benerf_mlp_bwd(ctypes.byref(s), net.packed.data_ptr(), net.channels, n_rays, n_samples,
-                                  _chk(d_raw, name="d_raw"), _chk(acts), dacts.data_ptr(), ws.data_ptr(), ws_floats,
-                                  ctypes.byref(g), int(bool(accumulate)), d_pts.data_ptr(), d_vd.data_ptr(), _stream()),
-               "mlp_bwd")
+    _timer("mlp_bwd_dx", M)
+    _lib.check(lib.benerf_mlp_bwd_dx(ctypes.byref(s), net.packed.data_ptr(), net.channels, n_rays, n_samples,
+                                     _chk(d_raw, name="d_raw"), _chk(acts), dacts.data_ptr(), d_pts.data_ptr(),
+                                     d_vd.data_ptr(), _stream()), "mlp_bwd_dx")
+    _timer("mlp_bwd_dw", M)
+    _lib.check(lib.benerf_mlp_bwd_dw(net.channels, n_rays, n_samples, _chk(d_raw), _chk(acts), dacts.data_ptr(),
+                                     ws.data_ptr(), ws_floats, ctypes.byref(g), int(bool(accumulate)), _stream()),
+               "mlp_bwd_dw")
+    _timer(None, 0)
     return d_pts, d_vd
 
 
@@ -245,11 +288,14 @@ def loss_stats(cfg, rgb_evt, rgb0_evt, target_acc, rgb_rgb, rgb0_rgb, target_rgb
     return stats
 
 
-def loss_grads(cfg, stats, rgb_evt, rgb0_evt, target_acc, rgb_rgb, rgb0_rgb, target_rgb):
+def loss_grads(cfg, stats, rgb_evt, rgb0_evt, target_acc, rgb_rgb, rgb0_rgb, target_rgb, out=None):
     lib = _lib.load()
     ref = rgb_evt if rgb_evt is not None else rgb_rgb
     losses = torch.empty(8, dtype=torch.float32, device=ref.device)
-    g = [None if t is None else torch.empty_like(t) for t in (rgb_evt, rgb0_evt, rgb_rgb, rgb0_rgb)]
+    if out is not None:
+        g = list(out)
+    else:
+        g = [None if t is None else torch.empty_like(t) for t in (rgb_evt, rgb0_evt, rgb_rgb, rgb0_rgb)]
     _lib.check(lib.benerf_loss_grads(ctypes.byref(cfg), _chk(stats, torch.float64), _chk(rgb_evt), _chk(rgb0_evt),
                                      _chk(target_acc), _chk(rgb_rgb), _chk(rgb0_rgb), _chk(target_rgb),
                                      losses.data_ptr(), _chk(g[0]), _chk(g[1]), _chk(g[2]), _chk(g[3]), _stream()),
@@ -292,3 +338,58 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, step, beta1=0.9, beta2=0.999
     lib = _lib.load()
     _lib.check(lib.benerf_adam_step(_chk(param), _chk(grad), _chk(exp_avg), _chk(exp_avg_sq), param.numel(), lr, beta1,
                                     beta2, eps, step, grad_scale, _stream()), "adam_step")
+
+
+# ----------------------------------------------------------------------------- stand-alone helpers
+def sample_pdf(bins, weights, n_draws, u=None, seed=0, offset=0, want_inds=False):
+    lib = _lib.load()
+    n_rays, n_bins = bins.shape
+    samples = _new((n_rays, n_draws), bins)
+    inds = _new((n_rays, n_draws), bins, torch.int64) if want_inds else None
+    _lib.check(lib.benerf_sample_pdf(_chk(bins), _chk(weights), _chk(u), seed, offset, n_rays, n_bins, n_draws,
+                                     samples.data_ptr(), _chk(inds, torch.int64), _stream()), "sample_pdf")
+    return (samples, inds) if want_inds else samples
+
+
+def pixel_rays(c2w, i, j, fx, fy, cx, cy):
+    lib = _lib.load()
+    n = i.numel()
+    per_ray = int(c2w.dim() == 3 and c2w.shape[0] == n and n > 1 or (c2w.dim() == 3 and c2w.shape[0] == n))
+    ro, rd = _new((n, 3), c2w), _new((n, 3), c2w)
+    _lib.check(lib.benerf_pixel_rays(_chk(c2w), per_ray, _chk(i, torch.int64), _chk(j, torch.int64), n, fx, fy, cx, cy,
+                                     ro.data_ptr(), rd.data_ptr(), _stream()), "pixel_rays")
+    return ro, rd
+
+
+def ndc_rays(H, W, focal, near, rays_o, rays_d):
+    lib = _lib.load()
+    n = rays_o.numel() // 3
+    oo, od = torch.empty_like(rays_o), torch.empty_like(rays_d)
+    _lib.check(lib.benerf_ndc_rays(H, W, focal, near, _chk(rays_o), _chk(rays_d), n, oo.data_ptr(), od.data_ptr(),
+                                   _stream()), "ndc_rays")
+    return oo, od
+
+
+def posenc(x, n_freqs, include_input=True):
+    lib = _lib.load()
+    dims = x.shape[-1]
+    n = x.numel() // dims
+    width = (dims if include_input else 0) + 2 * dims * n_freqs
+    out = _new(tuple(x.shape[:-1]) + (width,), x)
+    _lib.check(lib.benerf_posenc(_chk(x), n, dims, n_freqs, int(bool(include_input)), out.data_ptr(), _stream()), "posenc")
+    return out
+
+
+def mse_fwd(a, b):
+    lib = _lib.load()
+    out = _new((1,), a)
+    _lib.check(lib.benerf_mse_fwd(_chk(a), _chk(b), a.numel(), out.data_ptr(), _stream()), "mse_fwd")
+    return out
+
+
+def mse_bwd(a, b, grad_out, need_a=True, need_b=True):
+    lib = _lib.load()
+    da = torch.empty_like(a) if need_a else None
+    db = torch.empty_like(b) if need_b else None
+    _lib.check(lib.benerf_mse_bwd(_chk(a), _chk(b), a.numel(), _chk(grad_out), _chk(da), _chk(db), _stream()), "mse_bwd")
+    return da, db

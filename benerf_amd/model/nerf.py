@@ -1,0 +1,303 @@
+"""Host-side mirror of the reference's model/nerf.py: same classes, method names, argument
+order and return structures; all arithmetic runs in the HIP kernels (benerf_amd.engine).
+
+`from model.nerf import *` in a reference-style driver relies on np / torch / nn / F / os being
+re-exported from here (train.py:6,66), so this module defines no __all__.
+"""
+import os  # noqa: F401  (re-exported, see module docstring)
+import abc
+from datetime import datetime
+
+import numpy as np
+import torch
+import torch.nn.functional as F  # noqa: F401
+from torch import nn as nn
+
+from .. import engine
+from .. import kernels as K
+from ..engine import Camera, Draws
+from . import embedder  # noqa: F401
+
+
+class Model:
+    """Abstract trainer facade (model/nerf.py:28-38)."""
+
+    @abc.abstractmethod
+    def build_network(self, args, poses=None, event_poses=None):
+        pass
+
+    @abc.abstractmethod
+    def setup_optimizer(self, args):
+        pass
+
+    def after_train(self):
+        print(f"Successfully finished model on {datetime.now()}")
+
+
+def _draw(fn, shape, device, scale=None):
+    """One draw from the global torch generator, reference order/shape."""
+    t = fn(shape, device=device)
+    if scale is not None:
+        t = t * scale
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+class _MlpPoints(torch.autograd.Function):
+    """NeRF.forward on explicit points: pts [N,S,3], viewdirs [N,3] -> raw [N,S,C+1]  (K3)."""
+
+    @staticmethod
+    def forward(ctx, pts, viewdirs, net, *params):
+        N, S = pts.shape[0], pts.shape[1]
+        M = N * S
+        dev = pts.device
+        pts_c = pts.detach().reshape(M, 3).float().contiguous()
+        vd = viewdirs.detach().float()[:, None].expand(N, S, 3).reshape(M, 3).contiguous()
+        need = any(ctx.needs_input_grad)
+        net.pack_if_stale()
+        # pts = 0 + pts * 1: feed each point as a one-sample ray
+        raw, acts = K.mlp_fwd(net, torch.zeros((M, 3), device=dev), pts_c, vd, torch.ones((M, 1), device=dev), need)
+        ctx.net, ctx.acts, ctx.shape = net, acts, (N, S)
+        return raw.view(N, S, -1)
+
+    @staticmethod
+    def backward(ctx, d_raw):
+        net, (N, S) = ctx.net, ctx.shape
+        gw = [torch.empty_like(w) for w in net.weights]
+        gb = [torch.empty_like(b) for b in net.biases]
+        d_pts, d_vd = K.mlp_bwd(net, d_raw.contiguous().view(N * S, -1), ctx.acts, N * S, 1, gw, gb, False)
+        ctx.acts = None
+        return (d_pts.view(N, S, 3), d_vd.view(N, S, 3).sum(1), None) + tuple(gw) + tuple(gb)
+
+
+class _Composite(torch.autograd.Function):
+    """NeRF.raw2output (K4).  Differentiable w.r.t. raw and rays_d (through ||rays_d||)."""
+
+    @staticmethod
+    def forward(ctx, raw, z, rays_d, noise):
+        raw_c, z_c, rd_c = raw.detach().float().contiguous(), z.detach().float().contiguous(), rays_d.detach().float().contiguous()
+        out = K.composite_fwd(raw_c, z_c, rd_c, noise)
+        ctx.save_for_backward(raw_c, z_c, rd_c, noise)
+        ctx.mark_non_differentiable(out["weights"], out["sigma"])
+        return out["rgb_map"], out["disp"], out["acc"], out["weights"], out["depth"], out["sigma"]
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_disp, g_acc, g_w, g_depth, g_sigma):
+        raw, z, rd, noise = ctx.saved_tensors
+
+        def c(t):
+            return None if t is None else t.contiguous()
+
+        if g_rgb is None:
+            g_rgb = torch.zeros((raw.shape[0], raw.shape[2] - 1), device=raw.device)
+        d_raw, d_rd = K.composite_bwd(raw, z, rd, noise, 0.0, 0, 0, c(g_rgb), c(g_acc), c(g_depth), c(g_disp))
+        return d_raw, None, d_rd, None
+
+
+class NeRF(nn.Module):
+    """8x256 ReLU MLP with skip at layer 4 and a 128-wide view branch (model/nerf.py:40-64).
+    Same constructor and parameter names as the reference; the HIP kernels implement exactly
+    the architecture the reference hard-codes at model/optimize.py:9."""
+
+    def __init__(self, D=8, W=256, input_ch=63, input_ch_views=27, output_ch=4, skips=[4], use_viewdirs=False,
+                 channels=3):
+        super().__init__()
+        if not (D == 8 and W == 256 and input_ch == 63 and input_ch_views == 27 and list(skips) == [4] and use_viewdirs):
+            raise NotImplementedError("benerf_amd implements the BeNeRF network shape only: D=8, W=256, input_ch=63, "
+                                      "input_ch_views=27, skips=[4], use_viewdirs=True (model/optimize.py:9)")
+        if channels not in (1, 3):
+            raise NotImplementedError("channels must be 1 or 3")
+        self.D, self.W, self.input_ch, self.input_ch_views = D, W, input_ch, input_ch_views
+        self.skips, self.use_viewdirs, self.channels = skips, use_viewdirs, channels
+        self.pts_linears = nn.ModuleList(
+            [nn.Linear(input_ch, W)] + [nn.Linear(W + input_ch, W) if i in skips else nn.Linear(W, W) for i in range(D - 1)])
+        self.views_linears = nn.ModuleList([nn.Linear(input_ch_views + W, W // 2)])
+        self.feature_linear = nn.Linear(W, W)
+        self.alpha_linear = nn.Linear(W, 1)
+        self.rgb_linear = nn.Linear(W // 2, channels)
+        self._packed = None
+
+    # ---- kernel-side view of the parameters ----------------------------------------------------------
+    def param_lists(self):
+        return engine.nerf_param_lists(self)
+
+    def packed(self):
+        ws, bs = self.param_lists()
+        if self._packed is None or any(a is not b for a, b in zip(self._packed.weights, ws)):
+            self._packed = K.PackedMlp(ws, bs, self.channels)
+        return self._packed
+
+    def forward(self, iter_step, pts, viewdirs, args):
+        """pts [N,S,3], viewdirs [N,3] -> [N,S,channels+1] = [rgb..., sigma]  (model/nerf.py:67-116)."""
+        if getattr(args, "use_barf_c2f", False):
+            raise NotImplementedError("use_barf_c2f is off in every shipped config and not implemented (SURVEY 8f4)")
+        if viewdirs is None:
+            raise NotImplementedError("use_viewdirs=False is not supported")
+        net = self.packed()
+        return _MlpPoints.apply(pts, viewdirs, net, *net.weights, *net.biases)
+
+    def raw2output(self, crf_func, enable_crf: bool, sensor_type, raw, z_vals, rays_d, raw_noise_std=1.0):
+        """(model/nerf.py:118-148); crf_func / enable_crf / sensor_type are accepted and unused,
+        exactly as in the reference where the CRF call is commented out."""
+        noise = None
+        if raw_noise_std > 0.:
+            noise = _draw(torch.randn, raw[..., self.channels].shape, raw.device, raw_noise_std)
+        return _Composite.apply(raw, z_vals, rays_d, noise)
+
+
+class Graph(nn.Module):
+    """Scene graph: coarse + fine NeRF, render() and the training forward (model/nerf.py:150-398)."""
+
+    def __init__(self, args, D=8, W=256, input_ch=63, input_ch_views=27, output_ch=4, skips=[4], use_viewdirs=False):
+        super().__init__()
+        self.nerf = NeRF(D, W, input_ch, input_ch_views, output_ch, skips, use_viewdirs, args.channels)
+        self.channels = args.channels
+        if args.N_importance > 0:
+            self.nerf_fine = NeRF(D, W, input_ch, input_ch_views, output_ch, skips, use_viewdirs, args.channels)
+        self.pose_eye = torch.eye(3, 4)
+        self._event_cache = None
+
+    # ---- events -----------------------------------------------------------------------------------------
+    def _device(self):
+        return self.nerf.alpha_linear.weight.device
+
+    def _events_on_device(self, events):
+        """Upload the event stream once (sorted by ts as recorded) instead of masking it on the
+        host every iteration (model/nerf.py:170-178)."""
+        key = (id(events["ts"]), len(events["ts"]))
+        if self._event_cache is None or self._event_cache[0] != key:
+            dev = self._device()
+            ts = np.asarray(events["ts"], dtype=np.float64)
+            if ts.size > 1 and not bool(np.all(ts[1:] >= ts[:-1])):
+                raise ValueError("events['ts'] must be ascending")
+            cache = {"x": torch.as_tensor(np.asarray(events["x"]).astype(np.int32), device=dev),
+                     "y": torch.as_tensor(np.asarray(events["y"]).astype(np.int32), device=dev),
+                     "p": torch.as_tensor(np.asarray(events["pol"]).astype(np.float32), device=dev),
+                     "ts": torch.as_tensor(ts, device=dev)}
+            self._event_cache = (key, cache)
+        return self._event_cache[1]
+
+    def forward(self, iter_step, events, rgb_exp_ts, H, W, K, K_event, args, img_xy_remap, evt_xy_remap):
+        """One training iteration's rendering (model/nerf.py:160-234): event-window accumulation,
+        two trajectory queries, two renders.  Same return tuple as the reference."""
+        dev = self._device()
+        ev = self._events_on_device(events)
+        He, We = args.event_height, args.event_width
+        if args.dataset == "TUM_VIE":
+            raise NotImplementedError("TUM_VIE (polarity remap + fisheye LUT) is out of scope (SURVEY 8f4)")
+        if args.event_time_window:
+            window_t = args.accumulate_time_length
+            if args.random_sampling_window:
+                low_t = np.random.rand(1) * (1 - window_t)
+                upper_t = low_t + window_t
+            else:
+                low_t = np.random.randint((1 - window_t) // window_t) * window_t
+                upper_t = np.min((low_t + window_t, 1.0))
+            lo, up = float(np.asarray(low_t).reshape(-1)[0]), float(np.asarray(upper_t).reshape(-1)[0])
+            accu = K_.event_window_accumulate(ev["x"], ev["y"], ev["p"], ev["ts"], lo, up, He, We)
+            events_ts = np.stack((low_t, upper_t)).reshape(2)
+        else:
+            num = len(events["pol"])
+            N_window = round(num * args.accumulate_time_length)
+            if args.random_sampling_window:
+                lo_i = np.random.randint(num - N_window)
+            else:
+                lo_i = np.random.randint((num - N_window) // N_window) * N_window
+            hi_i = int(lo_i + N_window)
+            accu = K_.event_accumulate(ev["x"][lo_i:hi_i], ev["y"][lo_i:hi_i], ev["p"][lo_i:hi_i], He, We)
+            ts_np = np.asarray(events["ts"])
+            events_ts = ts_np[lo_i:hi_i][np.array([0, int(N_window) - 1])]
+        events_accu = accu.double()    # the reference returns float64 (utils/event_utils.py:256-257)
+
+        spline_evt_poses = self.get_pose_evt(args, torch.tensor(events_ts, dtype=torch.float32))
+        spline_rgb_poses = self.get_pose_rgb(args, torch.tensor(rgb_exp_ts, dtype=torch.float32))
+
+        ray_idx_event = torch.randperm(He * We, device=dev)[:args.sampling_event_rays]
+        ret_event = self.render(iter_step, spline_evt_poses, ray_idx_event.reshape(-1, 1).squeeze(), He, We,
+                                torch.Tensor(K_event), args, enable_crf=True, sensor_type="event",
+                                remap=torch.tensor(evt_xy_remap), training=True)
+        ray_idx_rgb = torch.randperm(H * W, device=dev)[:args.sampling_rgb_rays // args.num_interpolated_pose]
+        ret_rgb = self.render(iter_step, spline_rgb_poses, ray_idx_rgb.reshape(-1, 1).squeeze(), H, W, torch.Tensor(K),
+                              args, enable_crf=True, sensor_type="rgb", remap=torch.tensor(img_xy_remap), training=True)
+        return ret_event, ret_rgb, ray_idx_event, ray_idx_rgb, events_accu
+
+    # ---- render -------------------------------------------------------------------------------------------
+    def render(self, iter_step, poses, ray_idx, H, W, K, args, enable_crf: bool, sensor_type: str,
+               remap: torch.Tensor, near=0., far=1., training=False):
+        """rays (pose-major) -> stratified coarse pass -> importance sampling -> fine pass
+        (model/nerf.py:236-343).  `training` only selects how the reference builds its rays; both
+        branches give the same rays, generated on the fly here."""
+        if args.dataset == "TUM_VIE":
+            raise NotImplementedError("TUM_VIE remap LUT is out of scope (SURVEY 8f4)")
+        if not args.use_viewdirs:
+            raise NotImplementedError("use_viewdirs=False is not supported")
+        if near != 0. or far != 1.:
+            raise NotImplementedError("render() supports the reference's near=0, far=1 only")
+        dev = self._device()
+        poses = poses[:, :3, :4]
+        cam = Camera.from_K(H, W, K)
+        ray_idx = ray_idx.reshape(-1).to(device=dev, dtype=torch.int64).contiguous()
+        N = poses.shape[0] * ray_idx.shape[0]
+        S, Ni = args.N_samples, args.N_importance
+        std = float(getattr(args, "benerf_raw_noise_std", engine.NOISE_STD_DEFAULT))
+        if getattr(args, "benerf_rng", "torch") == "philox":
+            self._philox_calls = getattr(self, "_philox_calls", 0) + 1
+            draws = Draws(seed=int(getattr(args, "benerf_seed", 0)), offset=self._philox_calls, noise_std=std)
+        else:   # reference behaviour: four draws from the global torch generator, in its order
+            t_rand = _draw(torch.rand, (N, S), dev)
+            noise0 = _draw(torch.randn, (N, S), dev, std) if std > 0 else None
+            u = _draw(torch.rand, [N, Ni], dev) if Ni > 0 else None
+            noise1 = _draw(torch.randn, (N, S + Ni), dev, std) if (std > 0 and Ni > 0) else None
+            draws = Draws(t_rand, noise0, u, noise1, noise_std=0.0 if std <= 0 else std)
+        net_c = self.nerf.packed()
+        net_f = self.nerf_fine.packed() if Ni > 0 else None
+        params = list(net_c.weights) + list(net_c.biases)
+        if net_f is not None:
+            params += list(net_f.weights) + list(net_f.biases)
+        outs = engine.RenderRays.apply(poses.float(), ray_idx, cam, bool(args.ndc), S, Ni, draws, net_c, net_f, *params)
+        if Ni > 0:
+            keys = ("rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "sigma")
+        else:
+            keys = ("rgb_map", "disp_map", "acc_map", "sigma")
+        ret = dict(zip(keys, outs))
+        if Ni == 0:
+            ret.pop("sigma")
+        return ret
+
+    def camera_response_func(self, radience, sensor_type):
+        if sensor_type == "rgb":
+            return self.rgb_crf.forward(radience)
+        elif sensor_type == "event":
+            return self.event_crf.forward(radience)
+
+    @torch.no_grad()
+    def render_video(self, iter_step, poses, H, W, K, args, remap, type):
+        """Chunked full-image inference (model/nerf.py:353-390): dict of [H,W,...] tensors."""
+        all_ret = {}
+        dev = self._device()
+        ray_idx = torch.arange(0, H * W, device=dev)
+        render_type = str(type)
+        for i in range(0, ray_idx.shape[0], args.chunk):
+            if render_type == "radience":
+                ret = self.render(iter_step, poses, ray_idx[i:i + args.chunk], H, W, K, args, enable_crf=False,
+                                  sensor_type=None, remap=remap, training=False)
+            elif render_type == "rgb":
+                ret = self.render(iter_step, poses, ray_idx[i:i + args.chunk], H, W, K, args, enable_crf=True,
+                                  sensor_type="rgb", remap=remap, training=False)
+            else:
+                raise ValueError("render_video: type must be 'rgb' or 'radience'")
+            for k in ret:
+                all_ret.setdefault(k, []).append(ret[k])
+        for k in all_ret:
+            all_ret[k] = torch.cat(all_ret[k], 0).reshape([H, W] + list(all_ret[k][0].shape[1:]))
+        return all_ret
+
+    @abc.abstractmethod
+    def get_pose(self, args, events_ts):
+        pass
+
+    @abc.abstractmethod
+    def get_pose_rgb(self, args, seg_num=None):
+        pass
+
+
+K_ = K   # render()/forward() take the camera matrix as an argument named K, like the reference

@@ -44,15 +44,18 @@ const char* benerf_last_error(void);
  * spline.linear_pose_unit_time (spline.py:305-331) and the knot/transform/linspace
  * plumbing of Graph.get_pose_evt / get_pose_rgb (model/optimize.py:58-111).
  *   knots [4,6] se(3); transform [6] added to every knot in se(3) or NULL;
- *   ts2 [2] device floats = (t_start, t_end); pose p uses torch.linspace(t0,t1,n)[p];
+ *   explicit_ts == 0: ts [2] device floats = (t_start, t_end), pose p is evaluated at
+ *   torch.linspace(t0,t1,n)[p] (model/optimize.py:71,102); explicit_ts != 0: ts [n_poses]
+ *   sample times as passed to the reference's spline functions;
  *   traj 0 = cubic spline, 1 = linear (knots 0 and 3); poses out [n_poses,3,4]. */
-int benerf_spline_poses_fwd(const float* knots, const float* transform, const float* ts2,
-                            int n_poses, int traj, float* poses, benerf_stream_t stream);
+int benerf_spline_poses_fwd(const float* knots, const float* transform, const float* ts,
+                            int n_poses, int traj, int explicit_ts, float* poses,
+                            benerf_stream_t stream);
 /* d_poses [n_poses,3,4] -> d_knots [4,6] (overwritten), d_transform [6] (overwritten, may
  * be NULL).  Forward-mode duals over the same float code; deterministic reduction. */
-int benerf_spline_poses_bwd(const float* knots, const float* transform, const float* ts2,
-                            int n_poses, int traj, const float* d_poses, float* d_knots,
-                            float* d_transform, benerf_stream_t stream);
+int benerf_spline_poses_bwd(const float* knots, const float* transform, const float* ts,
+                            int n_poses, int traj, int explicit_ts, const float* d_poses,
+                            float* d_knots, float* d_transform, benerf_stream_t stream);
 
 /* ---------------------------------------------------------------- K2: rays --------- */
 /* Pinhole ray generation (pose-major, N = n_poses*n_pix), view directions and LLFF NDC.
@@ -125,6 +128,15 @@ int benerf_mlp_bwd(const BenerfMlpParams* params, const float* packed, int chann
                    const BenerfMlpGrads* grads, int accumulate, float* d_pts,
                    float* d_vdir_pts, benerf_stream_t stream);
 
+/* The two launches of benerf_mlp_bwd, separately callable (profiling / overlap):
+ *   _dx: activation-gradient chain -> dacts, d_pts, d_vdir_pts;  _dw: weight gradients. */
+int benerf_mlp_bwd_dx(const BenerfMlpParams* params, const float* packed, int channels,
+                      int n_rays, int n_samples, const float* d_raw, const float* acts,
+                      float* dacts, float* d_pts, float* d_vdir_pts, benerf_stream_t stream);
+int benerf_mlp_bwd_dw(int channels, int n_rays, int n_samples, const float* d_raw,
+                      const float* acts, const float* dacts, float* dw_ws, size_t dw_ws_floats,
+                      const BenerfMlpGrads* grads, int accumulate, benerf_stream_t stream);
+
 /* ---------------------------------------------------------------- K4: compositing -- */
 /* Alpha compositing, one wavefront per ray.  Replaces NeRF.raw2output
  * (model/nerf.py:118-148).  noise [n_rays,n_samples] = randn*raw_noise_std, or NULL with
@@ -156,6 +168,32 @@ int benerf_sample_pdf_merge(const float* z_coarse, const float* weights, const f
                             uint64_t seed, uint64_t offset, int n_rays, int n_samples,
                             int n_importance, float* z_fine, float* z_samples, int64_t* inds,
                             benerf_stream_t stream);
+
+/* Stand-alone sample_pdf with the reference's own signature (run_nerf_helpers.py:74):
+ * bins [n_rays,n_bins], weights [n_rays,n_bins-1], u [n_rays,n_draws] or NULL (Philox);
+ * samples out [n_rays,n_draws]; inds optional. */
+int benerf_sample_pdf(const float* bins, const float* weights, const float* u, uint64_t seed,
+                      uint64_t offset, int n_rays, int n_bins, int n_draws, float* samples,
+                      int64_t* inds, benerf_stream_t stream);
+
+/* ---------------------------------------------------------------- stand-alone helpers */
+/* Forward-only single operators backing the reference's public helper functions.
+ * benerf_pixel_rays: get_specific_rays / get_rays (run_nerf_helpers.py:13-44); c2w is
+ *   [n,3,4] (per_ray_pose != 0) or one [3,4] pose shared by all rays; i = column, j = row.
+ * benerf_ndc_rays: ndc_rays (run_nerf_helpers.py:46-71).
+ * benerf_posenc: Embedder.embed (model/embedder.py:9-34): [x | sin(2^k x), cos(2^k x)]_k.
+ * benerf_mse_fwd/bwd: MSELoss (loss/imgloss.py:3-5), out/grad_out are 1-element arrays. */
+int benerf_pixel_rays(const float* c2w, int per_ray_pose, const int64_t* i, const int64_t* j,
+                      int64_t n, float fx, float fy, float cx, float cy, float* rays_o,
+                      float* rays_d, benerf_stream_t stream);
+int benerf_ndc_rays(int H, int W, float focal, float near, const float* rays_o,
+                    const float* rays_d, int64_t n, float* out_o, float* out_d,
+                    benerf_stream_t stream);
+int benerf_posenc(const float* x, int64_t n, int dims, int n_freqs, int include_input,
+                  float* out, benerf_stream_t stream);
+int benerf_mse_fwd(const float* a, const float* b, int64_t n, float* out, benerf_stream_t stream);
+int benerf_mse_bwd(const float* a, const float* b, int64_t n, const float* grad_out, float* d_a,
+                   float* d_b, benerf_stream_t stream);
 
 /* ---------------------------------------------------------------- K6: losses ------- */
 typedef struct BenerfLossCfg {

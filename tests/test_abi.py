@@ -35,7 +35,7 @@ def test_size_queries(lib):
 
 
 def test_bad_arguments_are_reported(lib):
-    rc = lib.benerf_spline_poses_fwd(None, None, None, 2, 0, None, None)
+    rc = lib.benerf_spline_poses_fwd(None, None, None, 2, 0, 0, None, None)
     assert rc == -1 and b"null" in lib.benerf_last_error()
     rc = lib.benerf_composite_fwd(None, None, None, None, 0.0, 0, 0, 5, 1, 1, None, None, None, None, None, None, None)
     assert rc == -1

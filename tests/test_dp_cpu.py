@@ -1,0 +1,118 @@
+"""CPU, world_size 2, gloo: the data-parallel decomposition used by engine.TrainStep
+(pixel sharding + global-count loss scaling + sum all-reduce of stats and gradients) reproduces
+the single-process gradient.  The per-rank arithmetic here is the oracle (the HIP kernels need a
+GPU); what is under test is benerf_amd.dist and the normalisation scheme."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _local_backward(O, rgb_e, rgb0_e, tgt_acc, rgb_r, rgb0_r, tgt_rgb, C, dataset, thr, P, Re_g, Rr_g, stats_reduce):
+    """Backward of the GLOBAL loss from one rank's shard, split the way kernels K6 split it:
+    pass 1 local sums -> all-reduce -> pass 2 closed-form d loss / d diff with global counts and
+    norms (benerf_amd/csrc/loss.hip), then autograd through the local render."""
+    Re = tgt_acc.shape[0]
+
+    def diff(img):
+        a, b = img[:Re], img[Re:]
+        if C == 3:
+            a, b = O.to_gray(a), O.to_gray(b)
+        return O.bright_log(b, dataset) - O.bright_log(a, dataset)
+
+    df, dc = diff(rgb_e), diff(rgb0_e)
+    t = tgt_acc * (thr if thr > 0 else 1.0)
+    stats = torch.stack([(df.detach() ** 2).sum(), (df.detach() * t).sum(), (dc.detach() ** 2).sum(),
+                         (dc.detach() * t).sum(), (t ** 2).sum()]).double()
+    stats_reduce(stats)
+    outs, grads = [], []
+    for d, s_dd, s_dt in ((df, stats[0], stats[1]), (dc, stats[2], stats[3])):
+        if thr > 0:
+            g = 0.1 * 2.0 * (d.detach() - t) / Re_g
+        else:
+            n_d, n_t = s_dd.sqrt(), stats[4].sqrt()
+            sc_d, sc_t = n_d + 1e-9, n_t + 1e-9
+            gi = 2.0 * 2.0 * (d.detach() / sc_d - t / sc_t) / Re_g
+            sum_gd = 2.0 * 2.0 * (s_dd / sc_d - s_dt / sc_t) / Re_g
+            g = gi / sc_d - d.detach() / (sc_d * sc_d * n_d) * sum_gd
+        outs.append(d)
+        grads.append(g.float())
+    Rr = tgt_rgb.shape[0]
+    for img in (rgb_r, rgb0_r):
+        b = sum(img[j * Rr:(j + 1) * Rr] for j in range(P)) / P
+        outs.append(b)
+        grads.append((2.0 * (b.detach() - tgt_rgb) / (Rr_g * C)).float())
+    torch.autograd.backward(outs, grads)
+
+
+def _worker(rank, world, port, thr, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import benerf_oracle as O
+    from benerf_amd import dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    rng = np.random.default_rng(0)           # identical on every rank
+    C, P, Re_g, Rr_g, dataset = 3, 5, 16, 6, "E2NeRF_Real" if thr <= 0 else "BeNeRF_Unreal"
+    W = torch.from_numpy(rng.standard_normal((C, 8)).astype(np.float32)).requires_grad_(True)   # stand-in "network"
+    feat_e = torch.from_numpy(rng.standard_normal((2, Re_g, 8)).astype(np.float32))
+    feat_r = torch.from_numpy(rng.standard_normal((P, Rr_g, 8)).astype(np.float32))
+    acc = torch.from_numpy(rng.integers(-3, 4, (Re_g, 1)).astype(np.float32))
+    tgt = torch.from_numpy(rng.random((Rr_g, C)).astype(np.float32))
+
+    def render(feat):     # [poses, pixels, 8] -> pose-major [poses*pixels, C] in (0,1)
+        return torch.sigmoid(feat @ W.t()).reshape(-1, C)
+
+    pix_e = dist.shard_indices(torch.arange(Re_g), rank, world)
+    pix_r = dist.shard_indices(torch.arange(Rr_g), rank, world)
+    _local_backward(O, render(feat_e[:, pix_e]), render(feat_e[:, pix_e] * 0.9), acc[pix_e], render(feat_r[:, pix_r]),
+                    render(feat_r[:, pix_r] * 1.1), tgt[pix_r], C, dataset, thr, P, Re_g, Rr_g,
+                    lambda s: dist.allreduce_sum_(s, world))
+    g = W.grad.clone()
+    if world == 1:   # single rank: the closed form must equal plain autograd of the reference loss
+        W2 = W.detach().clone().requires_grad_(True)
+
+        def render2(feat):
+            return torch.sigmoid(feat @ W2.t()).reshape(-1, C)
+        le, _, _ = O.event_loss(render2(feat_e), render2(feat_e * 0.9), Re_g, acc.double(), C, dataset, thr, 0.1, 2.0)
+        lr, _, _ = O.blur_loss(render2(feat_r), render2(feat_r * 1.1), tgt, P, 1.0)
+        (le + lr).backward()
+        np.testing.assert_allclose(g.numpy(), W2.grad.numpy(), rtol=2e-4, atol=1e-7)
+    dist.allreduce_sum_(g, world)
+    if rank == 0:
+        q.put(g.numpy())
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("thr", [0.1, -1.0])
+def test_two_rank_gradient_equals_single_rank(thr):
+    ctx = mp.get_context("spawn")
+    out = {}
+    for world in (1, 2):
+        q = ctx.Queue()
+        port = 29500 + int(abs(thr) * 10) + world * 7 + (os.getpid() % 200)
+        procs = [ctx.Process(target=_worker, args=(r, world, port, thr, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        out[world] = q.get(timeout=120)
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    np.testing.assert_allclose(out[2], out[1], rtol=2e-5, atol=1e-7)
+
+
+def test_shard_indices():
+    sys.path.insert(0, ROOT)
+    from benerf_amd import dist
+    idx = torch.arange(12)
+    parts = [dist.shard_indices(idx, r, 4) for r in range(4)]
+    assert torch.equal(torch.cat(parts), idx)
+    with pytest.raises(ValueError):
+        dist.shard_indices(torch.arange(10), 0, 4)

@@ -100,7 +100,7 @@ def test_stratified_z(K):
         t = GI.f32(rng.random((77, S)))
         ref = O.stratified_z(77, S, t)
         got = K.stratified_z(77, S, DEV, t_rand=dev(t))
-        report("K2 stratified_z S=%d" % S, got, ref, atol=1e-7)
+        report("K2 stratified_z S=%d" % S, got, ref, atol=2.5e-7)
     z = K.stratified_z(1000, 64, DEV, seed=7, offset=1)
     z2 = K.stratified_z(1000, 64, DEV, seed=7, offset=1)
     assert torch.equal(z, z2), "Philox stream must be reproducible"
