@@ -41,7 +41,7 @@ _SIGNATURES = {
     "benerf_ray_grad_reduce": (c_int, [c_int, c_int, P, P, P, c_int, P, P, P, P]),
     "benerf_mlp_packed_floats": (c_size_t, []),
     "benerf_mlp_pack_weights": (c_int, [POINTER(MlpParams), c_int, P, P]),
-    "benerf_mlp_act_floats_per_point": (c_size_t, []),
+    "benerf_mlp_act_floats": (c_size_t, [c_int64]),
     "benerf_mlp_dact_floats_per_point": (c_size_t, []),
     "benerf_mlp_dw_workspace_floats": (c_size_t, [c_int64]),
     "benerf_mlp_fwd": (c_int, [POINTER(MlpParams), P, c_int, c_int, c_int, P, P, P, P, P, P, P]),

@@ -105,39 +105,44 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][NCT]) {
             for (int e = 0; e < 16; ++e) acc[r][c][e] = 0.f;
 }
 
-// saved activation values in accumulator layout (for the ReLU mask of the stage's output)
-__device__ __forceinline__ void load_mask(float (&hm)[2][2][16], const float* __restrict__ h, int ct0, int lane,
-                                          int64_t m0, int64_t M) {
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const int k = (ct0 + c) * 32 + (lane & 31);
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int64_t mm = m0 + r * 32 + acc_row(e, lane);
-                hm[r][c][e] = mm < M ? h[mm * 256 + k] : 0.f;
-            }
-    }
-}
-
-// dY = acc (+ extra) masked by hm > 0  -> LDS tile + DY array
+// dY = acc masked by the forward pass' ReLU sign bits (bit ((c*2+r)*16+e), see mlp_common.h)
+// -> LDS tile + DY array whose tile starts at `dy_tile` (row m0).  `rows_valid` is block-uniform
+// and < 64 only for the ragged last tile.
 template <bool MASK>
-__device__ __forceinline__ void epilogue(f32x16 (&acc)[2][2], const float (&hm)[2][2][16], float* __restrict__ Hs,
-                                         int ct0, int lane, float* __restrict__ dy, int64_t m0, int64_t M) {
+__device__ __forceinline__ void epilogue(f32x16 (&acc)[2][2], uint64_t bits, float* __restrict__ Hs, int ct0, int lane,
+                                         float* __restrict__ dy_tile, int rows_valid) {
+    const int lr = lane & 31, r4 = 4 * (lane >> 5);
+    float* hs_lane = Hs + r4 * LD + lr;
+    float* dy_lane = dy_tile + (int64_t)r4 * 256 + lr;
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const int k = (ct0 + c) * 32 + (lane & 31);
+    for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int pt = r * 32 + acc_row(e, lane);
                 float v = acc[r][c][e];
-                if (MASK) v = hm[r][c][e] > 0.f ? v : 0.f;
-                Hs[pt * LD + k] = v;
-                if (m0 + pt < M) dy[(m0 + pt) * 256 + k] = v;
+                if (MASK) v = ((bits >> ((c * 2 + r) * 16 + e)) & 1ull) ? v : 0.f;
+                acc[r][c][e] = v;
+                hs_lane[(r * 32 + (e & 3) + 8 * (e >> 2)) * LD + (ct0 + c) * 32] = v;
             }
+    if (rows_valid >= TM) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    dy_lane[(r * 32 + (e & 3) + 8 * (e >> 2)) * 256 + (ct0 + c) * 32] = acc[r][c][e];
+    } else {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int rowoff = r * 32 + (e & 3) + 8 * (e >> 2);
+                    if (rowoff + r4 < rows_valid) dy_lane[rowoff * 256 + (ct0 + c) * 32] = acc[r][c][e];
+                }
     }
 }
 
@@ -161,6 +166,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void mlp_bwd_kernel(BwdArgs a) {
     const float* acts = a.acts;
     float* dacts = a.dacts;
     const int ct0 = wave * 2;
+    const int rows_valid = (int)(M - m0 < TM ? M - m0 : TM);   // block-uniform
+    const uint64_t* mask_in = reinterpret_cast<const uint64_t*>(acts + act_mask(M)) + (int64_t)blockIdx.x * NTHREADS + tid;
+    const int64_t mask_stride = n_tiles(M) * NTHREADS;           // per layer
+    float* dyh_tile = dacts + dact_h(M, 0) + m0 * 256;           // layer l: + l * M * 256
 
     // ---- P0: d_raw tile, PE(dir) slice of the views weights --------------------------------------
     if (tid < 64) {
@@ -196,7 +205,6 @@ __global__ __launch_bounds__(NTHREADS, 1) void mlp_bwd_kernel(BwdArgs a) {
     __syncthreads();
 
     f32x16 acc[2][2];
-    float hm[2][2][16];
 
     // ---- P2: VIEWS^T: dFeat = dYv x Wv[:, :256]; dPE(dir) = dYv x Wv[:, 256:283] (VALU) ------------------
     zero_acc(acc);
@@ -225,7 +233,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void mlp_bwd_kernel(BwdArgs a) {
         }
     }
     __syncthreads();   // dYv fully consumed
-    epilogue<false>(acc, hm, Hs, ct0, lane, dacts + dact_feat(M), m0, M);
+    epilogue<false>(acc, 0ull, Hs, ct0, lane, dacts + dact_feat(M) + m0 * 256, rows_valid);
     if (grp == 0 && m < M) {   // d viewdirs (per point) through PE(dir)
         const float* ped = acts + act_ped(M) + m * ACT_PED_W;
         const float* g = dped + pt * WVD_LD;
@@ -240,7 +248,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void mlp_bwd_kernel(BwdArgs a) {
             a.d_vdir[m * 3 + d] = s;
         }
     }
-    load_mask(hm, acts + act_h(M, 7), ct0, lane, m0, M);
+    uint64_t bits = mask_in[7 * mask_stride];
     __syncthreads();
 
     // ---- P3: FEAT^T (+ alpha head), mask h7 -> dY7 ----------------------------------------------------
@@ -259,13 +267,13 @@ __global__ __launch_bounds__(NTHREADS, 1) void mlp_bwd_kernel(BwdArgs a) {
             }
     }
     __syncthreads();
-    epilogue<true>(acc, hm, Hs, ct0, lane, dacts + dact_h(M, 7), m0, M);
+    epilogue<true>(acc, bits, Hs, ct0, lane, dyh_tile + 7 * M * 256, rows_valid);
     __syncthreads();
 
     // ---- P4: L7 .. L1: dY_l x W_l, mask h_{l-1} -> dY_{l-1} ----------------------------------------------
 #pragma unroll 1
     for (int l = 7; l >= 1; --l) {
-        load_mask(hm, acts + act_h(M, l - 1), ct0, lane, m0, M);
+        bits = mask_in[(l - 1) * mask_stride];
         zero_acc(acc);
         const int pid = PB_L7 + (7 - l);
         gemm_stage<32, 2>(Hs, 0, a.packed + pack_offset(pid), ct0, lane, acc);
@@ -279,7 +287,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void mlp_bwd_kernel(BwdArgs a) {
             for (int e = 0; e < 16; ++e) Hs[((wave >> 1) * 32 + acc_row(e, lane)) * LD + col] = ap[e];
         }
         __syncthreads();
-        epilogue<true>(acc, hm, Hs, ct0, lane, dacts + dact_h(M, l - 1), m0, M);
+        epilogue<true>(acc, bits, Hs, ct0, lane, dyh_tile + (int64_t)(l - 1) * M * 256, rows_valid);
         __syncthreads();
     }
 

@@ -31,6 +31,12 @@ __host__ __device__ inline int64_t act_h(int64_t M, int l) { return M * ACT_PE_W
 __host__ __device__ inline int64_t act_feat(int64_t M) { return M * ACT_PE_W + 8 * M * 256; }
 __host__ __device__ inline int64_t act_hv(int64_t M) { return act_feat(M) + M * 256; }
 __host__ __device__ inline int64_t act_ped(int64_t M) { return act_hv(M) + M * ACT_HV_W; }
+// ReLU sign bits of h0..h7 in ACCUMULATOR layout: one uint64 per (layer, tile, thread); bit
+// ((c*2 + r)*16 + e) <-> accumulator element e of row tile r, column tile wave*2 + c.  The
+// backward kernel uses the same tiling, so each lane reads back exactly its own 64 bits.
+__host__ __device__ inline int64_t n_tiles(int64_t M) { return (M + TM - 1) / TM; }
+__host__ __device__ inline int64_t act_mask(int64_t M) { return act_ped(M) + M * ACT_PED_W; }   // float offset, 8-B aligned
+__host__ __device__ inline int64_t act_total_floats(int64_t M) { return act_mask(M) + 8 * n_tiles(M) * NTHREADS * 2; }
 __host__ __device__ inline int64_t dact_h(int64_t M, int l) { return (int64_t)l * M * 256; }
 __host__ __device__ inline int64_t dact_feat(int64_t M) { return 8 * M * 256; }
 __host__ __device__ inline int64_t dact_hv(int64_t M) { return 9 * M * 256; }
@@ -86,8 +92,28 @@ __host__ __device__ constexpr int layer_out(int l, int C) {
 // ---- weight-gradient workspace -------------------------------------------------------------
 // GEMM instances of the dW kernel (dW = dY^T X over all points), each split DW_SPLITS ways
 // along the point dimension; partials are summed in fixed order by the reduce kernel.
-constexpr int DW_SPLITS = 64;
 enum DwInst { DW_L1 = 0, DW_L2, DW_L3, DW_L4, DW_L5H, DW_L6, DW_L7, DW_FEAT, DW_VIEWSF, DW_L0, DW_L5P, DW_VIEWSP, DW_RGB, DW_COUNT };
+// Split counts follow the instance's cost per point so that every workgroup carries about the
+// same time and the grid is exactly 2 x 256 workgroups (one per CU, two rounds).  The MFMA
+// instances scale 256x256 : 128x256 : 256x64 = 4 : 2 : 1; the two tiny ones (128x32 block, VALU
+// rgb head) are latency-bound per chunk, not MFMA-bound, and get more splits than their FLOPs
+// suggest:  8*52 + 28 + 14 + 14 + 16 + 24 = 512.
+__host__ __device__ constexpr int dw_splits(int inst) {
+    switch (inst) {
+        case DW_VIEWSF: return 28;
+        case DW_L0: return 14;
+        case DW_L5P: return 14;
+        case DW_VIEWSP: return 16;
+        case DW_RGB: return 24;
+        default: return 52;
+    }
+}
+__host__ __device__ constexpr int dw_block_base(int inst) {   // first workgroup id of an instance
+    int b = 0;
+    for (int i = 0; i < inst; ++i) b += dw_splits(i);
+    return b;
+}
+constexpr int DW_TOTAL_BLOCKS = dw_block_base(DW_COUNT);
 struct DwShape { int n, k; };   // output rows (layer outputs) x cols (layer inputs of this instance)
 __host__ __device__ constexpr DwShape dw_shape(int inst) {
     switch (inst) {
@@ -105,7 +131,7 @@ __host__ __device__ constexpr int64_t dw_inst_floats(int inst) {
 }
 __host__ __device__ constexpr int64_t dw_inst_offset(int inst) {
     int64_t o = 0;
-    for (int i = 0; i < inst; ++i) o += dw_inst_floats(i) * DW_SPLITS;
+    for (int i = 0; i < inst; ++i) o += dw_inst_floats(i) * dw_splits(i);
     return o;
 }
 constexpr int64_t DW_WS_FLOATS = dw_inst_offset(DW_COUNT);

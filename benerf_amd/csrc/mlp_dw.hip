@@ -1,7 +1,7 @@
 // K3 backward, part 2: weight gradients dW_l = dY_l^T X_l summed over ALL sample points,
 // exact-f32 MFMA, + bias gradients (column sums) and the two tiny heads (alpha, rgb) on the
 // VALU.  The reduction dimension is the point index (hundreds of thousands), so every GEMM
-// instance is split DW_SPLITS ways along it; each workgroup keeps its whole output block
+// instance is split dw_splits(inst) ways along it (cost-proportional); each workgroup keeps its whole output block
 // (up to 256x256 = 256 accumulator registers per lane across 4 waves) in registers while it
 // streams 32-point chunks of dY and X through LDS (register-staged prefetch of the next
 // chunk during the MFMAs).  Partials are then summed in a fixed order by dw_reduce_kernel,
@@ -72,17 +72,26 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const InstSrc src, int6
     float rda = 0.f;
     auto prefetch = [&](int64_t chunk) {
         const int64_t row0 = chunk * CH;
+        const float4* py = reinterpret_cast<const float4*>(src.dy + row0 * N) + tid;
+        const float4* px = reinterpret_cast<const float4*>(src.x + row0 * K) + tid;
+        if (row0 + CH <= M) {   // block-uniform fast path: plain back-to-back loads
 #pragma unroll
-        for (int j = 0; j < NY4; ++j) {
-            const int q = tid + j * NTHREADS;
-            const int64_t row = row0 + (q * 4) / N;
-            ry[j] = row < M ? *reinterpret_cast<const float4*>(src.dy + row0 * N + (int64_t)q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+            for (int j = 0; j < NY4; ++j) ry[j] = py[j * NTHREADS];
 #pragma unroll
-        for (int j = 0; j < NX4; ++j) {
-            const int q = tid + j * NTHREADS;
-            const int64_t row = row0 + (q * 4) / K;
-            rx[j] = row < M ? *reinterpret_cast<const float4*>(src.x + row0 * K + (int64_t)q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j = 0; j < NX4; ++j) rx[j] = px[j * NTHREADS];
+        } else {                // ragged last chunk: rows >= M contribute zero
+#pragma unroll
+            for (int j = 0; j < NY4; ++j) {
+                const int64_t row = row0 + ((tid + j * NTHREADS) * 4) / N;
+                ry[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < M) ry[j] = py[j * NTHREADS];
+            }
+#pragma unroll
+            for (int j = 0; j < NX4; ++j) {
+                const int64_t row = row0 + ((tid + j * NTHREADS) * 4) / K;
+                rx[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < M) rx[j] = px[j * NTHREADS];
+            }
         }
         if (ALPHA && tid < CH) rda = row0 + tid < M ? a.d_raw[(row0 + tid) * (a.C + 1) + a.C] : 0.f;
     };
@@ -154,7 +163,26 @@ __device__ __forceinline__ void dw_rgb(const DwArgs& a, int64_t row_begin, int64
     const float* hv = a.acts + act_hv(a.M);
     const int C = a.C;
     float s[3] = {0.f, 0.f, 0.f}, sb[3] = {0.f, 0.f, 0.f};
-    for (int64_t mrow = row_begin + half; mrow < row_end; mrow += 2) {
+    // 8 rows in flight per thread (independent loads), fixed summation order
+    constexpr int U = 8;
+    int64_t mrow = row_begin + half;
+    for (; mrow + 2 * (U - 1) < row_end; mrow += 2 * U) {
+        float h[U], g[U][3];
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            h[q] = hv[(mrow + 2 * q) * ACT_HV_W + j];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) g[q][c] = c < C ? a.d_raw[(mrow + 2 * q) * (C + 1) + c] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < U; ++q)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                s[c] += g[q][c] * h[q];
+                sb[c] += g[q][c];
+            }
+    }
+    for (; mrow < row_end; mrow += 2) {
         const float h = hv[mrow * ACT_HV_W + j];
 #pragma unroll
         for (int c = 0; c < 3; ++c)
@@ -189,10 +217,14 @@ __device__ __forceinline__ void dw_rgb(const DwArgs& a, int64_t row_begin, int64
 
 __global__ __launch_bounds__(NTHREADS, 1) void mlp_dw_kernel(DwArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int inst = blockIdx.y;
-    const int split = blockIdx.x;
+    // workgroup -> (instance, split); instances in cost order, split counts proportional to cost
+    int split = blockIdx.x, inst = 0;
+    while (split >= dw_splits(inst)) {
+        split -= dw_splits(inst);
+        ++inst;
+    }
     const int64_t nchunks = (a.M + CH - 1) / CH;
-    const int64_t per = (nchunks + DW_SPLITS - 1) / DW_SPLITS;
+    const int64_t per = (nchunks + dw_splits(inst) - 1) / dw_splits(inst);
     int64_t cb = (int64_t)split * per, ce = cb + per;
     if (cb > nchunks) cb = nchunks;
     if (ce > nchunks) ce = nchunks;
@@ -226,9 +258,10 @@ struct ReduceArgs {
 __device__ __forceinline__ float sum_splits(const float* ws, int inst, int64_t elem) {
     const float* p = ws + dw_inst_offset(inst) + elem;
     const int64_t stride = dw_inst_floats(inst);
+    const int n = dw_splits(inst);
     float s = 0.f;
-#pragma unroll 8
-    for (int sp = 0; sp < DW_SPLITS; ++sp) s += p[sp * stride];
+#pragma unroll 4
+    for (int sp = 0; sp < n; ++sp) s += p[sp * stride];
     return s;
 }
 
@@ -295,7 +328,7 @@ int benerf_mlp_dw_launch(const BenerfMlpParams* params, int channels, int64_t M,
         (void)hipFuncSetAttribute((const void*)mlp_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DW_SMEM);
         attr_done = true;
     }
-    hipLaunchKernelGGL(mlp_dw_kernel, dim3(mlp::DW_SPLITS, mlp::DW_COUNT), dim3(mlp::NTHREADS), DW_SMEM, stream, a);
+    hipLaunchKernelGGL(mlp_dw_kernel, dim3(mlp::DW_TOTAL_BLOCKS), dim3(mlp::NTHREADS), DW_SMEM, stream, a);
     BENERF_LAUNCH_CHECK("mlp_bwd(dw)");
     ReduceArgs r;
     r.ws = dw_ws;

@@ -87,28 +87,60 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][NCT]) {
             for (int e = 0; e < 16; ++e) acc[r][c][e] = 0.f;
 }
 
-// bias (+ReLU) -> LDS tile columns [ct*32..) and, when `save` != nullptr, to the [M][ldo]
-// activation array (row m0+pt).  Every store instruction writes two full 128-B rows.
-template <int NCT, bool RELU>
-__device__ __forceinline__ void epilogue(f32x16 (&acc)[2][NCT], float* __restrict__ Hs, int ct0, int lane,
-                                         const float* __restrict__ bias, float* __restrict__ save, int ldo,
-                                         int64_t m0, int64_t M) {
+// bias (+ReLU) -> LDS tile columns [ct*32..) and, in training mode, to the [M][LDO] activation
+// array whose tile starts at `save_tile` (row m0).  Every store instruction writes two full 128-B
+// rows.  Returns the ReLU sign bits of this lane's accumulator elements (bit ((c*2+r)*16+e)).
+// `rows_valid` (block-uniform) < 64 only for the ragged last tile: the common path has no
+// per-element guards.
+template <int NCT, bool RELU, bool SAVE, int LDO>
+__device__ __forceinline__ uint64_t epilogue(f32x16 (&acc)[2][NCT], float* __restrict__ Hs, int ct0, int lane,
+                                             const float* __restrict__ bias, float* __restrict__ save_tile,
+                                             int rows_valid) {
+    const int lr = lane & 31, r4 = 4 * (lane >> 5);
+    float* hs_lane = Hs + r4 * LD + lr;
+    uint64_t bits = 0;
 #pragma unroll
     for (int c = 0; c < NCT; ++c) {
-        const int n = (ct0 + c) * 32 + (lane & 31);
-        const float bv = bias[n];
+        const int n0 = (ct0 + c) * 32;
+        const float bv = bias[n0 + lr];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int pt = r * 32 + acc_row(e, lane);
+                const int rowoff = r * 32 + (e & 3) + 8 * (e >> 2);
                 float v = acc[r][c][e] + bv;
-                if (RELU) v = fmaxf(v, 0.f);
-                Hs[pt * LD + n] = v;
-                if (save != nullptr && m0 + pt < M) save[(m0 + pt) * ldo + n] = v;
+                if (RELU) {
+                    v = fmaxf(v, 0.f);
+                    bits |= (uint64_t)(v > 0.f) << ((c * 2 + r) * 16 + e);
+                }
+                acc[r][c][e] = v;
+                hs_lane[rowoff * LD + n0] = v;
             }
         }
     }
+    if (SAVE) {
+        float* sv_lane = save_tile + (int64_t)r4 * LDO + lr;
+        if (rows_valid >= TM) {
+#pragma unroll
+            for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        sv_lane[(r * 32 + (e & 3) + 8 * (e >> 2)) * LDO + (ct0 + c) * 32] = acc[r][c][e];
+        } else {
+#pragma unroll
+            for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int rowoff = r * 32 + (e & 3) + 8 * (e >> 2);
+                        if (rowoff + r4 < rows_valid) sv_lane[rowoff * LDO + (ct0 + c) * 32] = acc[r][c][e];
+                    }
+        }
+    }
+    return bits;
 }
 
 template <int C, bool SAVE>
@@ -128,6 +160,11 @@ __global__ __launch_bounds__(NTHREADS, 1) void mlp_fwd_kernel(FwdArgs a) {
     const int64_t mc = m < M ? m : M - 1;
     const int64_t ray = mc / a.S;
     float* acts = a.acts;
+    const int rows_valid = (int)(M - m0 < TM ? M - m0 : TM);          // block-uniform; < 64 only in the last tile
+    float* act_h_tile = SAVE ? acts + act_h(M, 0) + m0 * 256 : nullptr;  // layer l: + l * M * 256
+    uint64_t* mask_out = SAVE ? reinterpret_cast<uint64_t*>(acts + act_mask(M)) + (int64_t)blockIdx.x * NTHREADS + tid
+                              : nullptr;                                 // layer l: + l * n_tiles * 256
+    const int64_t mask_stride = n_tiles(M) * NTHREADS;
 
     // ---- prologue: pts = o + d*z (separately rounded like torch), PE(pts) ----------------------
     {
@@ -170,7 +207,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void mlp_fwd_kernel(FwdArgs a) {
     zero_acc(acc);
     gemm_stage<8, 2>(Hs, COL_PE, a.packed + pack_offset(PF_L0), ct0, lane, acc);
     // L0 reads columns >= 256 and writes columns < 256: no barrier needed before the epilogue
-    epilogue<2, true>(acc, Hs, ct0, lane, a.bias[0], SAVE ? acts + act_h(M, 0) : nullptr, 256, m0, M);
+    {
+        const uint64_t bits = epilogue<2, true, SAVE, 256>(acc, Hs, ct0, lane, a.bias[0], act_h_tile, rows_valid);
+        if (SAVE) mask_out[0] = bits;
+    }
     __syncthreads();
 
     // ---- L1..L7 -------------------------------------------------------------------------------
@@ -180,7 +220,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void mlp_fwd_kernel(FwdArgs a) {
         if (l == 5) gemm_stage<40, 2>(Hs, 0, a.packed + pack_offset(PF_L5), ct0, lane, acc);
         else gemm_stage<32, 2>(Hs, 0, a.packed + pack_offset(PF_L0 + l), ct0, lane, acc);
         __syncthreads();   // every wave finished reading the previous hidden state
-        epilogue<2, true>(acc, Hs, ct0, lane, a.bias[l], SAVE ? acts + act_h(M, l) : nullptr, 256, m0, M);
+        const uint64_t bits = epilogue<2, true, SAVE, 256>(acc, Hs, ct0, lane, a.bias[l],
+                                                           SAVE ? act_h_tile + (int64_t)l * M * 256 : nullptr, rows_valid);
+        if (SAVE) mask_out[l * mask_stride] = bits;
         __syncthreads();
     }
 
@@ -223,7 +265,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void mlp_fwd_kernel(FwdArgs a) {
     zero_acc(acc);
     gemm_stage<32, 2>(Hs, 0, a.packed + pack_offset(PF_FEAT), ct0, lane, acc);
     __syncthreads();   // h7 fully consumed (GEMM + alpha partials); PE(dir) + red[] visible
-    epilogue<2, false>(acc, Hs, ct0, lane, a.bias[BENERF_L_FEAT], SAVE ? acts + act_feat(M) : nullptr, 256, m0, M);
+    epilogue<2, false, SAVE, 256>(acc, Hs, ct0, lane, a.bias[BENERF_L_FEAT], SAVE ? acts + act_feat(M) + m0 * 256 : nullptr,
+                                  rows_valid);
     if (tid < 64 && m < M) {
         a.raw[m * (C + 1) + C] = ((red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid])) + a.b_alpha[0];
     }
@@ -244,7 +287,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void mlp_fwd_kernel(FwdArgs a) {
         zero_acc(av);
         gemm_stage<36, 1>(Hs, 0, a.packed + pack_offset(PF_VIEWS), wave, lane, av);
         __syncthreads();
-        epilogue<1, true>(av, Hs, wave, lane, a.bias[BENERF_L_VIEWS], SAVE ? acts + act_hv(M) : nullptr, ACT_HV_W, m0, M);
+        epilogue<1, true, SAVE, ACT_HV_W>(av, Hs, wave, lane, a.bias[BENERF_L_VIEWS],
+                                          SAVE ? acts + act_hv(M) + m0 * ACT_HV_W : nullptr, rows_valid);
     }
     __syncthreads();
 

@@ -76,7 +76,7 @@ __global__ void pack_kernel(PackArgs a) {
 }  // namespace
 
 extern "C" size_t benerf_mlp_packed_floats(void) { return (size_t)mlp::PACKED_FLOATS; }
-extern "C" size_t benerf_mlp_act_floats_per_point(void) { return (size_t)mlp::ACT_PER_POINT; }
+extern "C" size_t benerf_mlp_act_floats(int64_t n_points) { return (size_t)mlp::act_total_floats(n_points); }
 extern "C" size_t benerf_mlp_dact_floats_per_point(void) { return (size_t)mlp::DACT_PER_POINT; }
 extern "C" size_t benerf_mlp_dw_workspace_floats(int64_t n_points) {
     (void)n_points;

@@ -182,8 +182,7 @@ def mlp_fwd(net, rays_o, rays_d, viewdirs, z, save_acts):
     raw = _new((n_rays, n_samples, C + 1), z)
     acts = None
     if save_acts:
-        acts = torch.empty(n_rays * n_samples * lib.benerf_mlp_act_floats_per_point(), dtype=torch.float32,
-                           device=z.device)
+        acts = torch.empty(lib.benerf_mlp_act_floats(n_rays * n_samples), dtype=torch.float32, device=z.device)
     s = net.struct()
     _timer("mlp_fwd", n_rays * n_samples)
     _lib.check(lib.benerf_mlp_fwd(ctypes.byref(s), net.packed.data_ptr(), C, n_rays, n_samples, _chk(rays_o),

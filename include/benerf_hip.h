@@ -101,8 +101,9 @@ size_t benerf_mlp_packed_floats(void);
 /* Re-pack one network (call after every optimiser step). packed [benerf_mlp_packed_floats()] */
 int benerf_mlp_pack_weights(const BenerfMlpParams* params, int channels, float* packed,
                             benerf_stream_t stream);
-/* floats per sample point of the saved-activation / activation-gradient buffers */
-size_t benerf_mlp_act_floats_per_point(void);
+/* floats of the saved-activation buffer for n_points sample points (layer outputs, PE tiles and
+ * the per-tile ReLU sign-bit words), and floats per point of the activation-gradient scratch */
+size_t benerf_mlp_act_floats(int64_t n_points);
 size_t benerf_mlp_dact_floats_per_point(void);
 /* floats of the weight-gradient partial-sum workspace for n_points */
 size_t benerf_mlp_dw_workspace_floats(int64_t n_points);
@@ -112,7 +113,7 @@ size_t benerf_mlp_dw_workspace_floats(int64_t n_points);
  * (model/nerf.py:67-116) incl. pts = o + d*z (model/nerf.py:308,327).
  *   rays_o, rays_d, viewdirs [n_rays,3]; z [n_rays,n_samples]; raw out
  *   [n_rays,n_samples,channels+1] = [rgb..., sigma] pre-activation.
- *   acts: NULL (inference) or [n_points * act_floats_per_point] saved for backward. */
+ *   acts: NULL (inference) or [benerf_mlp_act_floats(n_points)] saved for backward. */
 int benerf_mlp_fwd(const BenerfMlpParams* params, const float* packed, int channels,
                    int n_rays, int n_samples, const float* rays_o, const float* rays_d,
                    const float* viewdirs, const float* z, float* raw, float* acts,

@@ -28,7 +28,9 @@ def test_header_symbols_exported(lib):
 
 def test_size_queries(lib):
     assert lib.benerf_version() >= 100
-    assert lib.benerf_mlp_act_floats_per_point() == 64 + 8 * 256 + 256 + 128 + 32
+    per_point = 64 + 8 * 256 + 256 + 128 + 32
+    assert lib.benerf_mlp_act_floats(640) == 640 * per_point + 8 * 10 * 256 * 2     # + ReLU sign-bit words
+    assert lib.benerf_mlp_act_floats(641) == 641 * per_point + 8 * 11 * 256 * 2
     assert lib.benerf_mlp_dact_floats_per_point() == 8 * 256 + 256 + 128
     assert lib.benerf_mlp_packed_floats() > 2 * 593920 - 200000
     assert lib.benerf_mlp_dw_workspace_floats(1000) > 0
