@@ -10,10 +10,12 @@
 //   dPE -> d_pts, dPE(dir) -> d_viewdirs (per point) through the sin/cos derivatives, using
 //   the PE values saved by the forward pass (no sincos recomputation).
 //
-// The dY tiles are streamed to HBM for part 2 (mlp_dw.hip: dW = dY^T X).  Same tiling as the
-// forward kernel: the gradient tile lives in the LDS tile Hs, each wave owns 64 columns, B
-// operands (transposed-packed weights) stream from L2.  ReLU masks come from the saved
-// activations, prefetched into registers ahead of each stage's k-loop.
+// The dY tiles are streamed to HBM for part 2 (mlp_dw.hip: dW = dY^T X).  Same tiling, LDS tile
+// and swizzle as the forward kernel (mlp_common.h): the gradient tile lives in T, each wave owns
+// 64 columns, B operands (transposed-packed weights) stream from L2; ReLU masks are the sign-bit
+// words the forward pass wrote in accumulator layout (one 8-byte load per lane per stage).  All
+// small per-point scratch lives in the dead PE columns, so the tile is exactly 80 KiB and two
+// workgroups share a CU (one's MFMAs cover the other's epilogue / store phase).
 #include "mlp_common.h"
 
 namespace {
@@ -24,7 +26,6 @@ struct BwdArgs {
     const float* acts;
     float* dacts;
     const float* packed;
-    const float* w_views;   // [128][283]
     const float* w_alpha;   // [256]
     const float* w_rgb;     // [C][128]
     float* d_pts;           // [M][3]
@@ -32,18 +33,14 @@ struct BwdArgs {
     int64_t M;
 };
 
-constexpr int WVD_LD = 28;
-constexpr int OFF_DRAW = TM * LD;               // [64][4]
-constexpr int OFF_WVD = OFF_DRAW + TM * 4;      // [128][28]
-constexpr int OFF_DPED = OFF_WVD + 128 * WVD_LD;   // [64][28]
-constexpr int OFF_RED = OFF_DPED + TM * WVD_LD;    // [4][64][3]
-constexpr int BWD_SMEM_FLOATS = OFF_RED + 4 * TM * 3;
-
 template <int KB, int NCT>
-__device__ __forceinline__ void gemm_stage(const float* __restrict__ Hs, int kcol0, const float* __restrict__ wp,
+__device__ __forceinline__ void gemm_stage(const float* __restrict__ T, int kcol0, const float* __restrict__ wp,
                                            int ct0, int lane, f32x16 (&acc)[2][NCT]) {
-    const float* a0p = Hs + (lane & 31) * LD + kcol0 + 4 * (lane >> 5);
+    const int row = lane & 31;
+    const int sw = swz(row);
+    const float* a0p = T + row * LD + kcol0;
     const float* a1p = a0p + 32 * LD;
+    const int cl = 4 * (lane >> 5);
     const float4* bp[NCT];
     float4 bn[NCT];
 #pragma unroll
@@ -60,8 +57,9 @@ __device__ __forceinline__ void gemm_stage(const float* __restrict__ Hs, int kco
 #pragma unroll
             for (int c = 0; c < NCT; ++c) bn[c] = bp[c][(kb + 1) * 64];
         }
-        const float4 a0 = *reinterpret_cast<const float4*>(a0p + kb * 8);
-        const float4 a1 = *reinterpret_cast<const float4*>(a1p + kb * 8);
+        const int col = (kb * 8 + cl) ^ sw;
+        const float4 a0 = *reinterpret_cast<const float4*>(a0p + col);
+        const float4 a1 = *reinterpret_cast<const float4*>(a1p + col);
         const float a0v[4] = {a0.x, a0.y, a0.z, a0.w};
         const float a1v[4] = {a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
@@ -78,16 +76,19 @@ __device__ __forceinline__ void gemm_stage(const float* __restrict__ Hs, int kco
 
 // one 32x32 output tile: rows rt*32.., column tile `tile` of the packed block
 template <int KB>
-__device__ __forceinline__ void gemm_one(const float* __restrict__ Hs, int kcol0, const float* __restrict__ wp, int tile,
+__device__ __forceinline__ void gemm_one(const float* __restrict__ T, int kcol0, const float* __restrict__ wp, int tile,
                                          int rt, int lane, f32x16& acc) {
-    const float* ap = Hs + (rt * 32 + (lane & 31)) * LD + kcol0 + 4 * (lane >> 5);
+    const int row = rt * 32 + (lane & 31);
+    const int sw = swz(row);
+    const float* ap = T + row * LD + kcol0;
+    const int cl = 4 * (lane >> 5);
     const float4* bp = reinterpret_cast<const float4*>(wp) + (int64_t)tile * KB * 64 + lane;
     float4 bn = bp[0];
 #pragma unroll 4
     for (int kb = 0; kb < KB; ++kb) {
         const float4 b = bn;
         if (kb + 1 < KB) bn = bp[(kb + 1) * 64];
-        const float4 a = *reinterpret_cast<const float4*>(ap + kb * 8);
+        const float4 a = *reinterpret_cast<const float4*>(ap + ((kb * 8 + cl) ^ sw));
         acc = mfma32(a.x, b.x, acc);
         acc = mfma32(a.y, b.y, acc);
         acc = mfma32(a.z, b.z, acc);
@@ -109,10 +110,9 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][NCT]) {
 // -> LDS tile + DY array whose tile starts at `dy_tile` (row m0).  `rows_valid` is block-uniform
 // and < 64 only for the ragged last tile.
 template <bool MASK>
-__device__ __forceinline__ void epilogue(f32x16 (&acc)[2][2], uint64_t bits, float* __restrict__ Hs, int ct0, int lane,
+__device__ __forceinline__ void epilogue(f32x16 (&acc)[2][2], uint64_t bits, float* __restrict__ T, int ct0, int lane,
                                          float* __restrict__ dy_tile, int rows_valid) {
     const int lr = lane & 31, r4 = 4 * (lane >> 5);
-    float* hs_lane = Hs + r4 * LD + lr;
     float* dy_lane = dy_tile + (int64_t)r4 * 256 + lr;
 #pragma unroll
     for (int c = 0; c < 2; ++c)
@@ -123,7 +123,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[2][2], uint64_t bits, flo
                 float v = acc[r][c][e];
                 if (MASK) v = ((bits >> ((c * 2 + r) * 16 + e)) & 1ull) ? v : 0.f;
                 acc[r][c][e] = v;
-                hs_lane[(r * 32 + (e & 3) + 8 * (e >> 2)) * LD + (ct0 + c) * 32] = v;
+                T[tidx(r * 32 + (e & 3) + 8 * (e >> 2) + r4, (ct0 + c) * 32 + lr)] = v;
             }
     if (rows_valid >= TM) {
 #pragma unroll
@@ -147,13 +147,8 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[2][2], uint64_t bits, flo
 }
 
 template <int C>
-__global__ __launch_bounds__(NTHREADS, 1) void mlp_bwd_kernel(BwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Hs = smem;
-    float* draw = smem + OFF_DRAW;
-    float* wvd = smem + OFF_WVD;
-    float* dped = smem + OFF_DPED;
-    float* red = smem + OFF_RED;
+__global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_kernel(BwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float T[];   // [TM][LD], swizzled
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -161,7 +156,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void mlp_bwd_kernel(BwdArgs a) {
     const int64_t m0 = (int64_t)blockIdx.x * TM;
     const int64_t M = a.M;
     const int pt = tid & 63;
-    const int grp = tid >> 6;
+    const int grp = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (scalar) thread-group id
     const int64_t m = m0 + pt;
     const float* acts = a.acts;
     float* dacts = a.dacts;
@@ -170,19 +165,17 @@ __global__ __launch_bounds__(NTHREADS, 1) void mlp_bwd_kernel(BwdArgs a) {
     const uint64_t* mask_in = reinterpret_cast<const uint64_t*>(acts + act_mask(M)) + (int64_t)blockIdx.x * NTHREADS + tid;
     const int64_t mask_stride = n_tiles(M) * NTHREADS;           // per layer
     float* dyh_tile = dacts + dact_h(M, 0) + m0 * 256;           // layer l: + l * M * 256
+    float* trow = T + pt * LD;
+    const int psw = swz(pt);
 
-    // ---- P0: d_raw tile, PE(dir) slice of the views weights --------------------------------------
+    // ---- P0: d_raw tile -> scratch columns [288, 288+C] of each point's row --------------------------
     if (tid < 64) {
 #pragma unroll
-        for (int c = 0; c <= C; ++c) draw[tid * 4 + c] = m < M ? a.d_raw[m * (C + 1) + c] : 0.f;
-    }
-    for (int e = tid; e < 128 * 27; e += NTHREADS) {
-        const int n = e / 27, j = e - n * 27;
-        wvd[n * WVD_LD + j] = a.w_views[n * 283 + 256 + j];
+        for (int c = 0; c <= C; ++c) trow[(COL_SCR + c) ^ psw] = m < M ? a.d_raw[m * (C + 1) + c] : 0.f;
     }
     __syncthreads();
 
-    // ---- P1: rgb layer backward + ReLU mask of the views layer -> dYv in Hs[:,0:128) ------------------
+    // ---- P1: rgb layer backward + ReLU mask of the views layer -> dYv in T[:,0:128) ------------------
     {
         const int j = tid & 127, half = tid >> 7;
         float wr[C];
@@ -192,14 +185,15 @@ __global__ __launch_bounds__(NTHREADS, 1) void mlp_bwd_kernel(BwdArgs a) {
         float* dyv = dacts + dact_hv(M);
 #pragma unroll 4
         for (int p = half * 32; p < half * 32 + 32; ++p) {
-            const int64_t mm = m0 + p;
             float g = 0.f;
 #pragma unroll
-            for (int c = 0; c < C; ++c) g += draw[p * 4 + c] * wr[c];
-            const float h = mm < M ? hv[mm * ACT_HV_W + j] : 0.f;
-            const float v = h > 0.f ? g : 0.f;
-            Hs[p * LD + j] = v;
-            if (mm < M) dyv[mm * ACT_HV_W + j] = v;
+            for (int c = 0; c < C; ++c) g += T[tidx(p, COL_SCR + c)] * wr[c];
+            float v = 0.f;
+            if (p < rows_valid) {
+                v = hv[(m0 + p) * ACT_HV_W + j] > 0.f ? g : 0.f;
+                dyv[(m0 + p) * ACT_HV_W + j] = v;
+            }
+            T[tidx(p, j)] = v;
         }
     }
     __syncthreads();
@@ -208,42 +202,39 @@ __global__ __launch_bounds__(NTHREADS, 1) void mlp_bwd_kernel(BwdArgs a) {
 
     // ---- P2: VIEWS^T: dFeat = dYv x Wv[:, :256]; dPE(dir) = dYv x Wv[:, 256:283] (VALU) ------------------
     zero_acc(acc);
-    gemm_stage<16, 2>(Hs, 0, a.packed + pack_offset(PB_VIEWS), ct0, lane, acc);
+    gemm_stage<16, 2>(T, 0, a.packed + pack_offset(PB_VIEWS), ct0, lane, acc);
     {
+        // this wave's 7 PE(dir) columns j = grp + 4q; weights [grp][n][8] are wave-uniform (scalar loads)
+        const float* wq = a.packed + pack_offset(PB_VIEWSPE) + (int64_t)grp * 128 * 8;
         float s[7];
 #pragma unroll
         for (int q = 0; q < 7; ++q) s[q] = 0.f;
-        const float* hrow = Hs + pt * LD;
 #pragma unroll 2
         for (int n = 0; n < 128; n += 4) {
-            const float4 h4 = *reinterpret_cast<const float4*>(hrow + n);
+            const float4 h4 = *reinterpret_cast<const float4*>(trow + (n ^ psw));
             const float hv4[4] = {h4.x, h4.y, h4.z, h4.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int q = 0; q < 7; ++q) {
-                    const int j = grp + 4 * q;
-                    if (j < 27) s[q] += hv4[i] * wvd[(n + i) * WVD_LD + j];
-                }
+                for (int q = 0; q < 7; ++q) s[q] += hv4[i] * wq[(n + i) * 8 + q];
         }
 #pragma unroll
         for (int q = 0; q < 7; ++q) {
             const int j = grp + 4 * q;
-            if (j < 27) dped[pt * WVD_LD + j] = s[q];
+            if (j < 27) trow[(COL_PE + j) ^ psw] = s[q];
         }
     }
-    __syncthreads();   // dYv fully consumed
-    epilogue<false>(acc, 0ull, Hs, ct0, lane, dacts + dact_feat(M) + m0 * 256, rows_valid);
+    __syncthreads();   // dYv fully consumed; dPE(dir) visible
+    epilogue<false>(acc, 0ull, T, ct0, lane, dacts + dact_feat(M) + m0 * 256, rows_valid);
     if (grp == 0 && m < M) {   // d viewdirs (per point) through PE(dir)
         const float* ped = acts + act_ped(M) + m * ACT_PED_W;
-        const float* g = dped + pt * WVD_LD;
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            float s = g[d];
+            float s = trow[(COL_PE + d) ^ psw];
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
                 const float sn = ped[3 + f * 6 + d], cs = ped[3 + f * 6 + 3 + d];
-                s += (float)(1 << f) * (cs * g[3 + f * 6 + d] - sn * g[3 + f * 6 + 3 + d]);
+                s += (float)(1 << f) * (cs * trow[(COL_PE + 3 + f * 6 + d) ^ psw] - sn * trow[(COL_PE + 3 + f * 6 + 3 + d) ^ psw]);
             }
             a.d_vdir[m * 3 + d] = s;
         }
@@ -253,21 +244,22 @@ __global__ __launch_bounds__(NTHREADS, 1) void mlp_bwd_kernel(BwdArgs a) {
 
     // ---- P3: FEAT^T (+ alpha head), mask h7 -> dY7 ----------------------------------------------------
     zero_acc(acc);
-    gemm_stage<32, 2>(Hs, 0, a.packed + pack_offset(PB_FEAT), ct0, lane, acc);
+    gemm_stage<32, 2>(T, 0, a.packed + pack_offset(PB_FEAT), ct0, lane, acc);
     {
         const float wa0 = a.w_alpha[ct0 * 32 + (lane & 31)];
         const float wa1 = a.w_alpha[(ct0 + 1) * 32 + (lane & 31)];
+        const int r4 = 4 * (lane >> 5);
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const float ds = draw[(r * 32 + acc_row(e, lane)) * 4 + C];
+                const float ds = T[tidx(r * 32 + (e & 3) + 8 * (e >> 2) + r4, COL_SCR + C)];
                 acc[r][0][e] += ds * wa0;
                 acc[r][1][e] += ds * wa1;
             }
     }
     __syncthreads();
-    epilogue<true>(acc, bits, Hs, ct0, lane, dyh_tile + 7 * M * 256, rows_valid);
+    epilogue<true>(acc, bits, T, ct0, lane, dyh_tile + 7 * M * 256, rows_valid);
     __syncthreads();
 
     // ---- P4: L7 .. L1: dY_l x W_l, mask h_{l-1} -> dY_{l-1} ----------------------------------------------
@@ -276,18 +268,18 @@ __global__ __launch_bounds__(NTHREADS, 1) void mlp_bwd_kernel(BwdArgs a) {
         bits = mask_in[(l - 1) * mask_stride];
         zero_acc(acc);
         const int pid = PB_L7 + (7 - l);
-        gemm_stage<32, 2>(Hs, 0, a.packed + pack_offset(pid), ct0, lane, acc);
-        if (l == 5) {   // skip connection: dPE = dY5 x W5[:, PE part] (tiles 8, 9 of the block)
+        gemm_stage<32, 2>(T, 0, a.packed + pack_offset(pid), ct0, lane, acc);
+        if (l == 5) {   // skip connection: dPE = dY5 x W5[:, PE part] (tiles 8, 9 of the block) -> T[:,256:320)
             f32x16 ap;
 #pragma unroll
             for (int e = 0; e < 16; ++e) ap[e] = 0.f;
-            gemm_one<32>(Hs, 0, a.packed + pack_offset(PB_L5), 8 + (wave & 1), wave >> 1, lane, ap);
+            gemm_one<32>(T, 0, a.packed + pack_offset(PB_L5), 8 + (wave & 1), wave >> 1, lane, ap);
             const int col = COL_PE + (wave & 1) * 32 + (lane & 31);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) Hs[((wave >> 1) * 32 + acc_row(e, lane)) * LD + col] = ap[e];
+            for (int e = 0; e < 16; ++e) T[tidx((wave >> 1) * 32 + acc_row(e, lane), col)] = ap[e];
         }
         __syncthreads();
-        epilogue<true>(acc, bits, Hs, ct0, lane, dyh_tile + (int64_t)(l - 1) * M * 256, rows_valid);
+        epilogue<true>(acc, bits, T, ct0, lane, dyh_tile + (int64_t)(l - 1) * M * 256, rows_valid);
         __syncthreads();
     }
 
@@ -296,45 +288,41 @@ __global__ __launch_bounds__(NTHREADS, 1) void mlp_bwd_kernel(BwdArgs a) {
         f32x16 ap;
 #pragma unroll
         for (int e = 0; e < 16; ++e) ap[e] = 0.f;
-        gemm_one<32>(Hs, 0, a.packed + pack_offset(PB_L0), wave & 1, wave >> 1, lane, ap);
+        gemm_one<32>(T, 0, a.packed + pack_offset(PB_L0), wave & 1, wave >> 1, lane, ap);
         const int col = COL_PE + (wave & 1) * 32 + (lane & 31);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) Hs[((wave >> 1) * 32 + acc_row(e, lane)) * LD + col] += ap[e];
+        for (int e = 0; e < 16; ++e) T[tidx((wave >> 1) * 32 + acc_row(e, lane), col)] += ap[e];
     }
     __syncthreads();
 
-    // ---- P6: dPE -> d_pts through the saved PE values ------------------------------------------------------
+    // ---- P6: dPE -> d_pts through the saved PE values; group partials in columns [0,16) of the row --------
     {
         float s[3] = {0.f, 0.f, 0.f};
-        const float* g = Hs + pt * LD + COL_PE;
         const int64_t mc = m < M ? m : M - 1;
         const float* pe = acts + act_pe(M) + mc * ACT_PE_W;
         if (grp == 0) {
-            s[0] = g[0];
-            s[1] = g[1];
-            s[2] = g[2];
+            s[0] = trow[(COL_PE + 0) ^ psw];
+            s[1] = trow[(COL_PE + 1) ^ psw];
+            s[2] = trow[(COL_PE + 2) ^ psw];
         }
         for (int f = grp; f < 10; f += 4) {
             const float sc = (float)(1 << f);
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
                 const float sn = pe[3 + f * 6 + d], cs = pe[3 + f * 6 + 3 + d];
-                s[d] += sc * (cs * g[3 + f * 6 + d] - sn * g[3 + f * 6 + 3 + d]);
+                s[d] += sc * (cs * trow[(COL_PE + 3 + f * 6 + d) ^ psw] - sn * trow[(COL_PE + 3 + f * 6 + 3 + d) ^ psw]);
             }
         }
 #pragma unroll
-        for (int d = 0; d < 3; ++d) red[(grp * TM + pt) * 3 + d] = s[d];
+        for (int d = 0; d < 3; ++d) trow[(grp * 4 + d) ^ psw] = s[d];   // columns < 256 are dead (dY0 consumed)
     }
     __syncthreads();
     if (tid < 64 && m < M) {
 #pragma unroll
         for (int d = 0; d < 3; ++d)
-            a.d_pts[m * 3 + d] = (red[(0 * TM + tid) * 3 + d] + red[(1 * TM + tid) * 3 + d]) +
-                                 (red[(2 * TM + tid) * 3 + d] + red[(3 * TM + tid) * 3 + d]);
+            a.d_pts[m * 3 + d] = (trow[(0 + d) ^ psw] + trow[(4 + d) ^ psw]) + (trow[(8 + d) ^ psw] + trow[(12 + d) ^ psw]);
     }
 }
-
-constexpr size_t BWD_SMEM = (size_t)BWD_SMEM_FLOATS * sizeof(float);
 
 }  // namespace
 
@@ -350,7 +338,6 @@ static int launch_dx(const BenerfMlpParams* params, const float* packed, int cha
     a.acts = acts;
     a.dacts = dacts;
     a.packed = packed;
-    a.w_views = params->w[BENERF_L_VIEWS];
     a.w_alpha = params->w[BENERF_L_ALPHA];
     a.w_rgb = params->w[BENERF_L_RGB];
     a.d_pts = d_pts;
@@ -359,14 +346,15 @@ static int launch_dx(const BenerfMlpParams* params, const float* packed, int cha
     const int64_t tiles = (M + mlp::TM - 1) / mlp::TM;
     BENERF_REQUIRE(tiles < (1ll << 31), "mlp_bwd: too many points");
     dim3 grid((unsigned)tiles), block(mlp::NTHREADS);
+    const int smem = (int)mlp::TILE_SMEM;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)mlp_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_SMEM);
-        (void)hipFuncSetAttribute((const void*)mlp_bwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_SMEM);
+        (void)hipFuncSetAttribute((const void*)mlp_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        (void)hipFuncSetAttribute((const void*)mlp_bwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_done = true;
     }
-    if (channels == 1) hipLaunchKernelGGL((mlp_bwd_kernel<1>), grid, block, BWD_SMEM, stream, a);
-    else hipLaunchKernelGGL((mlp_bwd_kernel<3>), grid, block, BWD_SMEM, stream, a);
+    if (channels == 1) hipLaunchKernelGGL((mlp_bwd_kernel<1>), grid, block, smem, stream, a);
+    else hipLaunchKernelGGL((mlp_bwd_kernel<3>), grid, block, smem, stream, a);
     BENERF_LAUNCH_CHECK("mlp_bwd(dx)");
     return BENERF_OK;
 }

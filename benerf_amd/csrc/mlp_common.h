@@ -16,9 +16,19 @@
 namespace mlp {
 
 constexpr int TM = 64;        // sample points per workgroup tile
-constexpr int LD = 324;       // LDS row stride in floats (16 B aligned rows, 4-bank skew)
+constexpr int LD = 320;       // LDS row stride in floats: the tile is exactly 80 KiB -> 2 workgroups per CU
 constexpr int COL_PE = 256;   // first PE column of the LDS tile
+constexpr int COL_SCR = 288;  // 32 scratch columns (dead PE columns) for small per-point reductions
 constexpr int NTHREADS = 256; // 4 wavefronts
+constexpr size_t TILE_SMEM = (size_t)TM * LD * sizeof(float);   // 81 920 B
+
+// Bank-conflict-free addressing without padding: element (row, col) of the tile lives at
+// row*LD + (col ^ ((row & 15) << 2)).  The XOR permutes 16-byte slots inside each 64-column block,
+// so float4 groups stay contiguous, the MFMA A-operand ds_read_b128 (16 distinct rows per lane
+// group, one 4-column slot) and the epilogue ds_write_b32 (one row, 32 consecutive columns) are
+// both conflict free.
+__device__ __forceinline__ int swz(int row) { return (row & 15) << 2; }
+__device__ __forceinline__ int tidx(int row, int col) { return row * LD + (col ^ swz(row)); }
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
@@ -48,6 +58,7 @@ __host__ __device__ inline int64_t dact_hv(int64_t M) { return 9 * M * 256; }
 enum PackId {
     PF_L0 = 0, PF_L1, PF_L2, PF_L3, PF_L4, PF_L5, PF_L6, PF_L7, PF_FEAT, PF_VIEWS,   // forward: col = output feature
     PB_VIEWS, PB_FEAT, PB_L7, PB_L6, PB_L5, PB_L4, PB_L3, PB_L2, PB_L1, PB_L0,       // backward: col = input feature
+    PB_VIEWSPE,   // PE(dir) slice of the views weights as [4 thread groups][128 n][8]: (g, n, q) = Wv[n][256 + g + 4q]
     PACK_COUNT
 };
 struct PackShape { int tiles, kblocks; };
@@ -59,6 +70,7 @@ __host__ __device__ constexpr PackShape pack_shape(int id) {
         case PB_VIEWS: return {8, 16};    // out 256 feature cols, contraction n = 128
         case PB_L5: return {10, 32};      // out [h4 256 | PE 64]
         case PB_L0: return {2, 32};       // out PE 64
+        case PB_VIEWSPE: return {1, 16};  // 4 * 128 * 8 floats, own layout
         default: return {8, 32};
     }
 }
@@ -76,7 +88,7 @@ constexpr int64_t PACKED_FLOATS = pack_offset(PACK_COUNT);
 __host__ __device__ constexpr int pack_layer(int id) {
     switch (id) {
         case PF_FEAT: case PB_FEAT: return BENERF_L_FEAT;
-        case PF_VIEWS: case PB_VIEWS: return BENERF_L_VIEWS;
+        case PF_VIEWS: case PB_VIEWS: case PB_VIEWSPE: return BENERF_L_VIEWS;
         case PB_L7: return 7; case PB_L6: return 6; case PB_L5: return 5; case PB_L4: return 4;
         case PB_L3: return 3; case PB_L2: return 2; case PB_L1: return 1; case PB_L0: return 0;
         default: return id;   // PF_L0..PF_L7

@@ -2,21 +2,22 @@
 // workgroup (4 wavefronts), exact-f32 MFMA.  Replaces Embedder.embed (model/embedder.py:9-34)
 // + NeRF.forward (model/nerf.py:67-116) + pts = o + d*z (model/nerf.py:308,327).
 //
-// Data flow per tile (see mlp_common.h for the LDS tile layout):
-//   prologue : pts, PE(pts) -> Hs[:,256:320)
-//   L0       : Hs[:,256:320) x W0^T            -> relu -> Hs[:,0:256)
-//   L1..L4   : Hs[:,0:256)   x Wl^T            -> relu -> Hs[:,0:256)
-//   L5       : Hs[:,0:320)   x [W5h|W5pe]^T    -> relu -> Hs[:,0:256)   (skip connection)
+// Data flow per tile (LDS tile layout and swizzle: mlp_common.h):
+//   prologue : pts, PE(pts) -> T[:,256:320)
+//   L0       : T[:,256:320) x W0^T            -> relu -> T[:,0:256)
+//   L1..L4   : T[:,0:256)   x Wl^T            -> relu -> T[:,0:256)
+//   L5       : T[:,0:320)   x [W5h|W5pe]^T    -> relu -> T[:,0:256)   (skip connection)
 //   L6,L7    : as L1
-//   alpha    : VALU dot(Hs[:,0:256), w_alpha)  ; PE(dir) -> Hs[:,256:288)
-//   FEAT     : Hs[:,0:256)   x Wf^T   (linear) -> Hs[:,0:256)
-//   VIEWS    : Hs[:,0:288)   x Wv^T            -> relu -> Hs[:,0:128)
-//   rgb      : VALU dot(Hs[:,0:128), w_rgb[c])
+//   alpha    : VALU dot(T[:,0:256), w_alpha)  ; PE(dir) -> T[:,256:288)
+//   FEAT     : T[:,0:256)   x Wf^T   (linear) -> T[:,0:256)
+//   VIEWS    : T[:,0:288)   x Wv^T            -> relu -> T[:,0:128)
+//   rgb      : VALU dot(T[:,0:128), w_rgb[c])
 // Each wave owns 64 output features (2 MFMA column tiles) x all 64 points (2 row tiles):
 // per 8-deep k-block it issues 2 ds_read_b128 (A, points) + 2 global_load_dwordx4 (B,
 // weights, L2-resident) for 16 MFMAs (1024 cycles) - operand traffic is negligible, the
-// kernel is bound by the f32 matrix pipe.  In training mode every layer output is also
-// streamed to HBM (full 128-B lines per store instruction) for the backward pass.
+// kernel is bound by the f32 matrix pipe.  The tile is exactly 80 KiB and the kernel fits 256
+// registers, so TWO workgroups share a CU: while one is in an epilogue (bias/ReLU, LDS writes,
+// activation stores for the backward pass, barriers) the other keeps the matrix pipe busy.
 #include "mlp_common.h"
 
 namespace {
@@ -39,12 +40,15 @@ struct FwdArgs {
     int S;
 };
 
-// acc[r][c] += Hs[rows r*32.., kcol0 + 0..KB*8) x Wp(tile ct0+c)
+// acc[r][c] += T[rows r*32.., kcol0 + 0..KB*8) x Wp(tile ct0+c);  kcol0 is a multiple of 64
 template <int KB, int NCT>
-__device__ __forceinline__ void gemm_stage(const float* __restrict__ Hs, int kcol0, const float* __restrict__ wp,
+__device__ __forceinline__ void gemm_stage(const float* __restrict__ T, int kcol0, const float* __restrict__ wp,
                                            int ct0, int lane, f32x16 (&acc)[2][NCT]) {
-    const float* a0p = Hs + (lane & 31) * LD + kcol0 + 4 * (lane >> 5);
+    const int row = lane & 31;
+    const int sw = swz(row);                       // rows row and row+32 share the swizzle
+    const float* a0p = T + row * LD + kcol0;
     const float* a1p = a0p + 32 * LD;
+    const int cl = 4 * (lane >> 5);
     const float4* bp[NCT];
     float4 bn[NCT];
 #pragma unroll
@@ -61,8 +65,9 @@ __device__ __forceinline__ void gemm_stage(const float* __restrict__ Hs, int kco
 #pragma unroll
             for (int c = 0; c < NCT; ++c) bn[c] = bp[c][(kb + 1) * 64];
         }
-        const float4 a0 = *reinterpret_cast<const float4*>(a0p + kb * 8);
-        const float4 a1 = *reinterpret_cast<const float4*>(a1p + kb * 8);
+        const int col = (kb * 8 + cl) ^ sw;
+        const float4 a0 = *reinterpret_cast<const float4*>(a0p + col);
+        const float4 a1 = *reinterpret_cast<const float4*>(a1p + col);
         const float a0v[4] = {a0.x, a0.y, a0.z, a0.w};
         const float a1v[4] = {a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
@@ -93,28 +98,27 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][NCT]) {
 // `rows_valid` (block-uniform) < 64 only for the ragged last tile: the common path has no
 // per-element guards.
 template <int NCT, bool RELU, bool SAVE, int LDO>
-__device__ __forceinline__ uint64_t epilogue(f32x16 (&acc)[2][NCT], float* __restrict__ Hs, int ct0, int lane,
+__device__ __forceinline__ uint64_t epilogue(f32x16 (&acc)[2][NCT], float* __restrict__ T, int ct0, int lane,
                                              const float* __restrict__ bias, float* __restrict__ save_tile,
                                              int rows_valid) {
     const int lr = lane & 31, r4 = 4 * (lane >> 5);
-    float* hs_lane = Hs + r4 * LD + lr;
     uint64_t bits = 0;
 #pragma unroll
     for (int c = 0; c < NCT; ++c) {
-        const int n0 = (ct0 + c) * 32;
-        const float bv = bias[n0 + lr];
+        const int n = (ct0 + c) * 32 + lr;
+        const float bv = bias[n];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int rowoff = r * 32 + (e & 3) + 8 * (e >> 2);
+                const int row = r * 32 + (e & 3) + 8 * (e >> 2) + r4;
                 float v = acc[r][c][e] + bv;
                 if (RELU) {
                     v = fmaxf(v, 0.f);
                     bits |= (uint64_t)(v > 0.f) << ((c * 2 + r) * 16 + e);
                 }
                 acc[r][c][e] = v;
-                hs_lane[rowoff * LD + n0] = v;
+                T[tidx(row, n)] = v;
             }
         }
     }
@@ -144,10 +148,8 @@ __device__ __forceinline__ uint64_t epilogue(f32x16 (&acc)[2][NCT], float* __res
 }
 
 template <int C, bool SAVE>
-__global__ __launch_bounds__(NTHREADS, 1) void mlp_fwd_kernel(FwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Hs = smem;                  // [TM][LD]
-    float* red = smem + TM * LD;       // [3][4][64] partial dot products
+__global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_kernel(FwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float T[];   // [TM][LD], swizzled (mlp_common.h)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -165,6 +167,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void mlp_fwd_kernel(FwdArgs a) {
     uint64_t* mask_out = SAVE ? reinterpret_cast<uint64_t*>(acts + act_mask(M)) + (int64_t)blockIdx.x * NTHREADS + tid
                               : nullptr;                                 // layer l: + l * n_tiles * 256
     const int64_t mask_stride = n_tiles(M) * NTHREADS;
+    float* trow = T + pt * LD;          // this thread's point row; column c lives at trow[c ^ psw]
+    const int psw = swz(pt);
 
     // ---- prologue: pts = o + d*z (separately rounded like torch), PE(pts) ----------------------
     {
@@ -172,12 +176,11 @@ __global__ __launch_bounds__(NTHREADS, 1) void mlp_fwd_kernel(FwdArgs a) {
         float x[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) x[c] = __fadd_rn(a.rays_o[ray * 3 + c], __fmul_rn(a.rays_d[ray * 3 + c], zz));
-        float* row = Hs + pt * LD + COL_PE;
         if (grp == 0) {
-            row[0] = x[0];
-            row[1] = x[1];
-            row[2] = x[2];
-            row[63] = 0.f;
+            trow[(COL_PE + 0) ^ psw] = x[0];
+            trow[(COL_PE + 1) ^ psw] = x[1];
+            trow[(COL_PE + 2) ^ psw] = x[2];
+            trow[(COL_PE + 63) ^ psw] = 0.f;
         }
         // 30 (freq, dim) pairs, strided over the 4 thread groups        model/embedder.py:13-28
         for (int p = grp; p < 30; p += 4) {
@@ -185,18 +188,17 @@ __global__ __launch_bounds__(NTHREADS, 1) void mlp_fwd_kernel(FwdArgs a) {
             const float v = x[d] * (float)(1 << f);
             float s, c;
             sincosf(v, &s, &c);
-            row[3 + f * 6 + d] = s;
-            row[3 + f * 6 + 3 + d] = c;
+            trow[(COL_PE + 3 + f * 6 + d) ^ psw] = s;
+            trow[(COL_PE + 3 + f * 6 + 3 + d) ^ psw] = c;
         }
     }
     __syncthreads();
     if (SAVE) {   // PE tile -> acts (256 B per point, 4 threads per row)
         const int r = tid >> 2, q = tid & 3;
-        if (m0 + r < M) {
+        if (r < rows_valid) {
             float4* dst = reinterpret_cast<float4*>(acts + act_pe(M) + (m0 + r) * ACT_PE_W + q * 16);
-            const float4* src = reinterpret_cast<const float4*>(Hs + r * LD + COL_PE + q * 16);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) dst[j] = src[j];
+            for (int j = 0; j < 4; ++j) dst[j] = *reinterpret_cast<const float4*>(T + tidx(r, COL_PE + q * 16 + 4 * j));
         }
     }
 
@@ -205,10 +207,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void mlp_fwd_kernel(FwdArgs a) {
 
     // ---- L0 ---------------------------------------------------------------------------------
     zero_acc(acc);
-    gemm_stage<8, 2>(Hs, COL_PE, a.packed + pack_offset(PF_L0), ct0, lane, acc);
+    gemm_stage<8, 2>(T, COL_PE, a.packed + pack_offset(PF_L0), ct0, lane, acc);
     // L0 reads columns >= 256 and writes columns < 256: no barrier needed before the epilogue
     {
-        const uint64_t bits = epilogue<2, true, SAVE, 256>(acc, Hs, ct0, lane, a.bias[0], act_h_tile, rows_valid);
+        const uint64_t bits = epilogue<2, true, SAVE, 256>(acc, T, ct0, lane, a.bias[0], act_h_tile, rows_valid);
         if (SAVE) mask_out[0] = bits;
     }
     __syncthreads();
@@ -217,66 +219,65 @@ __global__ __launch_bounds__(NTHREADS, 1) void mlp_fwd_kernel(FwdArgs a) {
 #pragma unroll 1
     for (int l = 1; l < 8; ++l) {
         zero_acc(acc);
-        if (l == 5) gemm_stage<40, 2>(Hs, 0, a.packed + pack_offset(PF_L5), ct0, lane, acc);
-        else gemm_stage<32, 2>(Hs, 0, a.packed + pack_offset(PF_L0 + l), ct0, lane, acc);
+        if (l == 5) gemm_stage<40, 2>(T, 0, a.packed + pack_offset(PF_L5), ct0, lane, acc);
+        else gemm_stage<32, 2>(T, 0, a.packed + pack_offset(PF_L0 + l), ct0, lane, acc);
         __syncthreads();   // every wave finished reading the previous hidden state
-        const uint64_t bits = epilogue<2, true, SAVE, 256>(acc, Hs, ct0, lane, a.bias[l],
+        const uint64_t bits = epilogue<2, true, SAVE, 256>(acc, T, ct0, lane, a.bias[l],
                                                            SAVE ? act_h_tile + (int64_t)l * M * 256 : nullptr, rows_valid);
         if (SAVE) mask_out[l * mask_stride] = bits;
         __syncthreads();
     }
 
     // ---- alpha partials (reads h7) + PE(viewdir) into columns [256,288) ---------------------------
+    // scratch columns [288,320) (dead PE columns): alpha partial of group g at column 288 + g
     {
-        const float* hrow = Hs + pt * LD + grp * 64;
         const float* wa = a.w_alpha + grp * 64;
         float s = 0.f;
 #pragma unroll 4
         for (int k = 0; k < 64; k += 4) {
-            const float4 h = *reinterpret_cast<const float4*>(hrow + k);
+            const float4 h = *reinterpret_cast<const float4*>(trow + ((grp * 64 + k) ^ psw));
             const float4 w = *reinterpret_cast<const float4*>(wa + k);
             s += h.x * w.x + h.y * w.y + h.z * w.z + h.w * w.w;
         }
-        red[grp * 64 + pt] = s;
+        trow[(COL_SCR + grp) ^ psw] = s;
         float vd[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) vd[c] = a.viewdirs[ray * 3 + c];
-        float* row = Hs + pt * LD + COL_PE;
         if (grp == 0) {
-            row[0] = vd[0];
-            row[1] = vd[1];
-            row[2] = vd[2];
+            trow[(COL_PE + 0) ^ psw] = vd[0];
+            trow[(COL_PE + 1) ^ psw] = vd[1];
+            trow[(COL_PE + 2) ^ psw] = vd[2];
         }
         if (grp == 1) {
 #pragma unroll
-            for (int k = 27; k < 32; ++k) row[k] = 0.f;
+            for (int k = 27; k < 32; ++k) trow[(COL_PE + k) ^ psw] = 0.f;
         }
         for (int p = grp; p < 12; p += 4) {
             const int f = p / 3, d = p - 3 * f;
             const float v = vd[d] * (float)(1 << f);
             float sn, cs;
             sincosf(v, &sn, &cs);
-            row[3 + f * 6 + d] = sn;
-            row[3 + f * 6 + 3 + d] = cs;
+            trow[(COL_PE + 3 + f * 6 + d) ^ psw] = sn;
+            trow[(COL_PE + 3 + f * 6 + 3 + d) ^ psw] = cs;
         }
     }
 
     // ---- FEAT (linear) ----------------------------------------------------------------------------
     zero_acc(acc);
-    gemm_stage<32, 2>(Hs, 0, a.packed + pack_offset(PF_FEAT), ct0, lane, acc);
-    __syncthreads();   // h7 fully consumed (GEMM + alpha partials); PE(dir) + red[] visible
-    epilogue<2, false, SAVE, 256>(acc, Hs, ct0, lane, a.bias[BENERF_L_FEAT], SAVE ? acts + act_feat(M) + m0 * 256 : nullptr,
+    gemm_stage<32, 2>(T, 0, a.packed + pack_offset(PF_FEAT), ct0, lane, acc);
+    __syncthreads();   // h7 fully consumed (GEMM + alpha partials); PE(dir) + alpha partials visible
+    epilogue<2, false, SAVE, 256>(acc, T, ct0, lane, a.bias[BENERF_L_FEAT], SAVE ? acts + act_feat(M) + m0 * 256 : nullptr,
                                   rows_valid);
     if (tid < 64 && m < M) {
-        a.raw[m * (C + 1) + C] = ((red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid])) + a.b_alpha[0];
+        const float4 p = *reinterpret_cast<const float4*>(trow + (COL_SCR ^ psw));
+        a.raw[m * (C + 1) + C] = ((p.x + p.y) + (p.z + p.w)) + a.b_alpha[0];
     }
     if (SAVE) {   // PE(dir) tile -> acts (128 B per point)
         const int r = tid >> 2, q = tid & 3;
-        if (m0 + r < M) {
+        if (r < rows_valid) {
             float4* dst = reinterpret_cast<float4*>(acts + act_ped(M) + (m0 + r) * ACT_PED_W + q * 8);
-            const float4* src = reinterpret_cast<const float4*>(Hs + r * LD + COL_PE + q * 8);
-            dst[0] = src[0];
-            dst[1] = src[1];
+            dst[0] = *reinterpret_cast<const float4*>(T + tidx(r, COL_PE + q * 8));
+            dst[1] = *reinterpret_cast<const float4*>(T + tidx(r, COL_PE + q * 8 + 4));
         }
     }
     __syncthreads();
@@ -285,22 +286,21 @@ __global__ __launch_bounds__(NTHREADS, 1) void mlp_fwd_kernel(FwdArgs a) {
     {
         f32x16 av[2][1];
         zero_acc(av);
-        gemm_stage<36, 1>(Hs, 0, a.packed + pack_offset(PF_VIEWS), wave, lane, av);
+        gemm_stage<36, 1>(T, 0, a.packed + pack_offset(PF_VIEWS), wave, lane, av);
         __syncthreads();
-        epilogue<1, true, SAVE, ACT_HV_W>(av, Hs, wave, lane, a.bias[BENERF_L_VIEWS],
+        epilogue<1, true, SAVE, ACT_HV_W>(av, T, wave, lane, a.bias[BENERF_L_VIEWS],
                                           SAVE ? acts + act_hv(M) + m0 * ACT_HV_W : nullptr, rows_valid);
     }
     __syncthreads();
 
-    // ---- rgb: 128 -> C on the VALU -----------------------------------------------------------------------
+    // ---- rgb: 128 -> C on the VALU; partial of (channel c, group g) at scratch column 288 + 4 + 4c + g ----
     {
-        const float* hrow = Hs + pt * LD + grp * 32;
         float s[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) s[c] = 0.f;
 #pragma unroll 2
         for (int k = 0; k < 32; k += 4) {
-            const float4 h = *reinterpret_cast<const float4*>(hrow + k);
+            const float4 h = *reinterpret_cast<const float4*>(trow + ((grp * 32 + k) ^ psw));
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 const float4 w = *reinterpret_cast<const float4*>(a.w_rgb + c * 128 + grp * 32 + k);
@@ -308,19 +308,17 @@ __global__ __launch_bounds__(NTHREADS, 1) void mlp_fwd_kernel(FwdArgs a) {
             }
         }
 #pragma unroll
-        for (int c = 0; c < C; ++c) red[(c * 4 + grp) * 64 + pt] = s[c];
+        for (int c = 0; c < C; ++c) trow[(COL_SCR + 4 + 4 * c + grp) ^ psw] = s[c];
     }
     __syncthreads();
     if (tid < 64 && m < M) {
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            const float* rc = red + c * 256;
-            a.raw[m * (C + 1) + c] = ((rc[tid] + rc[64 + tid]) + (rc[128 + tid] + rc[192 + tid])) + a.b_rgb[c];
+            const float4 p = *reinterpret_cast<const float4*>(trow + ((COL_SCR + 4 + 4 * c) ^ psw));
+            a.raw[m * (C + 1) + c] = ((p.x + p.y) + (p.z + p.w)) + a.b_rgb[c];
         }
     }
 }
-
-constexpr size_t FWD_SMEM = (size_t)(TM * LD + 3 * 4 * 64) * sizeof(float);
 
 }  // namespace
 
@@ -351,20 +349,21 @@ extern "C" int benerf_mlp_fwd(const BenerfMlpParams* params, const float* packed
     const int64_t tiles = (a.M + mlp::TM - 1) / mlp::TM;
     BENERF_REQUIRE(tiles < (1ll << 31), "mlp_fwd: too many points");
     dim3 grid((unsigned)tiles), block(mlp::NTHREADS);
+    const int smem = (int)mlp::TILE_SMEM;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)mlp_fwd_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD_SMEM);
-        (void)hipFuncSetAttribute((const void*)mlp_fwd_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD_SMEM);
-        (void)hipFuncSetAttribute((const void*)mlp_fwd_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD_SMEM);
-        (void)hipFuncSetAttribute((const void*)mlp_fwd_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD_SMEM);
+        (void)hipFuncSetAttribute((const void*)mlp_fwd_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        (void)hipFuncSetAttribute((const void*)mlp_fwd_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        (void)hipFuncSetAttribute((const void*)mlp_fwd_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        (void)hipFuncSetAttribute((const void*)mlp_fwd_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_done = true;
     }
     if (channels == 1) {
-        if (acts) hipLaunchKernelGGL((mlp_fwd_kernel<1, true>), grid, block, FWD_SMEM, as_stream(stream), a);
-        else hipLaunchKernelGGL((mlp_fwd_kernel<1, false>), grid, block, FWD_SMEM, as_stream(stream), a);
+        if (acts) hipLaunchKernelGGL((mlp_fwd_kernel<1, true>), grid, block, smem, as_stream(stream), a);
+        else hipLaunchKernelGGL((mlp_fwd_kernel<1, false>), grid, block, smem, as_stream(stream), a);
     } else {
-        if (acts) hipLaunchKernelGGL((mlp_fwd_kernel<3, true>), grid, block, FWD_SMEM, as_stream(stream), a);
-        else hipLaunchKernelGGL((mlp_fwd_kernel<3, false>), grid, block, FWD_SMEM, as_stream(stream), a);
+        if (acts) hipLaunchKernelGGL((mlp_fwd_kernel<3, true>), grid, block, smem, as_stream(stream), a);
+        else hipLaunchKernelGGL((mlp_fwd_kernel<3, false>), grid, block, smem, as_stream(stream), a);
     }
     BENERF_LAUNCH_CHECK("mlp_fwd");
     return BENERF_OK;

@@ -57,6 +57,16 @@ __global__ void pack_kernel(PackArgs a) {
     const PackShape sh = pack_shape(id);
     const int64_t n4 = (int64_t)sh.tiles * sh.kblocks * 64;   // float4 slots
     float4* dst = reinterpret_cast<float4*>(a.packed + pack_offset(id));
+    if (id == PB_VIEWSPE) {   // [g][n][8] <- Wv[n][256 + g + 4q], zero beyond the 27 PE(dir) columns
+        float* d = a.packed + pack_offset(id);
+        const float* W = a.w[BENERF_L_VIEWS];
+        for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < 4 * 128 * 8; e += gridDim.x * blockDim.x) {
+            const int q = e & 7, n = (e >> 3) & 127, g = e >> 10;
+            const int j = g + 4 * q;
+            d[e] = j < 27 ? W[n * 283 + 256 + j] : 0.f;
+        }
+        return;
+    }
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += (int64_t)gridDim.x * blockDim.x) {
         int lane = (int)(e & 63);
         int64_t tb = e >> 6;
