@@ -207,6 +207,18 @@ def main():
         roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                 "avg_launch_ms": kern[dom]["avg_ms"], "per_kernel": kern}
+        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (separate runs of this
+        # same command; bench.py cannot collect counters itself) - see profiles/README.md
+        try:
+            import glob
+            latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))[-1]
+            pk = json.load(open(latest))["kernels"][dom]
+            if a.workload == "C2" and world == 1:
+                roof["traffic"] = int(pk["hbm_read_bytes_per_launch"] + pk["hbm_write_bytes_per_launch"])
+                roof["traffic_source"] = os.path.relpath(latest, ROOT)
+                roof["mfma_util_profiled"] = round(pk.get("mfma_util", 0.0), 4)
+        except (IndexError, KeyError, OSError, ValueError):
+            pass
     mlp_ms = sum(v[1] for v in summ.values()) / a.steps if summ else None
 
     out = {
