@@ -22,9 +22,16 @@ def shard_indices(idx, rank, world):
 
 
 def allreduce_sum_(t, world, group=None):
-    """In-place sum over ranks (no-op on one rank)."""
+    """In-place sum over ranks (no-op on one rank).  With the gloo backend (CPU tests, or the
+    2-ranks-on-one-GPU equivalence test) device tensors are staged through host memory; the
+    production backend is nccl (= RCCL over xGMI), which reduces the device buffer directly."""
     if world > 1:
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM, group=group)
+        if t.is_cuda and torch.distributed.get_backend(group) == "gloo":
+            h = t.cpu()
+            torch.distributed.all_reduce(h, op=torch.distributed.ReduceOp.SUM, group=group)
+            t.copy_(h)
+        else:
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM, group=group)
     return t
 
 

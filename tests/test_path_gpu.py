@@ -149,7 +149,7 @@ def _check_grads(g8, tag, named, knots_g, tr_g, who):
                g8[base + "__norm"], atol=1e-12, rtol=1e-3 if loose else 2e-4)
         ref_v = g8[base + "__val"]
         report("%s d%s[64] %s" % (who, key, tag), flat[g8[base + "__idx"]], ref_v,
-               atol=5e-3 * float(np.abs(ref_v).max()) + 1e-12, rtol=2e-3)
+               atol=(2e-2 if key.startswith("nerf_fine.") else 5e-3) * float(np.abs(ref_v).max()) + 1e-12, rtol=2e-3)
 
 
 @pytest.mark.parametrize("si", range(len(G8_SPECS)))
@@ -265,6 +265,32 @@ def test_training_iteration_golden_g8_fused(golden, si):
             named["%s.%s.weight" % (nn_, name)] = fn.gviews_w[i]
             named["%s.%s.bias" % (nn_, name)] = fn.gviews_b[i]
     _check_grads(g8, tag, named, step.g_knots, step.g_transform, "step(fused)")
+    # Fine-net gradients are looser than coarse-net ones for a structural reason: K5 is bit-exact given
+    # identical inputs (test_kernels_gpu), but its input - the coarse weights - carries ~1e-7 f32 noise
+    # between ANY two implementations, and sample_pdf amplifies that into ~1e-5 shifts of samples that sit
+    # next to a cdf knot; the high-frequency PE turns those shifts into ~1e-3-of-max wobble on the
+    # cancellation-heavy early-layer gradients.  The MLP / compositing backward kernels themselves are
+    # pinned at 1e-6 on fixed inputs (K3 / K4 tests).  Loss and all coarse quantities stay tight here.
+    cfg = O.StepConfig(H=cam["H"], W=cam["W"], fx=cam["fx"], fy=cam["fy"], cx=cam["cx"], cy=cam["cy"], channels=C,
+                       n_samples=S, n_importance=Ni, n_poses=P, dataset=dataset, threshold=thr, window=x["window"])
+    oc = {k: v.clone().requires_grad_(True) for k, v in x["pc"].items()}
+    of = {k: v.clone().requires_grad_(True) for k, v in x["pf"].items()}
+    ko, to = x["knots"].clone().requires_grad_(True), x["tr"].clone().requires_grad_(True)
+    target_acc = ref_accu.reshape(-1, 1)[x["idx_e"]]
+    target_rgb = img.cpu()[x["idx_r"]]
+    loss_o, _ = O.step_loss(cfg, oc, of, ko, to, evt_ts.cpu(), torch.tensor([0.0, 1.0]), x["idx_e"], x["idx_r"], target_acc,
+                            target_rgb, x["d_e"], x["d_r"], exact_pdf=True)
+    loss_o.backward()
+    report("step(fused) loss vs exact-pdf oracle " + tag, losses[0], loss_o.float(), atol=1e-6, rtol=2e-5)
+    for i, name in enumerate(K.LAYER_NAMES):
+        r = of[name + ".weight"].grad
+        report("step(fused) dnerf_fine.%s.weight vs exact-pdf oracle %s" % (name, tag), step.net_f.gviews_w[i], r,
+               atol=3e-2 * float(r.abs().max()), rtol=2e-3)
+        rc_ = oc[name + ".weight"].grad
+        # ReLU-kink flips bound how close two f32 implementations can be on the layers behind a ReLU:
+        # test_fine_pass_gradients_with_forced_samples measures the oracle's own 1-ulp sensitivity (1e-3..1e-2)
+        report("step(fused) dnerf.%s.weight vs exact-pdf oracle %s" % (name, tag), step.net_c.gviews_w[i], rc_,
+               atol=5e-3 * float(rc_.abs().max()), rtol=2e-3)
     # Adam touched every optimised parameter, parameters still alias the module's tensors
     assert not torch.equal(p_before, step.flat_p)
     assert g.nerf.pts_linears[0].weight.data_ptr() == step.net_c.views_w[0].data_ptr()
@@ -363,3 +389,78 @@ def test_full_size_properties():
     dp2, _ = K.mlp_bwd(net_f, (2 * graw).contiguous(), saved["acts1"], N, 128, gw2, gb2, False)
     report("full-size linearity d_pts", dp2, 2 * dp1, atol=1e-5 * float(dp1.abs().max()), rtol=1e-5)
     report("full-size linearity dW4", gw2[4], 2 * gw1[4], atol=1e-5 * float(gw1[4].abs().max()), rtol=1e-5)
+
+
+def test_fine_pass_gradients_with_forced_samples():
+    """Isolates the fine pass from sample_pdf's conditioning: the HIP kernels are fed the oracle's own
+    merged depths (clustered importance samples, near-duplicate z), then fine + coarse MLP / compositing
+    forward and backward are compared with the oracle's autograd at tight tolerance."""
+    from benerf_amd import kernels as K
+    rng = np.random.default_rng(99)
+    C, S, Ni, P, Rn = 3, 16, 32, 31, 3
+    cam = GI.CAMERAS["e2nerf_real"]
+    Kmat = GI.cam_K(cam)
+    pc, pf = O.xavier_params(rng, C), O.xavier_params(rng, C)
+    pc["alpha_linear.bias"] += 1.0
+    pf["alpha_linear.bias"] += 1.0
+    poses = O.trajectory_poses(GI.knots_init(rng) * 3, None, (0.0, 1.0), P, "spline").detach()
+    idx = GI.pixel_indices(rng, cam, Rn)
+    N = P * Rn
+    draws = GI.render_draws(rng, N, S, Ni)
+    G1, G0 = GI.f32(rng.standard_normal((N, C))), GI.f32(rng.standard_normal((N, C)))
+    oc = {k: v.clone().requires_grad_(True) for k, v in pc.items()}
+    of = {k: v.clone().requires_grad_(True) for k, v in pf.items()}
+    ret, ex = O.render(oc, of, poses, idx, cam["H"], cam["W"], Kmat, C, S, Ni, draws, exact_pdf=True, want_extras=True)
+    ex["raw1"].retain_grad()
+    ((ret["rgb_map"] * G1).sum() + (ret["rgb0"] * G0).sum()).backward()
+
+    def dev(t):
+        return t.detach().to(DEV).contiguous()
+
+    def net_of(p):
+        n = K.PackedMlp([dev(p[nm + ".weight"]) for nm in K.LAYER_NAMES], [dev(p[nm + ".bias"]) for nm in K.LAYER_NAMES], C)
+        n.pack()
+        return n
+
+    net_c, net_f = net_of(pc), net_of(pf)
+    ro, rd, vd = K.rays_fwd(dev(poses), dev(idx), cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"], True)
+    z = K.stratified_z(N, S, DEV, dev(draws["t_rand"]))
+    z_fine = dev(ex["z_fine"])                              # forced: the oracle's merged depths
+    raw1, acts1 = K.mlp_fwd(net_f, ro, rd, vd, z_fine, True)
+    c1 = K.composite_fwd(raw1, z_fine, rd, dev(draws["noise1"]), want=("rgb_map",))
+    report("forced-z fine rgb_map", c1["rgb_map"], ret["rgb_map"], atol=2e-6)
+    d_raw1, _ = K.composite_bwd(raw1, z_fine, rd, dev(draws["noise1"]), 0.0, 0, 0, dev(G1))
+    ref_draw = ex["raw1"].grad
+    report("forced-z d_raw (compositing backward)", d_raw1, ref_draw, atol=2e-5 * float(ref_draw.abs().max()), rtol=1e-3)
+
+    # Self-calibrated tolerance.  Layers behind a ReLU are discontinuous in their inputs: a pre-activation
+    # within f32 round-off of zero is "on" in one implementation and "off" in another, which flips a whole
+    # rank-1 term of dW.  Measure the ORACLE's own sensitivity: the same fine pass with every depth moved
+    # by one ulp; the HIP result has to be as close to the oracle as the oracle is to its perturbed self.
+    def oracle_fine_grads(zf):
+        p = {k: v.clone().requires_grad_(True) for k, v in pf.items()}
+        pts = ex["rays_o"].detach()[:, None, :] + ex["rays_d"].detach()[:, None, :] * zf[:, :, None]
+        raw = O.mlp_forward(p, pts, ex["viewdirs"].detach())
+        rgb = O.composite(raw, zf, ex["rays_d"].detach(), draws["noise1"], C)[0]
+        (rgb * G1).sum().backward()
+        return {k: v.grad for k, v in p.items()}
+
+    zf0 = ex["z_fine"].detach()
+    base = oracle_fine_grads(zf0)
+    pert = oracle_fine_grads(zf0 * (1.0 + 2.0 ** -23))
+    gw = [torch.zeros_like(w) for w in net_f.weights]
+    gb = [torch.zeros_like(b) for b in net_f.biases]
+    K.mlp_bwd(net_f, d_raw1.view(-1, C + 1), acts1, N, S + Ni, gw, gb, False)
+    errs = []
+    for i, name in enumerate(K.LAYER_NAMES):
+        for kind, got in (("weight", gw[i]), ("bias", gb[i])):
+            key = "%s.%s" % (name, kind)
+            r = base[key]
+            own = float((pert[key] - r).abs().max())
+            sc = float(r.abs().max())
+            try:
+                report("forced-z dnerf_fine.%s (oracle 1-ulp sensitivity %.1e)" % (key, own / sc), got, r,
+                       atol=4.0 * own + 2e-5 * sc, rtol=2e-3)
+            except AssertionError as e:
+                errs.append(str(e))
+    assert not errs, "\n".join(errs)
