@@ -2,7 +2,7 @@
 // exact-f32 MFMA, + bias gradients (column sums) and the two tiny heads (alpha, rgb) on the
 // VALU.  The reduction dimension is the point index (hundreds of thousands), so every GEMM
 // instance is split dw_splits(inst) ways along it (cost-proportional); each workgroup keeps its whole output block
-// (up to 256x256 = 256 accumulator registers per lane across 4 waves) in registers while it
+// (up to 256x256 = 128 accumulator registers per lane across 8 waves, 2 waves per SIMD) in registers while it
 // streams 32-point chunks of dY and X through LDS (register-staged prefetch of the next
 // chunk during the MFMAs).  Partials are then summed in a fixed order by dw_reduce_kernel,
 // which also scatters into nn.Linear layout ([out,in], model/nerf.py:53-64) -> deterministic.
@@ -11,7 +11,7 @@
 namespace {
 using namespace mlp;
 
-constexpr int CH = 32;   // points per chunk
+constexpr int CH = 32;   // points per chunk (64 measured slower: 6.3 vs 5.8 ms at M = 522k)
 
 struct DwArgs {
     const float* d_raw;
@@ -46,26 +46,34 @@ __device__ __forceinline__ InstSrc inst_src(const DwArgs& a, int inst) {
     }
 }
 
-// Output block (4*NRT*32) x (NCT*32); wave w owns rows [w*NRT*32, (w+1)*NRT*32).
-template <int NRT, int NCT, bool ALPHA>
+constexpr int DWT = 512;   // 8 waves = 2 per SIMD: one wave's LDS staging / VALU sums overlap the other's MFMAs
+
+// Output block N x K (N = WR*32).  The 8 waves form a WR x (8/WR) grid: wave w owns row tile
+// (w % WR) and NCT = max(1, K / (32 * 8/WR)) column tiles starting at (w / WR) * NCT.
+template <int N, int K, int WR, bool ALPHA>
 __device__ __forceinline__ void dw_gemm(const DwArgs& a, const InstSrc src, int64_t chunk_begin, int64_t chunk_end,
                                         float* __restrict__ part, float* __restrict__ smem) {
-    constexpr int N = 4 * NRT * 32, K = NCT * 32;
-    constexpr int NY4 = N / 32, NX4 = K / 32;   // float4 loads per thread per chunk
+    static_assert(N == WR * 32, "row tiles");
+    constexpr int WC = 8 / WR;
+    constexpr int NCT = (K / 32 >= WC) ? K / 32 / WC : 1;
+    constexpr int YQ = CH * N / 4, XQ = CH * K / 4;                       // float4 slots per chunk
+    constexpr int NY4 = (YQ + DWT - 1) / DWT, NX4 = (XQ + DWT - 1) / DWT;  // float4 loads per thread per chunk
+    constexpr bool XFULL = XQ % DWT == 0;                                  // the 128x32 block fills only half the threads
+    static_assert(YQ % DWT == 0, "staging shape");
     float* Ys = smem;                 // [CH][N]
     float* Xs = smem + CH * N;        // [CH][K]
     float* da = Xs + CH * K;          // [CH] d_sigma of the chunk (ALPHA only)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 31, lh = lane >> 5;
+    const int wr = wave % WR, wc = wave / WR;
+    const bool mma_wave = wc * NCT * 32 < K;      // waves beyond the block's columns only help staging
     const int64_t M = a.M;
 
-    f32x16 acc[NRT][NCT];
+    f32x16 acc[NCT];
 #pragma unroll
-    for (int r = 0; r < NRT; ++r)
+    for (int c = 0; c < NCT; ++c)
 #pragma unroll
-        for (int c = 0; c < NCT; ++c)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[r][c][e] = 0.f;
+        for (int e = 0; e < 16; ++e) acc[c][e] = 0.f;
     float bsum = 0.f, asum = 0.f, absum = 0.f;
 
     float4 ry[NY4], rx[NX4];
@@ -76,21 +84,24 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const InstSrc src, int6
         const float4* px = reinterpret_cast<const float4*>(src.x + row0 * K) + tid;
         if (row0 + CH <= M) {   // block-uniform fast path: plain back-to-back loads
 #pragma unroll
-            for (int j = 0; j < NY4; ++j) ry[j] = py[j * NTHREADS];
+            for (int j = 0; j < NY4; ++j) ry[j] = py[j * DWT];
 #pragma unroll
-            for (int j = 0; j < NX4; ++j) rx[j] = px[j * NTHREADS];
+            for (int j = 0; j < NX4; ++j) {
+                rx[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (XFULL || tid + j * DWT < XQ) rx[j] = px[j * DWT];
+            }
         } else {                // ragged last chunk: rows >= M contribute zero
 #pragma unroll
             for (int j = 0; j < NY4; ++j) {
-                const int64_t row = row0 + ((tid + j * NTHREADS) * 4) / N;
+                const int64_t row = row0 + ((tid + j * DWT) * 4) / N;
                 ry[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (row < M) ry[j] = py[j * NTHREADS];
+                if (row < M) ry[j] = py[j * DWT];
             }
 #pragma unroll
             for (int j = 0; j < NX4; ++j) {
-                const int64_t row = row0 + ((tid + j * NTHREADS) * 4) / K;
+                const int64_t row = row0 + ((tid + j * DWT) * 4) / K;
                 rx[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (row < M) rx[j] = px[j * NTHREADS];
+                if (row < M && (XFULL || tid + j * DWT < XQ)) rx[j] = px[j * DWT];
             }
         }
         if (ALPHA && tid < CH) rda = row0 + tid < M ? a.d_raw[(row0 + tid) * (a.C + 1) + a.C] : 0.f;
@@ -100,26 +111,26 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const InstSrc src, int6
     for (int64_t chunk = chunk_begin; chunk < chunk_end; ++chunk) {
         __syncthreads();   // previous chunk fully consumed
 #pragma unroll
-        for (int j = 0; j < NY4; ++j) *reinterpret_cast<float4*>(Ys + (tid + j * NTHREADS) * 4) = ry[j];
+        for (int j = 0; j < NY4; ++j) *reinterpret_cast<float4*>(Ys + (tid + j * DWT) * 4) = ry[j];
 #pragma unroll
-        for (int j = 0; j < NX4; ++j) *reinterpret_cast<float4*>(Xs + (tid + j * NTHREADS) * 4) = rx[j];
+        for (int j = 0; j < NX4; ++j)
+            if (XFULL || tid + j * DWT < XQ) *reinterpret_cast<float4*>(Xs + (tid + j * DWT) * 4) = rx[j];
         if (ALPHA && tid < CH) da[tid] = rda;
         __syncthreads();
         if (chunk + 1 < chunk_end) prefetch(chunk + 1);
 
-        const float* yp = Ys + lh * N + wave * NRT * 32 + lr;
-        const float* xp = Xs + lh * K + lr;
+        if (mma_wave) {
+            const float* yp = Ys + lh * N + wr * 32 + lr;
+            const float* xp = Xs + lh * K + wc * NCT * 32 + lr;
 #pragma unroll 4
-        for (int pp = 0; pp < CH; pp += 2) {
-            float av[NRT], bv[NCT];
+            for (int pp = 0; pp < CH; pp += 2) {
+                const float av = yp[pp * N];
+                float bv[NCT];
 #pragma unroll
-            for (int r = 0; r < NRT; ++r) av[r] = yp[pp * N + r * 32];
+                for (int c = 0; c < NCT; ++c) bv[c] = xp[pp * K + c * 32];
 #pragma unroll
-            for (int c = 0; c < NCT; ++c) bv[c] = xp[pp * K + c * 32];
-#pragma unroll
-            for (int r = 0; r < NRT; ++r)
-#pragma unroll
-                for (int c = 0; c < NCT; ++c) acc[r][c] = mfma32(av[r], bv[c], acc[r][c]);
+                for (int c = 0; c < NCT; ++c) acc[c] = mfma32(av, bv[c], acc[c]);
+            }
         }
         if (src.bias && tid < N) {
             float s = 0.f;
@@ -127,7 +138,7 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const InstSrc src, int6
             for (int p = 0; p < CH; ++p) s += Ys[p * N + tid];
             bsum += s;
         }
-        if (ALPHA) {   // K == 256 == NTHREADS
+        if (ALPHA && tid < K) {   // K == 256
             float s = 0.f, sb = 0.f;
 #pragma unroll 8
             for (int p = 0; p < CH; ++p) {
@@ -140,17 +151,17 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const InstSrc src, int6
     }
 
     // partial block -> workspace: [N][K] then bias [N] (then alpha row [256] + alpha bias)
-#pragma unroll
-    for (int r = 0; r < NRT; ++r)
+    if (mma_wave) {
 #pragma unroll
         for (int c = 0; c < NCT; ++c)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int row = wave * NRT * 32 + r * 32 + acc_row(e, lane);
-                part[(int64_t)row * K + c * 32 + lr] = acc[r][c][e];
+                const int row = wr * 32 + acc_row(e, lane);
+                part[(int64_t)row * K + (wc * NCT + c) * 32 + lr] = acc[c][e];
             }
+    }
     if (tid < N) part[(int64_t)N * K + tid] = src.bias ? bsum : 0.f;
-    if (ALPHA) {
+    if (ALPHA && tid < K) {
         part[(int64_t)N * K + N + tid] = asum;
         if (tid == 0) part[(int64_t)N * K + N + 256] = absum;
     }
@@ -159,20 +170,20 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const InstSrc src, int6
 // rgb head: dW_rgb[c][j] = sum_pt d_rgb[pt][c] * hv[pt][j], db_rgb[c] = sum_pt d_rgb[pt][c]
 __device__ __forceinline__ void dw_rgb(const DwArgs& a, int64_t row_begin, int64_t row_end, float* __restrict__ part,
                                        float* __restrict__ smem) {
-    const int tid = threadIdx.x, j = tid & 127, half = tid >> 7;
+    const int tid = threadIdx.x, j = tid & 127, half = tid >> 7;   // half = row phase 0..3 (512 threads)
     const float* hv = a.acts + act_hv(a.M);
     const int C = a.C;
     float s[3] = {0.f, 0.f, 0.f}, sb[3] = {0.f, 0.f, 0.f};
     // 8 rows in flight per thread (independent loads), fixed summation order
     constexpr int U = 8;
     int64_t mrow = row_begin + half;
-    for (; mrow + 2 * (U - 1) < row_end; mrow += 2 * U) {
+    for (; mrow + 4 * (U - 1) < row_end; mrow += 4 * U) {
         float h[U], g[U][3];
 #pragma unroll
         for (int q = 0; q < U; ++q) {
-            h[q] = hv[(mrow + 2 * q) * ACT_HV_W + j];
+            h[q] = hv[(mrow + 4 * q) * ACT_HV_W + j];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) g[q][c] = c < C ? a.d_raw[(mrow + 2 * q) * (C + 1) + c] : 0.f;
+            for (int c = 0; c < 3; ++c) g[q][c] = c < C ? a.d_raw[(mrow + 4 * q) * (C + 1) + c] : 0.f;
         }
 #pragma unroll
         for (int q = 0; q < U; ++q)
@@ -182,7 +193,7 @@ __device__ __forceinline__ void dw_rgb(const DwArgs& a, int64_t row_begin, int64
                 sb[c] += g[q][c];
             }
     }
-    for (; mrow < row_end; mrow += 2) {
+    for (; mrow < row_end; mrow += 4) {
         const float h = hv[mrow * ACT_HV_W + j];
 #pragma unroll
         for (int c = 0; c < 3; ++c)
@@ -192,11 +203,11 @@ __device__ __forceinline__ void dw_rgb(const DwArgs& a, int64_t row_begin, int64
                 sb[c] += g;
             }
     }
-    if (half == 1) {
+    if (half > 0) {   // phases 1..3 -> LDS [phase-1][{w,b}][3][128]
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            smem[c * 128 + j] = s[c];
-            smem[384 + c * 128 + j] = sb[c];
+            smem[((half - 1) * 6 + c) * 128 + j] = s[c];
+            smem[((half - 1) * 6 + 3 + c) * 128 + j] = sb[c];
         }
     }
     __syncthreads();
@@ -204,18 +215,21 @@ __device__ __forceinline__ void dw_rgb(const DwArgs& a, int64_t row_begin, int64
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             float v = 0.f;
-            if (c < 3 && c < C) v = s[c] + smem[c * 128 + j];
+            if (c < 3 && c < C) v = ((s[c] + smem[(0 * 6 + c) * 128 + j]) + smem[(1 * 6 + c) * 128 + j]) + smem[(2 * 6 + c) * 128 + j];
             part[c * 128 + j] = v;
         }
         if (j < 4) {
             float v = 0.f;
-            if (j < 3 && j < C) v = (j == 0 ? sb[0] : j == 1 ? sb[1] : sb[2]) + smem[384 + j * 128 + j];
+            if (j < 3 && j < C) {
+                const float own = j == 0 ? sb[0] : j == 1 ? sb[1] : sb[2];
+                v = ((own + smem[(0 * 6 + 3 + j) * 128 + j]) + smem[(1 * 6 + 3 + j) * 128 + j]) + smem[(2 * 6 + 3 + j) * 128 + j];
+            }
             part[4 * 128 + j] = v;
         }
     }
 }
 
-__global__ __launch_bounds__(NTHREADS, 1) void mlp_dw_kernel(DwArgs a) {
+__global__ __launch_bounds__(DWT, 2) void mlp_dw_kernel(DwArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // workgroup -> (instance, split); instances in cost order, split counts proportional to cost
     int split = blockIdx.x, inst = 0;
@@ -237,11 +251,11 @@ __global__ __launch_bounds__(NTHREADS, 1) void mlp_dw_kernel(DwArgs a) {
         return;
     }
     const InstSrc src = inst_src(a, inst);
-    if (inst == DW_FEAT) dw_gemm<2, 8, true>(a, src, cb, ce, part, smem);
-    else if (inst <= DW_L7) dw_gemm<2, 8, false>(a, src, cb, ce, part, smem);
-    else if (inst == DW_VIEWSF) dw_gemm<1, 8, false>(a, src, cb, ce, part, smem);
-    else if (inst == DW_VIEWSP) dw_gemm<1, 1, false>(a, src, cb, ce, part, smem);
-    else dw_gemm<2, 2, false>(a, src, cb, ce, part, smem);   // DW_L0, DW_L5P
+    if (inst == DW_FEAT) dw_gemm<256, 256, 8, true>(a, src, cb, ce, part, smem);
+    else if (inst <= DW_L7) dw_gemm<256, 256, 8, false>(a, src, cb, ce, part, smem);
+    else if (inst == DW_VIEWSF) dw_gemm<128, 256, 4, false>(a, src, cb, ce, part, smem);
+    else if (inst == DW_VIEWSP) dw_gemm<128, 32, 4, false>(a, src, cb, ce, part, smem);
+    else dw_gemm<256, 64, 8, false>(a, src, cb, ce, part, smem);   // DW_L0, DW_L5P
 }
 
 constexpr size_t DW_SMEM = (size_t)(CH * 256 + CH * 256 + CH) * sizeof(float);
@@ -328,7 +342,7 @@ int benerf_mlp_dw_launch(const BenerfMlpParams* params, int channels, int64_t M,
         (void)hipFuncSetAttribute((const void*)mlp_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DW_SMEM);
         attr_done = true;
     }
-    hipLaunchKernelGGL(mlp_dw_kernel, dim3(mlp::DW_TOTAL_BLOCKS), dim3(mlp::NTHREADS), DW_SMEM, stream, a);
+    hipLaunchKernelGGL(mlp_dw_kernel, dim3(mlp::DW_TOTAL_BLOCKS), dim3(DWT), DW_SMEM, stream, a);
     BENERF_LAUNCH_CHECK("mlp_bwd(dw)");
     ReduceArgs r;
     r.ws = dw_ws;
