@@ -181,18 +181,25 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_kernel(BwdArgs a) {
         float wr[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) wr[c] = a.w_rgb[c * 128 + j];
-        const float* hv = acts + act_hv(M);
-        float* dyv = dacts + dact_hv(M);
-#pragma unroll 4
-        for (int p = half * 32; p < half * 32 + 32; ++p) {
+        const float* hv = acts + act_hv(M) + (m0 + half * 32) * ACT_HV_W + j;
+        float* dyv = dacts + dact_hv(M) + (m0 + half * 32) * ACT_HV_W + j;
+        // all 32 saved activations of this thread's column in flight at once (one HBM round trip, not 8)
+        float hvv[32];
+        if (rows_valid >= TM) {
+#pragma unroll
+            for (int q = 0; q < 32; ++q) hvv[q] = hv[q * ACT_HV_W];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 32; ++q) hvv[q] = half * 32 + q < rows_valid ? hv[q * ACT_HV_W] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            const int p = half * 32 + q;
             float g = 0.f;
 #pragma unroll
             for (int c = 0; c < C; ++c) g += T[tidx(p, COL_SCR + c)] * wr[c];
-            float v = 0.f;
-            if (p < rows_valid) {
-                v = hv[(m0 + p) * ACT_HV_W + j] > 0.f ? g : 0.f;
-                dyv[(m0 + p) * ACT_HV_W + j] = v;
-            }
+            const float v = hvv[q] > 0.f ? g : 0.f;      // rows beyond the tail have hv = 0 and d_raw = 0
+            if (rows_valid >= TM || p < rows_valid) dyv[q * ACT_HV_W] = v;
             T[tidx(p, j)] = v;
         }
     }

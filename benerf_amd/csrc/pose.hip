@@ -328,7 +328,11 @@ extern "C" int benerf_spline_poses_bwd(const float* knots, const float* transfor
     BENERF_REQUIRE(knots && ts2 && d_poses && d_knots, "spline_poses_bwd: null pointer");
     BENERF_REQUIRE(n_poses > 0 && n_poses <= 512 && (traj == 0 || traj == 1), "spline_poses_bwd: n_poses must be in [1,512]");
     size_t smem = (size_t)n_poses * 24 * sizeof(float);
-    hipLaunchKernelGGL(spline_bwd_kernel, dim3(1), dim3(256), smem, as_stream(stream), knots, transform, ts2, n_poses,
+    // one (pose, tangent) evaluation per thread where possible: the dual-number evaluation is a long serial
+    // chain, so width beats depth (19 poses x 24 tangents = 456 threads in one block)
+    int threads = ((n_poses * 24 + 63) / 64) * 64;
+    if (threads > 1024) threads = 1024;
+    hipLaunchKernelGGL(spline_bwd_kernel, dim3(1), dim3(threads), smem, as_stream(stream), knots, transform, ts2, n_poses,
                        traj, explicit_ts, d_poses, d_knots, d_transform);
     BENERF_LAUNCH_CHECK("spline_poses_bwd");
     return BENERF_OK;
