@@ -92,6 +92,8 @@ def cpu_baseline(wl, seed):
     img = torch.from_numpy(rng.random((cam["H"] * cam["W"], C)).astype(np.float32))
     times = []
     n_steps = 3
+    # many small ops: a moderate thread count beats one thread per core of a 128-core host
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     for it in range(n_steps + 1):
         t0 = time.perf_counter()
         low_t = float(rng.random() * (1 - w["window"]))
@@ -115,6 +117,63 @@ def cpu_baseline(wl, seed):
             "kind": "port",
             "sample": "%d steps of 1/8 of %s (%d rays/step, %d+%d samples), oracle torch-CPU step incl. backward + Adam"
                       % (n_steps, wl, rays, S, S + Ni)}
+
+
+def torch_gpu_baseline(wl, seed, device):
+    """The oracle's op-for-op torch step run EAGERLY on the same MI355X (PyTorch-ROCm, hipBLASLt fp32 GEMMs,
+    autograd, unfused) at the FULL workload size: the stand-in for "reference single-GPU PyTorch"
+     - the reference itself cannot be shipped to the GPU box."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import benerf_oracle as O
+    import golden_inputs as GI
+    from benerf_amd import workloads as WL
+    w = WL.WORKLOADS[wl]
+    cam = WL.CAMERAS[w["cam"]]
+    Re, Rr, C, S, Ni, P = w["Re"], w["Rr"], w["channels"], w["S"], w["Ni"], w["n"]
+    rng = np.random.default_rng(seed)
+    prev = torch.get_default_device() if hasattr(torch, "get_default_device") else None
+    torch.set_default_device(device)
+    try:
+        cfg = O.StepConfig(H=cam["H"], W=cam["W"], fx=cam["fx"], fy=cam["fy"], cx=cam["cx"], cy=cam["cy"], channels=C,
+                           n_samples=S, n_importance=Ni, n_poses=P, dataset=w["dataset"], threshold=w["threshold"],
+                           window=w["window"])
+        pc = {k: v.to(device).requires_grad_(True) for k, v in O.xavier_params(rng, C).items()}
+        pf = {k: v.to(device).requires_grad_(True) for k, v in O.xavier_params(rng, C).items()}
+        knots = GI.knots_init(rng).to(device).requires_grad_(True)
+        tr = torch.zeros(1, 6)
+        params = list(pc.values()) + list(pf.values()) + [knots]
+        state = [(torch.zeros_like(p), torch.zeros_like(p)) for p in params]
+        HW = cam["H"] * cam["W"]
+        accu = torch.from_numpy(rng.integers(-3, 4, (HW, 1)).astype(np.float64)).to(device)
+        img = torch.from_numpy(rng.random((HW, C)).astype(np.float32)).to(device)
+        times = []
+        n_steps = 3
+        for it in range(n_steps + 1):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            low_t = float(rng.random() * (1 - w["window"]))
+            idx_e = torch.randperm(HW)[:Re]
+            idx_r = torch.randperm(HW)[:Rr]
+            d_e = {"t_rand": torch.rand(2 * Re, S), "noise0": torch.randn(2 * Re, S), "u": torch.rand(2 * Re, Ni),
+                   "noise1": torch.randn(2 * Re, S + Ni)}
+            d_r = {"t_rand": torch.rand(P * Rr, S), "noise0": torch.randn(P * Rr, S), "u": torch.rand(P * Rr, Ni),
+                   "noise1": torch.randn(P * Rr, S + Ni)}
+            loss, _ = O.step_loss(cfg, pc, pf, knots, tr, torch.tensor([low_t, low_t + w["window"]], dtype=torch.float32),
+                                  torch.tensor([0.0, 1.0]), idx_e, idx_r, accu[idx_e], img[idx_r], d_e, d_r)
+            for p in params:
+                p.grad = None
+            loss.backward()
+            with torch.no_grad():
+                for p, (m, v) in zip(params, state):
+                    O.adam_update(p, p.grad, m, v, it + 1, 5e-4)
+            torch.cuda.synchronize()
+            if it > 0:
+                times.append(time.perf_counter() - t0)
+    finally:
+        torch.set_default_device(prev if prev is not None else "cpu")
+    rays = 2 * Re + P * Rr
+    return {"value": round(rays / (sum(times) / len(times)), 1), "unit": "rays/s", "ms_per_step": round(1e3 * sum(times) / len(times), 2),
+            "kind": "port", "sample": "%d full-size %s steps of the oracle's torch step, eager PyTorch-ROCm on the same GPU" % (n_steps, wl)}
 
 
 def main():
@@ -188,6 +247,23 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
 
+    # ---- secondary: forward-only (inference) rays/s of the same ray batch, no activation saving ----------------------
+    infer = None
+    if world == 1:
+        with torch.no_grad():
+            idx_e = torch.randperm(HW, device=device, generator=gen)[:wl["Re"]]
+            poses = K.spline_poses_fwd(step.knots, None, torch.tensor([0.2, 0.3], device=device), 2, 0)
+            idx_all = torch.randperm(HW, device=device, generator=gen)[:WL.rays_per_step(a.workload) // 2]
+            d_inf = engine.Draws(seed=a.seed, offset=12345)
+            for i in range(a.steps + 2):
+                if i == 2:
+                    torch.cuda.synchronize()
+                    ti = time.perf_counter()
+                engine._render_forward(cam_o, True, wl["S"], wl["Ni"], d_inf, poses, idx_all, step.net_c.packed, step.net_f.packed, False)
+            torch.cuda.synchronize()
+            n_inf = 2 * idx_all.shape[0]
+            infer = round(n_inf / ((time.perf_counter() - ti) / a.steps), 1)
+
     rays_step = WL.rays_per_step(a.workload) * world
     ms_step = dt / a.steps * 1e3
     value = rays_step / (dt / a.steps)
@@ -230,12 +306,19 @@ def main():
                    "parallelism": "dp%d" % world, "mlp_ms_per_step": None if mlp_ms is None else round(mlp_ms, 3),
                    "step_tflops_algorithmic": round(rays_step / world * (wl["S"] + wl["S"] + wl["Ni"]) * fpp * 3 /
                                                     (dt / a.steps) / 1e12, 2),
-                   "final_loss": float(losses[0])},
+                   "final_loss": float(losses[0]), "inference_rays_per_s": infer},
         "roofline": roof,
     }
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.workload, a.seed)
+            try:
+                del step, g
+                torch.cuda.empty_cache()
+                out["torch_gpu_baseline"] = torch_gpu_baseline(a.workload, a.seed, device)
+                out["torch_gpu_baseline"]["speedup_vs_it"] = round(out["value"] / out["torch_gpu_baseline"]["value"], 2)
+            except Exception as e:   # informational leg only: never fail the bench line on it
+                out["torch_gpu_baseline"] = {"error": repr(e)[:200]}
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
