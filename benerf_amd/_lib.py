@@ -45,6 +45,9 @@ _SIGNATURES = {
     "benerf_mlp_dact_floats_per_point": (c_size_t, []),
     "benerf_mlp_dw_workspace_floats": (c_size_t, [c_int64]),
     "benerf_mlp_fwd": (c_int, [POINTER(MlpParams), P, c_int, c_int, c_int, P, P, P, P, P, P, P]),
+    "benerf_mlp_fwd_split": (c_int, [POINTER(MlpParams), P, c_int, c_int, c_int, P, P, P, P, P, P, P]),
+    "benerf_set_mlp_precision": (c_int, [c_int]),
+    "benerf_get_mlp_precision": (c_int, []),
     "benerf_mlp_bwd": (c_int, [POINTER(MlpParams), P, c_int, c_int, c_int, P, P, P, P, c_size_t, POINTER(MlpGrads),
                                c_int, P, P, P]),
     "benerf_mlp_bwd_dx": (c_int, [POINTER(MlpParams), P, c_int, c_int, c_int, P, P, P, P, P, P]),

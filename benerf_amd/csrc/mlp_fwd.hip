@@ -349,6 +349,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_kernel(FwdArgs a) {
 extern "C" int benerf_mlp_fwd(const BenerfMlpParams* params, const float* packed, int channels, int n_rays,
                               int n_samples, const float* rays_o, const float* rays_d, const float* viewdirs,
                               const float* z, float* raw, float* acts, benerf_stream_t stream) {
+    if (benerf_get_mlp_precision() == BENERF_MLP_SPLIT)
+        return benerf_mlp_fwd_split(params, packed, channels, n_rays, n_samples, rays_o, rays_d, viewdirs, z, raw, acts, stream);
     BENERF_REQUIRE(params && packed && rays_o && rays_d && viewdirs && z && raw, "mlp_fwd: null pointer");
     BENERF_REQUIRE(channels == 1 || channels == 3, "mlp_fwd: channels must be 1 or 3");
     BENERF_REQUIRE(n_rays > 0 && n_samples > 0, "mlp_fwd: bad sizes");

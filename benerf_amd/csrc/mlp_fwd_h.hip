@@ -1,0 +1,412 @@
+// K3 forward, split-f16 variant: same network, tiling and outputs as mlp_fwd.hip, but every f32 operand x
+// is carried as two f16 numbers  x = hi + lo * 2^-11  (hi = rn16(x), lo = rn16((x - hi) * 2^11)) and every
+// product a*b is evaluated as  hi_a*hi_b + (hi_a*lo_b + lo_a*hi_b) * 2^-11  on v_mfma_f32_32x32x16_f16 with
+// f32 accumulation.  The dropped lo*lo term is <= 2^-22 |a b|, i.e. the operands keep 22 significant bits
+// (f32: 24) and the sums are accumulated in f32 exactly like the f32 MFMA does: measured against an f64
+// evaluation the result error equals the exact-f32 kernel's (tests/test_kernels_gpu.py::test_mlp_split_*).
+// Three f16 MFMAs (16-deep, 32 cycles each) replace eight f32 MFMAs (2-deep, 32 cycles each).
+//
+// LDS: two f16 planes Th/Tl[64][320] (hi / scaled lo) = 80 KiB, so two workgroups still share a CU.
+// 16-byte slots (8 halfs) are XOR-swizzled: element (row, col) lives in slot (col>>3) ^ ((row>>1)&7).
+// Range: |x| must stay below 65504 (f16 max) - NeRF activations are O(1..100).
+#include "mlp_common.h"
+
+namespace {
+using namespace mlp;
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+constexpr float LO_SCALE = 2048.f, LO_INV = 1.f / 2048.f;
+
+struct FwdArgs {
+    const float* rays_o;
+    const float* rays_d;
+    const float* viewdirs;
+    const float* z;
+    const float* packed;     // split-f16 section of the packed buffer
+    const float* bias[10];
+    const float* w_alpha;
+    const float* b_alpha;
+    const float* w_rgb;
+    const float* b_rgb;
+    float* raw;
+    float* acts;
+    int64_t M;
+    int S;
+};
+
+__device__ __forceinline__ int hsw(int row) { return (row >> 1) & 7; }
+// half index of element (row, col) inside a plane
+__device__ __forceinline__ int hidx(int row, int col) { return row * LD + ((((col >> 3) ^ hsw(row)) << 3) | (col & 7)); }
+
+__device__ __forceinline__ void split_store(_Float16* __restrict__ Th, _Float16* __restrict__ Tl, int idx, float v) {
+    const _Float16 hi = (_Float16)v;
+    Th[idx] = hi;
+    Tl[idx] = (_Float16)((v - (float)hi) * LO_SCALE);
+}
+
+__device__ __forceinline__ f32x16 mfma16(half8 a, half8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// acc1 += hi x hi ; acc2 += hi x lo + lo x hi   over T[:, kcol0 .. kcol0 + KS*16) and packed tile ct0+c
+template <int KS, int NCT>
+__device__ __forceinline__ void gemm_stage(const _Float16* __restrict__ Th, const _Float16* __restrict__ Tl, int kcol0,
+                                           const float* __restrict__ wp, int ct0, int lane, f32x16 (&acc1)[2][NCT],
+                                           f32x16 (&acc2)[2][NCT]) {
+    const int row = lane & 31, lh = lane >> 5;
+    const int sw = hsw(row);                        // rows row and row + 32 share the swizzle
+    const int rbase = row * LD;
+    const uint4* bp[NCT];
+    uint4 bhn[NCT], bln[NCT];
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) {
+        bp[c] = reinterpret_cast<const uint4*>(wp) + (int64_t)(ct0 + c) * KS * 128 + lane;
+        bhn[c] = bp[c][0];
+        bln[c] = bp[c][64];
+    }
+    const int slot0 = kcol0 >> 3;
+#pragma unroll 2
+    for (int ks = 0; ks < KS; ++ks) {
+        half8 bh[NCT], bl[NCT];
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+            bh[c] = __builtin_bit_cast(half8, bhn[c]);
+            bl[c] = __builtin_bit_cast(half8, bln[c]);
+        }
+        if (ks + 1 < KS) {
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                bhn[c] = bp[c][(ks + 1) * 128];
+                bln[c] = bp[c][(ks + 1) * 128 + 64];
+            }
+        }
+        const int off = rbase + (((slot0 + ks * 2 + lh) ^ sw) << 3);
+        half8 ah[2], al[2];
+        ah[0] = *reinterpret_cast<const half8*>(Th + off);
+        ah[1] = *reinterpret_cast<const half8*>(Th + off + 32 * LD);
+        al[0] = *reinterpret_cast<const half8*>(Tl + off);
+        al[1] = *reinterpret_cast<const half8*>(Tl + off + 32 * LD);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) acc1[r][c] = mfma16(ah[r], bh[c], acc1[r][c]);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) acc2[r][c] = mfma16(ah[r], bl[c], acc2[r][c]);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) acc2[r][c] = mfma16(al[r], bh[c], acc2[r][c]);
+    }
+}
+
+template <int NCT>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][NCT]) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[r][c][e] = 0.f;
+}
+
+// combine the two accumulators, bias (+ReLU) -> both LDS planes and, in training mode, the f32 activation array
+// (same layout and ReLU sign-bit convention as mlp_fwd.hip, so the backward kernels are shared).
+template <int NCT, bool RELU, bool SAVE, int LDO>
+__device__ __forceinline__ uint64_t epilogue(f32x16 (&acc1)[2][NCT], f32x16 (&acc2)[2][NCT], _Float16* __restrict__ Th,
+                                             _Float16* __restrict__ Tl, int ct0, int lane, const float* __restrict__ bias,
+                                             float* __restrict__ save_tile, int rows_valid) {
+    const int lr = lane & 31, r4 = 4 * (lane >> 5);
+    uint64_t bits = 0;
+    // row = R(r,e) + r4 with R = r*32 + (e&3) + 8*(e>>2): its swizzle hsw(row) = e1 | r4bit<<1 | e2<<2, so every
+    // store address is one of 4 lane-dependent bases per column tile plus a compile-time row offset.
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) {
+        const int n = (ct0 + c) * 32 + lr;
+        const float bv = bias[n];
+        const int ns = (n >> 3) ^ ((lane >> 5) << 1);
+        int base[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) base[q] = r4 * LD + ((((ns ^ ((q & 1) | ((q >> 1) << 2)))) << 3) | (n & 7));
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = (acc1[r][c][e] + acc2[r][c][e] * LO_INV) + bv;
+                if (RELU) {
+                    v = fmaxf(v, 0.f);
+                    bits |= (uint64_t)(v > 0.f) << ((c * 2 + r) * 16 + e);
+                }
+                acc1[r][c][e] = v;
+                split_store(Th, Tl, base[((e >> 1) & 1) | (((e >> 2) & 1) << 1)] + (r * 32 + (e & 3) + 8 * (e >> 2)) * LD, v);
+            }
+        }
+    }
+    if (SAVE) {
+        float* sv_lane = save_tile + (int64_t)r4 * LDO + lr;
+        if (rows_valid >= TM) {
+#pragma unroll
+            for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        sv_lane[(r * 32 + (e & 3) + 8 * (e >> 2)) * LDO + (ct0 + c) * 32] = acc1[r][c][e];
+        } else {
+#pragma unroll
+            for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int rowoff = r * 32 + (e & 3) + 8 * (e >> 2);
+                        if (rowoff + r4 < rows_valid) sv_lane[rowoff * LDO + (ct0 + c) * 32] = acc1[r][c][e];
+                    }
+        }
+    }
+    return bits;
+}
+
+// 8 consecutive activations (one slot) of this thread's point row as f32
+__device__ __forceinline__ void load8(const _Float16* __restrict__ Th, const _Float16* __restrict__ Tl, int off, float (&v)[8]) {
+    const half8 h = *reinterpret_cast<const half8*>(Th + off);
+    const half8 l = *reinterpret_cast<const half8*>(Tl + off);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (float)h[j] + (float)l[j] * LO_INV;
+}
+
+template <int C, bool SAVE>
+__global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_split_kernel(FwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 Tsm[];   // Th | Tl
+    _Float16* Th = Tsm;
+    _Float16* Tl = Tsm + TM * LD;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int64_t m0 = (int64_t)blockIdx.x * TM;
+    const int64_t M = a.M;
+    const int pt = tid & 63;
+    const int grp = tid >> 6;
+    const int64_t m = m0 + pt;
+    const int64_t mc = m < M ? m : M - 1;
+    const int64_t ray = mc / a.S;
+    float* acts = a.acts;
+    const int rows_valid = (int)(M - m0 < TM ? M - m0 : TM);
+    float* act_h_tile = SAVE ? acts + act_h(M, 0) + m0 * 256 : nullptr;
+    uint64_t* mask_out = SAVE ? reinterpret_cast<uint64_t*>(acts + act_mask(M)) + (int64_t)blockIdx.x * NTHREADS + tid
+                              : nullptr;
+    const int64_t mask_stride = n_tiles(M) * NTHREADS;
+    const bool live = m < M;
+    // f32 scratch in the dead PE columns [288,320) of the lo plane: logical slot 36 + j of this thread's row
+    const int psw = hsw(pt);
+    auto scratch = [&](int j) { return reinterpret_cast<float*>(Tl + pt * LD + (((36 + j) ^ psw) << 3)); };
+
+    // ---- prologue: pts = o + d*z (separately rounded like torch), PE(pts) -> planes (+ acts) ------------
+    {
+        const float zz = a.z[mc];
+        float x[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) x[c] = __fadd_rn(a.rays_o[ray * 3 + c], __fmul_rn(a.rays_d[ray * 3 + c], zz));
+        float* ape = SAVE ? acts + act_pe(M) + m * ACT_PE_W : nullptr;
+        if (grp == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                split_store(Th, Tl, hidx(pt, COL_PE + c), x[c]);
+                if (SAVE && live) ape[c] = x[c];
+            }
+            split_store(Th, Tl, hidx(pt, COL_PE + 63), 0.f);
+            if (SAVE && live) ape[63] = 0.f;
+        }
+        for (int p = grp; p < 30; p += 4) {                    // model/embedder.py:13-28
+            const int f = p / 3, d = p - 3 * f;
+            const float v = x[d] * (float)(1 << f);
+            float s, c;
+            sincosf(v, &s, &c);
+            split_store(Th, Tl, hidx(pt, COL_PE + 3 + f * 6 + d), s);
+            split_store(Th, Tl, hidx(pt, COL_PE + 3 + f * 6 + 3 + d), c);
+            if (SAVE && live) {
+                ape[3 + f * 6 + d] = s;
+                ape[3 + f * 6 + 3 + d] = c;
+            }
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc1[2][2], acc2[2][2];
+    const int ct0 = wave * 2;
+
+    // ---- L0 ---------------------------------------------------------------------------------
+    zero_acc(acc1);
+    zero_acc(acc2);
+    gemm_stage<4, 2>(Th, Tl, COL_PE, a.packed + pack_offset(PF_L0), ct0, lane, acc1, acc2);
+    {
+        const uint64_t bits = epilogue<2, true, SAVE, 256>(acc1, acc2, Th, Tl, ct0, lane, a.bias[0], act_h_tile, rows_valid);
+        if (SAVE) mask_out[0] = bits;
+    }
+    __syncthreads();
+
+    // ---- L1..L7 -------------------------------------------------------------------------------
+#pragma unroll 1
+    for (int l = 1; l < 8; ++l) {
+        zero_acc(acc1);
+        zero_acc(acc2);
+        if (l == 5) gemm_stage<20, 2>(Th, Tl, 0, a.packed + pack_offset(PF_L5), ct0, lane, acc1, acc2);
+        else gemm_stage<16, 2>(Th, Tl, 0, a.packed + pack_offset(PF_L0 + l), ct0, lane, acc1, acc2);
+        __syncthreads();
+        const uint64_t bits = epilogue<2, true, SAVE, 256>(acc1, acc2, Th, Tl, ct0, lane, a.bias[l],
+                                                           SAVE ? act_h_tile + (int64_t)l * M * 256 : nullptr, rows_valid);
+        if (SAVE) mask_out[l * mask_stride] = bits;
+        __syncthreads();
+    }
+
+    // ---- alpha partials (reads h7) + PE(viewdir) into columns [256,288) ---------------------------
+    {
+        const float* wa = a.w_alpha + grp * 64;
+        float s = 0.f;
+#pragma unroll 2
+        for (int q = 0; q < 8; ++q) {
+            float h[8];
+            load8(Th, Tl, pt * LD + (((grp * 8 + q) ^ psw) << 3), h);
+            const float4 w0 = *reinterpret_cast<const float4*>(wa + q * 8);
+            const float4 w1 = *reinterpret_cast<const float4*>(wa + q * 8 + 4);
+            s += h[0] * w0.x + h[1] * w0.y + h[2] * w0.z + h[3] * w0.w;
+            s += h[4] * w1.x + h[5] * w1.y + h[6] * w1.z + h[7] * w1.w;
+        }
+        scratch(0)[grp] = s;
+        float vd[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) vd[c] = a.viewdirs[ray * 3 + c];
+        float* aped = SAVE ? acts + act_ped(M) + m * ACT_PED_W : nullptr;
+        if (grp == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                split_store(Th, Tl, hidx(pt, COL_PE + c), vd[c]);
+                if (SAVE && live) aped[c] = vd[c];
+            }
+        }
+        if (grp == 1) {
+#pragma unroll
+            for (int k = 27; k < 32; ++k) {
+                split_store(Th, Tl, hidx(pt, COL_PE + k), 0.f);
+                if (SAVE && live) aped[k] = 0.f;
+            }
+        }
+        for (int p = grp; p < 12; p += 4) {
+            const int f = p / 3, d = p - 3 * f;
+            const float v = vd[d] * (float)(1 << f);
+            float sn, cs;
+            sincosf(v, &sn, &cs);
+            split_store(Th, Tl, hidx(pt, COL_PE + 3 + f * 6 + d), sn);
+            split_store(Th, Tl, hidx(pt, COL_PE + 3 + f * 6 + 3 + d), cs);
+            if (SAVE && live) {
+                aped[3 + f * 6 + d] = sn;
+                aped[3 + f * 6 + 3 + d] = cs;
+            }
+        }
+    }
+
+    // ---- FEAT (linear) ----------------------------------------------------------------------------
+    zero_acc(acc1);
+    zero_acc(acc2);
+    gemm_stage<16, 2>(Th, Tl, 0, a.packed + pack_offset(PF_FEAT), ct0, lane, acc1, acc2);
+    __syncthreads();
+    epilogue<2, false, SAVE, 256>(acc1, acc2, Th, Tl, ct0, lane, a.bias[BENERF_L_FEAT],
+                                  SAVE ? acts + act_feat(M) + m0 * 256 : nullptr, rows_valid);
+    if (tid < 64 && live) {
+        const float4 p = *reinterpret_cast<const float4*>(scratch(0));
+        a.raw[m * (C + 1) + C] = ((p.x + p.y) + (p.z + p.w)) + a.b_alpha[0];
+    }
+    __syncthreads();
+
+    // ---- VIEWS: [feature | PE(dir)] (288) -> 128, one column tile per wave ----------------------------
+    {
+        f32x16 av1[2][1], av2[2][1];
+        zero_acc(av1);
+        zero_acc(av2);
+        gemm_stage<18, 1>(Th, Tl, 0, a.packed + pack_offset(PF_VIEWS), wave, lane, av1, av2);
+        __syncthreads();
+        epilogue<1, true, SAVE, ACT_HV_W>(av1, av2, Th, Tl, wave, lane, a.bias[BENERF_L_VIEWS],
+                                          SAVE ? acts + act_hv(M) + m0 * ACT_HV_W : nullptr, rows_valid);
+    }
+    __syncthreads();
+
+    // ---- rgb: 128 -> C on the VALU; partials of channel c in scratch slot 1 + c ------------------------
+    {
+        float s[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) s[c] = 0.f;
+#pragma unroll 2
+        for (int q = 0; q < 4; ++q) {
+            float h[8];
+            load8(Th, Tl, pt * LD + (((grp * 4 + q) ^ psw) << 3), h);
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float4 w0 = *reinterpret_cast<const float4*>(a.w_rgb + c * 128 + grp * 32 + q * 8);
+                const float4 w1 = *reinterpret_cast<const float4*>(a.w_rgb + c * 128 + grp * 32 + q * 8 + 4);
+                s[c] += h[0] * w0.x + h[1] * w0.y + h[2] * w0.z + h[3] * w0.w;
+                s[c] += h[4] * w1.x + h[5] * w1.y + h[6] * w1.z + h[7] * w1.w;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) scratch(1 + c)[grp] = s[c];
+    }
+    __syncthreads();
+    if (tid < 64 && live) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float4 p = *reinterpret_cast<const float4*>(scratch(1 + c));
+            a.raw[m * (C + 1) + c] = ((p.x + p.y) + (p.z + p.w)) + a.b_rgb[c];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int benerf_mlp_fwd_split(const BenerfMlpParams* params, const float* packed, int channels, int n_rays,
+                                    int n_samples, const float* rays_o, const float* rays_d, const float* viewdirs,
+                                    const float* z, float* raw, float* acts, benerf_stream_t stream) {
+    BENERF_REQUIRE(params && packed && rays_o && rays_d && viewdirs && z && raw, "mlp_fwd_split: null pointer");
+    BENERF_REQUIRE(channels == 1 || channels == 3, "mlp_fwd_split: channels must be 1 or 3");
+    BENERF_REQUIRE(n_rays > 0 && n_samples > 0, "mlp_fwd_split: bad sizes");
+    FwdArgs a;
+    a.rays_o = rays_o;
+    a.rays_d = rays_d;
+    a.viewdirs = viewdirs;
+    a.z = z;
+    a.packed = packed + mlp::PACKED_FLOATS;
+    for (int l = 0; l < 8; ++l) a.bias[l] = params->b[l];
+    a.bias[BENERF_L_VIEWS] = params->b[BENERF_L_VIEWS];
+    a.bias[BENERF_L_FEAT] = params->b[BENERF_L_FEAT];
+    a.w_alpha = params->w[BENERF_L_ALPHA];
+    a.b_alpha = params->b[BENERF_L_ALPHA];
+    a.w_rgb = params->w[BENERF_L_RGB];
+    a.b_rgb = params->b[BENERF_L_RGB];
+    for (int l = 0; l < BENERF_NLAYERS; ++l) BENERF_REQUIRE(params->b[l] && params->w[l], "mlp_fwd_split: null parameter %d", l);
+    a.raw = raw;
+    a.acts = acts;
+    a.M = (int64_t)n_rays * n_samples;
+    a.S = n_samples;
+    const int64_t tiles = (a.M + mlp::TM - 1) / mlp::TM;
+    BENERF_REQUIRE(tiles < (1ll << 31), "mlp_fwd_split: too many points");
+    dim3 grid((unsigned)tiles), block(mlp::NTHREADS);
+    const int smem = (int)mlp::TILE_SMEM;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)mlp_fwd_split_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        (void)hipFuncSetAttribute((const void*)mlp_fwd_split_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        (void)hipFuncSetAttribute((const void*)mlp_fwd_split_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        (void)hipFuncSetAttribute((const void*)mlp_fwd_split_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_done = true;
+    }
+    if (channels == 1) {
+        if (acts) hipLaunchKernelGGL((mlp_fwd_split_kernel<1, true>), grid, block, smem, as_stream(stream), a);
+        else hipLaunchKernelGGL((mlp_fwd_split_kernel<1, false>), grid, block, smem, as_stream(stream), a);
+    } else {
+        if (acts) hipLaunchKernelGGL((mlp_fwd_split_kernel<3, true>), grid, block, smem, as_stream(stream), a);
+        else hipLaunchKernelGGL((mlp_fwd_split_kernel<3, false>), grid, block, smem, as_stream(stream), a);
+    }
+    BENERF_LAUNCH_CHECK("mlp_fwd_split");
+    return BENERF_OK;
+}

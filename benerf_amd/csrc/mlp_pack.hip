@@ -1,6 +1,6 @@
 // K3 helper: re-pack one network's nn.Linear weights ([out,in] row-major, model/nerf.py:53-64)
 // into the MFMA-operand-shaped blocks described in mlp_common.h.  One launch per network
-// per optimiser step (2.4 M floats read, 4.9 M written).
+// per optimiser step (2.4 M floats read, 4.9 M written) - once as f32 blocks, once as split-f16 blocks.
 #include "mlp_common.h"
 
 namespace {
@@ -81,11 +81,34 @@ __global__ void pack_kernel(PackArgs a) {
         v.w = pack_source(a, id, col, k0 + 3);
         dst[e] = v;
     }
+    // split-f16 section (mlp_fwd_h.hip): [tile][kstep of 16][plane hi|lo][64 lanes][8 halfs]; lane l holds
+    // col = tile*32 + (l&31), k = kstep*16 + 8*(l>>5) + j.  Same float count as the f32 block.
+    typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+    half8* dsth = reinterpret_cast<half8*>(a.packed + PACKED_FLOATS + pack_offset(id));
+    const int ksteps = sh.kblocks / 2;
+    const int64_t n8 = (int64_t)sh.tiles * ksteps * 64;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n8; e += (int64_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(e & 63);
+        const int64_t tb = e >> 6;
+        const int ks = (int)(tb % ksteps);
+        const int tile = (int)(tb / ksteps);
+        const int col = tile * 32 + (lane & 31);
+        const int k0 = ks * 16 + 8 * (lane >> 5);
+        half8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float w = pack_source(a, id, col, k0 + j);
+            hi[j] = (_Float16)w;
+            lo[j] = (_Float16)((w - (float)hi[j]) * 2048.f);
+        }
+        dsth[tb * 128 + lane] = hi;
+        dsth[tb * 128 + 64 + lane] = lo;
+    }
 }
 
 }  // namespace
 
-extern "C" size_t benerf_mlp_packed_floats(void) { return (size_t)mlp::PACKED_FLOATS; }
+extern "C" size_t benerf_mlp_packed_floats(void) { return (size_t)(2 * mlp::PACKED_FLOATS); }   // f32 blocks | split-f16 blocks
 extern "C" size_t benerf_mlp_act_floats(int64_t n_points) { return (size_t)mlp::act_total_floats(n_points); }
 extern "C" size_t benerf_mlp_dact_floats_per_point(void) { return (size_t)mlp::DACT_PER_POINT; }
 extern "C" size_t benerf_mlp_dw_workspace_floats(int64_t n_points) {

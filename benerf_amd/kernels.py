@@ -148,6 +148,19 @@ def _param_struct(cls, tensors_w, tensors_b):
     return s
 
 
+MLP_PRECISIONS = {"f32": 0, "split": 1}
+
+
+def set_mlp_precision(mode):
+    """'f32': exact f32 MFMA;  'split': 3 x f16 MFMA on hi/lo-split operands, f32 accumulate (include/benerf_hip.h)."""
+    _lib.check(_lib.load().benerf_set_mlp_precision(MLP_PRECISIONS[mode]), "set_mlp_precision")
+
+
+def get_mlp_precision():
+    m = _lib.load().benerf_get_mlp_precision()
+    return [k for k, v in MLP_PRECISIONS.items() if v == m][0]
+
+
 class PackedMlp:
     """MFMA-shaped copy of one NeRF's weights; `pack()` after every optimiser step."""
 

@@ -96,7 +96,7 @@ typedef struct BenerfMlpGrads {
     float* b[BENERF_NLAYERS];
 } BenerfMlpGrads;
 
-/* floats needed for the MFMA-packed copies of one network's weights */
+/* floats needed for the MFMA-packed copies of one network's weights (f32 blocks + split-f16 blocks) */
 size_t benerf_mlp_packed_floats(void);
 /* Re-pack one network (call after every optimiser step). packed [benerf_mlp_packed_floats()] */
 int benerf_mlp_pack_weights(const BenerfMlpParams* params, int channels, float* packed,
@@ -118,6 +118,20 @@ int benerf_mlp_fwd(const BenerfMlpParams* params, const float* packed, int chann
                    int n_rays, int n_samples, const float* rays_o, const float* rays_d,
                    const float* viewdirs, const float* z, float* raw, float* acts,
                    benerf_stream_t stream);
+/* MFMA arithmetic of the fused MLP kernels (process-wide; default BENERF_MLP_F32):
+ *   BENERF_MLP_F32    exact f32 MFMA (v_mfma_f32_32x32x2_f32), bit-for-bit f32 products;
+ *   BENERF_MLP_SPLIT  every f32 operand as two f16 numbers (hi + lo*2^-11), three f16 MFMAs per product
+ *                     block, f32 accumulation: 22-bit operands, measured error equal to the f32 path.
+ * benerf_mlp_fwd / _bwd dispatch on it; the explicit *_split entry points ignore it.  Returns -1 on a
+ * bad mode. */
+enum { BENERF_MLP_F32 = 0, BENERF_MLP_SPLIT = 1 };
+int benerf_set_mlp_precision(int mode);
+int benerf_get_mlp_precision(void);
+/* Split-f16 variant of benerf_mlp_fwd: same arguments, outputs and saved-activation layout. */
+int benerf_mlp_fwd_split(const BenerfMlpParams* params, const float* packed, int channels,
+                         int n_rays, int n_samples, const float* rays_o, const float* rays_d,
+                         const float* viewdirs, const float* z, float* raw, float* acts,
+                         benerf_stream_t stream);
 /* Backward of the above.  d_raw [n_points,channels+1].
  *   dacts scratch [n_points * dact_floats_per_point]; dw_ws scratch
  *   [benerf_mlp_dw_workspace_floats(n_points)]; grads: overwritten when accumulate == 0,

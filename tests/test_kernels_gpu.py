@@ -139,6 +139,14 @@ def _g4_case(C, variant, S):
     return p, pts, vd, G
 
 
+@pytest.fixture(params=["f32", "split"])
+def mlp_mode(K, request):
+    """Every K3 test runs under both MFMA arithmetic modes with the SAME tolerances."""
+    K.set_mlp_precision(request.param)
+    yield request.param
+    K.set_mlp_precision("f32")
+
+
 def _run_mlp_on_points(K, net, pts, vd, save):
     """pts [N,S,3] arbitrary: feed as rays with o = 0, per-point d via S=1 rays."""
     N, S = pts.shape[:2]
@@ -169,7 +177,7 @@ def _act_views(acts, M):
 
 
 @pytest.mark.parametrize("C,variant,S", [(1, "xavier", 16), (3, "trained", 16), (1, "trained", 64), (3, "xavier", 64)])
-def test_mlp_fwd_golden(K, golden, C, variant, S):
+def test_mlp_fwd_golden(K, mlp_mode, golden, C, variant, S):
     g = golden("g4_mlp")
     tag = "C%d_%s_S%d" % (C, variant, S)
     p, pts, vd, G = _g4_case(C, variant, S)
@@ -189,7 +197,7 @@ def test_mlp_fwd_golden(K, golden, C, variant, S):
     assert torch.equal(raw2, raw), "inference and training forward must agree bit for bit"
 
 
-def test_mlp_fwd_rays_and_tail(K):
+def test_mlp_fwd_rays_and_tail(K, mlp_mode):
     """pts = o + d*z inside the kernel, ragged tile tail (M not a multiple of 64)."""
     rng = np.random.default_rng(77)
     C = 3
@@ -208,7 +216,7 @@ def test_mlp_fwd_rays_and_tail(K):
 
 
 @pytest.mark.parametrize("C,variant,S", [(1, "xavier", 16), (3, "trained", 16), (1, "trained", 64), (3, "xavier", 64)])
-def test_mlp_bwd_golden(K, golden, C, variant, S):
+def test_mlp_bwd_golden(K, mlp_mode, golden, C, variant, S):
     g = golden("g4_mlp")
     tag = "C%d_%s_S%d" % (C, variant, S)
     p, pts, vd, G = _g4_case(C, variant, S)
@@ -242,7 +250,7 @@ def test_mlp_bwd_golden(K, golden, C, variant, S):
     report("K3 accumulate doubles grads", gw2[3], 2 * gw[3], atol=1e-6 * float(gw[3].abs().max()), rtol=1e-6)
 
 
-def test_mlp_bwd_vs_oracle_tail_and_determinism(K):
+def test_mlp_bwd_vs_oracle_tail_and_determinism(K, mlp_mode):
     rng = np.random.default_rng(78)
     C = 1
     p = _params_for(rng, C, "trained")

@@ -19,10 +19,12 @@ def main():
     ap.add_argument("--samples", type=int, default=128)
     ap.add_argument("--channels", type=int, default=1)
     ap.add_argument("--iters", type=int, default=8)
+    ap.add_argument("--mode", default="f32", choices=["f32", "split"])
     a = ap.parse_args()
     import benerf_oracle as O
     from benerf_amd import kernels as K, workloads as WL
     dev = torch.device("cuda", 0)
+    K.set_mlp_precision(a.mode)
     rng = np.random.default_rng(0)
     p = O.xavier_params(rng, a.channels)
     net = K.PackedMlp([p[n + ".weight"].to(dev) for n in K.LAYER_NAMES], [p[n + ".bias"].to(dev) for n in K.LAYER_NAMES],
@@ -64,8 +66,8 @@ def main():
     for name, (n, ms, pts) in K.TIMERS.summary().items():
         res[name] = (ms / n, ms / n)
     for k, (med, mn) in res.items():
-        print("%-12s M=%d  median %.3f ms  min %.3f ms  -> %.1f TFLOP/s (algorithmic %d flop/pt)"
-              % (k, M, med, mn, M * fpp / (med * 1e-3) / 1e12, fpp))
+        print("[%s] %-12s M=%d  median %.3f ms  min %.3f ms  -> %.1f TFLOP/s (algorithmic %d flop/pt)"
+              % (a.mode, k, M, med, mn, M * fpp / (med * 1e-3) / 1e12, fpp))
 
 
 if __name__ == "__main__":
