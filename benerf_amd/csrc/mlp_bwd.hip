@@ -338,8 +338,14 @@ int benerf_mlp_dw_launch(const BenerfMlpParams* params, int channels, int64_t M,
                          const float* dacts, float* dw_ws, const BenerfMlpGrads* grads, int accumulate,
                          hipStream_t stream);
 
+// split-f16 variant (mlp_bwd_h.hip)
+int benerf_mlp_dx_split_launch(const BenerfMlpParams* params, const float* packed, int channels, int64_t M, const float* d_raw,
+                               const float* acts, float* dacts, float* d_pts, float* d_vdir_pts, hipStream_t stream);
+
 static int launch_dx(const BenerfMlpParams* params, const float* packed, int channels, int64_t M, const float* d_raw,
                      const float* acts, float* dacts, float* d_pts, float* d_vdir_pts, hipStream_t stream) {
+    if (benerf_get_mlp_precision() == BENERF_MLP_SPLIT)
+        return benerf_mlp_dx_split_launch(params, packed, channels, M, d_raw, acts, dacts, d_pts, d_vdir_pts, stream);
     BwdArgs a;
     a.d_raw = d_raw;
     a.acts = acts;

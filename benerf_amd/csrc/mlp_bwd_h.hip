@@ -1,0 +1,334 @@
+// K3 backward part 1, split-f16 variant of mlp_bwd.hip: the same activation-gradient chain (phases P0..P6, same
+// dacts / d_pts / d_viewdirs outputs) with every GEMM as three f16 MFMAs on hi/lo-split operands (mlp_split.h).
+//
+// Gradients are far outside the f16 range (d_raw ~ 1/n_rays), but the whole chain is LINEAR in d_raw: each
+// tile multiplies its d_raw by a power of two s = 2^(-4 - exponent(max|d_raw| of the tile)), runs the chain on the
+// scaled values (|dY| = O(2^-4 .. 2^6), inside f16's normal range with 2^20 of head room) and multiplies every
+// output by 1/s - both exact.  Elements more than 2^-14 below the tile's largest lose relative precision down to
+// an absolute floor of 2^-35 of that largest value, far below the f32 rounding of the sums they enter.
+//
+// LDS: two f16 planes (80 KiB, two workgroups per CU).  The planes' PE columns [256,320) are never a GEMM
+// operand here and serve as 64 floats of f32 scratch per point (fscr): scaled d_raw at [60,64), dPE(dir) at
+// [0,27) during P2, dPE at [0,64) from layer 5 on.
+#include "mlp_split.h"
+
+namespace {
+using namespace mlp;
+
+struct BwdArgs {
+    const float* d_raw;
+    const float* acts;
+    float* dacts;
+    const float* packed;    // f32 section (PB_VIEWSPE) ; split-f16 section at + PACKED_FLOATS
+    const float* w_alpha;   // [256]
+    const float* w_rgb;     // [C][128]
+    float* d_pts;           // [M][3]
+    float* d_vdir;          // [M][3]
+    int64_t M;
+};
+
+// one 32x32 output tile: rows rt*32.., column tile `tile` of the packed block; returns hi*hi + cross * 2^-11
+template <int KS>
+__device__ __forceinline__ f32x16 gemm_one(const _Float16* __restrict__ Th, const _Float16* __restrict__ Tl,
+                                           const float* __restrict__ wp, int tile, int rt, int lane) {
+    const int row = rt * 32 + (lane & 31), lh = lane >> 5;
+    const int sw = hsw(row);
+    const int rbase = row * LD;
+    const uint4* bp = reinterpret_cast<const uint4*>(wp) + (int64_t)tile * KS * 128 + lane;
+    f32x16 a1, a2;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) a1[e] = a2[e] = 0.f;
+    uint4 bhn = bp[0], bln = bp[64];
+#pragma unroll 4
+    for (int ks = 0; ks < KS; ++ks) {
+        const half8 bh = __builtin_bit_cast(half8, bhn), bl = __builtin_bit_cast(half8, bln);
+        if (ks + 1 < KS) {
+            bhn = bp[(ks + 1) * 128];
+            bln = bp[(ks + 1) * 128 + 64];
+        }
+        const int off = rbase + (((ks * 2 + lh) ^ sw) << 3);
+        const half8 ah = *reinterpret_cast<const half8*>(Th + off);
+        const half8 al = *reinterpret_cast<const half8*>(Tl + off);
+        a1 = mfma16(ah, bh, a1);
+        a2 = mfma16(ah, bl, a2);
+        a2 = mfma16(al, bh, a2);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) a1[e] += a2[e] * LO_INV;
+    return a1;
+}
+
+// dY = (acc1 + acc2 * 2^-11) masked by the forward pass' ReLU sign bits -> both planes (scaled) and, times inv_s,
+// the DY array whose tile starts at `dy_tile`.
+template <bool MASK>
+__device__ __forceinline__ void epilogue(f32x16 (&acc1)[2][2], f32x16 (&acc2)[2][2], uint64_t bits, _Float16* __restrict__ Th,
+                                         _Float16* __restrict__ Tl, int ct0, int lane, float* __restrict__ dy_tile,
+                                         int rows_valid, float inv_s) {
+    const int lr = lane & 31, r4 = 4 * (lane >> 5);
+    float* dy_lane = dy_tile + (int64_t)r4 * 256 + lr;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int n = (ct0 + c) * 32 + lr;
+        const int ns = (n >> 3) ^ ((lane >> 5) << 1);
+        int base[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) base[q] = r4 * LD + ((((ns ^ ((q & 1) | ((q >> 1) << 2)))) << 3) | (n & 7));
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = acc1[r][c][e] + acc2[r][c][e] * LO_INV;
+                if (MASK) v = ((bits >> ((c * 2 + r) * 16 + e)) & 1ull) ? v : 0.f;
+                split_store(Th, Tl, base[((e >> 1) & 1) | (((e >> 2) & 1) << 1)] + (r * 32 + (e & 3) + 8 * (e >> 2)) * LD, v);
+                acc1[r][c][e] = v * inv_s;
+            }
+    }
+    if (rows_valid >= TM) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    dy_lane[(r * 32 + (e & 3) + 8 * (e >> 2)) * 256 + (ct0 + c) * 32] = acc1[r][c][e];
+    } else {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int rowoff = r * 32 + (e & 3) + 8 * (e >> 2);
+                    if (rowoff + r4 < rows_valid) dy_lane[rowoff * 256 + (ct0 + c) * 32] = acc1[r][c][e];
+                }
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_split_kernel(BwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 Tsm[];   // Th | Tl
+    _Float16* Th = Tsm;
+    _Float16* Tl = Tsm + TM * LD;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int64_t m0 = (int64_t)blockIdx.x * TM;
+    const int64_t M = a.M;
+    const int pt = tid & 63;
+    const int grp = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t m = m0 + pt;
+    const float* acts = a.acts;
+    float* dacts = a.dacts;
+    const float* packed_h = a.packed + PACKED_FLOATS;
+    const int ct0 = wave * 2;
+    const int rows_valid = (int)(M - m0 < TM ? M - m0 : TM);
+    const uint64_t* mask_in = reinterpret_cast<const uint64_t*>(acts + act_mask(M)) + (int64_t)blockIdx.x * NTHREADS + tid;
+    const int64_t mask_stride = n_tiles(M) * NTHREADS;
+    float* dyh_tile = dacts + dact_h(M, 0) + m0 * 256;
+    const int psw = hsw(pt);
+    const int prow = pt * LD;
+
+    // ---- P0: d_raw tile, its power-of-two scale, scaled values -> scratch floats [60, 60+C] of each row ------
+    if (tid < 64) {
+        float dr[C + 1];
+        float mx = 0.f;
+#pragma unroll
+        for (int c = 0; c <= C; ++c) {
+            dr[c] = m < M ? a.d_raw[m * (C + 1) + c] : 0.f;
+            mx = fmaxf(mx, fabsf(dr[c]));
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        int be = (int)((__float_as_uint(mx) >> 23) & 0xffu);
+        be = be < 4 ? 4 : (be > 246 ? 246 : be);
+        const float s = __uint_as_float((uint32_t)(250 - be) << 23);       // 2^(-4 - exponent(max))
+#pragma unroll
+        for (int c = 0; c <= C; ++c) *fscr(Th, Tl, pt, 60 + c) = dr[c] * s;
+        if (tid == 0) *fscr(Th, Tl, 0, 56) = __uint_as_float((uint32_t)(be + 4) << 23);   // 1/s
+    }
+    __syncthreads();
+    const float inv_s = *fscr(Th, Tl, 0, 56);
+
+    // ---- P1: rgb layer backward + ReLU mask of the views layer -> dYv in planes[:,0:128) ---------------------
+    {
+        const int j = tid & 127, half = tid >> 7;
+        float wr[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) wr[c] = a.w_rgb[c * 128 + j];
+        const float* hv = acts + act_hv(M) + (m0 + half * 32) * ACT_HV_W + j;
+        float* dyv = dacts + dact_hv(M) + (m0 + half * 32) * ACT_HV_W + j;
+        float hvv[32];
+        if (rows_valid >= TM) {
+#pragma unroll
+            for (int q = 0; q < 32; ++q) hvv[q] = hv[q * ACT_HV_W];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 32; ++q) hvv[q] = half * 32 + q < rows_valid ? hv[q * ACT_HV_W] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            const int p = half * 32 + q;
+            const float4 dr = *reinterpret_cast<const float4*>(fscr(Th, Tl, p, 60));
+            const float drv[4] = {dr.x, dr.y, dr.z, dr.w};
+            float g = 0.f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) g += drv[c] * wr[c];
+            const float v = hvv[q] > 0.f ? g : 0.f;
+            if (rows_valid >= TM || p < rows_valid) dyv[q * ACT_HV_W] = v * inv_s;
+            split_store(Th, Tl, hidx(p, j), v);
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc1[2][2], acc2[2][2];
+
+    // ---- P2: VIEWS^T: dFeat = dYv x Wv[:, :256]; dPE(dir) = dYv x Wv[:, 256:283] (VALU, f32) ------------------
+    zero_acc(acc1);
+    zero_acc(acc2);
+    gemm_stage<8, 2>(Th, Tl, 0, packed_h + pack_offset(PB_VIEWS), ct0, lane, acc1, acc2);
+    {
+        const float* wq = a.packed + pack_offset(PB_VIEWSPE) + (int64_t)grp * 128 * 8;
+        float s[7];
+#pragma unroll
+        for (int q = 0; q < 7; ++q) s[q] = 0.f;
+#pragma unroll 1
+        for (int n8 = 0; n8 < 16; ++n8) {
+            float h[8];
+            load8(Th, Tl, prow + ((n8 ^ psw) << 3), h);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int q = 0; q < 7; ++q) s[q] += h[i] * wq[(n8 * 8 + i) * 8 + q];
+        }
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            const int j = grp + 4 * q;
+            if (j < 27) *fscr(Th, Tl, pt, j) = s[q];
+        }
+    }
+    __syncthreads();   // dYv fully consumed; dPE(dir) visible
+    epilogue<false>(acc1, acc2, 0ull, Th, Tl, ct0, lane, dacts + dact_feat(M) + m0 * 256, rows_valid, inv_s);
+    if (grp == 0 && m < M) {   // d viewdirs (per point) through PE(dir)
+        const float* ped = acts + act_ped(M) + m * ACT_PED_W;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            float s = *fscr(Th, Tl, pt, d);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const float sn = ped[3 + f * 6 + d], cs = ped[3 + f * 6 + 3 + d];
+                s += (float)(1 << f) * (cs * *fscr(Th, Tl, pt, 3 + f * 6 + d) - sn * *fscr(Th, Tl, pt, 3 + f * 6 + 3 + d));
+            }
+            a.d_vdir[m * 3 + d] = s * inv_s;
+        }
+    }
+    uint64_t bits = mask_in[7 * mask_stride];
+    __syncthreads();
+
+    // ---- P3: FEAT^T (+ alpha head), mask h7 -> dY7 ----------------------------------------------------
+    zero_acc(acc1);
+    zero_acc(acc2);
+    gemm_stage<16, 2>(Th, Tl, 0, packed_h + pack_offset(PB_FEAT), ct0, lane, acc1, acc2);
+    {
+        const float wa0 = a.w_alpha[ct0 * 32 + (lane & 31)];
+        const float wa1 = a.w_alpha[(ct0 + 1) * 32 + (lane & 31)];
+        const int r4 = 4 * (lane >> 5);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float ds = *fscr(Th, Tl, r * 32 + (e & 3) + 8 * (e >> 2) + r4, 60 + C);
+                acc1[r][0][e] += ds * wa0;
+                acc1[r][1][e] += ds * wa1;
+            }
+    }
+    __syncthreads();
+    epilogue<true>(acc1, acc2, bits, Th, Tl, ct0, lane, dyh_tile + 7 * M * 256, rows_valid, inv_s);
+    __syncthreads();
+
+    // ---- P4: L7 .. L1: dY_l x W_l, mask h_{l-1} -> dY_{l-1} ----------------------------------------------
+#pragma unroll 1
+    for (int l = 7; l >= 1; --l) {
+        bits = mask_in[(l - 1) * mask_stride];
+        zero_acc(acc1);
+        zero_acc(acc2);
+        const int pid = PB_L7 + (7 - l);
+        gemm_stage<16, 2>(Th, Tl, 0, packed_h + pack_offset(pid), ct0, lane, acc1, acc2);
+        if (l == 5) {   // skip connection: dPE = dY5 x W5[:, PE part] (tiles 8, 9 of the block) -> scratch [0,64)
+            const f32x16 ap = gemm_one<16>(Th, Tl, packed_h + pack_offset(PB_L5), 8 + (wave & 1), wave >> 1, lane);
+            const int col = (wave & 1) * 32 + (lane & 31);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) *fscr(Th, Tl, (wave >> 1) * 32 + acc_row(e, lane), col) = ap[e];
+        }
+        __syncthreads();
+        epilogue<true>(acc1, acc2, bits, Th, Tl, ct0, lane, dyh_tile + (int64_t)(l - 1) * M * 256, rows_valid, inv_s);
+        __syncthreads();
+    }
+
+    // ---- P5: L0^T: dPE += dY0 x W0 -----------------------------------------------------------------------
+    {
+        const f32x16 ap = gemm_one<16>(Th, Tl, packed_h + pack_offset(PB_L0), wave & 1, wave >> 1, lane);
+        const int col = (wave & 1) * 32 + (lane & 31);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) *fscr(Th, Tl, (wave >> 1) * 32 + acc_row(e, lane), col) += ap[e];
+    }
+    __syncthreads();
+
+    // ---- P6: dPE -> d_pts through the saved PE values; group partials as f32 in the (dead) hi-plane columns ----
+    float* part = reinterpret_cast<float*>(Th + prow);      // 4 groups x 4 floats = first 64 bytes of the row
+    {
+        float s[3] = {0.f, 0.f, 0.f};
+        const int64_t mc = m < M ? m : M - 1;
+        const float* pe = acts + act_pe(M) + mc * ACT_PE_W;
+        if (grp == 0) {
+            s[0] = *fscr(Th, Tl, pt, 0);
+            s[1] = *fscr(Th, Tl, pt, 1);
+            s[2] = *fscr(Th, Tl, pt, 2);
+        }
+        for (int f = grp; f < 10; f += 4) {
+            const float sc = (float)(1 << f);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const float sn = pe[3 + f * 6 + d], cs = pe[3 + f * 6 + 3 + d];
+                s[d] += sc * (cs * *fscr(Th, Tl, pt, 3 + f * 6 + d) - sn * *fscr(Th, Tl, pt, 3 + f * 6 + 3 + d));
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) part[grp * 4 + d] = s[d];
+    }
+    __syncthreads();
+    if (tid < 64 && m < M) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) a.d_pts[m * 3 + d] = ((part[d] + part[4 + d]) + (part[8 + d] + part[12 + d])) * inv_s;
+    }
+}
+
+}  // namespace
+
+int benerf_mlp_dx_split_launch(const BenerfMlpParams* params, const float* packed, int channels, int64_t M, const float* d_raw,
+                               const float* acts, float* dacts, float* d_pts, float* d_vdir_pts, hipStream_t stream) {
+    BwdArgs a;
+    a.d_raw = d_raw;
+    a.acts = acts;
+    a.dacts = dacts;
+    a.packed = packed;
+    a.w_alpha = params->w[BENERF_L_ALPHA];
+    a.w_rgb = params->w[BENERF_L_RGB];
+    a.d_pts = d_pts;
+    a.d_vdir = d_vdir_pts;
+    a.M = M;
+    const int64_t tiles = (M + mlp::TM - 1) / mlp::TM;
+    BENERF_REQUIRE(tiles < (1ll << 31), "mlp_bwd: too many points");
+    dim3 grid((unsigned)tiles), block(mlp::NTHREADS);
+    const int smem = (int)mlp::TILE_SMEM;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)mlp_bwd_split_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        (void)hipFuncSetAttribute((const void*)mlp_bwd_split_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_done = true;
+    }
+    if (channels == 1) hipLaunchKernelGGL((mlp_bwd_split_kernel<1>), grid, block, smem, stream, a);
+    else hipLaunchKernelGGL((mlp_bwd_split_kernel<3>), grid, block, smem, stream, a);
+    BENERF_LAUNCH_CHECK("mlp_bwd(dx, split)");
+    return BENERF_OK;
+}

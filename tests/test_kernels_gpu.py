@@ -287,6 +287,32 @@ def test_mlp_bwd_vs_oracle_tail_and_determinism(K, mlp_mode):
     assert all(torch.equal(a, b) for a, b in zip(gw, gw2)), "weight gradients must be run-to-run deterministic"
 
 
+def test_mlp_bwd_gradient_scale_invariance(K, mlp_mode):
+    """The chain is linear in d_raw: gradients 2^-40 times smaller (far below the f16 range the split mode computes
+    in) must give exactly 2^-40 times the outputs - the split kernels rescale per tile by powers of two."""
+    rng = np.random.default_rng(79)
+    C = 3
+    p = _params_for(rng, C, "trained")
+    net = _packed(K, p, C)
+    N, S = 16, 32
+    ro = GI.f32(rng.uniform(-0.5, 0.5, (N, 3)))
+    rd = GI.f32(rng.uniform(-1, 1, (N, 3)))
+    vd = GI.f32(rng.standard_normal((N, 3)))
+    vd = vd / vd.norm(dim=-1, keepdim=True)
+    z = GI.f32(np.sort(rng.random((N, S)), -1))
+    G = GI.f32(rng.standard_normal((N * S, C + 1)) * np.exp(rng.uniform(-6, 2, (N * S, 1))))   # wide dynamic range
+    raw, acts = K.mlp_fwd(net, dev(ro), dev(rd), dev(vd), dev(z), True)
+    outs = []
+    for sc in (1.0, 2.0 ** -40):
+        gw = [torch.zeros_like(w) for w in net.weights]
+        gb = [torch.zeros_like(b) for b in net.biases]
+        d_pts, d_vd = K.mlp_bwd(net, dev(G * sc), acts, N, S, gw, gb, False)
+        outs.append((d_pts / sc, d_vd / sc, [g / sc for g in gw]))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), "d_pts / d_viewdirs must scale exactly"
+    for a, b in zip(outs[0][2], outs[1][2]):
+        report("K3 dW scale invariance", b, a, atol=1e-6 * float(a.abs().max()), rtol=1e-5)
+
+
 # ------------------------------------------------------------------------------------ K4
 @pytest.mark.parametrize("C", [1, 3])
 def test_composite_golden(K, golden, C):
