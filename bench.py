@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--n-events", type=int, default=2_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--mlp-precision", default="f32", choices=["f32", "split"],
+                    help="MFMA arithmetic of the fused MLP kernels (include/benerf_hip.h: benerf_set_mlp_precision)")
     return ap.parse_args()
 
 
@@ -193,6 +195,7 @@ def main():
         pg = torch.distributed.group.WORLD
 
     from benerf_amd import engine, workloads as WL, kernels as K
+    K.set_mlp_precision(a.mlp_precision)
     wl = WL.WORKLOADS[a.workload]
     cam = WL.CAMERAS[wl["cam"]]
     args_ns = WL.make_args(a.workload)
