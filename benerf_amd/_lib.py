@@ -43,6 +43,7 @@ _SIGNATURES = {
     "benerf_mlp_pack_weights": (c_int, [POINTER(MlpParams), c_int, P, P]),
     "benerf_mlp_act_floats": (c_size_t, [c_int64]),
     "benerf_mlp_dact_floats_per_point": (c_size_t, []),
+    "benerf_mlp_dact_floats": (c_size_t, [c_int64]),
     "benerf_mlp_dw_workspace_floats": (c_size_t, [c_int64]),
     "benerf_mlp_fwd": (c_int, [POINTER(MlpParams), P, c_int, c_int, c_int, P, P, P, P, P, P, P]),
     "benerf_mlp_fwd_split": (c_int, [POINTER(MlpParams), P, c_int, c_int, c_int, P, P, P, P, P, P, P]),
@@ -94,6 +95,11 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    mode = os.environ.get("BENERF_MLP_PRECISION")          # "f32" | "split": process-wide MFMA arithmetic of the MLP kernels
+    if mode:
+        if mode not in ("f32", "split"):
+            raise BenerfHipError("BENERF_MLP_PRECISION must be 'f32' or 'split', not %r" % mode)
+        lib.benerf_set_mlp_precision(1 if mode == "split" else 0)
     return lib
 
 

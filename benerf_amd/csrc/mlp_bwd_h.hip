@@ -58,14 +58,13 @@ __device__ __forceinline__ f32x16 gemm_one(const _Float16* __restrict__ Th, cons
     return a1;
 }
 
-// dY = (acc1 + acc2 * 2^-11) masked by the forward pass' ReLU sign bits -> both planes (scaled) and, times inv_s,
-// the DY array whose tile starts at `dy_tile`.
+// dY = (acc1 + acc2 * 2^-11) masked by the forward pass' ReLU sign bits -> both planes (tile scale) and, times
+// gf = s_g / s_tile, the ST gradient array `st` (W = 256; m0 = first point of the tile).
 template <bool MASK>
 __device__ __forceinline__ void epilogue(f32x16 (&acc1)[2][2], f32x16 (&acc2)[2][2], uint64_t bits, _Float16* __restrict__ Th,
-                                         _Float16* __restrict__ Tl, int ct0, int lane, float* __restrict__ dy_tile,
-                                         int rows_valid, float inv_s) {
+                                         _Float16* __restrict__ Tl, int ct0, int lane, _Float16* __restrict__ st, int64_t m0,
+                                         float gf) {
     const int lr = lane & 31, r4 = 4 * (lane >> 5);
-    float* dy_lane = dy_tile + (int64_t)r4 * 256 + lr;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         const int n = (ct0 + c) * 32 + lr;
@@ -73,34 +72,22 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc1)[2][2], f32x16 (&acc2)[2]
         int base[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) base[q] = r4 * LD + ((((ns ^ ((q & 1) | ((q >> 1) << 2)))) << 3) | (n & 7));
+        _Float16* st_lane = st + st_half_index(m0 + r4, 256, n, 0);
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float v = acc1[r][c][e] + acc2[r][c][e] * LO_INV;
-                if (MASK) v = ((bits >> ((c * 2 + r) * 16 + e)) & 1ull) ? v : 0.f;
-                split_store(Th, Tl, base[((e >> 1) & 1) | (((e >> 2) & 1) << 1)] + (r * 32 + (e & 3) + 8 * (e >> 2)) * LD, v);
-                acc1[r][c][e] = v * inv_s;
-            }
-    }
-    if (rows_valid >= TM) {
+            for (int eq = 0; eq < 4; ++eq) {
+                float vg[4];
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    dy_lane[(r * 32 + (e & 3) + 8 * (e >> 2)) * 256 + (ct0 + c) * 32] = acc1[r][c][e];
-    } else {
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int rowoff = r * 32 + (e & 3) + 8 * (e >> 2);
-                    if (rowoff + r4 < rows_valid) dy_lane[rowoff * 256 + (ct0 + c) * 32] = acc1[r][c][e];
+                for (int j = 0; j < 4; ++j) {
+                    const int e = eq * 4 + j;
+                    float v = acc1[r][c][e] + acc2[r][c][e] * LO_INV;
+                    if (MASK) v = ((bits >> ((c * 2 + r) * 16 + e)) & 1ull) ? v : 0.f;
+                    split_store(Th, Tl, base[((e >> 1) & 1) | (((e >> 2) & 1) << 1)] + (r * 32 + (e & 3) + 8 * (e >> 2)) * LD, v);
+                    vg[j] = v * gf;
                 }
+                st_store_quad(st_lane, (int64_t)(r * 4 + eq) * 2 * 256 * 8, 256, vg);
+            }
     }
 }
 
@@ -122,10 +109,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_split_kernel(BwdArgs a) {
     float* dacts = a.dacts;
     const float* packed_h = a.packed + PACKED_FLOATS;
     const int ct0 = wave * 2;
-    const int rows_valid = (int)(M - m0 < TM ? M - m0 : TM);
-    const uint64_t* mask_in = reinterpret_cast<const uint64_t*>(acts + act_mask(M)) + (int64_t)blockIdx.x * NTHREADS + tid;
+    const int64_t Mp = m_pad(M);
+    const uint64_t* mask_in = reinterpret_cast<const uint64_t*>(acts + sact_mask(Mp)) + (int64_t)blockIdx.x * NTHREADS + tid;
     const int64_t mask_stride = n_tiles(M) * NTHREADS;
-    float* dyh_tile = dacts + dact_h(M, 0) + m0 * 256;
+    _Float16* st_dyh = reinterpret_cast<_Float16*>(dacts + sdact_h(Mp, 0));      // layer l: + l * Mp * 512 halfs
+    float s_g, inv_s_g;
+    pow2_scale(dacts[sdact_scale(Mp)], s_g, inv_s_g);                             // global scale of this call (pre-kernel)
     const int psw = hsw(pt);
     const int prow = pt * LD;
 
@@ -140,44 +129,46 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_split_kernel(BwdArgs a) {
         }
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-        int be = (int)((__float_as_uint(mx) >> 23) & 0xffu);
-        be = be < 4 ? 4 : (be > 246 ? 246 : be);
-        const float s = __uint_as_float((uint32_t)(250 - be) << 23);       // 2^(-4 - exponent(max))
+        float s, inv;
+        pow2_scale(mx, s, inv);                                             // 2^(-4 - exponent(max)), exact inverse
 #pragma unroll
         for (int c = 0; c <= C; ++c) *fscr(Th, Tl, pt, 60 + c) = dr[c] * s;
-        if (tid == 0) *fscr(Th, Tl, 0, 56) = __uint_as_float((uint32_t)(be + 4) << 23);   // 1/s
+        if (tid == 0) *fscr(Th, Tl, 0, 56) = inv;
     }
     __syncthreads();
     const float inv_s = *fscr(Th, Tl, 0, 56);
+    const float gf = s_g * inv_s;            // tile scale -> global scale (<= 1, power of two)
 
-    // ---- P1: rgb layer backward + ReLU mask of the views layer -> dYv in planes[:,0:128) ---------------------
+    // ---- P1: rgb layer backward + ReLU mask of the views layer -> dYv in planes[:,0:128), accumulator layout ----
+    // thread <-> (column wave*32 + lane&31, rows r*32 + acc_row(e)): the hv sign bits the forward pass saved for
+    // its VIEWS accumulators line up with this thread's elements, so hv itself is not read.
     {
-        const int j = tid & 127, half = tid >> 7;
+        const uint64_t hvbits = mask_in[8 * mask_stride];
+        const int col = wave * 32 + (lane & 31), r4 = 4 * (lane >> 5);
         float wr[C];
 #pragma unroll
-        for (int c = 0; c < C; ++c) wr[c] = a.w_rgb[c * 128 + j];
-        const float* hv = acts + act_hv(M) + (m0 + half * 32) * ACT_HV_W + j;
-        float* dyv = dacts + dact_hv(M) + (m0 + half * 32) * ACT_HV_W + j;
-        float hvv[32];
-        if (rows_valid >= TM) {
+        for (int c = 0; c < C; ++c) wr[c] = a.w_rgb[c * 128 + col];
+        _Float16* st_lane = reinterpret_cast<_Float16*>(dacts + sdact_hv(Mp)) + st_half_index(m0 + r4, ACT_HV_W, col, 0);
 #pragma unroll
-            for (int q = 0; q < 32; ++q) hvv[q] = hv[q * ACT_HV_W];
-        } else {
+        for (int r = 0; r < 2; ++r)
 #pragma unroll
-            for (int q = 0; q < 32; ++q) hvv[q] = half * 32 + q < rows_valid ? hv[q * ACT_HV_W] : 0.f;
-        }
+            for (int eq = 0; eq < 4; ++eq) {
+                float vg[4];
 #pragma unroll
-        for (int q = 0; q < 32; ++q) {
-            const int p = half * 32 + q;
-            const float4 dr = *reinterpret_cast<const float4*>(fscr(Th, Tl, p, 60));
-            const float drv[4] = {dr.x, dr.y, dr.z, dr.w};
-            float g = 0.f;
+                for (int j = 0; j < 4; ++j) {
+                    const int e = eq * 4 + j;
+                    const int p = r * 32 + (e & 3) + 8 * (e >> 2) + r4;
+                    const float4 dr = *reinterpret_cast<const float4*>(fscr(Th, Tl, p, 60));
+                    const float drv[4] = {dr.x, dr.y, dr.z, dr.w};
+                    float g = 0.f;
 #pragma unroll
-            for (int c = 0; c < C; ++c) g += drv[c] * wr[c];
-            const float v = hvv[q] > 0.f ? g : 0.f;
-            if (rows_valid >= TM || p < rows_valid) dyv[q * ACT_HV_W] = v * inv_s;
-            split_store(Th, Tl, hidx(p, j), v);
-        }
+                    for (int c = 0; c < C; ++c) g += drv[c] * wr[c];
+                    const float v = ((hvbits >> (r * 16 + e)) & 1ull) ? g : 0.f;
+                    split_store(Th, Tl, hidx(p, col), v);
+                    vg[j] = v * gf;
+                }
+                st_store_quad(st_lane, (int64_t)(r * 4 + eq) * 2 * ACT_HV_W * 8, ACT_HV_W, vg);
+            }
     }
     __syncthreads();
 
@@ -208,9 +199,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_split_kernel(BwdArgs a) {
         }
     }
     __syncthreads();   // dYv fully consumed; dPE(dir) visible
-    epilogue<false>(acc1, acc2, 0ull, Th, Tl, ct0, lane, dacts + dact_feat(M) + m0 * 256, rows_valid, inv_s);
+    epilogue<false>(acc1, acc2, 0ull, Th, Tl, ct0, lane, reinterpret_cast<_Float16*>(dacts + sdact_feat(Mp)), m0, gf);
     if (grp == 0 && m < M) {   // d viewdirs (per point) through PE(dir)
-        const float* ped = acts + act_ped(M) + m * ACT_PED_W;
+        const float* ped = acts + sact_ped32(Mp) + m * ACT_PED_W;
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             float s = *fscr(Th, Tl, pt, d);
@@ -243,7 +234,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_split_kernel(BwdArgs a) {
             }
     }
     __syncthreads();
-    epilogue<true>(acc1, acc2, bits, Th, Tl, ct0, lane, dyh_tile + 7 * M * 256, rows_valid, inv_s);
+    epilogue<true>(acc1, acc2, bits, Th, Tl, ct0, lane, st_dyh + 7 * Mp * 512, m0, gf);
     __syncthreads();
 
     // ---- P4: L7 .. L1: dY_l x W_l, mask h_{l-1} -> dY_{l-1} ----------------------------------------------
@@ -261,7 +252,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_split_kernel(BwdArgs a) {
             for (int e = 0; e < 16; ++e) *fscr(Th, Tl, (wave >> 1) * 32 + acc_row(e, lane), col) = ap[e];
         }
         __syncthreads();
-        epilogue<true>(acc1, acc2, bits, Th, Tl, ct0, lane, dyh_tile + (int64_t)(l - 1) * M * 256, rows_valid, inv_s);
+        epilogue<true>(acc1, acc2, bits, Th, Tl, ct0, lane, st_dyh + (int64_t)(l - 1) * Mp * 512, m0, gf);
         __syncthreads();
     }
 
@@ -279,7 +270,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_split_kernel(BwdArgs a) {
     {
         float s[3] = {0.f, 0.f, 0.f};
         const int64_t mc = m < M ? m : M - 1;
-        const float* pe = acts + act_pe(M) + mc * ACT_PE_W;
+        const float* pe = acts + sact_pe32(Mp) + mc * ACT_PE_W;
         if (grp == 0) {
             s[0] = *fscr(Th, Tl, pt, 0);
             s[1] = *fscr(Th, Tl, pt, 1);
@@ -303,6 +294,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_split_kernel(BwdArgs a) {
     }
 }
 
+// max |d_raw| -> dacts[sdact_scale] (zeroed by the launcher; non-negative floats order like their bit patterns)
+__global__ void grad_absmax_kernel(const float* __restrict__ d_raw, int64_t n, float* __restrict__ out) {
+    float mx = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        mx = fmaxf(mx, fabsf(d_raw[i]));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(mx));
+}
+
 }  // namespace
 
 int benerf_mlp_dx_split_launch(const BenerfMlpParams* params, const float* packed, int channels, int64_t M, const float* d_raw,
@@ -319,6 +320,12 @@ int benerf_mlp_dx_split_launch(const BenerfMlpParams* params, const float* packe
     a.M = M;
     const int64_t tiles = (M + mlp::TM - 1) / mlp::TM;
     BENERF_REQUIRE(tiles < (1ll << 31), "mlp_bwd: too many points");
+    float* absmax = dacts + mlp::sdact_scale(mlp::m_pad(M));
+    if (hipMemsetAsync(absmax, 0, sizeof(float), stream) != hipSuccess) {
+        benerf_set_error("mlp_bwd: memset failed");
+        return BENERF_EHIP;
+    }
+    hipLaunchKernelGGL(grad_absmax_kernel, dim3(256), dim3(256), 0, stream, d_raw, M * (channels + 1), absmax);
     dim3 grid((unsigned)tiles), block(mlp::NTHREADS);
     const int smem = (int)mlp::TILE_SMEM;
     static bool attr_done = false;

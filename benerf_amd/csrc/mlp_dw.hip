@@ -6,7 +6,7 @@
 // streams 32-point chunks of dY and X through LDS (register-staged prefetch of the next
 // chunk during the MFMAs).  Partials are then summed in a fixed order by dw_reduce_kernel,
 // which also scatters into nn.Linear layout ([out,in], model/nerf.py:53-64) -> deterministic.
-#include "mlp_common.h"
+#include "mlp_split.h"
 
 namespace {
 using namespace mlp;
@@ -267,17 +267,21 @@ struct ReduceArgs {
     float* gb[BENERF_NLAYERS];
     int C;
     int accumulate;
+    int split_mode;          // partials written by mlp_dw_h.hip: other split table; dY-derived sums carry the factor s_g
+    const float* absmax;     // split mode: -> max |d_raw| of the call (s_g = pow2_scale of it)
 };
 
-__device__ __forceinline__ float sum_splits(const float* ws, int inst, int64_t elem) {
-    const float* p = ws + dw_inst_offset(inst) + elem;
+template <bool SPLIT>
+__device__ __forceinline__ float sum_splits_t(const float* ws, int inst, int64_t elem) {
+    const float* p = ws + (SPLIT ? dwh_inst_offset(inst) : dw_inst_offset(inst)) + elem;
     const int64_t stride = dw_inst_floats(inst);
-    const int n = dw_splits(inst);
+    const int n = SPLIT ? dwh_splits(inst) : dw_splits(inst);
     float s = 0.f;
 #pragma unroll 4
     for (int sp = 0; sp < n; ++sp) s += p[sp * stride];
     return s;
 }
+#define sum_splits(ws, inst, elem) sum_splits_t<SPLIT>(ws, inst, elem)
 
 __device__ __forceinline__ int layer_inst(int l) {   // instance holding the bias / main block of layer l
     switch (l) {
@@ -293,8 +297,15 @@ __device__ __forceinline__ int layer_inst(int l) {   // instance holding the bia
     }
 }
 
+template <bool SPLIT>
 __global__ void dw_reduce_kernel(ReduceArgs a) {
     const int l = blockIdx.y;
+    // the alpha and rgb heads are summed from the unscaled d_raw, everything else from the scaled dY arrays
+    float unscale = 1.f;
+    if (SPLIT && l != BENERF_L_ALPHA && l != BENERF_L_RGB) {
+        float s_g;
+        pow2_scale(a.absmax[0], s_g, unscale);
+    }
     const int C = a.C;
     const int in = layer_in(l), out = layer_out(l, C);
     const int64_t nw = (int64_t)in * out;
@@ -320,16 +331,42 @@ __global__ void dw_reduce_kernel(ReduceArgs a) {
                 v = sum_splits(a.ws, inst, (int64_t)dw_shape(inst).n * dw_shape(inst).k + n);
             }
         }
+        v *= unscale;
         *dst = a.accumulate ? *dst + v : v;
     }
 }
+#undef sum_splits
 
 }  // namespace
+
+int benerf_mlp_dw_reduce_launch(const float* ws, const BenerfMlpGrads* grads, int channels, int accumulate, int split_mode,
+                                const float* absmax, hipStream_t stream) {
+    ReduceArgs r;
+    r.ws = ws;
+    for (int l = 0; l < BENERF_NLAYERS; ++l) {
+        r.gw[l] = grads->w[l];
+        r.gb[l] = grads->b[l];
+    }
+    r.C = channels;
+    r.accumulate = accumulate;
+    r.split_mode = split_mode;
+    r.absmax = absmax;
+    if (split_mode) hipLaunchKernelGGL(dw_reduce_kernel<true>, dim3(64, BENERF_NLAYERS), dim3(256), 0, stream, r);
+    else hipLaunchKernelGGL(dw_reduce_kernel<false>, dim3(64, BENERF_NLAYERS), dim3(256), 0, stream, r);
+    BENERF_LAUNCH_CHECK("mlp_bwd(reduce)");
+    return BENERF_OK;
+}
+
+// split-f16 variant (mlp_dw_h.hip)
+int benerf_mlp_dw_split_launch(int channels, int64_t M, const float* d_raw, const float* acts, const float* dacts, float* dw_ws,
+                               const BenerfMlpGrads* grads, int accumulate, hipStream_t stream);
 
 int benerf_mlp_dw_launch(const BenerfMlpParams* params, int channels, int64_t M, const float* d_raw, const float* acts,
                          const float* dacts, float* dw_ws, const BenerfMlpGrads* grads, int accumulate,
                          hipStream_t stream) {
     (void)params;
+    if (benerf_get_mlp_precision() == BENERF_MLP_SPLIT)
+        return benerf_mlp_dw_split_launch(channels, M, d_raw, acts, dacts, dw_ws, grads, accumulate, stream);
     DwArgs a;
     a.d_raw = d_raw;
     a.acts = acts;
@@ -344,15 +381,5 @@ int benerf_mlp_dw_launch(const BenerfMlpParams* params, int channels, int64_t M,
     }
     hipLaunchKernelGGL(mlp_dw_kernel, dim3(mlp::DW_TOTAL_BLOCKS), dim3(DWT), DW_SMEM, stream, a);
     BENERF_LAUNCH_CHECK("mlp_bwd(dw)");
-    ReduceArgs r;
-    r.ws = dw_ws;
-    for (int l = 0; l < BENERF_NLAYERS; ++l) {
-        r.gw[l] = grads->w[l];
-        r.gb[l] = grads->b[l];
-    }
-    r.C = channels;
-    r.accumulate = accumulate;
-    hipLaunchKernelGGL(dw_reduce_kernel, dim3(64, BENERF_NLAYERS), dim3(256), 0, stream, r);
-    BENERF_LAUNCH_CHECK("mlp_bwd(reduce)");
-    return BENERF_OK;
+    return benerf_mlp_dw_reduce_launch(dw_ws, grads, channels, accumulate, 0, nullptr, stream);
 }

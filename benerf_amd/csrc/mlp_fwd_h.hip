@@ -31,16 +31,17 @@ struct FwdArgs {
     int S;
 };
 
-// combine the two accumulators, bias (+ReLU) -> both LDS planes and, in training mode, the f32 activation array
-// (same layout and ReLU sign-bit convention as mlp_fwd.hip, so the backward kernels are shared).
-template <int NCT, bool RELU, bool SAVE, int LDO>
+// combine the two accumulators, bias (+ReLU) -> both LDS planes and, in training mode, the ST activation array `st`
+// of width W (mlp_split.h; m0 = first point of the tile).  Returns the ReLU sign bits in the accumulator-layout
+// convention of mlp_common.h, so the mask words are shared with the f32 kernels.
+template <int NCT, bool RELU, bool SAVE, int W>
 __device__ __forceinline__ uint64_t epilogue(f32x16 (&acc1)[2][NCT], f32x16 (&acc2)[2][NCT], _Float16* __restrict__ Th,
                                              _Float16* __restrict__ Tl, int ct0, int lane, const float* __restrict__ bias,
-                                             float* __restrict__ save_tile, int rows_valid) {
+                                             _Float16* __restrict__ st, int64_t m0) {
     const int lr = lane & 31, r4 = 4 * (lane >> 5);
     uint64_t bits = 0;
     // row = R(r,e) + r4 with R = r*32 + (e&3) + 8*(e>>2): its swizzle hsw(row) = e1 | r4bit<<1 | e2<<2, so every
-    // store address is one of 4 lane-dependent bases per column tile plus a compile-time row offset.
+    // LDS store address is one of 4 lane-dependent bases per column tile plus a compile-time row offset.
 #pragma unroll
     for (int c = 0; c < NCT; ++c) {
         const int n = (ct0 + c) * 32 + lr;
@@ -49,40 +50,34 @@ __device__ __forceinline__ uint64_t epilogue(f32x16 (&acc1)[2][NCT], f32x16 (&ac
         int base[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) base[q] = r4 * LD + ((((ns ^ ((q & 1) | ((q >> 1) << 2)))) << 3) | (n & 7));
+        _Float16* st_lane = SAVE ? st + st_half_index(m0 + r4, W, n, 0) : nullptr;    // + (r*4 + eq) * 2*W*8 per quad
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float v = (acc1[r][c][e] + acc2[r][c][e] * LO_INV) + bv;
-                if (RELU) {
-                    v = fmaxf(v, 0.f);
-                    bits |= (uint64_t)(v > 0.f) << ((c * 2 + r) * 16 + e);
-                }
-                acc1[r][c][e] = v;
-                split_store(Th, Tl, base[((e >> 1) & 1) | (((e >> 2) & 1) << 1)] + (r * 32 + (e & 3) + 8 * (e >> 2)) * LD, v);
-            }
-        }
-    }
-    if (SAVE) {
-        float* sv_lane = save_tile + (int64_t)r4 * LDO + lr;
-        if (rows_valid >= TM) {
+            for (int eq = 0; eq < 4; ++eq) {
+                Quad16 qh, ql;
 #pragma unroll
-            for (int c = 0; c < NCT; ++c)
-#pragma unroll
-                for (int r = 0; r < 2; ++r)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e)
-                        sv_lane[(r * 32 + (e & 3) + 8 * (e >> 2)) * LDO + (ct0 + c) * 32] = acc1[r][c][e];
-        } else {
-#pragma unroll
-            for (int c = 0; c < NCT; ++c)
-#pragma unroll
-                for (int r = 0; r < 2; ++r)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int rowoff = r * 32 + (e & 3) + 8 * (e >> 2);
-                        if (rowoff + r4 < rows_valid) sv_lane[rowoff * LDO + (ct0 + c) * 32] = acc1[r][c][e];
+                for (int j = 0; j < 4; ++j) {
+                    const int e = eq * 4 + j;
+                    float v = (acc1[r][c][e] + acc2[r][c][e] * LO_INV) + bv;
+                    if (RELU) {
+                        v = fmaxf(v, 0.f);
+                        bits |= (uint64_t)(v > 0.f) << ((c * 2 + r) * 16 + e);
                     }
+                    const _Float16 hi = (_Float16)v;
+                    const _Float16 lo = (_Float16)((v - (float)hi) * LO_SCALE);
+                    const int idx = base[((e >> 1) & 1) | (((e >> 2) & 1) << 1)] + (r * 32 + (e & 3) + 8 * (e >> 2)) * LD;
+                    Th[idx] = hi;
+                    Tl[idx] = lo;
+                    qh.v[j] = hi;
+                    ql.v[j] = lo;
+                }
+                if (SAVE) {
+                    _Float16* dst = st_lane + (int64_t)(r * 4 + eq) * 2 * W * 8;
+                    *reinterpret_cast<uint2*>(dst) = __builtin_bit_cast(uint2, qh);
+                    *reinterpret_cast<uint2*>(dst + W * 8) = __builtin_bit_cast(uint2, ql);
+                }
+            }
         }
     }
     return bits;
@@ -105,9 +100,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_split_kernel(FwdArgs a) {
     const int64_t mc = m < M ? m : M - 1;
     const int64_t ray = mc / a.S;
     float* acts = a.acts;
-    const int rows_valid = (int)(M - m0 < TM ? M - m0 : TM);
-    float* act_h_tile = SAVE ? acts + act_h(M, 0) + m0 * 256 : nullptr;
-    uint64_t* mask_out = SAVE ? reinterpret_cast<uint64_t*>(acts + act_mask(M)) + (int64_t)blockIdx.x * NTHREADS + tid
+    const int64_t Mp = m_pad(M);
+    _Float16* st_h = SAVE ? reinterpret_cast<_Float16*>(acts + sact_h(Mp, 0)) : nullptr;     // layer l: + l * Mp * 256 * 2 halfs
+    uint64_t* mask_out = SAVE ? reinterpret_cast<uint64_t*>(acts + sact_mask(Mp)) + (int64_t)blockIdx.x * NTHREADS + tid
                               : nullptr;
     const int64_t mask_stride = n_tiles(M) * NTHREADS;
     const bool live = m < M;
@@ -121,27 +116,33 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_split_kernel(FwdArgs a) {
         float x[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) x[c] = __fadd_rn(a.rays_o[ray * 3 + c], __fmul_rn(a.rays_d[ray * 3 + c], zz));
-        float* ape = SAVE ? acts + act_pe(M) + m * ACT_PE_W : nullptr;
+        // training: PE as f32 rows (dX kernel, sin/cos derivatives) and as an ST array (dW operand), all Mp rows
+        float* ape = SAVE ? acts + sact_pe32(Mp) + m * ACT_PE_W : nullptr;
+        _Float16* spe = SAVE ? reinterpret_cast<_Float16*>(acts + sact_pe(Mp)) : nullptr;
+        auto put = [&](int col, float v) {
+            const _Float16 hi = (_Float16)v;
+            const _Float16 lo = (_Float16)((v - (float)hi) * LO_SCALE);
+            const int idx = hidx(pt, COL_PE + col);
+            Th[idx] = hi;
+            Tl[idx] = lo;
+            if (SAVE) {
+                ape[col] = v;
+                spe[st_half_index(m, ACT_PE_W, col, 0)] = hi;
+                spe[st_half_index(m, ACT_PE_W, col, 1)] = lo;
+            }
+        };
         if (grp == 0) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                split_store(Th, Tl, hidx(pt, COL_PE + c), x[c]);
-                if (SAVE && live) ape[c] = x[c];
-            }
-            split_store(Th, Tl, hidx(pt, COL_PE + 63), 0.f);
-            if (SAVE && live) ape[63] = 0.f;
+            for (int c = 0; c < 3; ++c) put(c, x[c]);
+            put(63, 0.f);
         }
         for (int p = grp; p < 30; p += 4) {                    // model/embedder.py:13-28
             const int f = p / 3, d = p - 3 * f;
             const float v = x[d] * (float)(1 << f);
             float s, c;
             sincosf(v, &s, &c);
-            split_store(Th, Tl, hidx(pt, COL_PE + 3 + f * 6 + d), s);
-            split_store(Th, Tl, hidx(pt, COL_PE + 3 + f * 6 + 3 + d), c);
-            if (SAVE && live) {
-                ape[3 + f * 6 + d] = s;
-                ape[3 + f * 6 + 3 + d] = c;
-            }
+            put(3 + f * 6 + d, s);
+            put(3 + f * 6 + 3 + d, c);
         }
     }
     __syncthreads();
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_split_kernel(FwdArgs a) {
     zero_acc(acc2);
     gemm_stage<4, 2>(Th, Tl, COL_PE, a.packed + pack_offset(PF_L0), ct0, lane, acc1, acc2);
     {
-        const uint64_t bits = epilogue<2, true, SAVE, 256>(acc1, acc2, Th, Tl, ct0, lane, a.bias[0], act_h_tile, rows_valid);
+        const uint64_t bits = epilogue<2, true, SAVE, 256>(acc1, acc2, Th, Tl, ct0, lane, a.bias[0], st_h, m0);
         if (SAVE) mask_out[0] = bits;
     }
     __syncthreads();
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_split_kernel(FwdArgs a) {
         else gemm_stage<16, 2>(Th, Tl, 0, a.packed + pack_offset(PF_L0 + l), ct0, lane, acc1, acc2);
         __syncthreads();
         const uint64_t bits = epilogue<2, true, SAVE, 256>(acc1, acc2, Th, Tl, ct0, lane, a.bias[l],
-                                                           SAVE ? act_h_tile + (int64_t)l * M * 256 : nullptr, rows_valid);
+                                                           SAVE ? st_h + (int64_t)l * Mp * 512 : nullptr, m0);
         if (SAVE) mask_out[l * mask_stride] = bits;
         __syncthreads();
     }
@@ -190,32 +191,35 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_split_kernel(FwdArgs a) {
         float vd[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) vd[c] = a.viewdirs[ray * 3 + c];
-        float* aped = SAVE ? acts + act_ped(M) + m * ACT_PED_W : nullptr;
+        float* aped = SAVE ? acts + sact_ped32(Mp) + m * ACT_PED_W : nullptr;
+        _Float16* sped = SAVE ? reinterpret_cast<_Float16*>(acts + sact_ped(Mp)) : nullptr;
+        auto put = [&](int col, float v) {
+            const _Float16 hi = (_Float16)v;
+            const _Float16 lo = (_Float16)((v - (float)hi) * LO_SCALE);
+            const int idx = hidx(pt, COL_PE + col);
+            Th[idx] = hi;
+            Tl[idx] = lo;
+            if (SAVE) {
+                aped[col] = v;
+                sped[st_half_index(m, ACT_PED_W, col, 0)] = hi;
+                sped[st_half_index(m, ACT_PED_W, col, 1)] = lo;
+            }
+        };
         if (grp == 0) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                split_store(Th, Tl, hidx(pt, COL_PE + c), vd[c]);
-                if (SAVE && live) aped[c] = vd[c];
-            }
+            for (int c = 0; c < 3; ++c) put(c, vd[c]);
         }
         if (grp == 1) {
 #pragma unroll
-            for (int k = 27; k < 32; ++k) {
-                split_store(Th, Tl, hidx(pt, COL_PE + k), 0.f);
-                if (SAVE && live) aped[k] = 0.f;
-            }
+            for (int k = 27; k < 32; ++k) put(k, 0.f);
         }
         for (int p = grp; p < 12; p += 4) {
             const int f = p / 3, d = p - 3 * f;
             const float v = vd[d] * (float)(1 << f);
             float sn, cs;
             sincosf(v, &sn, &cs);
-            split_store(Th, Tl, hidx(pt, COL_PE + 3 + f * 6 + d), sn);
-            split_store(Th, Tl, hidx(pt, COL_PE + 3 + f * 6 + 3 + d), cs);
-            if (SAVE && live) {
-                aped[3 + f * 6 + d] = sn;
-                aped[3 + f * 6 + 3 + d] = cs;
-            }
+            put(3 + f * 6 + d, sn);
+            put(3 + f * 6 + 3 + d, cs);
         }
     }
 
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_split_kernel(FwdArgs a) {
     gemm_stage<16, 2>(Th, Tl, 0, a.packed + pack_offset(PF_FEAT), ct0, lane, acc1, acc2);
     __syncthreads();
     epilogue<2, false, SAVE, 256>(acc1, acc2, Th, Tl, ct0, lane, a.bias[BENERF_L_FEAT],
-                                  SAVE ? acts + act_feat(M) + m0 * 256 : nullptr, rows_valid);
+                                  SAVE ? reinterpret_cast<_Float16*>(acts + sact_feat(Mp)) : nullptr, m0);
     if (tid < 64 && live) {
         const float4 p = *reinterpret_cast<const float4*>(scratch(0));
         a.raw[m * (C + 1) + C] = ((p.x + p.y) + (p.z + p.w)) + a.b_alpha[0];
@@ -239,8 +243,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_split_kernel(FwdArgs a) {
         zero_acc(av2);
         gemm_stage<18, 1>(Th, Tl, 0, a.packed + pack_offset(PF_VIEWS), wave, lane, av1, av2);
         __syncthreads();
-        epilogue<1, true, SAVE, ACT_HV_W>(av1, av2, Th, Tl, wave, lane, a.bias[BENERF_L_VIEWS],
-                                          SAVE ? acts + act_hv(M) + m0 * ACT_HV_W : nullptr, rows_valid);
+        const uint64_t bits = epilogue<1, true, SAVE, ACT_HV_W>(av1, av2, Th, Tl, wave, lane, a.bias[BENERF_L_VIEWS],
+                                                                SAVE ? reinterpret_cast<_Float16*>(acts + sact_hv(Mp)) : nullptr, m0);
+        if (SAVE) mask_out[8 * mask_stride] = bits;     // bit r*16 + e: element e of row tile r, column tile = wave
     }
     __syncthreads();
 

@@ -1,7 +1,7 @@
 // K3 helper: re-pack one network's nn.Linear weights ([out,in] row-major, model/nerf.py:53-64)
 // into the MFMA-operand-shaped blocks described in mlp_common.h.  One launch per network
 // per optimiser step (2.4 M floats read, 4.9 M written) - once as f32 blocks, once as split-f16 blocks.
-#include "mlp_common.h"
+#include "mlp_split.h"
 
 namespace {
 using namespace mlp;
@@ -109,8 +109,16 @@ __global__ void pack_kernel(PackArgs a) {
 }  // namespace
 
 extern "C" size_t benerf_mlp_packed_floats(void) { return (size_t)(2 * mlp::PACKED_FLOATS); }   // f32 blocks | split-f16 blocks
-extern "C" size_t benerf_mlp_act_floats(int64_t n_points) { return (size_t)mlp::act_total_floats(n_points); }
+// buffers are sized for either arithmetic mode (the split mode pads the point count to whole 64-point tiles)
+extern "C" size_t benerf_mlp_act_floats(int64_t n_points) {
+    const int64_t a = mlp::act_total_floats(n_points), b = mlp::sact_total_floats(n_points);
+    return (size_t)(a > b ? a : b);
+}
 extern "C" size_t benerf_mlp_dact_floats_per_point(void) { return (size_t)mlp::DACT_PER_POINT; }
+extern "C" size_t benerf_mlp_dact_floats(int64_t n_points) {
+    const int64_t a = n_points * mlp::DACT_PER_POINT, b = mlp::sdact_total_floats(n_points);
+    return (size_t)(a > b ? a : b);
+}
 extern "C" size_t benerf_mlp_dw_workspace_floats(int64_t n_points) {
     (void)n_points;
     return (size_t)mlp::DW_WS_FLOATS;

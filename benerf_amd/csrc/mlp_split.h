@@ -96,6 +96,61 @@ __device__ __forceinline__ void load8(const _Float16* __restrict__ Th, const _Fl
 }
 
 
+// ---- saved activations / activation gradients in split mode ("ST" arrays) -------------------------------------
+// An ST array of width W over Mp = 64 * n_tiles points stores the split value of (m, w) as two halfs at
+//   half index  (((m >> 3) * 2 + plane) * W + w) * 8 + (m & 7)          plane 0 = hi, 1 = lo (scaled by 2^11)
+// i.e. blocks of 8 points, feature-major inside: the 8 points of one feature are one 16-byte slot, which is exactly
+// the A/B operand fragment of v_mfma_f32_32x32x16_f16 when the contraction runs over points (dW = dY^T X).  The
+// forward / dX epilogues hold 4 consecutive points of a feature per lane and write 8-byte pieces (a wave covers
+// 512 contiguous bytes); the dW kernel copies chunks straight into LDS without any transposition.  Same bytes per
+// element (4) as the f32 arrays.  Rows m >= M of the last tile are written too (duplicates of the last point for
+// activations, exact zeros for gradients), so no store is masked and no dW chunk is ragged.
+__host__ __device__ inline int64_t st_half_index(int64_t m, int W, int w, int plane) {
+    return (((m >> 3) * 2 + plane) * W + w) * 8 + (m & 7);
+}
+__host__ __device__ inline int64_t m_pad(int64_t M) { return n_tiles(M) * TM; }
+// float (4-byte) offsets inside the split-mode activation buffer
+constexpr int SACT_MASK_LAYERS = 9;                                       // h0..h7 + hv
+__host__ __device__ inline int64_t sact_pe32(int64_t Mp) { (void)Mp; return 0; }                 // f32 [Mp][64]  (dX: sin/cos)
+__host__ __device__ inline int64_t sact_ped32(int64_t Mp) { return Mp * ACT_PE_W; }               // f32 [Mp][32]
+__host__ __device__ inline int64_t sact_pe(int64_t Mp) { return sact_ped32(Mp) + Mp * ACT_PED_W; }   // ST W = 64
+__host__ __device__ inline int64_t sact_ped(int64_t Mp) { return sact_pe(Mp) + Mp * ACT_PE_W; }      // ST W = 32
+__host__ __device__ inline int64_t sact_h(int64_t Mp, int l) { return sact_ped(Mp) + Mp * ACT_PED_W + (int64_t)l * Mp * 256; }
+__host__ __device__ inline int64_t sact_feat(int64_t Mp) { return sact_h(Mp, 8); }                // ST W = 256
+__host__ __device__ inline int64_t sact_hv(int64_t Mp) { return sact_feat(Mp) + Mp * 256; }       // ST W = 128
+__host__ __device__ inline int64_t sact_mask(int64_t Mp) { return sact_hv(Mp) + Mp * ACT_HV_W; }  // uint64 [9][tiles][256]
+__host__ __device__ inline int64_t sact_total_floats(int64_t M) {
+    return sact_mask(m_pad(M)) + (int64_t)SACT_MASK_LAYERS * n_tiles(M) * NTHREADS * 2;
+}
+// activation gradients: ST arrays holding dY * s_g (s_g = global power-of-two scale of this backward call), then
+// max |d_raw| of the call (one float; s_g = pow2_scale of it)
+__host__ __device__ inline int64_t sdact_h(int64_t Mp, int l) { return (int64_t)l * Mp * 256; }
+__host__ __device__ inline int64_t sdact_feat(int64_t Mp) { return 8 * Mp * 256; }
+__host__ __device__ inline int64_t sdact_hv(int64_t Mp) { return 9 * Mp * 256; }
+__host__ __device__ inline int64_t sdact_scale(int64_t Mp) { return 9 * Mp * 256 + Mp * ACT_HV_W; }
+__host__ __device__ inline int64_t sdact_total_floats(int64_t M) { return sdact_scale(m_pad(M)) + 16; }
+
+// power-of-two scale s = 2^(-4 - exponent(mx)) that brings values of magnitude <= mx to <= 2^-3, and its inverse
+__device__ __forceinline__ void pow2_scale(float mx, float& s, float& inv_s) {
+    int be = (int)((__float_as_uint(mx) >> 23) & 0xffu);
+    be = be < 4 ? 4 : (be > 246 ? 246 : be);
+    s = __uint_as_float((uint32_t)(250 - be) << 23);
+    inv_s = __uint_as_float((uint32_t)(be + 4) << 23);
+}
+
+// 4 consecutive points (one accumulator quad) of one feature -> 8-byte pieces of an ST array
+struct Quad16 { _Float16 v[4]; };
+__device__ __forceinline__ void st_store_quad(_Float16* __restrict__ base, int64_t hi_index, int W, const float (&v)[4]) {
+    Quad16 h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        h.v[j] = (_Float16)v[j];
+        l.v[j] = (_Float16)((v[j] - (float)h.v[j]) * LO_SCALE);
+    }
+    *reinterpret_cast<uint2*>(base + hi_index) = __builtin_bit_cast(uint2, h);
+    *reinterpret_cast<uint2*>(base + hi_index + (int64_t)W * 8) = __builtin_bit_cast(uint2, l);
+}
+
 // f32 scratch inside the planes' PE columns [256,320): 64 floats per row, floats [0,32) in the hi plane, [32,64)
 // in the lo plane (slot 32 + i/4 of the plane, swizzled like everything else).
 __device__ __forceinline__ float* fscr(_Float16* Th, _Float16* Tl, int row, int i) {

@@ -210,7 +210,7 @@ def mlp_bwd(net, d_raw, acts, n_rays, n_samples, grad_w, grad_b, accumulate):
     lib = _lib.load()
     M = n_rays * n_samples
     dev = d_raw.device
-    dacts = scratch("dacts", M * lib.benerf_mlp_dact_floats_per_point(), dev)
+    dacts = scratch("dacts", lib.benerf_mlp_dact_floats(M), dev)
     ws_floats = lib.benerf_mlp_dw_workspace_floats(M)
     ws = scratch("dw_ws", ws_floats, dev)
     d_pts = torch.empty((M, 3), dtype=torch.float32, device=dev)

@@ -105,6 +105,9 @@ int benerf_mlp_pack_weights(const BenerfMlpParams* params, int channels, float* 
  * the per-tile ReLU sign-bit words), and floats per point of the activation-gradient scratch */
 size_t benerf_mlp_act_floats(int64_t n_points);
 size_t benerf_mlp_dact_floats_per_point(void);
+/* floats of the activation-gradient scratch for n_points (valid for either arithmetic mode; >= n_points *
+ * benerf_mlp_dact_floats_per_point()) */
+size_t benerf_mlp_dact_floats(int64_t n_points);
 /* floats of the weight-gradient partial-sum workspace for n_points */
 size_t benerf_mlp_dw_workspace_floats(int64_t n_points);
 
@@ -133,7 +136,7 @@ int benerf_mlp_fwd_split(const BenerfMlpParams* params, const float* packed, int
                          const float* viewdirs, const float* z, float* raw, float* acts,
                          benerf_stream_t stream);
 /* Backward of the above.  d_raw [n_points,channels+1].
- *   dacts scratch [n_points * dact_floats_per_point]; dw_ws scratch
+ *   dacts scratch [benerf_mlp_dact_floats(n_points)]; dw_ws scratch
  *   [benerf_mlp_dw_workspace_floats(n_points)]; grads: overwritten when accumulate == 0,
  *   added to otherwise; d_pts [n_points,3], d_vdir_pts [n_points,3] out (per point; reduce
  *   with benerf_ray_grad_reduce). */

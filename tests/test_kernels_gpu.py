@@ -159,20 +159,39 @@ def _run_mlp_on_points(K, net, pts, vd, save):
     return raw.reshape(N, S, -1), acts, M
 
 
-def _act_views(acts, M):
+def _act_views(acts, M, mode="f32"):
+    """Decode the saved-activation buffer: f32 rows (mlp_common.h) or, in split mode, ST arrays (mlp_split.h)."""
     a = acts.cpu()
-    off = 0
     out = {}
-    out["pe"] = a[off:off + M * 64].reshape(M, 64)
-    off += M * 64
-    for l in range(8):
-        out["h%d" % l] = a[off:off + M * 256].reshape(M, 256)
+    if mode == "f32":
+        off = 0
+        out["pe"] = a[off:off + M * 64].reshape(M, 64)
+        off += M * 64
+        for l in range(8):
+            out["h%d" % l] = a[off:off + M * 256].reshape(M, 256)
+            off += M * 256
+        out["feat"] = a[off:off + M * 256].reshape(M, 256)
         off += M * 256
-    out["feat"] = a[off:off + M * 256].reshape(M, 256)
-    off += M * 256
-    out["hv"] = a[off:off + M * 128].reshape(M, 128)
-    off += M * 128
-    out["ped"] = a[off:off + M * 32].reshape(M, 32)
+        out["hv"] = a[off:off + M * 128].reshape(M, 128)
+        off += M * 128
+        out["ped"] = a[off:off + M * 32].reshape(M, 32)
+        return out
+    Mp = (M + 63) // 64 * 64
+    halfs = a.numpy().view(np.float16)
+
+    def st(off, W):
+        blk = halfs[off * 2: off * 2 + Mp * W * 2].reshape(Mp // 8, 2, W, 8).astype(np.float32)
+        val = blk[:, 0] + blk[:, 1] / 2048.0                       # [Mp/8, W, 8]
+        return torch.from_numpy(np.ascontiguousarray(val.transpose(0, 2, 1)).reshape(Mp, W)[:M])
+
+    out["pe"] = a[0:Mp * 64].reshape(Mp, 64)[:M]
+    out["ped"] = a[Mp * 64:Mp * 96].reshape(Mp, 32)[:M]
+    out["pe_st"] = st(Mp * 96, 64)
+    out["ped_st"] = st(Mp * 160, 32)
+    for l in range(8):
+        out["h%d" % l] = st(Mp * 192 + l * Mp * 256, 256)
+    out["feat"] = st(Mp * 192 + 8 * Mp * 256, 256)
+    out["hv"] = st(Mp * 192 + 9 * Mp * 256, 128)
     return out
 
 
@@ -186,9 +205,11 @@ def test_mlp_fwd_golden(K, mlp_mode, golden, C, variant, S):
     ref = g[tag + "_raw"]
     sc = float(np.abs(ref).max())
     if tag + "_h0" in g:
-        av = _act_views(acts, M)
+        av = _act_views(acts, M, mlp_mode)
         report("K3 PE " + tag, av["pe"][:, :63], g[tag + "_pe"], atol=2e-6)
         assert float(av["pe"][:, 63].abs().max()) == 0.0
+        if mlp_mode == "split":      # the dW operand copies carry 22 of the 24 significand bits
+            report("K3 PE (ST copy) " + tag, av["pe_st"], av["pe"], atol=1e-6, rtol=1e-6)
         for name in ("h0", "h4", "h7", "feat", "hv"):
             r = g[tag + "_" + name]
             report("K3 act %s %s" % (name, tag), av[name], r, atol=2e-5 * float(np.abs(r).max()), rtol=1e-4)
