@@ -173,7 +173,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_kernel(BwdArgs a) {
 #pragma unroll
         for (int c = 0; c <= C; ++c) trow[(COL_SCR + c) ^ psw] = m < M ? a.d_raw[m * (C + 1) + c] : 0.f;
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---- P1: rgb layer backward + ReLU mask of the views layer -> dYv in T[:,0:128) ------------------
     {
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_kernel(BwdArgs a) {
             T[tidx(p, j)] = v;
         }
     }
-    __syncthreads();
+    lds_barrier();
 
     f32x16 acc[2][2];
 
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_kernel(BwdArgs a) {
             if (j < 27) trow[(COL_PE + j) ^ psw] = s[q];
         }
     }
-    __syncthreads();   // dYv fully consumed; dPE(dir) visible
+    lds_barrier();   // dYv fully consumed; dPE(dir) visible
     epilogue<false>(acc, 0ull, T, ct0, lane, dacts + dact_feat(M) + m0 * 256, rows_valid);
     if (grp == 0 && m < M) {   // d viewdirs (per point) through PE(dir)
         const float* ped = acts + act_ped(M) + m * ACT_PED_W;
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_kernel(BwdArgs a) {
         }
     }
     uint64_t bits = mask_in[7 * mask_stride];
-    __syncthreads();
+    lds_barrier();
 
     // ---- P3: FEAT^T (+ alpha head), mask h7 -> dY7 ----------------------------------------------------
     zero_acc(acc);
@@ -265,9 +265,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_kernel(BwdArgs a) {
                 acc[r][1][e] += ds * wa1;
             }
     }
-    __syncthreads();
+    lds_barrier();
     epilogue<true>(acc, bits, T, ct0, lane, dyh_tile + 7 * M * 256, rows_valid);
-    __syncthreads();
+    lds_barrier();
 
     // ---- P4: L7 .. L1: dY_l x W_l, mask h_{l-1} -> dY_{l-1} ----------------------------------------------
 #pragma unroll 1
@@ -285,9 +285,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_kernel(BwdArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) T[tidx((wave >> 1) * 32 + acc_row(e, lane), col)] = ap[e];
         }
-        __syncthreads();
+        lds_barrier();
         epilogue<true>(acc, bits, T, ct0, lane, dyh_tile + (int64_t)(l - 1) * M * 256, rows_valid);
-        __syncthreads();
+        lds_barrier();
     }
 
     // ---- P5: L0^T: dPE += dY0 x W0 -----------------------------------------------------------------------
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_kernel(BwdArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) T[tidx((wave >> 1) * 32 + acc_row(e, lane), col)] += ap[e];
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---- P6: dPE -> d_pts through the saved PE values; group partials in columns [0,16) of the row --------
     {
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_kernel(BwdArgs a) {
 #pragma unroll
         for (int d = 0; d < 3; ++d) trow[(grp * 4 + d) ^ psw] = s[d];   // columns < 256 are dead (dY0 consumed)
     }
-    __syncthreads();
+    lds_barrier();
     if (tid < 64 && m < M) {
 #pragma unroll
         for (int d = 0; d < 3; ++d)

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_split_kernel(BwdArgs a) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: weight pointers stay scalar
     const int64_t m0 = (int64_t)blockIdx.x * TM;
     const int64_t M = a.M;
     const int pt = tid & 63;
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_split_kernel(BwdArgs a) {
         for (int c = 0; c <= C; ++c) *fscr(Th, Tl, pt, 60 + c) = dr[c] * s;
         if (tid == 0) *fscr(Th, Tl, 0, 56) = inv;
     }
-    __syncthreads();
+    lds_barrier();
     const float inv_s = *fscr(Th, Tl, 0, 56);
     const float gf = s_g * inv_s;            // tile scale -> global scale (<= 1, power of two)
 
@@ -170,14 +170,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_split_kernel(BwdArgs a) {
                 st_store_quad(st_lane, (int64_t)(r * 4 + eq) * 2 * ACT_HV_W * 8, ACT_HV_W, vg);
             }
     }
-    __syncthreads();
+    lds_barrier();
 
     f32x16 acc1[2][2], acc2[2][2];
 
     // ---- P2: VIEWS^T: dFeat = dYv x Wv[:, :256]; dPE(dir) = dYv x Wv[:, 256:283] (VALU, f32) ------------------
     zero_acc(acc1);
     zero_acc(acc2);
-    gemm_stage<8, 2>(Th, Tl, 0, packed_h + pack_offset(PB_VIEWS), ct0, lane, acc1, acc2);
+    gemm_stage_rolled<8, 2>(Th, Tl, 0, packed_h + pack_offset(PB_VIEWS), ct0, lane, acc1, acc2);
     {
         const float* wq = a.packed + pack_offset(PB_VIEWSPE) + (int64_t)grp * 128 * 8;
         float s[7];
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_split_kernel(BwdArgs a) {
             if (j < 27) *fscr(Th, Tl, pt, j) = s[q];
         }
     }
-    __syncthreads();   // dYv fully consumed; dPE(dir) visible
+    lds_barrier();   // dYv fully consumed; dPE(dir) visible
     epilogue<false>(acc1, acc2, 0ull, Th, Tl, ct0, lane, reinterpret_cast<_Float16*>(dacts + sdact_feat(Mp)), m0, gf);
     if (grp == 0 && m < M) {   // d viewdirs (per point) through PE(dir)
         const float* ped = acts + sact_ped32(Mp) + m * ACT_PED_W;
@@ -214,12 +214,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_split_kernel(BwdArgs a) {
         }
     }
     uint64_t bits = mask_in[7 * mask_stride];
-    __syncthreads();
+    lds_barrier();
 
     // ---- P3: FEAT^T (+ alpha head), mask h7 -> dY7 ----------------------------------------------------
     zero_acc(acc1);
     zero_acc(acc2);
-    gemm_stage<16, 2>(Th, Tl, 0, packed_h + pack_offset(PB_FEAT), ct0, lane, acc1, acc2);
+    gemm_stage_rolled<16, 2>(Th, Tl, 0, packed_h + pack_offset(PB_FEAT), ct0, lane, acc1, acc2);
     {
         const float wa0 = a.w_alpha[ct0 * 32 + (lane & 31)];
         const float wa1 = a.w_alpha[(ct0 + 1) * 32 + (lane & 31)];
@@ -233,9 +233,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_split_kernel(BwdArgs a) {
                 acc1[r][1][e] += ds * wa1;
             }
     }
-    __syncthreads();
+    lds_barrier();
     epilogue<true>(acc1, acc2, bits, Th, Tl, ct0, lane, st_dyh + 7 * Mp * 512, m0, gf);
-    __syncthreads();
+    lds_barrier();
 
     // ---- P4: L7 .. L1: dY_l x W_l, mask h_{l-1} -> dY_{l-1} ----------------------------------------------
 #pragma unroll 1
@@ -244,16 +244,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_split_kernel(BwdArgs a) {
         zero_acc(acc1);
         zero_acc(acc2);
         const int pid = PB_L7 + (7 - l);
-        gemm_stage<16, 2>(Th, Tl, 0, packed_h + pack_offset(pid), ct0, lane, acc1, acc2);
+        gemm_stage_rolled<16, 2>(Th, Tl, 0, packed_h + pack_offset(pid), ct0, lane, acc1, acc2);
         if (l == 5) {   // skip connection: dPE = dY5 x W5[:, PE part] (tiles 8, 9 of the block) -> scratch [0,64)
             const f32x16 ap = gemm_one<16>(Th, Tl, packed_h + pack_offset(PB_L5), 8 + (wave & 1), wave >> 1, lane);
             const int col = (wave & 1) * 32 + (lane & 31);
 #pragma unroll
             for (int e = 0; e < 16; ++e) *fscr(Th, Tl, (wave >> 1) * 32 + acc_row(e, lane), col) = ap[e];
         }
-        __syncthreads();
+        lds_barrier();
         epilogue<true>(acc1, acc2, bits, Th, Tl, ct0, lane, st_dyh + (int64_t)(l - 1) * Mp * 512, m0, gf);
-        __syncthreads();
+        lds_barrier();
     }
 
     // ---- P5: L0^T: dPE += dY0 x W0 -----------------------------------------------------------------------
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_split_kernel(BwdArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) *fscr(Th, Tl, (wave >> 1) * 32 + acc_row(e, lane), col) += ap[e];
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---- P6: dPE -> d_pts through the saved PE values; group partials as f32 in the (dead) hi-plane columns ----
     float* part = reinterpret_cast<float*>(Th + prow);      // 4 groups x 4 floats = first 64 bytes of the row
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_split_kernel(BwdArgs a) {
 #pragma unroll
         for (int d = 0; d < 3; ++d) part[grp * 4 + d] = s[d];
     }
-    __syncthreads();
+    lds_barrier();
     if (tid < 64 && m < M) {
 #pragma unroll
         for (int d = 0; d < 3; ++d) a.d_pts[m * 3 + d] = ((part[d] + part[4 + d]) + (part[8 + d] + part[12 + d])) * inv_s;

@@ -172,6 +172,15 @@ __host__ __device__ constexpr int64_t dwh_inst_offset(int inst) {
 static_assert(dwh_inst_offset(DW_COUNT) <= DW_WS_FLOATS, "split-mode partials fit the f32-mode workspace");
 static_assert(DWH_BIG_BLOCKS == 256, "one workgroup per CU");
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global load and
+// STORE (s_waitcnt vmcnt(0)) - with ~10 KB of activations stored per point that is one HBM write latency per stage.
+// None of the MLP kernels passes data between threads through global memory, so LDS ordering is all they need.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }

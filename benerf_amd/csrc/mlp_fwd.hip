@@ -212,7 +212,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_kernel(FwdArgs a) {
             trow[(COL_PE + 3 + f * 6 + 3 + d) ^ psw] = c;
         }
     }
-    __syncthreads();
+    lds_barrier();
     if (SAVE) {   // PE tile -> acts (256 B per point, 4 threads per row)
         const int r = tid >> 2, q = tid & 3;
         if (r < rows_valid) {
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_kernel(FwdArgs a) {
         const uint64_t bits = epilogue<2, true, SAVE, 256>(acc, T, ct0, lane, a.bias[0], act_h_tile, rows_valid);
         if (SAVE) mask_out[0] = bits;
     }
-    __syncthreads();
+    lds_barrier();
     if (SAVE && STAGED) copy_tile<256>(T, act_h_tile, rows_valid);
 
     // ---- L1..L7 -------------------------------------------------------------------------------
@@ -242,11 +242,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_kernel(FwdArgs a) {
         zero_acc(acc);
         if (l == 5) gemm_stage<40, 2>(T, 0, a.packed + pack_offset(PF_L5), ct0, lane, acc);
         else gemm_stage<32, 2>(T, 0, a.packed + pack_offset(PF_L0 + l), ct0, lane, acc);
-        __syncthreads();   // every wave finished reading the previous hidden state
+        lds_barrier();   // every wave finished reading the previous hidden state
         const uint64_t bits = epilogue<2, true, SAVE, 256>(acc, T, ct0, lane, a.bias[l],
                                                            SAVE ? act_h_tile + (int64_t)l * M * 256 : nullptr, rows_valid);
         if (SAVE) mask_out[l * mask_stride] = bits;
-        __syncthreads();
+        lds_barrier();
         if (SAVE && STAGED) copy_tile<256>(T, act_h_tile + (int64_t)l * M * 256, rows_valid);
     }
 
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_kernel(FwdArgs a) {
     // ---- FEAT (linear) ----------------------------------------------------------------------------
     zero_acc(acc);
     gemm_stage<32, 2>(T, 0, a.packed + pack_offset(PF_FEAT), ct0, lane, acc);
-    __syncthreads();   // h7 fully consumed (GEMM + alpha partials); PE(dir) + alpha partials visible
+    lds_barrier();   // h7 fully consumed (GEMM + alpha partials); PE(dir) + alpha partials visible
     epilogue<2, false, SAVE, 256>(acc, T, ct0, lane, a.bias[BENERF_L_FEAT], SAVE ? acts + act_feat(M) + m0 * 256 : nullptr,
                                   rows_valid);
     if (tid < 64 && m < M) {
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_kernel(FwdArgs a) {
             dst[1] = *reinterpret_cast<const float4*>(T + tidx(r, COL_PE + q * 8 + 4));
         }
     }
-    __syncthreads();
+    lds_barrier();
     if (SAVE && STAGED) copy_tile<256>(T, acts + act_feat(M) + m0 * 256, rows_valid);
 
     // ---- VIEWS: [feature | PE(dir)] (288) -> 128, one column tile per wave ----------------------------
@@ -310,11 +310,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_kernel(FwdArgs a) {
         f32x16 av[2][1];
         zero_acc(av);
         gemm_stage<36, 1>(T, 0, a.packed + pack_offset(PF_VIEWS), wave, lane, av);
-        __syncthreads();
+        lds_barrier();
         epilogue<1, true, SAVE, ACT_HV_W>(av, T, wave, lane, a.bias[BENERF_L_VIEWS],
                                           SAVE ? acts + act_hv(M) + m0 * ACT_HV_W : nullptr, rows_valid);
     }
-    __syncthreads();
+    lds_barrier();
     if (SAVE && STAGED) copy_tile<ACT_HV_W>(T, acts + act_hv(M) + m0 * ACT_HV_W, rows_valid);
 
     // ---- rgb: 128 -> C on the VALU; partial of (channel c, group g) at scratch column 288 + 4 + 4c + g ----
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_kernel(FwdArgs a) {
 #pragma unroll
         for (int c = 0; c < C; ++c) trow[(COL_SCR + 4 + 4 * c + grp) ^ psw] = s[c];
     }
-    __syncthreads();
+    lds_barrier();
     if (tid < 64 && m < M) {
 #pragma unroll
         for (int c = 0; c < C; ++c) {

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_split_kernel(FwdArgs a) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: weight pointers stay scalar
     const int64_t m0 = (int64_t)blockIdx.x * TM;
     const int64_t M = a.M;
     const int pt = tid & 63;
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_split_kernel(FwdArgs a) {
             put(3 + f * 6 + 3 + d, c);
         }
     }
-    __syncthreads();
+    lds_barrier();
 
     f32x16 acc1[2][2], acc2[2][2];
     const int ct0 = wave * 2;
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_split_kernel(FwdArgs a) {
         const uint64_t bits = epilogue<2, true, SAVE, 256>(acc1, acc2, Th, Tl, ct0, lane, a.bias[0], st_h, m0);
         if (SAVE) mask_out[0] = bits;
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---- L1..L7 -------------------------------------------------------------------------------
 #pragma unroll 1
@@ -167,11 +167,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_split_kernel(FwdArgs a) {
         zero_acc(acc2);
         if (l == 5) gemm_stage<20, 2>(Th, Tl, 0, a.packed + pack_offset(PF_L5), ct0, lane, acc1, acc2);
         else gemm_stage<16, 2>(Th, Tl, 0, a.packed + pack_offset(PF_L0 + l), ct0, lane, acc1, acc2);
-        __syncthreads();
+        lds_barrier();
         const uint64_t bits = epilogue<2, true, SAVE, 256>(acc1, acc2, Th, Tl, ct0, lane, a.bias[l],
                                                            SAVE ? st_h + (int64_t)l * Mp * 512 : nullptr, m0);
         if (SAVE) mask_out[l * mask_stride] = bits;
-        __syncthreads();
+        lds_barrier();
     }
 
     // ---- alpha partials (reads h7) + PE(viewdir) into columns [256,288) ---------------------------
@@ -227,14 +227,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_split_kernel(FwdArgs a) {
     zero_acc(acc1);
     zero_acc(acc2);
     gemm_stage<16, 2>(Th, Tl, 0, a.packed + pack_offset(PF_FEAT), ct0, lane, acc1, acc2);
-    __syncthreads();
+    lds_barrier();
     epilogue<2, false, SAVE, 256>(acc1, acc2, Th, Tl, ct0, lane, a.bias[BENERF_L_FEAT],
                                   SAVE ? reinterpret_cast<_Float16*>(acts + sact_feat(Mp)) : nullptr, m0);
     if (tid < 64 && live) {
         const float4 p = *reinterpret_cast<const float4*>(scratch(0));
         a.raw[m * (C + 1) + C] = ((p.x + p.y) + (p.z + p.w)) + a.b_alpha[0];
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---- VIEWS: [feature | PE(dir)] (288) -> 128, one column tile per wave ----------------------------
     {
@@ -242,12 +242,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_split_kernel(FwdArgs a) {
         zero_acc(av1);
         zero_acc(av2);
         gemm_stage<18, 1>(Th, Tl, 0, a.packed + pack_offset(PF_VIEWS), wave, lane, av1, av2);
-        __syncthreads();
+        lds_barrier();
         const uint64_t bits = epilogue<1, true, SAVE, ACT_HV_W>(av1, av2, Th, Tl, wave, lane, a.bias[BENERF_L_VIEWS],
                                                                 SAVE ? reinterpret_cast<_Float16*>(acts + sact_hv(Mp)) : nullptr, m0);
         if (SAVE) mask_out[8 * mask_stride] = bits;     // bit r*16 + e: element e of row tile r, column tile = wave
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---- rgb: 128 -> C on the VALU; partials of channel c in scratch slot 1 + c ------------------------
     {
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_split_kernel(FwdArgs a) {
 #pragma unroll
         for (int c = 0; c < C; ++c) scratch(1 + c)[grp] = s[c];
     }
-    __syncthreads();
+    lds_barrier();
     if (tid < 64 && live) {
 #pragma unroll
         for (int c = 0; c < C; ++c) {

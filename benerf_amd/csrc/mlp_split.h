@@ -24,9 +24,89 @@ __device__ __forceinline__ f32x16 mfma16(half8 a, half8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
-// acc1 += hi x hi ; acc2 += hi x lo + lo x hi   over T[:, kcol0 .. kcol0 + KS*16) and packed tile ct0+c
-template <int KS, int NCT>
+// acc1 += hi x hi ; acc2 += hi x lo + lo x hi   over T[:, kcol0 .. kcol0 + KS*16) and packed tile ct0+c.
+// Weight fragments stream from L2 PF k-steps ahead (a k-step is only 12 MFMAs = 384 cycles, less than an L2 round
+// trip under load); the loop is fully unrolled so the PF+1 register sets rotate at compile time.
+template <int KS, int NCT, int PF = 2>
 __device__ __forceinline__ void gemm_stage(const _Float16* __restrict__ Th, const _Float16* __restrict__ Tl, int kcol0,
+                                           const float* __restrict__ wp, int ct0, int lane, f32x16 (&acc1)[2][NCT],
+                                           f32x16 (&acc2)[2][NCT]) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const int row = lane & 31, lh = lane >> 5;
+    const int sw = hsw(row);                        // rows row and row + 32 share the swizzle
+    const int rbase = row * LD;
+    // Weight fragments through a buffer descriptor: base and k-step offset stay in SGPRs, the only VGPR is lane*16
+    // (plain pointers made the compiler materialise and spill one 64-bit VGPR address per unrolled k-step).
+    const uint64_t wa = reinterpret_cast<uint64_t>(wp);
+    const uint64_t wau = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(wa >> 32)) << 32) |
+                         (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)wa);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(wau), 0, 0x7fffffff, 0x00020000);
+    const int voff = lane * 16;
+    const int tbase = __builtin_amdgcn_readfirstlane(ct0) * KS * 2048;       // bytes; tile t at + t * KS * 2048
+    auto load_b = [&](int c, int ks, int plane) -> u32x4 {
+        return __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, tbase + (c * KS + ks) * 2048 + plane * 1024, 0);
+    };
+    u32x4 bq[PF + 1][NCT][2];
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+        if (p < KS) {
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                bq[p][c][0] = load_b(c, p, 0);
+                bq[p][c][1] = load_b(c, p, 1);
+            }
+        }
+    const int slot0 = kcol0 >> 3;                    // multiple of 8: the swizzle only permutes slots inside 8-slot groups
+    // slot (slot0 + 2ks + lh) ^ sw = group base (compile-time) + ((2(ks&3) + lh) ^ sw): four lane-dependent bases
+    int abase[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) abase[j] = rbase + (((2 * j + lh) ^ sw) << 3);
+    half8 an[2][2];                                  // A fragments (hi, lo) x (row tile) of the NEXT k-step
+    auto load_a = [&](int ks) {
+        const int off = abase[ks & 3] + ((slot0 + ((2 * ks) & ~7)) << 3);
+        an[0][0] = *reinterpret_cast<const half8*>(Th + off);
+        an[0][1] = *reinterpret_cast<const half8*>(Th + off + 32 * LD);
+        an[1][0] = *reinterpret_cast<const half8*>(Tl + off);
+        an[1][1] = *reinterpret_cast<const half8*>(Tl + off + 32 * LD);
+    };
+    load_a(0);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        half8 ah[2] = {an[0][0], an[0][1]}, al[2] = {an[1][0], an[1][1]};
+        if (ks + PF < KS) {
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) {
+                bq[(ks + PF) % (PF + 1)][c][0] = load_b(c, ks + PF, 0);
+                bq[(ks + PF) % (PF + 1)][c][1] = load_b(c, ks + PF, 1);
+            }
+        }
+        if (ks + 1 < KS) load_a(ks + 1);
+        half8 bh[NCT], bl[NCT];
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+            bh[c] = __builtin_bit_cast(half8, bq[ks % (PF + 1)][c][0]);
+            bl[c] = __builtin_bit_cast(half8, bq[ks % (PF + 1)][c][1]);
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) acc1[r][c] = mfma16(ah[r], bh[c], acc1[r][c]);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) acc2[r][c] = mfma16(ah[r], bl[c], acc2[r][c]);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < NCT; ++c) acc2[r][c] = mfma16(al[r], bh[c], acc2[r][c]);
+        __builtin_amdgcn_sched_barrier(0);          // one k-step per scheduling region: keeps the prefetch distances as written
+    }
+}
+
+// Rolled variant (weights one k-step ahead, plain pointers): same result as gemm_stage; the dX kernel keeps it
+// because the unrolled, descriptor-based version drives that kernel into heavy register spilling.
+template <int KS, int NCT>
+__device__ __forceinline__ void gemm_stage_rolled(const _Float16* __restrict__ Th, const _Float16* __restrict__ Tl, int kcol0,
                                            const float* __restrict__ wp, int ct0, int lane, f32x16 (&acc1)[2][NCT],
                                            f32x16 (&acc2)[2][NCT]) {
     const int row = lane & 31, lh = lane >> 5;
