@@ -34,7 +34,7 @@ __device__ __forceinline__ f32x16 gemm_one(const _Float16* __restrict__ Th, cons
     const int row = rt * 32 + (lane & 31), lh = lane >> 5;
     const int sw = hsw(row);
     const int rbase = row * LD;
-    const uint4* bp = reinterpret_cast<const uint4*>(wp) + (int64_t)tile * KS * 128 + lane;
+    const uint4* bp = reinterpret_cast<const uint4*>(wp) + ((int64_t)(tile >> 1) * KS * 4 + (tile & 1) * 2) * 64 + lane;   // mlp_pack.hip layout
     f32x16 a1, a2;
 #pragma unroll
     for (int e = 0; e < 16; ++e) a1[e] = a2[e] = 0.f;
@@ -43,8 +43,8 @@ __device__ __forceinline__ f32x16 gemm_one(const _Float16* __restrict__ Th, cons
     for (int ks = 0; ks < KS; ++ks) {
         const half8 bh = __builtin_bit_cast(half8, bhn), bl = __builtin_bit_cast(half8, bln);
         if (ks + 1 < KS) {
-            bhn = bp[(ks + 1) * 128];
-            bln = bp[(ks + 1) * 128 + 64];
+            bhn = bp[(ks + 1) * 256];
+            bln = bp[(ks + 1) * 256 + 64];
         }
         const int off = rbase + (((ks * 2 + lh) ^ sw) << 3);
         const half8 ah = *reinterpret_cast<const half8*>(Th + off);
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_split_kernel(BwdArgs a) {
         zero_acc(acc1);
         zero_acc(acc2);
         const int pid = PB_L7 + (7 - l);
-        gemm_stage_rolled<16, 2>(Th, Tl, 0, packed_h + pack_offset(pid), ct0, lane, acc1, acc2);
+        gemm_stage<16, 2>(Th, Tl, 0, packed_h + pack_offset(pid), ct0, lane, acc1, acc2);
         if (l == 5) {   // skip connection: dPE = dY5 x W5[:, PE part] (tiles 8, 9 of the block) -> scratch [0,64)
             const f32x16 ap = gemm_one<16>(Th, Tl, packed_h + pack_offset(PB_L5), 8 + (wave & 1), wave >> 1, lane);
             const int col = (wave & 1) * 32 + (lane & 31);

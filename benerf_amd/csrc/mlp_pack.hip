@@ -81,8 +81,9 @@ __global__ void pack_kernel(PackArgs a) {
         v.w = pack_source(a, id, col, k0 + 3);
         dst[e] = v;
     }
-    // split-f16 section (mlp_fwd_h.hip): [tile][kstep of 16][plane hi|lo][64 lanes][8 halfs]; lane l holds
-    // col = tile*32 + (l&31), k = kstep*16 + 8*(l>>5) + j.  Same float count as the f32 block.
+    // split-f16 section (mlp_split.h): [tile pair][kstep of 16][tile in pair][plane hi|lo][64 lanes][8 halfs]; lane l
+    // holds col = tile*32 + (l&31), k = kstep*16 + 8*(l>>5) + j.  The four fragments a wave needs per k-step (two
+    // column tiles x hi/lo) are one contiguous 4 KiB.  Same float count as the f32 block.
     typedef _Float16 half8 __attribute__((ext_vector_type(8)));
     half8* dsth = reinterpret_cast<half8*>(a.packed + PACKED_FLOATS + pack_offset(id));
     const int ksteps = sh.kblocks / 2;
@@ -101,8 +102,9 @@ __global__ void pack_kernel(PackArgs a) {
             hi[j] = (_Float16)w;
             lo[j] = (_Float16)((w - (float)hi[j]) * 2048.f);
         }
-        dsth[tb * 128 + lane] = hi;
-        dsth[tb * 128 + 64 + lane] = lo;
+        const int64_t frag = (((int64_t)(tile >> 1) * ksteps + ks) * 2 + (tile & 1)) * 2;   // 1 KiB fragments
+        dsth[frag * 64 + lane] = hi;
+        dsth[(frag + 1) * 64 + lane] = lo;
     }
 }
 

@@ -27,7 +27,7 @@ __device__ __forceinline__ f32x16 mfma16(half8 a, half8 b, f32x16 c) {
 // acc1 += hi x hi ; acc2 += hi x lo + lo x hi   over T[:, kcol0 .. kcol0 + KS*16) and packed tile ct0+c.
 // Weight fragments stream from L2 PF k-steps ahead (a k-step is only 12 MFMAs = 384 cycles, less than an L2 round
 // trip under load); the loop is fully unrolled so the PF+1 register sets rotate at compile time.
-template <int KS, int NCT, int PF = 2>
+template <int KS, int NCT, int PF = 2, bool APF = true>
 __device__ __forceinline__ void gemm_stage(const _Float16* __restrict__ Th, const _Float16* __restrict__ Tl, int kcol0,
                                            const float* __restrict__ wp, int ct0, int lane, f32x16 (&acc1)[2][NCT],
                                            f32x16 (&acc2)[2][NCT]) {
@@ -42,9 +42,12 @@ __device__ __forceinline__ void gemm_stage(const _Float16* __restrict__ Th, cons
                          (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)wa);
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(wau), 0, 0x7fffffff, 0x00020000);
     const int voff = lane * 16;
-    const int tbase = __builtin_amdgcn_readfirstlane(ct0) * KS * 2048;       // bytes; tile t at + t * KS * 2048
+    // packed layout (mlp_pack.hip): fragment (tile t, k-step ks, plane) at ((((t>>1)*KS + ks)*2 + (t&1))*2 + plane) KiB:
+    // one SGPR offset per k-step, the four fragments of a tile pair at immediate offsets 0 / 1 / 2 / 3 KiB
+    const int ct0u = __builtin_amdgcn_readfirstlane(ct0);
+    const int tbase = (ct0u >> 1) * KS * 4096 + (ct0u & 1) * 2048;
     auto load_b = [&](int c, int ks, int plane) -> u32x4 {
-        return __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, tbase + (c * KS + ks) * 2048 + plane * 1024, 0);
+        return __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + c * 2048 + plane * 1024, tbase + ks * 4096, 0);
     };
     u32x4 bq[PF + 1][NCT][2];
 #pragma unroll
@@ -69,9 +72,10 @@ __device__ __forceinline__ void gemm_stage(const _Float16* __restrict__ Th, cons
         an[1][0] = *reinterpret_cast<const half8*>(Tl + off);
         an[1][1] = *reinterpret_cast<const half8*>(Tl + off + 32 * LD);
     };
-    load_a(0);
+    if (APF) load_a(0);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
+        if (!APF) load_a(ks);
         half8 ah[2] = {an[0][0], an[0][1]}, al[2] = {an[1][0], an[1][1]};
         if (ks + PF < KS) {
 #pragma unroll
@@ -80,7 +84,7 @@ __device__ __forceinline__ void gemm_stage(const _Float16* __restrict__ Th, cons
                 bq[(ks + PF) % (PF + 1)][c][1] = load_b(c, ks + PF, 1);
             }
         }
-        if (ks + 1 < KS) load_a(ks + 1);
+        if (APF && ks + 1 < KS) load_a(ks + 1);
         half8 bh[NCT], bl[NCT];
 #pragma unroll
         for (int c = 0; c < NCT; ++c) {
@@ -116,7 +120,7 @@ __device__ __forceinline__ void gemm_stage_rolled(const _Float16* __restrict__ T
     uint4 bhn[NCT], bln[NCT];
 #pragma unroll
     for (int c = 0; c < NCT; ++c) {
-        bp[c] = reinterpret_cast<const uint4*>(wp) + (int64_t)(ct0 + c) * KS * 128 + lane;
+        bp[c] = reinterpret_cast<const uint4*>(wp) + ((int64_t)((ct0 + c) >> 1) * KS * 4 + ((ct0 + c) & 1) * 2) * 64 + lane;
         bhn[c] = bp[c][0];
         bln[c] = bp[c][64];
     }
@@ -132,8 +136,8 @@ __device__ __forceinline__ void gemm_stage_rolled(const _Float16* __restrict__ T
         if (ks + 1 < KS) {
 #pragma unroll
             for (int c = 0; c < NCT; ++c) {
-                bhn[c] = bp[c][(ks + 1) * 128];
-                bln[c] = bp[c][(ks + 1) * 128 + 64];
+                bhn[c] = bp[c][(ks + 1) * 256];
+                bln[c] = bp[c][(ks + 1) * 256 + 64];
             }
         }
         const int off = rbase + (((slot0 + ks * 2 + lh) ^ sw) << 3);
