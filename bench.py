@@ -28,7 +28,11 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X f32 matrix peak (MI355X_MICROARCH.md)
+F32_MFMA_PEAK_TFLOPS = 157.3    # MI355X f32 matrix peak (MI355X_MICROARCH.md)
+F16_MFMA_PEAK_TFLOPS = 2516.6   # dense f16 matrix peak: 256 CUs x 4 SIMDs x 1024 flop/clk x 2.4 GHz
+HBM_PEAK_GBS = 8000.0
+# dW in split mode streams every saved activation and activation gradient once (DESIGN.md, K3 dW): bytes per point
+DW_SPLIT_BYTES_PER_POINT = 4 * ((64 + 32 + 8 * 256 + 256 + 128) + (8 * 256 + 256 + 128)) + 8
 
 
 def parse():
@@ -39,10 +43,15 @@ def parse():
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--n-events", type=int, default=2_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--primary-only", action="store_true", help="timed training steps only (profiling runs): no secondary legs")
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--mlp-precision", default="f32", choices=["f32", "split"],
+    ap.add_argument("--mlp-precision", default="split", choices=["f32", "split"],
                     help="MFMA arithmetic of the fused MLP kernels (include/benerf_hip.h: benerf_set_mlp_precision)")
     return ap.parse_args()
+
+
+def split_mode(a):
+    return a.mlp_precision == "split"
 
 
 def build_graph(args_ns, device, seed):
@@ -252,7 +261,7 @@ def main():
 
     # ---- secondary: forward-only (inference) rays/s of the same ray batch, no activation saving ----------------------
     infer = None
-    if world == 1:
+    if world == 1 and not a.primary_only:
         with torch.no_grad():
             idx_e = torch.randperm(HW, device=device, generator=gen)[:wl["Re"]]
             poses = K.spline_poses_fwd(step.knots, None, torch.tensor([0.2, 0.3], device=device), 2, 0)
@@ -267,6 +276,21 @@ def main():
             n_inf = 2 * idx_all.shape[0]
             infer = round(n_inf / ((time.perf_counter() - ti) / a.steps), 1)
 
+    # ---- secondary: the same training step with exact-f32 MFMA products (the other arithmetic mode) -------------------
+    other = None
+    if world == 1 and split_mode(a) and not a.primary_only:
+        K.set_mlp_precision("f32")
+        for _ in range(2):
+            one_step()
+        torch.cuda.synchronize()
+        to = time.perf_counter()
+        n_other = max(4, a.steps // 3)
+        for _ in range(n_other):
+            one_step()
+        torch.cuda.synchronize()
+        other = round(WL.rays_per_step(a.workload) / ((time.perf_counter() - to) / n_other), 1)
+        K.set_mlp_precision(a.mlp_precision)
+
     rays_step = WL.rays_per_step(a.workload) * world
     ms_step = dt / a.steps * 1e3
     value = rays_step / (dt / a.steps)
@@ -274,28 +298,40 @@ def main():
     # ---- roofline of the dominant kernel, from the HIP-event brackets of the timed region ---------------------
     fpp = WL.mlp_flops_per_point(wl["channels"])
     summ = K.TIMERS.summary()
+    split = a.mlp_precision == "split"
     roof = None
     kern = {}
     for name, (n, ms, pts) in summ.items():
         # algorithmic flops: fwd = fpp/point; dx chain = fpp/point; dW = fpp/point (training = 3 x fwd)
         tf = pts * fpp / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         kern[name] = {"launches": n, "avg_ms": round(ms / n, 4), "tflops": round(tf, 2)}
+        if split:   # three f16 MFMAs per algorithmic product block: executed matrix flops = 3 x algorithmic
+            kern[name]["mfma_frac_f16_peak"] = round(3 * tf / F16_MFMA_PEAK_TFLOPS, 4)
     if kern:
         dom = max(summ.items(), key=lambda kv: kv[1][1])[0]
-        ach = kern[dom]["tflops"]
-        roof = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                "avg_launch_ms": kern[dom]["avg_ms"], "per_kernel": kern}
+        n_dom, ms_dom, pts_dom = summ[dom]
+        if split and dom == "mlp_bwd_dw":
+            # HBM-bound: operands streamed once, 3 f16 MFMAs per block leave the matrix pipe two thirds idle
+            gbs = pts_dom * DW_SPLIT_BYTES_PER_POINT / (ms_dom * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": dom, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_ms": kern[dom]["avg_ms"],
+                    "algorithmic_bytes_per_launch": int(pts_dom / n_dom * DW_SPLIT_BYTES_PER_POINT), "per_kernel": kern}
+        else:
+            peak = F16_MFMA_PEAK_TFLOPS if split else F32_MFMA_PEAK_TFLOPS
+            ach = kern[dom]["tflops"] * (3 if split else 1)
+            roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": None, "avg_launch_ms": kern[dom]["avg_ms"], "per_kernel": kern}
         # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (separate runs of this
         # same command; bench.py cannot collect counters itself) - see profiles/README.md
         try:
             import glob
-            latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))[-1]
+            latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc_summary.json" % a.mlp_precision)))[-1]
             pk = json.load(open(latest))["kernels"][dom]
             if a.workload == "C2" and world == 1:
                 roof["traffic"] = int(pk["hbm_read_bytes_per_launch"] + pk["hbm_write_bytes_per_launch"])
                 roof["traffic_source"] = os.path.relpath(latest, ROOT)
-                roof["mfma_util_profiled"] = round(pk.get("mfma_util", 0.0), 4)
+                if "mfma_util" in pk:
+                    roof["mfma_util_profiled"] = round(pk["mfma_util"], 4)
         except (IndexError, KeyError, OSError, ValueError):
             pass
     mlp_ms = sum(v[1] for v in summ.values()) / a.steps if summ else None
@@ -303,17 +339,20 @@ def main():
     out = {
         "metric": "training rays/s", "value": round(value, 1), "unit": "rays/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None,
+        "dtype": "f32 (MLP products as 3 f16 MFMAs on hi/lo-split operands, f32 accumulate)" if split else "f32",
+        "data": "synthetic",
         "config": {"workload": "%s: %s" % (a.workload, wl["name"]), "rays_per_step_per_gpu": WL.rays_per_step(a.workload),
                    "samples": "%d+%d" % (wl["S"], wl["S"] + wl["Ni"]), "channels": wl["channels"],
                    "parallelism": "dp%d" % world, "mlp_ms_per_step": None if mlp_ms is None else round(mlp_ms, 3),
                    "step_tflops_algorithmic": round(rays_step / world * (wl["S"] + wl["S"] + wl["Ni"]) * fpp * 3 /
                                                     (dt / a.steps) / 1e12, 2),
-                   "final_loss": float(losses[0]), "inference_rays_per_s": infer},
+                   "final_loss": float(losses[0]), "inference_rays_per_s": infer, "mlp_precision": a.mlp_precision,
+                   "exact_f32_mfma_rays_per_s": other},
         "roofline": roof,
     }
     if rank == 0:
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and not a.primary_only:
             out["cpu_baseline"] = cpu_baseline(a.workload, a.seed)
             try:
                 del step, g

@@ -14,7 +14,7 @@ void benerf_set_error(const char* fmt, ...) {
 extern "C" int benerf_version(void) { return 100; }
 extern "C" const char* benerf_last_error(void) { return g_err; }
 
-static int g_mlp_precision = BENERF_MLP_F32;
+static int g_mlp_precision = BENERF_MLP_SPLIT;
 extern "C" int benerf_set_mlp_precision(int mode) {
     if (mode != BENERF_MLP_F32 && mode != BENERF_MLP_SPLIT) {
         benerf_set_error("set_mlp_precision: unknown mode %d", mode);

@@ -6,9 +6,11 @@
 // (8 waves, one per CU) copies 32-point chunks straight into a double-buffered LDS image (16-byte units, no
 // transposition, conflict-free fragment reads) while it multiplies the previous chunk; one barrier per chunk.
 // Two accumulator sets (hi*hi and the cross terms) fill the register file at a 256 x 128 output block, so the eight
-// 256x256 instances run as pairs of column halves placed on the same XCD (workgroup ids 8 apart), where the
-// second reader of the shared dY chunk hits in L2.  dY carries the call's global power-of-two scale s_g (written by
-// the dX launch); the reduce kernel multiplies by 1/s_g.
+// 256x256 instances run as pairs of column halves (workgroup ids 8 apart = same XCD); both halves stream the same
+// dY chunk.  Measured (FETCH_SIZE, profiles/): the second read is NOT absorbed by L2 whatever the id mapping or lag
+// between the halves - 13.3 GB cross the fabric per launch at M = 522k against 9.4 GB of distinct operands - so the
+// kernel runs at the fabric/HBM streaming rate for 1.5 KB per point and half-instance.  dY carries the call's
+// global power-of-two scale s_g (max|d_raw| from the dX launch); the reduce kernel multiplies by 1/s_g.
 #include "mlp_split.h"
 
 namespace {
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(DWT, 2) void mlp_dw_split_big_kernel(DwArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32x4 smem_u[];
     const int id = blockIdx.x;
     int inst, split, half = 0;
-    if (id < DWH_PAIR_BLOCKS) {           // id = 16*q + 8*half + x  <->  pair q*8 + x: both halves on XCD x
+    if (id < DWH_PAIR_BLOCKS) {           // id = 16*q + 8*half + x  <->  pair q*8 + x
         const int pair = (id >> 4) * 8 + (id & 7);
         half = (id >> 3) & 1;
         inst = pair / 15;                 // DW_L1 .. DW_FEAT

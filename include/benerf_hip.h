@@ -121,10 +121,14 @@ int benerf_mlp_fwd(const BenerfMlpParams* params, const float* packed, int chann
                    int n_rays, int n_samples, const float* rays_o, const float* rays_d,
                    const float* viewdirs, const float* z, float* raw, float* acts,
                    benerf_stream_t stream);
-/* MFMA arithmetic of the fused MLP kernels (process-wide; default BENERF_MLP_F32):
+/* MFMA arithmetic of the fused MLP kernels (process-wide; default BENERF_MLP_SPLIT):
  *   BENERF_MLP_F32    exact f32 MFMA (v_mfma_f32_32x32x2_f32), bit-for-bit f32 products;
  *   BENERF_MLP_SPLIT  every f32 operand as two f16 numbers (hi + lo*2^-11), three f16 MFMAs per product
- *                     block, f32 accumulation: 22-bit operands, measured error equal to the f32 path.
+ *                     block, f32 accumulation: 22-bit operands, measured error equal to the f32 path (every
+ *                     parity test runs in both modes with the same tolerances).  Activations must stay below
+ *                     65504 in magnitude (f16 range); gradients are rescaled by exact powers of two.
+ * The saved-activation / gradient buffers have a mode-specific layout: forward and backward of one step must
+ * run in the same mode.
  * benerf_mlp_fwd / _bwd dispatch on it; the explicit *_split entry points ignore it.  Returns -1 on a
  * bad mode. */
 enum { BENERF_MLP_F32 = 0, BENERF_MLP_SPLIT = 1 };

@@ -17,6 +17,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(params=["split", "f32"])
+def mlp_precision(request):
+    """Runs a GPU test under both MFMA arithmetic modes of the fused MLP kernels (include/benerf_hip.h) with the SAME
+    tolerances: 'split' (3 x f16 MFMA on hi/lo operands, f32 accumulate; the default) and 'f32' (exact f32 MFMA)."""
+    from benerf_amd import kernels
+    kernels.set_mlp_precision(request.param)
+    REPORT.append("---- mlp precision: %s (%s)" % (request.param, request.node.name))
+    yield request.param
+    kernels.set_mlp_precision("split")
+
+
 @pytest.fixture(scope="session")
 def golden():
     cache = {}

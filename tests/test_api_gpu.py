@@ -14,7 +14,7 @@ import benerf_oracle as O
 import golden_inputs as GI
 from conftest import report
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("mlp_precision")]
 DEV = "cuda:0"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 

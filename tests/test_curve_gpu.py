@@ -12,7 +12,7 @@ import torch
 import curve_scene as CS
 from conftest import report
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("mlp_precision")]
 DEV = "cuda:0"
 
 

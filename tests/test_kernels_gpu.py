@@ -144,7 +144,7 @@ def mlp_mode(K, request):
     """Every K3 test runs under both MFMA arithmetic modes with the SAME tolerances."""
     K.set_mlp_precision(request.param)
     yield request.param
-    K.set_mlp_precision("f32")
+    K.set_mlp_precision("split")
 
 
 def _run_mlp_on_points(K, net, pts, vd, save):

@@ -10,7 +10,7 @@ import benerf_oracle as O
 import golden_inputs as GI
 from conftest import report
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("mlp_precision")]
 DEV = "cuda:0"
 
 
