@@ -228,14 +228,19 @@ def main():
     accu = torch.zeros((cam["H"], cam["W"]), dtype=torch.float32, device=device)
     Re_g, Rr_g = wl["Re"] * world, wl["Rr"] * world
 
+    draw = [0]
+
     def one_step():
         low_t = float(rng.random() * (1 - wl["window"]))
         up_t = low_t + wl["window"]
         accu.zero_()
         K.event_window_accumulate(ev_x, ev_y, ev_p, ev_t, low_t, up_t, cam["H"], cam["W"], out=accu)
         evt_ts = torch.tensor([low_t, up_t], dtype=torch.float32).to(device, non_blocking=True)
-        idx_e = torch.randperm(HW, device=device, generator=gen)[:Re_g]
-        idx_r = torch.randperm(HW, device=device, generator=gen)[:Rr_g]
+        # pixel draws without replacement (np.random.choice(..., replace=False) in train.py): a keyed bijection,
+        # identical on every rank; TrainStep shards them
+        draw[0] += 2
+        idx_e = K.sample_pixels(HW, Re_g, a.seed + 1234, draw[0], device)
+        idx_r = K.sample_pixels(HW, Rr_g, a.seed + 1234, draw[0] + 1, device)
         return step.step(evt_ts, rgb_ts, idx_e, idx_r, accu.view(-1), image)
 
     def sync():

@@ -68,6 +68,7 @@ _SIGNATURES = {
     "benerf_event_accumulate": (c_int, [P, P, P, c_int64, c_int, c_int, P, P]),
     "benerf_event_window_accumulate": (c_int, [P, P, P, P, c_int64, c_double, c_double, c_int, c_int, P, P]),
     "benerf_gather_rows": (c_int, [P, P, c_int64, c_int, P, P]),
+    "benerf_sample_pixels": (c_int, [c_int64, c_int64, ctypes.c_uint64, ctypes.c_uint64, P, P]),
     "benerf_adam_step": (c_int, [P, P, P, P, c_int64, c_double, c_double, c_double, c_double, c_int, c_double, P]),
 }
 

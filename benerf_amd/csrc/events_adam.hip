@@ -95,6 +95,49 @@ extern "C" int benerf_event_window_accumulate(const int32_t* xs, const int32_t* 
     return BENERF_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Pixel selection without replacement (train.py:171-175, 296-299: np.random.choice(H*W, N_rand, replace=False)).
+// A keyed pseudo-random BIJECTION of [0, n_total) - 4-round Feistel network on ceil(log2 n) bits (even), round
+// function = Philox block, cycle-walking for values >= n_total - evaluated at 0..count-1: distinct indices in O(count)
+// work, no sort, and a pure function of (seed, offset), so every data-parallel rank draws the same vector.
+__device__ __forceinline__ uint32_t feistel_perm(uint32_t x, int half_bits, uint64_t seed, uint64_t offset) {
+    const uint32_t mask = (1u << half_bits) - 1u;
+    uint32_t l = x >> half_bits, r = x & mask;
+#pragma unroll
+    for (int round = 0; round < 4; ++round) {
+        const uint4 h = philox4x32_10(make_uint4(r, (uint32_t)round, (uint32_t)offset, (uint32_t)(offset >> 32)),
+                                      make_uint2((uint32_t)seed, (uint32_t)(seed >> 32) ^ 0x5bd1e995u));
+        const uint32_t nl = r;
+        r = (l ^ h.x) & mask;
+        l = nl;
+    }
+    return (l << half_bits) | r;
+}
+
+__global__ void sample_pixels_kernel(int64_t n_total, int64_t count, int half_bits, uint64_t seed, uint64_t offset,
+                                     int64_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    uint32_t x = (uint32_t)i;
+    do {
+        x = feistel_perm(x, half_bits, seed, offset);     // the domain is < 4 n_total: a few walks at most
+    } while ((int64_t)x >= n_total);
+    out[i] = (int64_t)x;
+}
+
+extern "C" int benerf_sample_pixels(int64_t n_total, int64_t count, uint64_t seed, uint64_t offset, int64_t* out,
+                                    benerf_stream_t stream) {
+    BENERF_REQUIRE(out, "sample_pixels: null pointer");
+    BENERF_REQUIRE(n_total > 0 && n_total < (1ll << 31) && count >= 0 && count <= n_total, "sample_pixels: bad sizes");
+    if (count == 0) return BENERF_OK;
+    int bits = 2;
+    while ((1ll << bits) < n_total) bits += 2;
+    hipLaunchKernelGGL(sample_pixels_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, as_stream(stream), n_total,
+                       count, bits / 2, seed, offset, out);
+    BENERF_LAUNCH_CHECK("sample_pixels");
+    return BENERF_OK;
+}
+
 extern "C" int benerf_gather_rows(const float* src, const int64_t* idx, int64_t n_idx, int width, float* out,
                                   benerf_stream_t stream) {
     BENERF_REQUIRE(src && idx && out && width > 0 && n_idx >= 0, "gather_rows: bad args");

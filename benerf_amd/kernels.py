@@ -345,6 +345,14 @@ def gather_rows(src, idx):
     return out
 
 
+def sample_pixels(n_total, count, seed, offset, device):
+    """`count` distinct pixel indices in [0, n_total): deterministic in (seed, offset) (include/benerf_hip.h)."""
+    lib = _lib.load()
+    out = torch.empty((count,), dtype=torch.int64, device=device)
+    _lib.check(lib.benerf_sample_pixels(n_total, count, seed, offset, out.data_ptr(), _stream()), "sample_pixels")
+    return out
+
+
 # ----------------------------------------------------------------------------- K8 optimiser
 def adam_step(param, grad, exp_avg, exp_avg_sq, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
     lib = _lib.load()

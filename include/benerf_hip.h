@@ -259,6 +259,11 @@ int benerf_event_accumulate(const int32_t* xs, const int32_t* ys, const float* p
 int benerf_event_window_accumulate(const int32_t* xs, const int32_t* ys, const float* ps,
                                    const double* ts, int64_t n, double low_t, double upper_t,
                                    int H, int W, float* out, benerf_stream_t stream);
+/* `count` distinct pseudo-random pixel indices in [0, n_total), a pure function of (seed, offset) - the
+ * np.random.choice(H*W, N_rand, replace=False) of train.py:171-175 / 296-299 as a keyed bijection evaluated at
+ * 0..count-1 (no sort; identical on every data-parallel rank).  out [count] int64. */
+int benerf_sample_pixels(int64_t n_total, int64_t count, uint64_t seed, uint64_t offset, int64_t* out,
+                         benerf_stream_t stream);
 /* out[i] = src[idx[i]] (target gather: train.py:177,301-302). src float32 [n_src,width] */
 int benerf_gather_rows(const float* src, const int64_t* idx, int64_t n_idx, int width,
                        float* out, benerf_stream_t stream);

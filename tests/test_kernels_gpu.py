@@ -334,6 +334,22 @@ def test_mlp_bwd_gradient_scale_invariance(K, mlp_mode):
         report("K3 dW scale invariance", b, a, atol=1e-6 * float(a.abs().max()), rtol=1e-5)
 
 
+def test_sample_pixels_without_replacement(K):
+    """np.random.choice(H*W, N, replace=False) stand-in: distinct, in range, deterministic, roughly uniform."""
+    n = 480 * 768
+    a = K.sample_pixels(n, 4096, 7, 3, torch.device(DEV))
+    b = K.sample_pixels(n, 4096, 7, 3, torch.device(DEV))
+    c = K.sample_pixels(n, 4096, 7, 4, torch.device(DEV))
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert int(a.min()) >= 0 and int(a.max()) < n and a.unique().numel() == 4096
+    full = K.sample_pixels(1000, 1000, 1, 0, torch.device(DEV))          # a complete permutation
+    assert torch.equal(full.sort()[0], torch.arange(1000, device=DEV))
+    big = K.sample_pixels(n, 65536, 11, 0, torch.device(DEV)).double()
+    assert abs(float(big.mean()) / n - 0.5) < 0.01 and abs(float(big.std()) / n - 12 ** -0.5) < 0.01
+    hist = torch.histc(big.float(), bins=16, min=0, max=n)
+    assert float((hist - 4096).abs().max()) < 6 * 4096 ** 0.5
+
+
 # ------------------------------------------------------------------------------------ K4
 @pytest.mark.parametrize("C", [1, 3])
 def test_composite_golden(K, golden, C):
