@@ -282,6 +282,45 @@ class TrainStep:
         k = max(self.global_step, 1) - 1
         return lr0 * (decay ** (k / (self.cfg.lrate_decay * 1000)))
 
+    # -- optimiser state <-> torch.optim.Adam (checkpoint format of train.py:443-455) ------------------------------
+    def _flat_slice(self, p):
+        off = (p.data_ptr() - self.flat_p.data_ptr()) // 4
+        assert 0 <= off and off + p.numel() <= self.flat_p.numel(), "parameter is not backed by this TrainStep's flat buffer"
+        return off, p.numel()
+
+    def _trained_optimizers(self, optimizers):
+        cfg = self.cfg
+        return ((optimizers[0], self._lr(cfg.lrate, cfg.decay_rate)), (optimizers[1], self._lr(cfg.pose_lrate, cfg.decay_rate_pose)),
+                (optimizers[2], self._lr(cfg.transform_lrate, cfg.decay_rate_transform)))
+
+    def export_optimizer_state(self, optimizers):
+        """Fills the Adam objects of Model.setup_optimizer (nerf, pose, transform, ...) with this step's moments, step
+        count and current learning rates, ready for checkpoint.save.  The CRF optimisers hold no state on this path."""
+        for opt, lr in self._trained_optimizers(optimizers):
+            for group in opt.param_groups:
+                group["lr"] = lr
+                for p in group["params"]:
+                    off, n = self._flat_slice(p)
+                    opt.state[p] = {"step": torch.tensor(float(self.global_step)),
+                                    "exp_avg": self.flat_m[off:off + n].view_as(p).clone(),
+                                    "exp_avg_sq": self.flat_v[off:off + n].view_as(p).clone()}
+
+    def import_optimizer_state(self, optimizers, global_step):
+        """Inverse of export_optimizer_state after checkpoint.load: parameters were restored in place (they alias the
+        flat buffer); moments and the step counter come from the Adam objects; weights are re-packed."""
+        for opt, _ in self._trained_optimizers(optimizers):
+            for group in opt.param_groups:
+                for p in group["params"]:
+                    st = opt.state.get(p)
+                    if not st:
+                        continue
+                    off, n = self._flat_slice(p)
+                    self.flat_m[off:off + n].copy_(st["exp_avg"].reshape(-1))
+                    self.flat_v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+        self.global_step = int(global_step)
+        self.net_c.packed.pack()
+        self.net_f.packed.pack()
+
     def shard(self, idx):
         """Contiguous slice of a global pixel-index vector for this rank."""
         return dist.shard_indices(idx, self.rank, self.world)

@@ -137,6 +137,56 @@ def test_render_video_and_image_test(tmp_path):
     assert rgbs.shape == (3, Hh, Ww, 1) and disps.shape == (3, Hh, Ww)
 
 
+def test_checkpoint_resume_equals_uninterrupted(tmp_path):
+    """a reference-format .tar (train.py:443-455) written after 3 fused steps and loaded into a fresh
+    graph + optimisers + TrainStep continues exactly like the uninterrupted run (Philox draws are a function of
+    the step index, so the comparison is bit for bit); the file also loads through plain torch.optim objects the way
+    test.py:98-107 does."""
+    from benerf_amd import engine, workloads as WL, checkpoint as CK, kernels as K
+    wl = dict(WL.WORKLOADS["C3"], S=16, Ni=16, Re=32, Rr=4, n=5)
+    args = WL.make_args(wl, optimize_trans=True)
+    cam = WL.CAMERAS[wl["cam"]]
+    cam_o = engine.Camera(cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+    HW = cam["H"] * cam["W"]
+    rng = np.random.default_rng(5)
+    accu = torch.from_numpy(rng.integers(-3, 4, HW).astype(np.float32)).to(DEV)
+    img = torch.from_numpy(rng.random((HW, 3)).astype(np.float32)).to(DEV)
+    ts_e, ts_r = torch.tensor([0.2, 0.3], device=DEV), torch.tensor([0.0, 1.0], device=DEV)
+
+    def run(step, n0, n1):
+        for it in range(n0, n1):
+            idx_e = K.sample_pixels(HW, 32, 9, 2 * it, torch.device(DEV))
+            idx_r = K.sample_pixels(HW, 4, 9, 2 * it + 1, torch.device(DEV))
+            step.step(ts_e, ts_r, idx_e, idx_r, accu, img)
+
+    model_a, g_a = _graph(args, seed=3)
+    step_a = engine.TrainStep(g_a, args, cam_o, cam_o, torch.device(DEV), seed=21)
+    run(step_a, 0, 5)
+
+    model_b, g_b = _graph(args, seed=3)
+    step_b = engine.TrainStep(g_b, args, cam_o, cam_o, torch.device(DEV), seed=21)
+    run(step_b, 0, 3)
+    optims_b = model_b.setup_optimizer(args)
+    step_b.export_optimizer_state(optims_b)
+    path = str(tmp_path / "000003.tar")
+    CK.save(path, g_b, optims_b, step_b.global_step)
+    ck = torch.load(path)
+    assert sorted(ck) == sorted(["global_step", "graph"] + list(CK.OPTIMIZER_KEYS)) and ck["global_step"] == 3
+    st0 = ck["optimizer_nerf"]["state"][0]
+    assert sorted(st0) == ["exp_avg", "exp_avg_sq", "step"] and float(st0["step"]) == 3.0
+    assert len(ck["optimizer_nerf"]["state"]) == 48 and len(ck["optimizer_pose"]["state"]) == 1
+
+    model_c, g_c = _graph(args, seed=99)                      # different initial weights: everything must come from the file
+    optims_c = model_c.setup_optimizer(args)
+    step_c = engine.TrainStep(g_c, args, cam_o, cam_o, torch.device(DEV), seed=21)
+    gs = CK.load(path, g_c, optims_c)
+    step_c.import_optimizer_state(optims_c, gs)
+    assert torch.equal(step_c.flat_p, step_b.flat_p) and torch.equal(step_c.flat_m, step_b.flat_m)
+    run(step_c, 3, 5)
+    assert torch.equal(step_c.flat_p, step_a.flat_p), "resumed run must equal the uninterrupted one bit for bit"
+    assert torch.equal(step_c.flat_v, step_a.flat_v) and step_c.global_step == 5
+
+
 def _dp_worker(rank, world, port, out_q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
