@@ -1,0 +1,66 @@
+// Hardware probe: K-loop efficiency of the split-f16 MLP stage (mlp_split.h gemm_stage: LDS A fragments, L2 weight
+// fragments through a buffer descriptor, 3 MFMAs per product block, barrier per stage) at
+//   (a) 4 waves per workgroup, 2x2 tiles per wave, 256 registers  -> 2 waves per SIMD   (the shipped tiling)
+//   (b) 8 waves per workgroup, 2x1 tiles per wave, 128 registers  -> 4 waves per SIMD
+// Both: 64-point tile, 80 KiB LDS, two workgroups per CU, 11 stages of K = 256 per tile.
+#include "../../benerf_amd/csrc/mlp_split.h"
+#include <stdio.h>
+#include <vector>
+using namespace mlp;
+
+template <int NWAVES, int NCT>
+__global__ __launch_bounds__(NWAVES * 64, NWAVES / 2) void k(const float* __restrict__ packed, float* out, int tiles_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 Tsm[];
+    _Float16* Th = Tsm;
+    _Float16* Tl = Tsm + TM * LD;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < TM * LD; i += NWAVES * 64) {
+        Th[i] = (_Float16)(0.001f * (i & 255));
+        Tl[i] = (_Float16)0.25f;
+    }
+    lds_barrier();
+    float sink = 0.f;
+    for (int t = 0; t < tiles_per_wg; ++t) {
+#pragma unroll 1
+        for (int st = 0; st < 11; ++st) {
+            f32x16 acc1[2][NCT], acc2[2][NCT];
+            zero_acc(acc1);
+            zero_acc(acc2);
+            gemm_stage<16, NCT>(Th, Tl, 0, packed + pack_offset(PF_L1 + (st % 4)), wave * NCT, lane, acc1, acc2);
+            lds_barrier();
+            for (int c = 0; c < NCT; ++c) sink += acc1[0][c][0] + acc2[1][c][3] + acc1[1][c][5] + acc2[0][c][9];
+            if (sink == 12345.f) Th[lane] = (_Float16)sink;     // never true; keeps the accumulators live
+            lds_barrier();
+        }
+    }
+    if (sink == 54321.f) out[0] = sink;
+}
+
+template <int NWAVES, int NCT>
+void run(const float* packed, float* d, const char* label) {
+    (void)hipFuncSetAttribute((const void*)k<NWAVES, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TILE_SMEM);
+    hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    hipLaunchKernelGGL((k<NWAVES, NCT>), dim3(512), dim3(NWAVES * 64), TILE_SMEM, 0, packed, d, 2);
+    (void)hipEventRecord(a, 0);
+    const int tiles = 16;
+    hipLaunchKernelGGL((k<NWAVES, NCT>), dim3(512), dim3(NWAVES * 64), TILE_SMEM, 0, packed, d, tiles);
+    (void)hipEventRecord(b, 0);
+    (void)hipDeviceSynchronize();
+    float ms; (void)hipEventElapsedTime(&ms, a, b);
+    // MFMAs per tile: 11 stages x 16 k-steps x (64 tiles-of-32x32 ... ) = 11*16*4 waves*12 = 8448 per workgroup-tile
+    const double mfma = 512.0 * tiles * 11 * 16 * 48;
+    const double ideal_ms = mfma * 32 / (1024.0 * 2.4e9) * 1e3;      // 1024 SIMDs, 32 cycles per MFMA, 2.4 GHz
+    printf("%s: %.3f ms for %d tiles per workgroup slot; MFMA-bound time at 2.4 GHz %.3f ms -> %.0f %%\n", label, ms, tiles, ideal_ms,
+           100 * ideal_ms / ms);
+}
+
+int main() {
+    float *packed, *d;
+    (void)hipMalloc(&packed, 2 * PACKED_FLOATS * 4);
+    (void)hipMemset(packed, 0, 2 * PACKED_FLOATS * 4);
+    (void)hipMalloc(&d, 4);
+    run<4, 2>(packed + PACKED_FLOATS, d, "4 waves x (2x2 tiles), 2 waves/SIMD");
+    run<8, 1>(packed + PACKED_FLOATS, d, "8 waves x (2x1 tiles), 4 waves/SIMD");
+    return 0;
+}
