@@ -115,7 +115,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_split_kernel(BwdArgs a) {
     _Float16* st_dyh = reinterpret_cast<_Float16*>(dacts + sdact_h(Mp, 0));      // layer l: + l * Mp * 512 halfs
     float s_g, inv_s_g;
     pow2_scale(dacts[sdact_scale(Mp)], s_g, inv_s_g);                             // global scale of this call (pre-kernel)
-    const int psw = hsw(pt);
     const int prow = pt * LD;
 
     // ---- P0: d_raw tile, its power-of-two scale, scaled values -> scratch floats [60, 60+C] of each row ------
@@ -174,29 +173,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_split_kernel(BwdArgs a) {
 
     f32x16 acc1[2][2], acc2[2][2];
 
-    // ---- P2: VIEWS^T: dFeat = dYv x Wv[:, :256]; dPE(dir) = dYv x Wv[:, 256:283] (VALU, f32) ------------------
+    // ---- P2: VIEWS^T: dFeat = dYv x Wv[:, :256]; dPE(dir) = dYv x Wv[:, 256:283] --------------------------------
     zero_acc(acc1);
     zero_acc(acc2);
     gemm_stage_rolled<8, 2>(Th, Tl, 0, packed_h + pack_offset(PB_VIEWS), ct0, lane, acc1, acc2);
-    {
-        const float* wq = a.packed + pack_offset(PB_VIEWSPE) + (int64_t)grp * 128 * 8;
-        float s[7];
+    if (wave < 2) {   // dPE(dir) = dYv x Wv[:, 256:283]: tile 8 of the block, one row tile per wave -> scratch floats [0,32)
+        const f32x16 ap = gemm_one<8>(Th, Tl, packed_h + pack_offset(PB_VIEWS), 8, wave, lane);
 #pragma unroll
-        for (int q = 0; q < 7; ++q) s[q] = 0.f;
-#pragma unroll 1
-        for (int n8 = 0; n8 < 16; ++n8) {
-            float h[8];
-            load8(Th, Tl, prow + ((n8 ^ psw) << 3), h);
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int q = 0; q < 7; ++q) s[q] += h[i] * wq[(n8 * 8 + i) * 8 + q];
-        }
-#pragma unroll
-        for (int q = 0; q < 7; ++q) {
-            const int j = grp + 4 * q;
-            if (j < 27) *fscr(Th, Tl, pt, j) = s[q];
-        }
+        for (int e = 0; e < 16; ++e) *fscr(Th, Tl, wave * 32 + acc_row(e, lane), lane & 31) = ap[e];
     }
     lds_barrier();   // dYv fully consumed; dPE(dir) visible
     epilogue<false>(acc1, acc2, 0ull, Th, Tl, ct0, lane, reinterpret_cast<_Float16*>(dacts + sdact_feat(Mp)), m0, gf);

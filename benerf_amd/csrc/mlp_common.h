@@ -67,7 +67,7 @@ __host__ __device__ constexpr PackShape pack_shape(int id) {
         case PF_L0: return {8, 8};        // K 63 -> 64
         case PF_L5: return {8, 40};       // K [h4 256 | PE 63 -> 64]
         case PF_VIEWS: return {4, 36};    // N 128, K [feature 256 | PE_dir 27 -> 32]
-        case PB_VIEWS: return {8, 16};    // out 256 feature cols, contraction n = 128
+        case PB_VIEWS: return {10, 16};   // out 256 feature cols + tile 8 = the 27 PE(dir) cols (tile 9: zero pad), contraction n = 128
         case PB_L5: return {10, 32};      // out [h4 256 | PE 64]
         case PB_L0: return {2, 32};       // out PE 64
         case PB_VIEWSPE: return {1, 16};  // 4 * 128 * 8 floats, own layout

@@ -47,7 +47,8 @@ __device__ __forceinline__ float pack_source(const PackArgs& a, int id, int col,
         if (col >= 63) return 0.f;
         k = col;
     } else {
-        k = col;                           // PB_VIEWS: feature columns 0..255 only
+        if (id == PB_VIEWS && col >= 283) return 0.f;   // PB_VIEWS: 256 feature columns, then the 27 PE(dir) columns, then padding
+        k = col;
     }
     return W[(int64_t)n * in + k];
 }
