@@ -86,7 +86,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc1)[2][2], f32x16 (&acc2)[2]
                     split_store(Th, Tl, base[((e >> 1) & 1) | (((e >> 2) & 1) << 1)] + (r * 32 + (e & 3) + 8 * (e >> 2)) * LD, v);
                     vg[j] = v * gf;
                 }
-                st_store_quad(st_lane, (int64_t)(r * 4 + eq) * 2 * 256 * 8, 256, vg);
+                st_store_quad(st_lane, (int64_t)(r * 4 + eq) * 256 * 16, vg);
             }
     }
 }
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_split_kernel(BwdArgs a) {
                     split_store(Th, Tl, hidx(p, col), v);
                     vg[j] = v * gf;
                 }
-                st_store_quad(st_lane, (int64_t)(r * 4 + eq) * 2 * ACT_HV_W * 8, ACT_HV_W, vg);
+                st_store_quad(st_lane, (int64_t)(r * 4 + eq) * ACT_HV_W * 16, vg);
             }
     }
     lds_barrier();

@@ -2,9 +2,10 @@
 // per product block (mlp_split.h), f32 accumulation, + bias sums and the alpha / rgb heads on the VALU.
 //
 // Operands arrive in the ST layout the split forward / dX kernels write (mlp_split.h): blocks of 8 points,
-// feature-major, hi and lo planes - already the MFMA fragment order for a contraction over points.  A workgroup
-// (8 waves, one per CU) copies 32-point chunks straight into a double-buffered LDS image (16-byte units, no
-// transposition, conflict-free fragment reads) while it multiplies the previous chunk; one barrier per chunk.
+// feature-major, 16-byte units {hi x4, lo x4} - one split away from the MFMA fragment order for a contraction over
+// points.  A workgroup (8 waves, one per CU) copies 32-point chunks into a double-buffered LDS image
+// [block][plane][feature][8 points] (each unit lands as two 8-byte quads; conflict-free fragment reads, no
+// transposition pass) while it multiplies the previous chunk; one barrier per chunk.
 // Two accumulator sets (hi*hi and the cross terms) fill the register file at a 256 x 128 output block, so the eight
 // 256x256 instances run as pairs of column halves (workgroup ids 8 apart = same XCD); both halves stream the same
 // dY chunk.  Measured (FETCH_SIZE, profiles/): the second read is NOT absorbed by L2 whatever the id mapping or lag
@@ -20,6 +21,7 @@ constexpr int DWT = 512;
 constexpr int CHP = 32;             // points per chunk = 4 blocks of 8 = 2 MFMA k-steps
 // 16-byte unit as a first-class vector (arrays of HIP's uint4 struct were left in scratch memory by the compiler)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 struct DwArgs {
     const float* d_raw;
@@ -101,7 +103,8 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int k0, 
         _Pragma("unroll") for (int j = 0; j < NX; ++j) {                                                  \
             const int u = tid + j * DWT;                                                                  \
             RX[j] = u32x4{0u, 0u, 0u, 0u};                                                               \
-            if (XFULL || u < XU) RX[j] = src.x[((CHUNK) * 8 + u / K) * XW + k0 + u % K];                  \
+            if (XFULL || u < XU)                                                                          \
+                RX[j] = src.x[((((CHUNK) * 4 + u / (2 * K)) * XW) + k0 + ((u % (2 * K)) >> 1)) * 2 + (u & 1)];       \
         }                                                                                                 \
         if (ALPHA && tid < CHP) {                                                                         \
             const int64_t row = (CHUNK) * CHP + tid;                                                      \
@@ -112,9 +115,22 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int k0, 
     {                                                                                                     \
         u32x4* Ys_ = smem + (B) * BUF;                                                                    \
         u32x4* Xs_ = Ys_ + YU;                                                                            \
-        _Pragma("unroll") for (int j = 0; j < NY; ++j) Ys_[tid + j * DWT] = RY[j];                        \
-        _Pragma("unroll") for (int j = 0; j < NX; ++j)                                                    \
-            if (XFULL || tid + j * DWT < XU) Xs_[tid + j * DWT] = RX[j];                                  \
+        /* global unit u = ((block * W + w) * 2 + half) holds {hi x4, lo x4} of 4 points: the two quads go to the */ \
+        /* hi / lo fragment planes of the LDS image [block][plane][w][8 points] (8-byte writes, conflict free)   */ \
+        _Pragma("unroll") for (int j = 0; j < NY; ++j) {                                                  \
+            const int u = tid + j * DWT, mb = u / (2 * N), rem = u % (2 * N);                             \
+            u32x2* d = reinterpret_cast<u32x2*>(Ys_) + ((mb * 2) * N + (rem >> 1)) * 2 + (rem & 1);       \
+            d[0] = u32x2{RY[j].x, RY[j].y};                                                               \
+            d[2 * N] = u32x2{RY[j].z, RY[j].w};                                                           \
+        }                                                                                                 \
+        _Pragma("unroll") for (int j = 0; j < NX; ++j) {                                                  \
+            const int u = tid + j * DWT, mb = u / (2 * K), rem = u % (2 * K);                             \
+            if (XFULL || u < XU) {                                                                        \
+                u32x2* d = reinterpret_cast<u32x2*>(Xs_) + ((mb * 2) * K + (rem >> 1)) * 2 + (rem & 1);   \
+                d[0] = u32x2{RX[j].x, RX[j].y};                                                           \
+                d[2 * K] = u32x2{RX[j].z, RX[j].w};                                                       \
+            }                                                                                             \
+        }                                                                                                 \
         if (ALPHA && tid < CHP) reinterpret_cast<float*>(Xs_ + XU)[tid] = RDA;                            \
         /* buffer B was last read two chunks ago, and every wave has passed the barrier in between */    \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");                                   \
@@ -246,16 +262,17 @@ __device__ __forceinline__ void dw_rgb(const DwArgs& a, int64_t blk_begin, int64
             const int64_t mb = b0 + ph + 4 * i;
             hh[i] = hl[i] = u32x4{0u, 0u, 0u, 0u};
             if (mb < blk_end) {
-                hh[i] = hv[(mb * 2) * ACT_HV_W + j];
-                hl[i] = hv[(mb * 2 + 1) * ACT_HV_W + j];
+                hh[i] = hv[(mb * ACT_HV_W + j) * 2];          // points 0-3: {hi x4, lo x4}
+                hl[i] = hv[(mb * ACT_HV_W + j) * 2 + 1];      // points 4-7
             }
         }
 #pragma unroll
         for (int i = 0; i < BB / 4; ++i) {
-            const half8 h = __builtin_bit_cast(half8, hh[i]), l = __builtin_bit_cast(half8, hl[i]);
+            const half8 p0 = __builtin_bit_cast(half8, hh[i]), p1 = __builtin_bit_cast(half8, hl[i]);
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const float x = (float)h[q] + (float)l[q] * LO_INV;
+                const half8& pq = q < 4 ? p0 : p1;
+                const float x = (float)pq[q & 3] + (float)pq[4 + (q & 3)] * LO_INV;
                 const float4 g = reinterpret_cast<const float4*>(dr)[(ph + 4 * i) * 8 + q];   // zero beyond the range
                 s[0] += g.x * x;
                 s[1] += g.y * x;

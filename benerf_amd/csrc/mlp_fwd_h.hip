@@ -50,7 +50,7 @@ __device__ __forceinline__ uint64_t epilogue(f32x16 (&acc1)[2][NCT], f32x16 (&ac
         int base[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) base[q] = r4 * LD + ((((ns ^ ((q & 1) | ((q >> 1) << 2)))) << 3) | (n & 7));
-        _Float16* st_lane = SAVE ? st + st_half_index(m0 + r4, W, n, 0) : nullptr;    // + (r*4 + eq) * 2*W*8 per quad
+        _Float16* st_lane = SAVE ? st + st_half_index(m0 + r4, W, n, 0) : nullptr;    // + (r*4 + eq) * W*16 per quad
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
 #pragma unroll
@@ -73,9 +73,8 @@ __device__ __forceinline__ uint64_t epilogue(f32x16 (&acc1)[2][NCT], f32x16 (&ac
                     ql.v[j] = lo;
                 }
                 if (SAVE) {
-                    _Float16* dst = st_lane + (int64_t)(r * 4 + eq) * 2 * W * 8;
-                    *reinterpret_cast<uint2*>(dst) = __builtin_bit_cast(uint2, qh);
-                    *reinterpret_cast<uint2*>(dst + W * 8) = __builtin_bit_cast(uint2, ql);
+                    const Quad16x2 q = {qh, ql};
+                    *reinterpret_cast<uint4*>(st_lane + (int64_t)(r * 4 + eq) * W * 16) = __builtin_bit_cast(uint4, q);
                 }
             }
         }

@@ -182,15 +182,16 @@ __device__ __forceinline__ void load8(const _Float16* __restrict__ Th, const _Fl
 
 // ---- saved activations / activation gradients in split mode ("ST" arrays) -------------------------------------
 // An ST array of width W over Mp = 64 * n_tiles points stores the split value of (m, w) as two halfs at
-//   half index  (((m >> 3) * 2 + plane) * W + w) * 8 + (m & 7)          plane 0 = hi, 1 = lo (scaled by 2^11)
-// i.e. blocks of 8 points, feature-major inside: the 8 points of one feature are one 16-byte slot, which is exactly
-// the A/B operand fragment of v_mfma_f32_32x32x16_f16 when the contraction runs over points (dW = dY^T X).  The
-// forward / dX epilogues hold 4 consecutive points of a feature per lane and write 8-byte pieces (a wave covers
-// 512 contiguous bytes); the dW kernel copies chunks straight into LDS without any transposition.  Same bytes per
-// element (4) as the f32 arrays.  Rows m >= M of the last tile are written too (duplicates of the last point for
-// activations, exact zeros for gradients), so no store is masked and no dW chunk is ragged.
+//   half index  ((m >> 3) * W + w) * 16 + ((m >> 2) & 1) * 8 + plane * 4 + (m & 3)        plane 0 = hi, 1 = lo * 2^11
+// i.e. blocks of 8 points, feature-major; per (block, feature) 32 bytes = [points 0-3: hi x4, lo x4][points 4-7:
+// hi x4, lo x4].  A lane of the forward / dX epilogue holds 4 consecutive points of one feature, so it writes its
+// hi and lo quads as ONE 16-byte store and a wave covers 1 KiB contiguous.  The dW kernel copies chunks into LDS
+// 16 bytes at a time and splits each unit into its two 8-byte quads there, which yields the MFMA fragment order
+// (8 points of a feature contiguous per plane) without a transposition pass.  Same bytes per element (4) as the f32
+// arrays.  Rows m >= M of the last tile are written too (duplicates of the last point for activations, exact
+// zeros for gradients), so no store is masked and no dW chunk is ragged.
 __host__ __device__ inline int64_t st_half_index(int64_t m, int W, int w, int plane) {
-    return (((m >> 3) * 2 + plane) * W + w) * 8 + (m & 7);
+    return ((m >> 3) * W + w) * 16 + ((m >> 2) & 1) * 8 + plane * 4 + (m & 3);
 }
 __host__ __device__ inline int64_t m_pad(int64_t M) { return n_tiles(M) * TM; }
 // float (4-byte) offsets inside the split-mode activation buffer
@@ -222,17 +223,18 @@ __device__ __forceinline__ void pow2_scale(float mx, float& s, float& inv_s) {
     inv_s = __uint_as_float((uint32_t)(be + 4) << 23);
 }
 
-// 4 consecutive points (one accumulator quad) of one feature -> 8-byte pieces of an ST array
+// 4 consecutive points (one accumulator quad) of one feature -> one 16-byte piece {hi x4, lo x4} of an ST array;
+// `index` = st_half_index of the quad's first point, plane 0
 struct Quad16 { _Float16 v[4]; };
-__device__ __forceinline__ void st_store_quad(_Float16* __restrict__ base, int64_t hi_index, int W, const float (&v)[4]) {
-    Quad16 h, l;
+struct Quad16x2 { Quad16 hi, lo; };
+__device__ __forceinline__ void st_store_quad(_Float16* __restrict__ base, int64_t index, const float (&v)[4]) {
+    Quad16x2 q;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        h.v[j] = (_Float16)v[j];
-        l.v[j] = (_Float16)((v[j] - (float)h.v[j]) * LO_SCALE);
+        q.hi.v[j] = (_Float16)v[j];
+        q.lo.v[j] = (_Float16)((v[j] - (float)q.hi.v[j]) * LO_SCALE);
     }
-    *reinterpret_cast<uint2*>(base + hi_index) = __builtin_bit_cast(uint2, h);
-    *reinterpret_cast<uint2*>(base + hi_index + (int64_t)W * 8) = __builtin_bit_cast(uint2, l);
+    *reinterpret_cast<uint4*>(base + index) = __builtin_bit_cast(uint4, q);
 }
 
 // f32 scratch inside the planes' PE columns [256,320): 64 floats per row, floats [0,32) in the hi plane, [32,64)

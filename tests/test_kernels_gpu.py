@@ -179,10 +179,10 @@ def _act_views(acts, M, mode="f32"):
     Mp = (M + 63) // 64 * 64
     halfs = a.numpy().view(np.float16)
 
-    def st(off, W):
-        blk = halfs[off * 2: off * 2 + Mp * W * 2].reshape(Mp // 8, 2, W, 8).astype(np.float32)
-        val = blk[:, 0] + blk[:, 1] / 2048.0                       # [Mp/8, W, 8]
-        return torch.from_numpy(np.ascontiguousarray(val.transpose(0, 2, 1)).reshape(Mp, W)[:M])
+    def st(off, W):   # [block of 8 points][feature][points 0-3 | 4-7][hi x4, lo x4]
+        blk = halfs[off * 2: off * 2 + Mp * W * 2].reshape(Mp // 8, W, 2, 2, 4).astype(np.float32)
+        val = blk[:, :, :, 0] + blk[:, :, :, 1] / 2048.0            # [Mp/8, W, 2, 4]
+        return torch.from_numpy(np.ascontiguousarray(val.reshape(Mp // 8, W, 8).transpose(0, 2, 1)).reshape(Mp, W)[:M])
 
     out["pe"] = a[0:Mp * 64].reshape(Mp, 64)[:M]
     out["ped"] = a[Mp * 64:Mp * 96].reshape(Mp, 32)[:M]
