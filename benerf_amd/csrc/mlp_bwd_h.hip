@@ -1,11 +1,14 @@
 // K3 backward part 1, split-f16 variant of mlp_bwd.hip: the same activation-gradient chain (phases P0..P6, same
-// dacts / d_pts / d_viewdirs outputs) with every GEMM as three f16 MFMAs on hi/lo-split operands (mlp_split.h).
+// d_pts / d_viewdirs outputs; the dY arrays in ST layout, mlp_split.h) with every GEMM as three f16 MFMAs on
+// hi/lo-split operands.
 //
 // Gradients are far outside the f16 range (d_raw ~ 1/n_rays), but the whole chain is LINEAR in d_raw: each
 // tile multiplies its d_raw by a power of two s = 2^(-4 - exponent(max|d_raw| of the tile)), runs the chain on the
 // scaled values (|dY| = O(2^-4 .. 2^6), inside f16's normal range with 2^20 of head room) and multiplies every
 // output by 1/s - both exact.  Elements more than 2^-14 below the tile's largest lose relative precision down to
-// an absolute floor of 2^-35 of that largest value, far below the f32 rounding of the sums they enter.
+// an absolute floor of 2^-35 of that largest value, far below the f32 rounding of the sums they enter.  The dY arrays
+// for the dW kernels are stored with ONE scale per call (s_g from max|d_raw| over the whole launch, computed by a
+// small pre-kernel) so that dW can accumulate across tiles; the dW reduce kernel divides by s_g.
 //
 // LDS: two f16 planes (80 KiB, two workgroups per CU).  The planes' PE columns [256,320) are never a GEMM
 // operand here and serve as 64 floats of f32 scratch per point (fscr): scaled d_raw at [60,64), dPE(dir) at

@@ -1,14 +1,16 @@
-// K3 forward, split-f16 variant: same network, tiling and outputs as mlp_fwd.hip, but every f32 operand x
+// K3 forward, split-f16 variant: same network, tiling and raw outputs as mlp_fwd.hip, but every f32 operand x
 // is carried as two f16 numbers  x = hi + lo * 2^-11  (hi = rn16(x), lo = rn16((x - hi) * 2^11)) and every
 // product a*b is evaluated as  hi_a*hi_b + (hi_a*lo_b + lo_a*hi_b) * 2^-11  on v_mfma_f32_32x32x16_f16 with
 // f32 accumulation.  The dropped lo*lo term is <= 2^-22 |a b|, i.e. the operands keep 22 significant bits
 // (f32: 24) and the sums are accumulated in f32 exactly like the f32 MFMA does: measured against an f64
-// evaluation the result error equals the exact-f32 kernel's (tests/test_kernels_gpu.py::test_mlp_split_*).
+// evaluation the result error equals the exact-f32 kernel's (every K3 test in tests/test_kernels_gpu.py runs in
+// both modes; test_mlp_modes_agree_at_full_size compares them at BASELINE size).
 // Three f16 MFMAs (16-deep, 32 cycles each) replace eight f32 MFMAs (2-deep, 32 cycles each).
 //
 // LDS: two f16 planes Th/Tl[64][320] (hi / scaled lo) = 80 KiB, so two workgroups still share a CU.
 // 16-byte slots (8 halfs) are XOR-swizzled: element (row, col) lives in slot (col>>3) ^ ((row>>1)&7).
 // Range: |x| must stay below 65504 (f16 max) - NeRF activations are O(1..100).
+// Training mode saves the activations as ST arrays (mlp_split.h) + ReLU sign-bit words for the split dX / dW kernels.
 #include "mlp_split.h"
 
 namespace {

@@ -8,18 +8,25 @@
 #include <vector>
 using namespace mlp;
 
-template <int NWAVES, int NCT>
-__global__ __launch_bounds__(NWAVES * 64, NWAVES / 2) void k(const float* __restrict__ packed, float* out, int tiles_per_wg) {
+//   (c) 8 waves per workgroup as 2 row halves x 4 column groups over a 128-point tile (160 KiB LDS, ONE workgroup per
+//       CU): the two waves of a SIMD belong to the same workgroup and run their K-loops in lockstep
+template <int NWAVES, int NCT, int ROWS = 64>
+__global__ __launch_bounds__(NWAVES * 64, ROWS == 128 ? 2 : NWAVES / 2) void k(const float* __restrict__ packed, float* out, int tiles_per_wg) {
     extern __shared__ __attribute__((aligned(16))) _Float16 Tsm[];
     _Float16* Th = Tsm;
-    _Float16* Tl = Tsm + TM * LD;
+    _Float16* Tl = Tsm + ROWS * LD;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int i = tid; i < TM * LD; i += NWAVES * 64) {
+    int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < ROWS * LD; i += NWAVES * 64) {
         Th[i] = (_Float16)(0.001f * (i & 255));
         Tl[i] = (_Float16)0.25f;
     }
     lds_barrier();
+    if (ROWS == 128) {          // row half wave>>2, column group wave&3
+        Th += (wave >> 2) * 64 * LD;
+        Tl += (wave >> 2) * 64 * LD;
+        wave &= 3;
+    }
     float sink = 0.f;
     for (int t = 0; t < tiles_per_wg; ++t) {
 #pragma unroll 1
@@ -37,14 +44,15 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES / 2) void k(const float* __rest
     if (sink == 54321.f) out[0] = sink;
 }
 
-template <int NWAVES, int NCT>
+template <int NWAVES, int NCT, int ROWS = 64>
 void run(const float* packed, float* d, const char* label) {
-    (void)hipFuncSetAttribute((const void*)k<NWAVES, NCT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TILE_SMEM);
+    const int smem = (int)TILE_SMEM * (ROWS / 64), grid = 512 / (ROWS / 64);
+    (void)hipFuncSetAttribute((const void*)k<NWAVES, NCT, ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
-    hipLaunchKernelGGL((k<NWAVES, NCT>), dim3(512), dim3(NWAVES * 64), TILE_SMEM, 0, packed, d, 2);
+    hipLaunchKernelGGL((k<NWAVES, NCT, ROWS>), dim3(grid), dim3(NWAVES * 64), smem, 0, packed, d, 2);
     (void)hipEventRecord(a, 0);
     const int tiles = 16;
-    hipLaunchKernelGGL((k<NWAVES, NCT>), dim3(512), dim3(NWAVES * 64), TILE_SMEM, 0, packed, d, tiles);
+    hipLaunchKernelGGL((k<NWAVES, NCT, ROWS>), dim3(grid), dim3(NWAVES * 64), smem, 0, packed, d, tiles);
     (void)hipEventRecord(b, 0);
     (void)hipDeviceSynchronize();
     float ms; (void)hipEventElapsedTime(&ms, a, b);
@@ -62,5 +70,6 @@ int main() {
     (void)hipMalloc(&d, 4);
     run<4, 2>(packed + PACKED_FLOATS, d, "4 waves x (2x2 tiles), 2 waves/SIMD");
     run<8, 1>(packed + PACKED_FLOATS, d, "8 waves x (2x1 tiles), 4 waves/SIMD");
+    run<8, 2, 128>(packed + PACKED_FLOATS, d, "8 waves x (2x2 tiles) on 128 points, 1 workgroup/CU, lockstep");
     return 0;
 }
