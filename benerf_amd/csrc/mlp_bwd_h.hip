@@ -66,8 +66,10 @@ __device__ __forceinline__ f32x16 gemm_one(const _Float16* __restrict__ Th, cons
 template <bool MASK>
 __device__ __forceinline__ void epilogue(f32x16 (&acc1)[2][2], f32x16 (&acc2)[2][2], uint64_t bits, _Float16* __restrict__ Th,
                                          _Float16* __restrict__ Tl, int ct0, int lane, _Float16* __restrict__ st, int64_t m0,
-                                         float gf) {
+                                         float gf, float* __restrict__ absmax_entry) {
     const int lr = lane & 31, r4 = 4 * (lane >> 5);
+    float amax = 0.f;          // max |stored value| of this stage (live only inside the epilogue: the kernel is at the
+                               // register limit, a running maximum across the GEMMs cost 35 extra spills)
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         const int n = (ct0 + c) * 32 + lr;
@@ -88,10 +90,12 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc1)[2][2], f32x16 (&acc2)[2]
                     if (MASK) v = ((bits >> ((c * 2 + r) * 16 + e)) & 1ull) ? v : 0.f;
                     split_store(Th, Tl, base[((e >> 1) & 1) | (((e >> 2) & 1) << 1)] + (r * 32 + (e & 3) + 8 * (e >> 2)) * LD, v);
                     vg[j] = v * gf;
+                    amax = fmaxf(amax, fabsf(vg[j]));
                 }
                 st_store_quad(st_lane, (int64_t)(r * 4 + eq) * 256 * 16, vg);
             }
     }
+    publish_absmax(amax, absmax_entry);
 }
 
 template <int C>
@@ -116,8 +120,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_split_kernel(BwdArgs a) {
     const uint64_t* mask_in = reinterpret_cast<const uint64_t*>(acts + sact_mask(Mp)) + (int64_t)blockIdx.x * NTHREADS + tid;
     const int64_t mask_stride = n_tiles(M) * NTHREADS;
     _Float16* st_dyh = reinterpret_cast<_Float16*>(dacts + sdact_h(Mp, 0));      // layer l: + l * Mp * 512 halfs
+    const float* absmax_y = dacts + sdact_scale(Mp);                              // [0] max|d_raw| (pre-kernel)
+    float* absmax_row = dacts + sdact_absmax_table(Mp) + ((int64_t)blockIdx.x * 4 + wave) * 16;   // max |stored gradient| per stage of this wave
     float s_g, inv_s_g;
-    pow2_scale(dacts[sdact_scale(Mp)], s_g, inv_s_g);                             // global scale of this call (pre-kernel)
+    pow2_scale(absmax_y[AY_DRAW], s_g, inv_s_g);                                  // global scale of this call
     const int prow = pt * LD;
 
     // ---- P0: d_raw tile, its power-of-two scale, scaled values -> scratch floats [60, 60+C] of each row ------
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_split_kernel(BwdArgs a) {
     }
     lds_barrier();
     const float inv_s = *fscr(Th, Tl, 0, 56);
-    const float gf = s_g * inv_s;            // tile scale -> global scale (<= 1, power of two)
+    const float gf = s_g * inv_s;            // tile scale -> scale of the stored dY (power of two)
 
     // ---- P1: rgb layer backward + ReLU mask of the views layer -> dYv in planes[:,0:128), accumulator layout ----
     // thread <-> (column wave*32 + lane&31, rows r*32 + acc_row(e)): the hv sign bits the forward pass saved for
@@ -151,6 +157,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_split_kernel(BwdArgs a) {
 #pragma unroll
         for (int c = 0; c < C; ++c) wr[c] = a.w_rgb[c * 128 + col];
         _Float16* st_lane = reinterpret_cast<_Float16*>(dacts + sdact_hv(Mp)) + st_half_index(m0 + r4, ACT_HV_W, col, 0);
+        float amax = 0.f;
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -168,9 +175,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_split_kernel(BwdArgs a) {
                     const float v = ((hvbits >> (r * 16 + e)) & 1ull) ? g : 0.f;
                     split_store(Th, Tl, hidx(p, col), v);
                     vg[j] = v * gf;
+                    amax = fmaxf(amax, fabsf(vg[j]));
                 }
                 st_store_quad(st_lane, (int64_t)(r * 4 + eq) * ACT_HV_W * 16, vg);
             }
+        publish_absmax(amax, absmax_row + 9);
     }
     lds_barrier();
 
@@ -186,7 +195,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_split_kernel(BwdArgs a) {
         for (int e = 0; e < 16; ++e) *fscr(Th, Tl, wave * 32 + acc_row(e, lane), lane & 31) = ap[e];
     }
     lds_barrier();   // dYv fully consumed; dPE(dir) visible
-    epilogue<false>(acc1, acc2, 0ull, Th, Tl, ct0, lane, reinterpret_cast<_Float16*>(dacts + sdact_feat(Mp)), m0, gf);
+    epilogue<false>(acc1, acc2, 0ull, Th, Tl, ct0, lane, reinterpret_cast<_Float16*>(dacts + sdact_feat(Mp)), m0, gf, absmax_row + 8);
     if (grp == 0 && m < M) {   // d viewdirs (per point) through PE(dir)
         const float* ped = acts + sact_ped32(Mp) + m * ACT_PED_W;
 #pragma unroll
@@ -221,7 +230,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_split_kernel(BwdArgs a) {
             }
     }
     lds_barrier();
-    epilogue<true>(acc1, acc2, bits, Th, Tl, ct0, lane, st_dyh + 7 * Mp * 512, m0, gf);
+    epilogue<true>(acc1, acc2, bits, Th, Tl, ct0, lane, st_dyh + 7 * Mp * 512, m0, gf, absmax_row + 7);
     lds_barrier();
 
     // ---- P4: L7 .. L1: dY_l x W_l, mask h_{l-1} -> dY_{l-1} ----------------------------------------------
@@ -239,9 +248,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_split_kernel(BwdArgs a) {
             for (int e = 0; e < 16; ++e) *fscr(Th, Tl, (wave >> 1) * 32 + acc_row(e, lane), col) = ap[e];
         }
         lds_barrier();
-        epilogue<true>(acc1, acc2, bits, Th, Tl, ct0, lane, st_dyh + (int64_t)(l - 1) * Mp * 512, m0, gf);
+        epilogue<true>(acc1, acc2, bits, Th, Tl, ct0, lane, st_dyh + (int64_t)(l - 1) * Mp * 512, m0, gf, absmax_row + (l - 1));
         lds_barrier();
     }
+
+    if (lane < 6) absmax_row[10 + lane] = 0.f;     // unused entries of the row
 
     // ---- P5: L0^T: dPE += dY0 x W0 -----------------------------------------------------------------------
     {
@@ -308,7 +319,7 @@ int benerf_mlp_dx_split_launch(const BenerfMlpParams* params, const float* packe
     const int64_t tiles = (M + mlp::TM - 1) / mlp::TM;
     BENERF_REQUIRE(tiles < (1ll << 31), "mlp_bwd: too many points");
     float* absmax = dacts + mlp::sdact_scale(mlp::m_pad(M));
-    if (hipMemsetAsync(absmax, 0, sizeof(float), stream) != hipSuccess) {
+    if (hipMemsetAsync(absmax, 0, mlp::AY_COUNT * sizeof(float), stream) != hipSuccess) {
         benerf_set_error("mlp_bwd: memset failed");
         return BENERF_EHIP;
     }
@@ -324,5 +335,5 @@ int benerf_mlp_dx_split_launch(const BenerfMlpParams* params, const float* packe
     if (channels == 1) hipLaunchKernelGGL((mlp_bwd_split_kernel<1>), grid, block, smem, stream, a);
     else hipLaunchKernelGGL((mlp_bwd_split_kernel<3>), grid, block, smem, stream, a);
     BENERF_LAUNCH_CHECK("mlp_bwd(dx, split)");
-    return BENERF_OK;
+    return mlp::absmax_reduce_launch(dacts + mlp::sdact_absmax_table(mlp::m_pad(M)), tiles * 64, absmax + mlp::AY_ALL, stream);
 }

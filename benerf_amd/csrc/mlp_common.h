@@ -149,19 +149,18 @@ __host__ __device__ constexpr int64_t dw_inst_offset(int inst) {
 constexpr int64_t DW_WS_FLOATS = dw_inst_offset(DW_COUNT);
 
 // Split-f16 dW (mlp_dw_h.hip): HBM-bound, so workgroup counts follow the bytes an instance streams per point.
-//   big kernel, one workgroup per CU: output block 256 x 128 (two accumulator sets fill the register file), so the
-//     eight 256x256 instances run as PAIRS of column halves, 15 point-splits each, + 16 for the 128x256 views block:
-//     8*15*2 + 16 = 256.
+//   big kernel, one workgroup per CU: a whole 256x256 instance block per workgroup (one accumulator set), 30 point-
+//     splits for each of the eight instances + 16 for the 128x256 views block: 8*30 + 16 = 256.
 //   small kernel: the thin instances (PE / PE(dir) operands, rgb head) move few bytes per chunk and are latency-
 //     bound per workgroup; 64 point-splits each = 256 light workgroups.
 __host__ __device__ constexpr int dwh_splits(int inst) {
     switch (inst) {
         case DW_VIEWSF: return 16;
         case DW_L0: case DW_L5P: case DW_VIEWSP: case DW_RGB: return 64;
-        default: return 15;
+        default: return 30;
     }
 }
-constexpr int DWH_PAIR_BLOCKS = 8 * 15 * 2;
+constexpr int DWH_PAIR_BLOCKS = 8 * 30;
 constexpr int DWH_BIG_BLOCKS = DWH_PAIR_BLOCKS + 16;
 constexpr int DWH_SMALL_BLOCKS = 4 * 64;
 __host__ __device__ constexpr int64_t dwh_inst_offset(int inst) {

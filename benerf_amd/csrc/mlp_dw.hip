@@ -268,7 +268,8 @@ struct ReduceArgs {
     int C;
     int accumulate;
     int split_mode;          // partials written by mlp_dw_h.hip: other split table; dY-derived sums carry the factor s_g
-    const float* absmax;     // split mode: -> max |d_raw| of the call (s_g = pow2_scale of it)
+    const float* absmax_y;   // split mode: absmax slots of the dY arrays ([0] = max |d_raw|, s_g derives from it) ...
+    const float* absmax_x;   // ... and of the activation arrays: the per-array rescale exponents of mlp_dw_h.hip
 };
 
 template <bool SPLIT>
@@ -281,7 +282,19 @@ __device__ __forceinline__ float sum_splits_t(const float* ws, int inst, int64_t
     for (int sp = 0; sp < n; ++sp) s += p[sp * stride];
     return s;
 }
-#define sum_splits(ws, inst, elem) sum_splits_t<SPLIT>(ws, inst, elem)
+// split mode: a weight block of instance `inst` carries s_g * 2^(kY + kX), its bias sums s_g * 2^kY (mlp_split.h,
+// 'dW operand formats'); the alpha / rgb heads are written unscaled
+template <bool SPLIT>
+__device__ __forceinline__ float unscale_of(const float* absmax_y, const float* absmax_x, int inst, bool bias) {
+    if (!SPLIT || inst == DW_RGB) return 1.f;
+    float s_g, inv_s_g;
+    pow2_scale(absmax_y[AY_DRAW], s_g, inv_s_g);
+    const int k = rescale_exp(absmax_y[AY_ALL]) + (bias ? 0 : rescale_exp(absmax_x[AX_ALL]));
+    return inv_s_g * exp2i(-k);
+}
+#define sum_splits(ws, inst, elem) (sum_splits_t<SPLIT>(ws, inst, elem) * unscale_of<SPLIT>(a.absmax_y, a.absmax_x, inst, false))
+#define sum_bias(ws, inst, elem) (sum_splits_t<SPLIT>(ws, inst, elem) * unscale_of<SPLIT>(a.absmax_y, a.absmax_x, inst, true))
+#define sum_raw(ws, inst, elem) sum_splits_t<SPLIT>(ws, inst, elem)
 
 __device__ __forceinline__ int layer_inst(int l) {   // instance holding the bias / main block of layer l
     switch (l) {
@@ -300,12 +313,6 @@ __device__ __forceinline__ int layer_inst(int l) {   // instance holding the bia
 template <bool SPLIT>
 __global__ void dw_reduce_kernel(ReduceArgs a) {
     const int l = blockIdx.y;
-    // the alpha and rgb heads are summed from the unscaled d_raw, everything else from the scaled dY arrays
-    float unscale = 1.f;
-    if (SPLIT && l != BENERF_L_ALPHA && l != BENERF_L_RGB) {
-        float s_g;
-        pow2_scale(a.absmax[0], s_g, unscale);
-    }
     const int C = a.C;
     const int in = layer_in(l), out = layer_out(l, C);
     const int64_t nw = (int64_t)in * out;
@@ -318,29 +325,30 @@ __global__ void dw_reduce_kernel(ReduceArgs a) {
             if (l == 0) v = sum_splits(a.ws, DW_L0, (int64_t)n * 64 + j);
             else if (l == 5) v = j < 63 ? sum_splits(a.ws, DW_L5P, (int64_t)n * 64 + j) : sum_splits(a.ws, DW_L5H, (int64_t)n * 256 + (j - 63));
             else if (l == BENERF_L_VIEWS) v = j < 256 ? sum_splits(a.ws, DW_VIEWSF, (int64_t)n * 256 + j) : sum_splits(a.ws, DW_VIEWSP, (int64_t)n * 32 + (j - 256));
-            else if (l == BENERF_L_ALPHA) v = sum_splits(a.ws, DW_FEAT, (int64_t)256 * 256 + 256 + j);
+            else if (l == BENERF_L_ALPHA) v = sum_raw(a.ws, DW_FEAT, (int64_t)256 * 256 + 256 + j);
             else if (l == BENERF_L_RGB) v = sum_splits(a.ws, DW_RGB, (int64_t)n * 128 + j);
             else v = sum_splits(a.ws, layer_inst(l), (int64_t)n * 256 + j);
         } else {
             const int n = (int)(e - nw);
             dst = a.gb[l] + n;
-            if (l == BENERF_L_ALPHA) v = sum_splits(a.ws, DW_FEAT, (int64_t)256 * 256 + 256 + 256);
-            else if (l == BENERF_L_RGB) v = sum_splits(a.ws, DW_RGB, (int64_t)4 * 128 + n);
+            if (l == BENERF_L_ALPHA) v = sum_raw(a.ws, DW_FEAT, (int64_t)256 * 256 + 256 + 256);
+            else if (l == BENERF_L_RGB) v = sum_raw(a.ws, DW_RGB, (int64_t)4 * 128 + n);
             else {
                 const int inst = layer_inst(l);
-                v = sum_splits(a.ws, inst, (int64_t)dw_shape(inst).n * dw_shape(inst).k + n);
+                v = sum_bias(a.ws, inst, (int64_t)dw_shape(inst).n * dw_shape(inst).k + n);
             }
         }
-        v *= unscale;
         *dst = a.accumulate ? *dst + v : v;
     }
 }
 #undef sum_splits
+#undef sum_bias
+#undef sum_raw
 
 }  // namespace
 
 int benerf_mlp_dw_reduce_launch(const float* ws, const BenerfMlpGrads* grads, int channels, int accumulate, int split_mode,
-                                const float* absmax, hipStream_t stream) {
+                                const float* absmax_y, const float* absmax_x, hipStream_t stream) {
     ReduceArgs r;
     r.ws = ws;
     for (int l = 0; l < BENERF_NLAYERS; ++l) {
@@ -350,7 +358,8 @@ int benerf_mlp_dw_reduce_launch(const float* ws, const BenerfMlpGrads* grads, in
     r.C = channels;
     r.accumulate = accumulate;
     r.split_mode = split_mode;
-    r.absmax = absmax;
+    r.absmax_y = absmax_y;
+    r.absmax_x = absmax_x;
     if (split_mode) hipLaunchKernelGGL(dw_reduce_kernel<true>, dim3(64, BENERF_NLAYERS), dim3(256), 0, stream, r);
     else hipLaunchKernelGGL(dw_reduce_kernel<false>, dim3(64, BENERF_NLAYERS), dim3(256), 0, stream, r);
     BENERF_LAUNCH_CHECK("mlp_bwd(reduce)");
@@ -381,5 +390,5 @@ int benerf_mlp_dw_launch(const BenerfMlpParams* params, int channels, int64_t M,
     }
     hipLaunchKernelGGL(mlp_dw_kernel, dim3(mlp::DW_TOTAL_BLOCKS), dim3(DWT), DW_SMEM, stream, a);
     BENERF_LAUNCH_CHECK("mlp_bwd(dw)");
-    return benerf_mlp_dw_reduce_launch(dw_ws, grads, channels, accumulate, 0, nullptr, stream);
+    return benerf_mlp_dw_reduce_launch(dw_ws, grads, channels, accumulate, 0, nullptr, nullptr, stream);
 }

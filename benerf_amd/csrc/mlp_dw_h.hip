@@ -1,24 +1,23 @@
 // K3 backward part 2, split-f16 variant of mlp_dw.hip: dW_l = dY_l^T X_l over all sample points as three f16 MFMAs
-// per product block (mlp_split.h), f32 accumulation, + bias sums and the alpha / rgb heads on the VALU.
+// per product block, f32 accumulation, + bias sums and the alpha / rgb heads on the VALU.
 //
 // Operands arrive in the ST layout the split forward / dX kernels write (mlp_split.h): blocks of 8 points,
 // feature-major, 16-byte units {hi x4, lo x4} - one split away from the MFMA fragment order for a contraction over
-// points.  A workgroup (8 waves, one per CU) copies 32-point chunks into a double-buffered LDS image
-// [block][plane][feature][8 points] (each unit lands as two 8-byte quads; conflict-free fragment reads, no
-// transposition pass) while it multiplies the previous chunk; one barrier per chunk.
-// Two accumulator sets (hi*hi and the cross terms) fill the register file at a 256 x 128 output block, so the eight
-// 256x256 instances run as pairs of column halves (workgroup ids 8 apart = same XCD); both halves stream the same
-// dY chunk.  Measured (FETCH_SIZE, profiles/): the second read is NOT absorbed by L2 whatever the id mapping or lag
-// between the halves - 13.3 GB cross the fabric per launch at M = 522k against 9.4 GB of distinct operands - so the
-// kernel runs at the fabric/HBM streaming rate for 1.5 KB per point and half-instance.  dY carries the call's
-// global power-of-two scale s_g (max|d_raw| from the dX launch); the reduce kernel multiplies by 1/s_g.
+// points.  A workgroup (8 waves, one per CU) copies 16-point chunks (one MFMA k-step) into a triple-buffered LDS
+// image [block][plane][feature][8 points] (each unit lands as two 8-byte quads; conflict-free fragment reads, no
+// transposition pass) with three chunks in flight in registers and one LDS-only barrier per chunk.
+// The three products of a block go into ONE accumulator set: while staging, every operand unit is rescaled by its
+// array's power of two so that its lo part can be used UNSCALED ('dW operand formats', mlp_split.h).
+// With one set a workgroup holds a whole 256 x 256 output block (128 accumulator registers x 8 waves), so every
+// operand byte is read exactly once: HBM traffic = the algorithmic bytes.  (With two accumulator sets the block was
+// 256 x 128 and dY was streamed twice: 13.3 GB against 9.4 GB of operands per launch at M = 522k.)
 #include "mlp_split.h"
 
 namespace {
 using namespace mlp;
 
 constexpr int DWT = 512;
-constexpr int CHP = 32;             // points per chunk = 4 blocks of 8 = 2 MFMA k-steps
+constexpr int CHP = 16;             // points per chunk = 2 blocks of 8 = one MFMA k-step
 // 16-byte unit as a first-class vector (arrays of HIP's uint4 struct were left in scratch memory by the compiler)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -65,74 +64,104 @@ __device__ __forceinline__ float sum8(u32x4 hi, u32x4 lo) {
     return s + t * LO_INV;
 }
 
-// Output block N x K at columns [k0, k0+K) of an instance whose X array is XW wide and whose partial block is KW
-// wide.  Waves form a WN x (8/WN) grid; each owns TR x TC MFMA tiles.
-template <int N, int K, int XW, int KW, int WN, int TR, int TC, bool ALPHA>
-__device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int k0, bool lead, int64_t chunk_begin,
-                                        int64_t chunk_end, float* __restrict__ part, u32x4* __restrict__ smem) {
+// Output block N x K (the whole instance: K = width of X).  Waves form a WN x (8/WN) grid; each owns TR x TC MFMA
+// tiles in ONE accumulator set: per 16-point chunk (= one MFMA k-step) acc += Yh Xh + Yh Xl + Yl Xh with unscaled
+// lo parts (mlp_split.h, 'dW operand formats').  Three chunks are in flight in registers (sets A, B, C) and the LDS
+// image is triple-buffered, so there is one LDS-only barrier per chunk and every operand byte is read once.
+template <int N, int K, int WN, int TR, int TC, bool ALPHA>
+__device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int kY, int kX, int64_t chunk_begin, int64_t chunk_end,
+                                        float* __restrict__ part, u32x4* __restrict__ smem) {
     static_assert(WN * TR * 32 == N, "row tiling");
-    constexpr int YU = 8 * N, XU = 8 * K;                      // 16-byte units per chunk (4 blocks x 2 planes x width)
-    constexpr int NY = YU / DWT, NX = (XU + DWT - 1) / DWT;
-    static_assert(YU % DWT == 0, "staging shape");
-    constexpr bool XFULL = XU % DWT == 0;
-    constexpr int BUF = YU + XU + 8;                           // + 32 floats of d_sigma
+    constexpr int YU = 4 * N, XU = 4 * K;                      // 16-byte units per chunk (2 blocks x width x 2 halves)
+    constexpr int NY = (YU + DWT - 1) / DWT, NX = (XU + DWT - 1) / DWT;
+    constexpr bool YFULL = YU % DWT == 0, XFULL = XU % DWT == 0;
+    constexpr int BUF = YU + XU + 4;                           // + 16 floats of d_sigma
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 31, lh = lane >> 5;
     const int wn = wave % WN, wk = wave / WN;
     const bool mma_wave = wk * TC * 32 < K;
     const int64_t M = a.M;
 
-    f32x16 acc1[TR][TC], acc2[TR][TC];
+    f32x16 acc[TR][TC];
 #pragma unroll
     for (int r = 0; r < TR; ++r)
 #pragma unroll
         for (int c = 0; c < TC; ++c)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc1[r][c][e] = acc2[r][c][e] = 0.f;
+            for (int e = 0; e < 16; ++e) acc[r][c][e] = 0.f;
     float bsum = 0.f, asum = 0.f, absum = 0.f;
 
-    // Two chunks are always in flight (register sets A and B): with one chunk the loop runs at one HBM latency per
-    // 48 KB per CU.  The barrier is LDS-only (no vmcnt(0)), so the younger set's loads stay in flight across it.
-    // (Macros, not lambdas taking the sets by reference: those left the sets in scratch memory.)
-    u32x4 ryA[NY], rxA[NX], ryB[NY], rxB[NX];
-    float rdaA = 0.f, rdaB = 0.f;
+    // stored (hi, lo * 2^11)  ->  (hi * 2^k, lo * 2^(k-11)): the array's largest element lands in [2^14, 2^15) and lo is
+    // unscaled.  2^k as a product of two f16-representable powers of two (packed-f16 multiplies, all exact).
+    // a unit is {hi x4, lo x4} = words {hi, hi, lo, lo}: per operand four packed-f16 multipliers (2^k = m1 * m2 for the
+    // hi words, 2^(k-11) for the lo words), kept as wave-uniform 32-bit patterns so they live in SGPRs
+    typedef _Float16 half2 __attribute__((ext_vector_type(2)));
+    struct Mul4 { unsigned int h1, h2, l1, l2; };
+    auto mul4 = [](int k) -> Mul4 {
+        const int kl = k - 11;
+        const int h1 = k < -14 ? -14 : (k > 15 ? 15 : k), l1 = kl < -14 ? -14 : (kl > 15 ? 15 : kl);
+        auto pat = [](int e) -> unsigned int {                       // {2^e, 2^e} as packed f16, e in [-14, 15]
+            const unsigned int b = (unsigned int)((e + 15) << 10);
+            return (unsigned int)__builtin_amdgcn_readfirstlane((int)(b | (b << 16)));
+        };
+        return Mul4{pat(h1), pat(k - h1), pat(l1), pat(kl - l1)};
+    };
+    const Mul4 ym = mul4(kY), xm = mul4(kX);
+    auto mulw = [](unsigned int w, unsigned int m1, unsigned int m2) -> unsigned int {
+        const half2 t = (__builtin_bit_cast(half2, w) * __builtin_bit_cast(half2, m1)) * __builtin_bit_cast(half2, m2);
+        return __builtin_bit_cast(unsigned int, t);
+    };
+    auto rescale = [&](u32x4 unit, const Mul4& m) -> u32x4 {
+        return u32x4{mulw(unit.x, m.h1, m.h2), mulw(unit.y, m.h1, m.h2), mulw(unit.z, m.l1, m.l2), mulw(unit.w, m.l1, m.l2)};
+    };
+
+    u32x4 ryA[NY], rxA[NX], ryB[NY], rxB[NX], ryC[NY], rxC[NX];
+    float rdaA = 0.f, rdaB = 0.f, rdaC = 0.f;
+    // Loads are UNCONDITIONAL (a chunk index past the range is clamped to the last chunk and its staged dY zeroed):
+    // with the loads under branches the compiler's waitcnt bookkeeping fell back to vmcnt(0) at every stage, i.e. one
+    // chunk in flight instead of three.
 #define DW_PREFETCH(RY, RX, RDA, CHUNK)                                                                   \
-    if ((CHUNK) < chunk_end) {                                                                            \
-        const u32x4* py = src.y + (CHUNK) * YU + tid;                                                     \
-        _Pragma("unroll") for (int j = 0; j < NY; ++j) RY[j] = py[j * DWT];                               \
-        _Pragma("unroll") for (int j = 0; j < NX; ++j) {                                                  \
-            const int u = tid + j * DWT;                                                                  \
-            RX[j] = u32x4{0u, 0u, 0u, 0u};                                                               \
-            if (XFULL || u < XU)                                                                          \
-                RX[j] = src.x[((((CHUNK) * 4 + u / (2 * K)) * XW) + k0 + ((u % (2 * K)) >> 1)) * 2 + (u & 1)];       \
-        }                                                                                                 \
-        if (ALPHA && tid < CHP) {                                                                         \
-            const int64_t row = (CHUNK) * CHP + tid;                                                      \
-            RDA = row < M ? a.d_raw[row * (a.C + 1) + a.C] : 0.f;                                         \
+    {                                                                                                     \
+        const int64_t cc = (CHUNK) < chunk_end ? (CHUNK) : chunk_end - 1;                                 \
+        const u32x4* py = src.y + cc * YU + tid;                                                          \
+        const u32x4* px = src.x + cc * XU + tid;                                                          \
+        _Pragma("unroll") for (int j = 0; j < NY; ++j)                                                    \
+            if (YFULL || tid + j * DWT < YU) RY[j] = py[j * DWT];                                         \
+        _Pragma("unroll") for (int j = 0; j < NX; ++j)                                                    \
+            if (XFULL || tid + j * DWT < XU) RX[j] = px[j * DWT];                                         \
+        if (ALPHA) {                                                                                      \
+            const int64_t row = cc * CHP + (tid & (CHP - 1));                                             \
+            RDA = a.d_raw[(row < M ? row : M - 1) * (a.C + 1) + a.C];                                     \
+            if (row >= M) RDA = 0.f;                                                                      \
         }                                                                                                 \
     }
-#define DW_STAGE(RY, RX, RDA, B)                                                                          \
+    // global unit u = ((block * W + w) * 2 + half) holds {hi x4, lo x4} of 4 points: the two quads go to the hi / lo
+    // fragment planes of the LDS image [block][plane][w][8 points] (8-byte writes, conflict free)
+#define DW_STAGE(RY, RX, RDA, B, VALID)                                                                   \
     {                                                                                                     \
         u32x4* Ys_ = smem + (B) * BUF;                                                                    \
         u32x4* Xs_ = Ys_ + YU;                                                                            \
-        /* global unit u = ((block * W + w) * 2 + half) holds {hi x4, lo x4} of 4 points: the two quads go to the */ \
-        /* hi / lo fragment planes of the LDS image [block][plane][w][8 points] (8-byte writes, conflict free)   */ \
         _Pragma("unroll") for (int j = 0; j < NY; ++j) {                                                  \
             const int u = tid + j * DWT, mb = u / (2 * N), rem = u % (2 * N);                             \
-            u32x2* d = reinterpret_cast<u32x2*>(Ys_) + ((mb * 2) * N + (rem >> 1)) * 2 + (rem & 1);       \
-            d[0] = u32x2{RY[j].x, RY[j].y};                                                               \
-            d[2 * N] = u32x2{RY[j].z, RY[j].w};                                                           \
+            if (YFULL || u < YU) {                                                                        \
+                u32x2* d = reinterpret_cast<u32x2*>(Ys_) + ((mb * 2) * N + (rem >> 1)) * 2 + (rem & 1);   \
+                u32x4 q = rescale(RY[j], ym);                                                       \
+                if (!(VALID)) q = u32x4{0u, 0u, 0u, 0u};       /* past the range: contributes nothing */ \
+                d[0] = u32x2{q.x, q.y};                                                                   \
+                d[2 * N] = u32x2{q.z, q.w};                                                               \
+            }                                                                                             \
         }                                                                                                 \
         _Pragma("unroll") for (int j = 0; j < NX; ++j) {                                                  \
             const int u = tid + j * DWT, mb = u / (2 * K), rem = u % (2 * K);                             \
             if (XFULL || u < XU) {                                                                        \
                 u32x2* d = reinterpret_cast<u32x2*>(Xs_) + ((mb * 2) * K + (rem >> 1)) * 2 + (rem & 1);   \
-                d[0] = u32x2{RX[j].x, RX[j].y};                                                           \
-                d[2 * K] = u32x2{RX[j].z, RX[j].w};                                                       \
+                const u32x4 q = rescale(RX[j], xm);                                                 \
+                d[0] = u32x2{q.x, q.y};                                                                   \
+                d[2 * K] = u32x2{q.z, q.w};                                                               \
             }                                                                                             \
         }                                                                                                 \
-        if (ALPHA && tid < CHP) reinterpret_cast<float*>(Xs_ + XU)[tid] = RDA;                            \
-        /* buffer B was last read two chunks ago, and every wave has passed the barrier in between */    \
+        if (ALPHA && tid < CHP) reinterpret_cast<float*>(Xs_ + XU)[tid] = (VALID) ? RDA : 0.f;            \
+        /* buffer B was last read three chunks ago, and every wave has passed two barriers in between */ \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");                                   \
         __builtin_amdgcn_s_barrier();                                                                     \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");                                   \
@@ -142,50 +171,57 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int k0, 
         const u32x4* Xl = Yl + YU;
         const float* da = reinterpret_cast<const float*>(Xl + XU);
         if (mma_wave) {
+            half8 ah[TR], al[TR];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int mb = ks * 2 + lh;
-                half8 ah[TR], al[TR], bh[TC], bl[TC];
+            for (int r = 0; r < TR; ++r) {
+                ah[r] = __builtin_bit_cast(half8, Yl[(lh * 2 + 0) * N + (wn * TR + r) * 32 + lr]);
+                al[r] = __builtin_bit_cast(half8, Yl[(lh * 2 + 1) * N + (wn * TR + r) * 32 + lr]);
+            }
+            // column tiles in groups of two (fragment registers: 16 + 16 instead of 16 + 32); inside a group all tiles
+            // per product kind, so an accumulator is touched again only after TR*2 other MFMAs
+            constexpr int CG = TC >= 2 ? 2 : 1;
 #pragma unroll
-                for (int r = 0; r < TR; ++r) {
-                    ah[r] = __builtin_bit_cast(half8, Yl[(mb * 2 + 0) * N + (wn * TR + r) * 32 + lr]);
-                    al[r] = __builtin_bit_cast(half8, Yl[(mb * 2 + 1) * N + (wn * TR + r) * 32 + lr]);
+            for (int c0 = 0; c0 < TC; c0 += CG) {
+                half8 bh[CG], bl[CG];
+#pragma unroll
+                for (int c = 0; c < CG; ++c) {
+                    bh[c] = __builtin_bit_cast(half8, Xl[(lh * 2 + 0) * K + (wk * TC + c0 + c) * 32 + lr]);
+                    bl[c] = __builtin_bit_cast(half8, Xl[(lh * 2 + 1) * K + (wk * TC + c0 + c) * 32 + lr]);
                 }
 #pragma unroll
-                for (int c = 0; c < TC; ++c) {
-                    bh[c] = __builtin_bit_cast(half8, Xl[(mb * 2 + 0) * K + (wk * TC + c) * 32 + lr]);
-                    bl[c] = __builtin_bit_cast(half8, Xl[(mb * 2 + 1) * K + (wk * TC + c) * 32 + lr]);
-                }
+                for (int r = 0; r < TR; ++r)
+#pragma unroll
+                    for (int c = 0; c < CG; ++c) acc[r][c0 + c] = mfma16(ah[r], bh[c], acc[r][c0 + c]);
 #pragma unroll
                 for (int r = 0; r < TR; ++r)
 #pragma unroll
-                    for (int c = 0; c < TC; ++c) acc1[r][c] = mfma16(ah[r], bh[c], acc1[r][c]);
+                    for (int c = 0; c < CG; ++c) acc[r][c0 + c] = mfma16(ah[r], bl[c], acc[r][c0 + c]);
 #pragma unroll
                 for (int r = 0; r < TR; ++r)
 #pragma unroll
-                    for (int c = 0; c < TC; ++c) acc2[r][c] = mfma16(ah[r], bl[c], acc2[r][c]);
-#pragma unroll
-                for (int r = 0; r < TR; ++r)
-#pragma unroll
-                    for (int c = 0; c < TC; ++c) acc2[r][c] = mfma16(al[r], bh[c], acc2[r][c]);
+                    for (int c = 0; c < CG; ++c) acc[r][c0 + c] = mfma16(al[r], bh[c], acc[r][c0 + c]);
             }
         }
-        if (lead && src.bias && tid < N) {
+        if (src.bias && tid < N) {
             float s = 0.f;
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) s += sum8(Yl[(mb * 2) * N + tid], Yl[(mb * 2 + 1) * N + tid]);
+            for (int mb = 0; mb < 2; ++mb) {
+                const half8 h = __builtin_bit_cast(half8, Yl[(mb * 2) * N + tid]), l = __builtin_bit_cast(half8, Yl[(mb * 2 + 1) * N + tid]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += (float)h[j] + (float)l[j];
+            }
             bsum += s;
         }
         if (ALPHA && tid < K) {
             float s = 0.f, sb = 0.f;
 #pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
+            for (int mb = 0; mb < 2; ++mb) {
                 const half8 h = __builtin_bit_cast(half8, Xl[(mb * 2) * K + tid]);
                 const half8 l = __builtin_bit_cast(half8, Xl[(mb * 2 + 1) * K + tid]);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float d = da[mb * 8 + j];
-                    s += d * ((float)h[j] + (float)l[j] * LO_INV);
+                    s += d * ((float)h[j] + (float)l[j]);
                     sb += d;
                 }
             }
@@ -194,24 +230,31 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int k0, 
         }
     };
 
-    DW_PREFETCH(ryA, rxA, rdaA, chunk_begin);
-    DW_PREFETCH(ryB, rxB, rdaB, chunk_begin + 1);
-    for (int64_t chunk = chunk_begin; chunk < chunk_end; chunk += 2) {
-        DW_STAGE(ryA, rxA, rdaA, 0);
-        DW_PREFETCH(ryA, rxA, rdaA, chunk + 2);
-        __builtin_amdgcn_sched_barrier(0);   // keep the loads HERE: the scheduler otherwise sinks them below the MFMAs
-        compute(0);
-        if (chunk + 1 < chunk_end) {
-            DW_STAGE(ryB, rxB, rdaB, 1);
-            DW_PREFETCH(ryB, rxB, rdaB, chunk + 3);
+    if (chunk_begin < chunk_end) {
+        DW_PREFETCH(ryA, rxA, rdaA, chunk_begin);
+        DW_PREFETCH(ryB, rxB, rdaB, chunk_begin + 1);
+        DW_PREFETCH(ryC, rxC, rdaC, chunk_begin + 2);
+        for (int64_t chunk = chunk_begin; chunk < chunk_end; chunk += 3) {
+            DW_STAGE(ryA, rxA, rdaA, 0, true);
+            DW_PREFETCH(ryA, rxA, rdaA, chunk + 3);
+            __builtin_amdgcn_sched_barrier(0);   // keep the loads HERE: the scheduler otherwise sinks them below the MFMAs
+            compute(0);
+            const bool v1 = chunk + 1 < chunk_end, v2 = chunk + 2 < chunk_end;
+            DW_STAGE(ryB, rxB, rdaB, 1, v1);
+            DW_PREFETCH(ryB, rxB, rdaB, chunk + 4);
             __builtin_amdgcn_sched_barrier(0);
             compute(1);
+            DW_STAGE(ryC, rxC, rdaC, 2, v2);
+            DW_PREFETCH(ryC, rxC, rdaC, chunk + 5);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(2);
         }
     }
 #undef DW_PREFETCH
 #undef DW_STAGE
 
-    // partial block -> workspace: [N][KW] then bias [N] (then alpha row [256] + alpha bias)
+    // partial block -> workspace: [N][K] then bias [N] (then alpha row [256] + alpha bias).  Block and bias stay at
+    // the operand scales (the reduce kernel divides them out); the alpha row only carries the activation scale
     if (mma_wave) {
 #pragma unroll
         for (int r = 0; r < TR; ++r)
@@ -220,13 +263,13 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int k0, 
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int row = (wn * TR + r) * 32 + acc_row(e, lane);
-                    part[(int64_t)row * KW + k0 + (wk * TC + c) * 32 + lr] = acc1[r][c][e] + acc2[r][c][e] * LO_INV;
+                    part[(int64_t)row * K + (wk * TC + c) * 32 + lr] = acc[r][c][e];
                 }
     }
-    if (lead && tid < N) part[(int64_t)N * KW + tid] = src.bias ? bsum : 0.f;
+    if (tid < N) part[(int64_t)N * K + tid] = src.bias ? bsum : 0.f;
     if (ALPHA && tid < K) {
-        part[(int64_t)N * KW + N + k0 + tid] = asum;
-        if (lead && tid == 0) part[(int64_t)N * KW + N + 256] = absum;
+        part[(int64_t)N * K + N + tid] = asum * exp2i(-kX);
+        if (tid == 0) part[(int64_t)N * K + N + 256] = absum;
     }
 }
 
@@ -311,8 +354,15 @@ __device__ __forceinline__ void dw_rgb(const DwArgs& a, int64_t blk_begin, int64
     }
 }
 
-constexpr size_t DWH_SMEM = 2 * (size_t)(8 * 256 + 8 * 128 + 8) * 16;        // two chunk images of the 256 x 128 block: 98 560 B
-constexpr size_t DWH_SMEM_SMALL = 2 * (size_t)(8 * 256 + 8 * 64 + 8) * 16;   // 256 x 64 block: 82 176 B
+constexpr size_t DWH_SMEM = 3 * (size_t)(4 * 256 + 4 * 256 + 4) * 16;       // three chunk images of the 256 x 256 block: 98 496 B
+constexpr size_t DWH_SMEM_SMALL = 3 * (size_t)(4 * 256 + 4 * 64 + 4) * 16;  // 256 x 64 block: 61 632 B
+
+// rescale exponents of the operands from the absmax slots the forward / dX launches published
+__device__ __forceinline__ void operand_scales(const DwArgs& a, int inst, int& kY, int& kX) {
+    (void)inst;
+    kY = __builtin_amdgcn_readfirstlane(rescale_exp(a.dacts[sdact_scale(m_pad(a.M)) + AY_ALL]));
+    kX = __builtin_amdgcn_readfirstlane(rescale_exp(a.acts[sact_absmax(a.M) + AX_ALL]));
+}
 
 __device__ __forceinline__ void chunk_range(const DwArgs& a, int inst, int split, int64_t& cb, int64_t& ce) {
     const int64_t nchunks = m_pad(a.M) / CHP;
@@ -323,16 +373,14 @@ __device__ __forceinline__ void chunk_range(const DwArgs& a, int inst, int split
     if (ce > nchunks) ce = nchunks;
 }
 
-// the eight 256x256 instances as column-half pairs + the 128x256 views block: one workgroup per CU
+// the eight 256x256 instances + the 128x256 views block: one workgroup per CU, every operand byte read once
 __global__ __launch_bounds__(DWT, 2) void mlp_dw_split_big_kernel(DwArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32x4 smem_u[];
     const int id = blockIdx.x;
-    int inst, split, half = 0;
-    if (id < DWH_PAIR_BLOCKS) {           // id = 16*q + 8*half + x  <->  pair q*8 + x
-        const int pair = (id >> 4) * 8 + (id & 7);
-        half = (id >> 3) & 1;
-        inst = pair / 15;                 // DW_L1 .. DW_FEAT
-        split = pair % 15;
+    int inst, split;
+    if (id < DWH_PAIR_BLOCKS) {
+        inst = id / dwh_splits(DW_L1);    // DW_L1 .. DW_FEAT
+        split = id % dwh_splits(DW_L1);
     } else {
         inst = DW_VIEWSF;
         split = id - DWH_PAIR_BLOCKS;
@@ -341,9 +389,11 @@ __global__ __launch_bounds__(DWT, 2) void mlp_dw_split_big_kernel(DwArgs a) {
     chunk_range(a, inst, split, cb, ce);
     float* part = a.ws + dwh_inst_offset(inst) + (int64_t)split * dw_inst_floats(inst);
     const Src src = inst_src(a, inst);
-    if (inst == DW_FEAT) dw_gemm<256, 128, 256, 256, 4, 2, 2, true>(a, src, half * 128, half == 0, cb, ce, part, smem_u);
-    else if (inst <= DW_L7) dw_gemm<256, 128, 256, 256, 4, 2, 2, false>(a, src, half * 128, half == 0, cb, ce, part, smem_u);
-    else dw_gemm<128, 256, 256, 256, 2, 2, 2, false>(a, src, 0, true, cb, ce, part, smem_u);
+    int kY, kX;
+    operand_scales(a, inst, kY, kX);
+    if (inst == DW_FEAT) dw_gemm<256, 256, 4, 2, 4, true>(a, src, kY, kX, cb, ce, part, smem_u);
+    else if (inst <= DW_L7) dw_gemm<256, 256, 4, 2, 4, false>(a, src, kY, kX, cb, ce, part, smem_u);
+    else dw_gemm<128, 256, 2, 2, 2, false>(a, src, kY, kX, cb, ce, part, smem_u);
 }
 
 // the thin instances: L0 and L5P (256 x 64, X = PE), VIEWSP (128 x 32, X = PE(dir)), rgb head (VALU)
@@ -354,18 +404,20 @@ __global__ __launch_bounds__(DWT, 2) void mlp_dw_split_small_kernel(DwArgs a) {
     chunk_range(a, inst, split, cb, ce);
     float* part = a.ws + dwh_inst_offset(inst) + (int64_t)split * dw_inst_floats(inst);
     if (inst == DW_RGB) {
-        dw_rgb(a, cb * 4, ce * 4, part, reinterpret_cast<float*>(smem_u));
+        dw_rgb(a, cb * 2, ce * 2, part, reinterpret_cast<float*>(smem_u));
         return;
     }
     const Src src = inst_src(a, inst);
-    if (inst == DW_VIEWSP) dw_gemm<128, 32, 32, 32, 4, 1, 1, false>(a, src, 0, true, cb, ce, part, smem_u);
-    else dw_gemm<256, 64, 64, 64, 4, 2, 1, false>(a, src, 0, true, cb, ce, part, smem_u);   // DW_L0, DW_L5P
+    int kY, kX;
+    operand_scales(a, inst, kY, kX);
+    if (inst == DW_VIEWSP) dw_gemm<128, 32, 4, 1, 1, false>(a, src, kY, kX, cb, ce, part, smem_u);
+    else dw_gemm<256, 64, 4, 2, 1, false>(a, src, kY, kX, cb, ce, part, smem_u);   // DW_L0, DW_L5P
 }
 
 }  // namespace
 
 int benerf_mlp_dw_reduce_launch(const float* ws, const BenerfMlpGrads* grads, int channels, int accumulate, int split_mode,
-                                const float* absmax, hipStream_t stream);
+                                const float* absmax_y, const float* absmax_x, hipStream_t stream);
 
 int benerf_mlp_dw_split_launch(int channels, int64_t M, const float* d_raw, const float* acts, const float* dacts, float* dw_ws,
                                const BenerfMlpGrads* grads, int accumulate, hipStream_t stream) {
@@ -388,5 +440,6 @@ int benerf_mlp_dw_split_launch(int channels, int64_t M, const float* d_raw, cons
     BENERF_LAUNCH_CHECK("mlp_bwd(dw small, split)");
     hipLaunchKernelGGL(mlp_dw_split_big_kernel, dim3(mlp::DWH_BIG_BLOCKS), dim3(DWT), DWH_SMEM, stream, a);
     BENERF_LAUNCH_CHECK("mlp_bwd(dw, split)");
-    return benerf_mlp_dw_reduce_launch(dw_ws, grads, channels, accumulate, 1, dacts + mlp::sdact_scale(mlp::m_pad(M)), stream);
+    return benerf_mlp_dw_reduce_launch(dw_ws, grads, channels, accumulate, 1, dacts + mlp::sdact_scale(mlp::m_pad(M)),
+                                       acts + mlp::sact_absmax(M), stream);
 }

@@ -39,7 +39,7 @@ struct FwdArgs {
 template <int NCT, bool RELU, bool SAVE, int W>
 __device__ __forceinline__ uint64_t epilogue(f32x16 (&acc1)[2][NCT], f32x16 (&acc2)[2][NCT], _Float16* __restrict__ Th,
                                              _Float16* __restrict__ Tl, int ct0, int lane, const float* __restrict__ bias,
-                                             _Float16* __restrict__ st, int64_t m0) {
+                                             _Float16* __restrict__ st, int64_t m0, float& amax) {
     const int lr = lane & 31, r4 = 4 * (lane >> 5);
     uint64_t bits = 0;
     // row = R(r,e) + r4 with R = r*32 + (e&3) + 8*(e>>2): its swizzle hsw(row) = e1 | r4bit<<1 | e2<<2, so every
@@ -66,6 +66,7 @@ __device__ __forceinline__ uint64_t epilogue(f32x16 (&acc1)[2][NCT], f32x16 (&ac
                         v = fmaxf(v, 0.f);
                         bits |= (uint64_t)(v > 0.f) << ((c * 2 + r) * 16 + e);
                     }
+                    if (SAVE) amax = fmaxf(amax, RELU ? v : fabsf(v));      // for the dW kernel's per-array rescale
                     const _Float16 hi = (_Float16)v;
                     const _Float16 lo = (_Float16)((v - (float)hi) * LO_SCALE);
                     const int idx = base[((e >> 1) & 1) | (((e >> 2) & 1) << 1)] + (r * 32 + (e & 3) + 8 * (e >> 2)) * LD;
@@ -107,6 +108,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_split_kernel(FwdArgs a) {
                               : nullptr;
     const int64_t mask_stride = n_tiles(M) * NTHREADS;
     const bool live = m < M;
+    // running max |value| over everything this wave saves (-> the dW kernel's operand rescale; table entry per wave)
+    float* absmax = SAVE ? acts + sact_absmax_table(M) + (int64_t)blockIdx.x * 4 + wave : nullptr;
+    float amax = 0.f;
     // f32 scratch in the dead PE columns [288,320) of the lo plane: logical slot 36 + j of this thread's row
     const int psw = hsw(pt);
     auto scratch = [&](int j) { return reinterpret_cast<float*>(Tl + pt * LD + (((36 + j) ^ psw) << 3)); };
@@ -130,6 +134,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_split_kernel(FwdArgs a) {
                 ape[col] = v;
                 spe[st_half_index(m, ACT_PE_W, col, 0)] = hi;
                 spe[st_half_index(m, ACT_PE_W, col, 1)] = lo;
+                amax = fmaxf(amax, fabsf(v));
             }
         };
         if (grp == 0) {
@@ -146,6 +151,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_split_kernel(FwdArgs a) {
             put(3 + f * 6 + 3 + d, c);
         }
     }
+    if (SAVE) {
+        amax = fmaxf(amax, 1.f);                                    // PE(dir): |sin|, |cos|, |viewdir| <= 1
+    }
     lds_barrier();
 
     f32x16 acc1[2][2], acc2[2][2];
@@ -156,8 +164,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_split_kernel(FwdArgs a) {
     zero_acc(acc2);
     gemm_stage<4, 2>(Th, Tl, COL_PE, a.packed + pack_offset(PF_L0), ct0, lane, acc1, acc2);
     {
-        const uint64_t bits = epilogue<2, true, SAVE, 256>(acc1, acc2, Th, Tl, ct0, lane, a.bias[0], st_h, m0);
-        if (SAVE) mask_out[0] = bits;
+        const uint64_t bits = epilogue<2, true, SAVE, 256>(acc1, acc2, Th, Tl, ct0, lane, a.bias[0], st_h, m0, amax);
+        if (SAVE) {
+            mask_out[0] = bits;
+        }
     }
     lds_barrier();
 
@@ -170,8 +180,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_split_kernel(FwdArgs a) {
         else gemm_stage<16, 2>(Th, Tl, 0, a.packed + pack_offset(PF_L0 + l), ct0, lane, acc1, acc2);
         lds_barrier();
         const uint64_t bits = epilogue<2, true, SAVE, 256>(acc1, acc2, Th, Tl, ct0, lane, a.bias[l],
-                                                           SAVE ? st_h + (int64_t)l * Mp * 512 : nullptr, m0);
-        if (SAVE) mask_out[l * mask_stride] = bits;
+                                                           SAVE ? st_h + (int64_t)l * Mp * 512 : nullptr, m0, amax);
+        if (SAVE) {
+            mask_out[l * mask_stride] = bits;
+        }
         lds_barrier();
     }
 
@@ -230,7 +242,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_split_kernel(FwdArgs a) {
     gemm_stage<16, 2>(Th, Tl, 0, a.packed + pack_offset(PF_FEAT), ct0, lane, acc1, acc2);
     lds_barrier();
     epilogue<2, false, SAVE, 256>(acc1, acc2, Th, Tl, ct0, lane, a.bias[BENERF_L_FEAT],
-                                  SAVE ? reinterpret_cast<_Float16*>(acts + sact_feat(Mp)) : nullptr, m0);
+                                  SAVE ? reinterpret_cast<_Float16*>(acts + sact_feat(Mp)) : nullptr, m0, amax);
     if (tid < 64 && live) {
         const float4 p = *reinterpret_cast<const float4*>(scratch(0));
         a.raw[m * (C + 1) + C] = ((p.x + p.y) + (p.z + p.w)) + a.b_alpha[0];
@@ -245,8 +257,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_split_kernel(FwdArgs a) {
         gemm_stage<18, 1>(Th, Tl, 0, a.packed + pack_offset(PF_VIEWS), wave, lane, av1, av2);
         lds_barrier();
         const uint64_t bits = epilogue<1, true, SAVE, ACT_HV_W>(av1, av2, Th, Tl, wave, lane, a.bias[BENERF_L_VIEWS],
-                                                                SAVE ? reinterpret_cast<_Float16*>(acts + sact_hv(Mp)) : nullptr, m0);
-        if (SAVE) mask_out[8 * mask_stride] = bits;     // bit r*16 + e: element e of row tile r, column tile = wave
+                                                                SAVE ? reinterpret_cast<_Float16*>(acts + sact_hv(Mp)) : nullptr, m0, amax);
+        if (SAVE) {
+            mask_out[8 * mask_stride] = bits;     // bit r*16 + e: element e of row tile r, column tile = wave
+        }
     }
     lds_barrier();
 
@@ -270,6 +284,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_split_kernel(FwdArgs a) {
 #pragma unroll
         for (int c = 0; c < C; ++c) scratch(1 + c)[grp] = s[c];
     }
+    if (SAVE) publish_absmax(amax, absmax);
     lds_barrier();
     if (tid < 64 && live) {
 #pragma unroll
@@ -308,6 +323,11 @@ extern "C" int benerf_mlp_fwd_split(const BenerfMlpParams* params, const float* 
     a.S = n_samples;
     const int64_t tiles = (a.M + mlp::TM - 1) / mlp::TM;
     BENERF_REQUIRE(tiles < (1ll << 31), "mlp_fwd_split: too many points");
+    if (acts && hipMemsetAsync(acts + mlp::sact_absmax(a.M), 0, mlp::AX_COUNT * sizeof(float), as_stream(stream)) != hipSuccess) {
+        benerf_set_error("mlp_fwd_split: memset failed");
+        return BENERF_EHIP;
+    }
+
     dim3 grid((unsigned)tiles), block(mlp::NTHREADS);
     const int smem = (int)mlp::TILE_SMEM;
     static bool attr_done = false;
@@ -326,5 +346,6 @@ extern "C" int benerf_mlp_fwd_split(const BenerfMlpParams* params, const float* 
         else hipLaunchKernelGGL((mlp_fwd_split_kernel<3, false>), grid, block, smem, as_stream(stream), a);
     }
     BENERF_LAUNCH_CHECK("mlp_fwd_split");
+    if (acts) return mlp::absmax_reduce_launch(acts + mlp::sact_absmax_table(a.M), tiles * 4, acts + mlp::sact_absmax(a.M) + mlp::AX_ALL, as_stream(stream));
     return BENERF_OK;
 }

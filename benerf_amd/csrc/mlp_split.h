@@ -205,15 +205,16 @@ __host__ __device__ inline int64_t sact_feat(int64_t Mp) { return sact_h(Mp, 8);
 __host__ __device__ inline int64_t sact_hv(int64_t Mp) { return sact_feat(Mp) + Mp * 256; }       // ST W = 128
 __host__ __device__ inline int64_t sact_mask(int64_t Mp) { return sact_hv(Mp) + Mp * ACT_HV_W; }  // uint64 [9][tiles][256]
 __host__ __device__ inline int64_t sact_total_floats(int64_t M) {
-    return sact_mask(m_pad(M)) + (int64_t)SACT_MASK_LAYERS * n_tiles(M) * NTHREADS * 2;
+    return sact_mask(m_pad(M)) + (int64_t)SACT_MASK_LAYERS * n_tiles(M) * NTHREADS * 2 + 16 + n_tiles(M) * 4;   // + absmax slots + per-wave table
 }
-// activation gradients: ST arrays holding dY * s_g (s_g = global power-of-two scale of this backward call), then
-// max |d_raw| of the call (one float; s_g = pow2_scale of it)
+// activation gradients: ST arrays holding dY * s_g (s_g = power-of-two scale of this backward call from max|d_raw|),
+// then 16 absmax slots: [0] max|d_raw|, [1..10] max|dY * s_g| of every array (see 'dW operand formats')
 __host__ __device__ inline int64_t sdact_h(int64_t Mp, int l) { return (int64_t)l * Mp * 256; }
 __host__ __device__ inline int64_t sdact_feat(int64_t Mp) { return 8 * Mp * 256; }
 __host__ __device__ inline int64_t sdact_hv(int64_t Mp) { return 9 * Mp * 256; }
 __host__ __device__ inline int64_t sdact_scale(int64_t Mp) { return 9 * Mp * 256 + Mp * ACT_HV_W; }
-__host__ __device__ inline int64_t sdact_total_floats(int64_t M) { return sdact_scale(m_pad(M)) + 16; }
+__host__ __device__ inline int64_t sdact_absmax_table(int64_t Mp) { return sdact_scale(Mp) + 16; }                      // [tiles][4 waves][16 stages]
+__host__ __device__ inline int64_t sdact_total_floats(int64_t M) { return sdact_scale(m_pad(M)) + 16 + n_tiles(M) * 64; }
 
 // power-of-two scale s = 2^(-4 - exponent(mx)) that brings values of magnitude <= mx to <= 2^-3, and its inverse
 __device__ __forceinline__ void pow2_scale(float mx, float& s, float& inv_s) {
@@ -222,6 +223,57 @@ __device__ __forceinline__ void pow2_scale(float mx, float& s, float& inv_s) {
     s = __uint_as_float((uint32_t)(250 - be) << 23);
     inv_s = __uint_as_float((uint32_t)(be + 4) << 23);
 }
+// ---- dW operand formats ---------------------------------------------------------------------------------------
+// The dW kernels add the three products of a block (hi*hi, hi*lo, lo*hi) into ONE accumulator set - that is what lets
+// a workgroup hold a whole 256x256 output block and read every operand byte once.  It needs the lo parts UNSCALED
+// (x = hi + lo), i.e. operands scaled so that lo stays inside f16's range for every element that matters.  The
+// stored ST arrays keep the robust (hi, lo * 2^11) form; the forward / dX kernels also publish max|value| of every
+// value they save (one running maximum per wave -> table -> absmax_reduce_kernel -> absmax slot), and the dW kernel
+// rescales each unit while staging it into LDS:  hi' = hi * 2^k,  lo' = lo * 2^(k-11)  with k = 14 - exponent(absmax),
+// one k for all activation arrays of the forward launch and one for all gradient arrays of the backward launch
+// (they are all of one order of magnitude), so the largest stored element lands in [2^14, 2^15).  Both are exact powers of two (two packed-f16 multiplies each,
+// every factor inside f16's range); elements down to 2^-17 of the maximum keep a normal lo', smaller ones an
+// absolute floor of 2^-38 of the maximum.  The reduce kernel multiplies by 2^-(kY + kX) (and 1/s_g for dY).
+// absmax slots: acts buffer [AX_ALL] = max |saved activation|; dacts buffer [AY_DRAW] = max|d_raw|, [AY_ALL] = max
+// |stored gradient| (at the stored scale dY * s_g)
+enum { AX_ALL = 0, AX_COUNT = 16 };
+enum { AY_DRAW = 0, AY_ALL = 1, AY_COUNT = 16 };
+__host__ __device__ inline int64_t sact_absmax(int64_t M) {
+    return sact_mask(m_pad(M)) + (int64_t)SACT_MASK_LAYERS * n_tiles(M) * NTHREADS * 2;
+}
+__host__ __device__ inline int64_t sact_absmax_table(int64_t M) { return sact_absmax(M) + AX_COUNT; }   // [tiles][4 waves]
+// k = 14 - exponent(mx), clamped so that 2^k and 2^(k-11) are products of two f16-representable powers of two
+__device__ __forceinline__ int rescale_exp(float mx) {
+    const int be = (int)((__float_as_uint(mx) >> 23) & 0xffu);
+    if (be == 0) return 0;
+    int k = 14 - (be - 127);
+    return k < -14 ? -14 : (k > 30 ? 30 : k);
+}
+__device__ __forceinline__ float exp2i(int k) { return __uint_as_float((uint32_t)(127 + k) << 23); }   // 2^k, |k| <= 126
+// wave-wide max of non-negative values on the VALU (DPP row shifts + broadcasts, no LDS traffic); result in lane 63
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_max_step(float v) {
+    const int o = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false);
+    return fmaxf(v, __builtin_bit_cast(float, o));
+}
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+    v = dpp_max_step<0x111, 0xf>(v);   // row_shr:1
+    v = dpp_max_step<0x112, 0xf>(v);   // row_shr:2
+    v = dpp_max_step<0x114, 0xf>(v);   // row_shr:4
+    v = dpp_max_step<0x118, 0xf>(v);   // row_shr:8
+    v = dpp_max_step<0x142, 0xa>(v);   // row_bcast:15 -> rows 1, 3
+    v = dpp_max_step<0x143, 0xc>(v);   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+// one plain store per wave into a [tile][wave] table (no atomics: thousands of workgroups hammering one address
+// serialise in L2; no read-compare: it would make the wave wait for all its outstanding stores).
+// absmax_reduce_kernel folds the table into the slot after the kernel.
+__device__ __forceinline__ void publish_absmax(float mx, float* wave_entry) {
+    mx = wave_max_nonneg(mx);
+    if ((threadIdx.x & 63) == 63) *wave_entry = mx;
+}
+__global__ void absmax_reduce_kernel(const float* __restrict__ table, int64_t n, float* __restrict__ slot);
+int absmax_reduce_launch(const float* table, int64_t n, float* slot, hipStream_t stream);
 
 // 4 consecutive points (one accumulator quad) of one feature -> one 16-byte piece {hi x4, lo x4} of an ST array;
 // `index` = st_half_index of the quad's first point, plane 0

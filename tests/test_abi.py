@@ -31,10 +31,11 @@ def test_size_queries(lib):
     # sized for either arithmetic mode: the split mode pads to whole 64-point tiles, keeps PE / PE(dir) twice
     # (f32 rows + ST operand copy) and 9 layers of ReLU sign-bit words
     per_point = 2 * (64 + 32) + 8 * 256 + 256 + 128
-    assert lib.benerf_mlp_act_floats(640) == 640 * per_point + 9 * 10 * 256 * 2
-    assert lib.benerf_mlp_act_floats(641) == 704 * per_point + 9 * 11 * 256 * 2
+    # + ReLU sign-bit words + 16 absmax slots + per-wave absmax table [tiles][4]
+    assert lib.benerf_mlp_act_floats(640) == 640 * per_point + 9 * 10 * 256 * 2 + 16 + 10 * 4
+    assert lib.benerf_mlp_act_floats(641) == 704 * per_point + 9 * 11 * 256 * 2 + 16 + 11 * 4
     assert lib.benerf_mlp_dact_floats_per_point() == 8 * 256 + 256 + 128
-    assert lib.benerf_mlp_dact_floats(641) == 704 * (8 * 256 + 256 + 128) + 16
+    assert lib.benerf_mlp_dact_floats(641) == 704 * (8 * 256 + 256 + 128) + 16 + 11 * 64
     assert lib.benerf_mlp_packed_floats() > 2 * 593920 - 200000
     assert lib.benerf_mlp_dw_workspace_floats(1000) > 0
 
