@@ -61,14 +61,23 @@ __device__ __forceinline__ f32x16 gemm_one(const _Float16* __restrict__ Th, cons
     return a1;
 }
 
-// dY = (acc1 + acc2 * 2^-11) masked by the forward pass' ReLU sign bits -> both planes (tile scale) and, times
-// gf = s_g / s_tile, the ST gradient array `st` (W = 256; m0 = first point of the tile).
+// {hi x4, lo x4} * s (packed f16)
+__device__ __forceinline__ uint4 scale_quad(const Quad16x2& q, _Float16 s) {
+    const half8 v = __builtin_bit_cast(half8, q) * half8{s, s, s, s, s, s, s, s};
+    return __builtin_bit_cast(uint4, v);
+}
+
+// dY = (acc1 + acc2 * 2^-11) masked by the forward pass' ReLU sign bits -> both planes (tile scale) and, as the SAME
+// hi / lo halfs times gf = 2^8 s_g / s_tile (a power of two <= 2^8: four packed-f16 multiplies per quad, exact unless the
+// result is subnormal, i.e. 2^-18 below the call's largest gradient), the ST gradient array `st` (W = 256; m0 = first
+// point of the tile).
 template <bool MASK>
 __device__ __forceinline__ void epilogue(f32x16 (&acc1)[2][2], f32x16 (&acc2)[2][2], uint64_t bits, _Float16* __restrict__ Th,
                                          _Float16* __restrict__ Tl, int ct0, int lane, _Float16* __restrict__ st, int64_t m0,
                                          float gf, float* __restrict__ absmax_entry) {
     const int lr = lane & 31, r4 = 4 * (lane >> 5);
-    float amax = 0.f;          // max |stored value| of this stage (live only inside the epilogue: the kernel is at the
+    const _Float16 gfh = (_Float16)gf;
+    float amax = 0.f;          // max |value| of this stage (live only inside the epilogue: the kernel is at the
                                // register limit, a running maximum across the GEMMs cost 35 extra spills)
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -82,20 +91,25 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc1)[2][2], f32x16 (&acc2)[2]
         for (int r = 0; r < 2; ++r)
 #pragma unroll
             for (int eq = 0; eq < 4; ++eq) {
-                float vg[4];
+                Quad16x2 q;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int e = eq * 4 + j;
                     float v = acc1[r][c][e] + acc2[r][c][e] * LO_INV;
                     if (MASK) v = ((bits >> ((c * 2 + r) * 16 + e)) & 1ull) ? v : 0.f;
-                    split_store(Th, Tl, base[((e >> 1) & 1) | (((e >> 2) & 1) << 1)] + (r * 32 + (e & 3) + 8 * (e >> 2)) * LD, v);
-                    vg[j] = v * gf;
-                    amax = fmaxf(amax, fabsf(vg[j]));
+                    amax = fmaxf(amax, fabsf(v));
+                    const _Float16 hi = (_Float16)v;
+                    const _Float16 lo = (_Float16)((v - (float)hi) * LO_SCALE);
+                    const int idx = base[((e >> 1) & 1) | (((e >> 2) & 1) << 1)] + (r * 32 + (e & 3) + 8 * (e >> 2)) * LD;
+                    Th[idx] = hi;
+                    Tl[idx] = lo;
+                    q.hi.v[j] = hi;
+                    q.lo.v[j] = lo;
                 }
-                st_store_quad(st_lane, (int64_t)(r * 4 + eq) * 256 * 16, vg);
+                *reinterpret_cast<uint4*>(st_lane + (int64_t)(r * 4 + eq) * 256 * 16) = scale_quad(q, gfh);
             }
     }
-    publish_absmax(amax, absmax_entry);
+    publish_absmax(amax * gf, absmax_entry);
 }
 
 template <int C>
@@ -145,7 +159,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_split_kernel(BwdArgs a) {
     }
     lds_barrier();
     const float inv_s = *fscr(Th, Tl, 0, 56);
-    const float gf = s_g * inv_s;            // tile scale -> scale of the stored dY (power of two)
+    const float gf = s_g * inv_s * DY_STORE_BOOST;   // tile scale -> scale of the stored dY (power of two <= 2^8)
 
     // ---- P1: rgb layer backward + ReLU mask of the views layer -> dYv in planes[:,0:128), accumulator layout ----
     // thread <-> (column wave*32 + lane&31, rows r*32 + acc_row(e)): the hv sign bits the forward pass saved for
@@ -162,7 +176,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_split_kernel(BwdArgs a) {
         for (int r = 0; r < 2; ++r)
 #pragma unroll
             for (int eq = 0; eq < 4; ++eq) {
-                float vg[4];
+                Quad16x2 q;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int e = eq * 4 + j;
@@ -173,13 +187,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_split_kernel(BwdArgs a) {
 #pragma unroll
                     for (int c = 0; c < C; ++c) g += drv[c] * wr[c];
                     const float v = ((hvbits >> (r * 16 + e)) & 1ull) ? g : 0.f;
-                    split_store(Th, Tl, hidx(p, col), v);
-                    vg[j] = v * gf;
-                    amax = fmaxf(amax, fabsf(vg[j]));
+                    amax = fmaxf(amax, fabsf(v));
+                    const _Float16 hi = (_Float16)v;
+                    const _Float16 lo = (_Float16)((v - (float)hi) * LO_SCALE);
+                    const int idx = hidx(p, col);
+                    Th[idx] = hi;
+                    Tl[idx] = lo;
+                    q.hi.v[j] = hi;
+                    q.lo.v[j] = lo;
                 }
-                st_store_quad(st_lane, (int64_t)(r * 4 + eq) * ACT_HV_W * 16, vg);
+                *reinterpret_cast<uint4*>(st_lane + (int64_t)(r * 4 + eq) * ACT_HV_W * 16) = scale_quad(q, (_Float16)gf);
             }
-        publish_absmax(amax, absmax_row + 9);
+        publish_absmax(amax * gf, absmax_row + 9);
     }
     lds_barrier();
 

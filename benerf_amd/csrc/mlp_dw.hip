@@ -290,7 +290,7 @@ __device__ __forceinline__ float unscale_of(const float* absmax_y, const float* 
     float s_g, inv_s_g;
     pow2_scale(absmax_y[AY_DRAW], s_g, inv_s_g);
     const int k = rescale_exp(absmax_y[AY_ALL]) + (bias ? 0 : rescale_exp(absmax_x[AX_ALL]));
-    return inv_s_g * exp2i(-k);
+    return inv_s_g * (1.f / DY_STORE_BOOST) * exp2i(-k);
 }
 #define sum_splits(ws, inst, elem) (sum_splits_t<SPLIT>(ws, inst, elem) * unscale_of<SPLIT>(a.absmax_y, a.absmax_x, inst, false))
 #define sum_bias(ws, inst, elem) (sum_splits_t<SPLIT>(ws, inst, elem) * unscale_of<SPLIT>(a.absmax_y, a.absmax_x, inst, true))

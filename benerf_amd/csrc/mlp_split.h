@@ -223,6 +223,10 @@ __device__ __forceinline__ void pow2_scale(float mx, float& s, float& inv_s) {
     s = __uint_as_float((uint32_t)(250 - be) << 23);
     inv_s = __uint_as_float((uint32_t)(be + 4) << 23);
 }
+// The dX chain works at 2^-4 (head room for growth through the layers); the dY arrays it STORES sit 2^8 higher
+// (max|d_raw| in [2^4, 2^5)): the tile -> call factor is then a power of two <= 2^8 applied to the f16 halfs, which
+// stays exact for every element down to 2^-18 of the call's largest gradient.
+constexpr float DY_STORE_BOOST = 256.f;
 // ---- dW operand formats ---------------------------------------------------------------------------------------
 // The dW kernels add the three products of a block (hi*hi, hi*lo, lo*hi) into ONE accumulator set - that is what lets
 // a workgroup hold a whole 256x256 output block and read every operand byte once.  It needs the lo parts UNSCALED
