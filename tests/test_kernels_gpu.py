@@ -379,6 +379,40 @@ def test_mlp_modes_agree_at_full_size(K):
             assert float((x - y).norm() / y.norm()) < 3e-3
 
 
+@pytest.mark.parametrize("wscale,gscale", [(3.0, 1.0), (0.35, 1e-12), (1.0, 1e6)])
+def test_mlp_split_operand_rescale_ranges(K, wscale, gscale):
+    """The split dW kernels rescale activations and gradients by per-launch powers of two (from published maxima) so
+    that the lo parts can be used unscaled.  Activations of very different magnitude (weights x3: hidden values in the
+    hundreds; x0.35: 1e-3) and gradients from 1e-12 to 1e6 must give the same weight gradients as the exact-f32 mode."""
+    rng = np.random.default_rng(81)
+    C, N, S = 3, 96, 64
+    p = {k: (v * wscale if k.endswith("weight") and not k.startswith(("rgb", "alpha")) else v) for k, v in _params_for(rng, C, "trained").items()}
+    net = _packed(K, p, C)
+    ro = dev(GI.f32(rng.uniform(-0.5, 0.5, (N, 3))))
+    rd = dev(GI.f32(rng.uniform(-1, 1, (N, 3))))
+    vd = GI.f32(rng.standard_normal((N, 3)))
+    vd = dev(vd / vd.norm(dim=-1, keepdim=True))
+    z = dev(GI.f32(np.sort(rng.random((N, S)), -1)))
+    G = dev(GI.f32(rng.standard_normal((N * S, C + 1)) * np.exp(rng.uniform(-5, 0, (N * S, 1))) * gscale))
+    out = {}
+    for mode in ("f32", "split"):
+        K.set_mlp_precision(mode)
+        raw, acts = K.mlp_fwd(net, ro, rd, vd, z, True)
+        gw = [torch.zeros_like(w) for w in net.weights]
+        gb = [torch.zeros_like(b) for b in net.biases]
+        K.mlp_bwd(net, G, acts, N, S, gw, gb, False)
+        out[mode] = (raw.clone(), gw, gb)
+    K.set_mlp_precision("split")
+    print("max |raw| = %.3g" % float(out["f32"][0].abs().max()))
+    assert torch.isfinite(out["split"][0]).all()
+    for i, name in enumerate(K.LAYER_NAMES):
+        for kind, x, y in (("weight", out["split"][1][i], out["f32"][1][i]), ("bias", out["split"][2][i], out["f32"][2][i])):
+            assert torch.isfinite(x).all(), name
+            rel = float((x - y).norm() / y.norm())
+            print("rescale ranges w x%g, g x%g: d%s.%s relative L2 %.2e" % (wscale, gscale, name, kind, rel))
+            assert rel < 3e-3, (name, kind, rel)      # ReLU-kink flips included (test_mlp_modes_agree_at_full_size)
+
+
 def test_sample_pixels_without_replacement(K):
     """np.random.choice(H*W, N, replace=False) stand-in: distinct, in range, deterministic, roughly uniform."""
     n = 480 * 768
