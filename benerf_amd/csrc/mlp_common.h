@@ -160,8 +160,8 @@ __host__ __device__ constexpr int dwh_splits(int inst) {
         default: return 30;
     }
 }
-constexpr int DWH_PAIR_BLOCKS = 8 * 30;
-constexpr int DWH_BIG_BLOCKS = DWH_PAIR_BLOCKS + 16;
+constexpr int DWH_FULL_BLOCKS = 8 * 30;
+constexpr int DWH_BIG_BLOCKS = DWH_FULL_BLOCKS + 16;
 constexpr int DWH_SMALL_BLOCKS = 4 * 64;
 __host__ __device__ constexpr int64_t dwh_inst_offset(int inst) {
     int64_t o = 0;

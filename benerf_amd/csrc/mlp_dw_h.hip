@@ -7,7 +7,7 @@
 // image [block][plane][feature][8 points] (each unit lands as two 8-byte quads; conflict-free fragment reads, no
 // transposition pass) with three chunks in flight in registers and one LDS-only barrier per chunk.
 // The three products of a block go into ONE accumulator set: while staging, every operand unit is rescaled by its
-// array's power of two so that its lo part can be used UNSCALED ('dW operand formats', mlp_split.h).
+// launch-wide power of two so that its lo part can be used UNSCALED ('dW operand formats', mlp_split.h).
 // With one set a workgroup holds a whole 256 x 256 output block (128 accumulator registers x 8 waves), so every
 // operand byte is read exactly once: HBM traffic = the algorithmic bytes.  (With two accumulator sets the block was
 // 256 x 128 and dY was streamed twice: 13.3 GB against 9.4 GB of operands per launch at M = 522k.)
@@ -378,12 +378,12 @@ __global__ __launch_bounds__(DWT, 2) void mlp_dw_split_big_kernel(DwArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32x4 smem_u[];
     const int id = blockIdx.x;
     int inst, split;
-    if (id < DWH_PAIR_BLOCKS) {
+    if (id < DWH_FULL_BLOCKS) {
         inst = id / dwh_splits(DW_L1);    // DW_L1 .. DW_FEAT
         split = id % dwh_splits(DW_L1);
     } else {
         inst = DW_VIEWSF;
-        split = id - DWH_PAIR_BLOCKS;
+        split = id - DWH_FULL_BLOCKS;
     }
     int64_t cb, ce;
     chunk_range(a, inst, split, cb, ce);
