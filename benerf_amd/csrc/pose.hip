@@ -271,11 +271,10 @@ __global__ void spline_fwd_kernel(const float* __restrict__ knots, const float* 
 
 // one block; thread (p, j): tangent of pose p w.r.t. effective-knot coefficient j (0..23);
 // contrib[p][j] = <d_poses[p], tangent>; then j-threads sum over p in index order.
-__global__ void spline_bwd_kernel(const float* __restrict__ knots, const float* __restrict__ transform,
-                                  const float* __restrict__ ts2, int n_poses, int traj, int explicit_ts,
-                                  const float* __restrict__ d_poses, float* __restrict__ d_knots,
-                                  float* __restrict__ d_transform) {
-    extern __shared__ float contrib[];   // [n_poses][24]
+__device__ __forceinline__ void spline_bwd_body(const float* __restrict__ knots, const float* __restrict__ transform,
+                                                const float* __restrict__ ts2, int n_poses, int traj, int explicit_ts,
+                                                const float* __restrict__ d_poses, float* __restrict__ d_knots,
+                                                float* __restrict__ d_transform, float* contrib) {
     for (int w = threadIdx.x; w < n_poses * 24; w += blockDim.x) {
         int p = w / 24, j = w % 24;
         Dual k[4][6];
@@ -309,6 +308,30 @@ __global__ void spline_bwd_kernel(const float* __restrict__ knots, const float* 
     }
 }
 
+__global__ void spline_bwd_kernel(const float* __restrict__ knots, const float* __restrict__ transform,
+                                  const float* __restrict__ ts2, int n_poses, int traj, int explicit_ts,
+                                  const float* __restrict__ d_poses, float* __restrict__ d_knots,
+                                  float* __restrict__ d_transform) {
+    extern __shared__ float contrib[];   // [n_poses][24]
+    spline_bwd_body(knots, transform, ts2, n_poses, traj, explicit_ts, d_poses, d_knots, d_transform, contrib);
+}
+
+// the two trajectories of a training step (event camera: no transform; RGB camera: knots + transform) as the two
+// blocks of ONE launch - each is a single block bound by the latency of the dual-number evaluation
+struct SplinePair {
+    const float* ts[2];
+    const float* d_poses[2];
+    float* d_knots[2];
+    int n_poses[2];
+};
+__global__ void spline_bwd_pair_kernel(const float* __restrict__ knots, const float* __restrict__ transform_b, SplinePair p,
+                                       int traj, float* __restrict__ d_transform_b) {
+    extern __shared__ float contrib[];
+    const int b = blockIdx.x;
+    spline_bwd_body(knots, b ? transform_b : nullptr, p.ts[b], p.n_poses[b], traj, 0, p.d_poses[b], p.d_knots[b],
+                    b ? d_transform_b : nullptr, contrib);
+}
+
 }  // namespace
 
 extern "C" int benerf_spline_poses_fwd(const float* knots, const float* transform, const float* ts2, int n_poses,
@@ -335,5 +358,26 @@ extern "C" int benerf_spline_poses_bwd(const float* knots, const float* transfor
     hipLaunchKernelGGL(spline_bwd_kernel, dim3(1), dim3(threads), smem, as_stream(stream), knots, transform, ts2, n_poses,
                        traj, explicit_ts, d_poses, d_knots, d_transform);
     BENERF_LAUNCH_CHECK("spline_poses_bwd");
+    return BENERF_OK;
+}
+
+extern "C" int benerf_spline_poses_bwd_pair(const float* knots, const float* transform_b, const float* ts_a, int n_a,
+                                            const float* ts_b, int n_b, int traj, const float* d_poses_a,
+                                            const float* d_poses_b, float* d_knots_a, float* d_knots_b, float* d_transform_b,
+                                            benerf_stream_t stream) {
+    BENERF_REQUIRE(knots && transform_b && ts_a && ts_b && d_poses_a && d_poses_b && d_knots_a && d_knots_b && d_transform_b,
+                   "spline_poses_bwd_pair: null pointer");
+    BENERF_REQUIRE(n_a > 0 && n_a <= 512 && n_b > 0 && n_b <= 512 && (traj == 0 || traj == 1), "spline_poses_bwd_pair: bad sizes");
+    const int n_max = n_a > n_b ? n_a : n_b;
+    int threads = ((n_max * 24 + 63) / 64) * 64;
+    if (threads > 1024) threads = 1024;
+    SplinePair p;
+    p.ts[0] = ts_a; p.ts[1] = ts_b;
+    p.d_poses[0] = d_poses_a; p.d_poses[1] = d_poses_b;
+    p.d_knots[0] = d_knots_a; p.d_knots[1] = d_knots_b;
+    p.n_poses[0] = n_a; p.n_poses[1] = n_b;
+    hipLaunchKernelGGL(spline_bwd_pair_kernel, dim3(2), dim3(threads), (size_t)n_max * 24 * sizeof(float), as_stream(stream), knots,
+                       transform_b, p, traj, d_transform_b);
+    BENERF_LAUNCH_CHECK("spline_poses_bwd_pair");
     return BENERF_OK;
 }

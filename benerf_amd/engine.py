@@ -393,8 +393,7 @@ class TrainStep:
         K.ray_grad_reduce(z, d_pts, d_vp, d_o, d_d, d_v, True)
         dp_e = K.rays_bwd(poses_e, idx_e, ce.H, ce.W, ce.fx, ce.fy, ce.cx, ce.cy, cfg.ndc, d_o[:Ne], d_d[:Ne], d_v[:Ne])
         dp_r = K.rays_bwd(poses_r, idx_r, cr.H, cr.W, cr.fx, cr.fy, cr.cx, cr.cy, cfg.ndc, d_o[Ne:], d_d[Ne:], d_v[Ne:])
-        dk_e, _ = K.spline_poses_bwd(self.knots, None, evt_ts2, 2, traj, dp_e)
-        dk_r, dt_r = K.spline_poses_bwd(self.knots, self.transform.view(6), rgb_ts2, P, traj, dp_r)
+        dk_e, dk_r, dt_r = K.spline_poses_bwd_pair(self.knots, self.transform.view(6), evt_ts2, 2, rgb_ts2, P, traj, dp_e, dp_r)
         torch.add(dk_e, dk_r, out=self.g_knots)
         self.g_transform.copy_(dt_r)
 

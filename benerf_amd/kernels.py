@@ -68,6 +68,17 @@ def spline_poses_bwd(knots, transform, ts, n_poses, traj, d_poses, explicit_ts=F
     return d_knots, d_tr
 
 
+def spline_poses_bwd_pair(knots, transform_b, ts_a, n_a, ts_b, n_b, traj, d_poses_a, d_poses_b):
+    """Both trajectory backward passes of a step in one launch -> (d_knots_a, d_knots_b, d_transform_b)."""
+    lib = _lib.load()
+    dk_a, dk_b, dt_b = _new((4, 6), knots), _new((4, 6), knots), _new((1, 6), knots)
+    _lib.check(lib.benerf_spline_poses_bwd_pair(_chk(knots), _chk(transform_b), _chk(ts_a), n_a, _chk(ts_b), n_b, traj,
+                                                _chk(d_poses_a, name="d_poses_a"), _chk(d_poses_b, name="d_poses_b"),
+                                                dk_a.data_ptr(), dk_b.data_ptr(), dt_b.data_ptr(), _stream()),
+               "spline_poses_bwd_pair")
+    return dk_a, dk_b, dt_b
+
+
 # ----------------------------------------------------------------------------- K2 rays
 def rays_fwd(poses, ray_idx, H, W, fx, fy, cx, cy, ndc=True, out=None):
     lib = _lib.load()

@@ -56,6 +56,12 @@ int benerf_spline_poses_fwd(const float* knots, const float* transform, const fl
 int benerf_spline_poses_bwd(const float* knots, const float* transform, const float* ts,
                             int n_poses, int traj, int explicit_ts, const float* d_poses,
                             float* d_knots, float* d_transform, benerf_stream_t stream);
+/* The two trajectory backward passes of one training step (a: event camera, no transform; b: RGB camera with
+ * transform; both linspace timestamps) as one launch.  Same results as two benerf_spline_poses_bwd calls. */
+int benerf_spline_poses_bwd_pair(const float* knots, const float* transform_b, const float* ts_a, int n_a,
+                                 const float* ts_b, int n_b, int traj, const float* d_poses_a,
+                                 const float* d_poses_b, float* d_knots_a, float* d_knots_b,
+                                 float* d_transform_b, benerf_stream_t stream);
 
 /* ---------------------------------------------------------------- K2: rays --------- */
 /* Pinhole ray generation (pose-major, N = n_poses*n_pix), view directions and LLFF NDC.

@@ -52,6 +52,20 @@ def test_spline_fwd_bwd_golden(K, golden):
     print("K1 worst pose error", worst)
 
 
+def test_spline_bwd_pair_equals_two_calls(K):
+    """The fused launch for the two trajectories of a training step gives exactly the two separate calls."""
+    rng = np.random.default_rng(5)
+    knots = dev(GI.knots_init(rng) * 3)
+    tr = dev(GI.f32(rng.uniform(-0.02, 0.02, (6,))))
+    ts_a, ts_b = dev(GI.f32([0.2, 0.35])), dev(GI.f32([0.0, 1.0]))
+    dp_a, dp_b = dev(GI.f32(rng.standard_normal((2, 3, 4)))), dev(GI.f32(rng.standard_normal((19, 3, 4))))
+    for traj in (0, 1):
+        ka, _ = K.spline_poses_bwd(knots, None, ts_a, 2, traj, dp_a)
+        kb, tb = K.spline_poses_bwd(knots, tr, ts_b, 19, traj, dp_b)
+        pa, pb, ptb = K.spline_poses_bwd_pair(knots, tr, ts_a, 2, ts_b, 19, traj, dp_a, dp_b)
+        assert torch.equal(ka, pa) and torch.equal(kb, pb) and torch.equal(tb, ptb)
+
+
 def test_spline_no_transform(K):
     rng = np.random.default_rng(5)
     knots = GI.knots_init(rng)
