@@ -53,17 +53,6 @@ __device__ __forceinline__ Src inst_src(const DwArgs& a, int inst) {
     }
 }
 
-__device__ __forceinline__ float sum8(u32x4 hi, u32x4 lo) {
-    const half8 h = __builtin_bit_cast(half8, hi), l = __builtin_bit_cast(half8, lo);
-    float s = 0.f, t = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        s += (float)h[j];
-        t += (float)l[j];
-    }
-    return s + t * LO_INV;
-}
-
 // Output block N x K (the whole instance: K = width of X).  Waves form a WN x (8/WN) grid; each owns TR x TC MFMA
 // tiles in ONE accumulator set: per 16-point chunk (= one MFMA k-step) acc += Yh Xh + Yh Xl + Yl Xh with unscaled
 // lo parts (mlp_split.h, 'dW operand formats').  Three chunks are in flight in registers (sets A, B, C) and the LDS

@@ -14,12 +14,6 @@ __device__ __forceinline__ int hsw(int row) { return (row >> 1) & 7; }
 // half index of element (row, col) inside a plane
 __device__ __forceinline__ int hidx(int row, int col) { return row * LD + ((((col >> 3) ^ hsw(row)) << 3) | (col & 7)); }
 
-__device__ __forceinline__ void split_store(_Float16* __restrict__ Th, _Float16* __restrict__ Tl, int idx, float v) {
-    const _Float16 hi = (_Float16)v;
-    Th[idx] = hi;
-    Tl[idx] = (_Float16)((v - (float)hi) * LO_SCALE);
-}
-
 __device__ __forceinline__ f32x16 mfma16(half8 a, half8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
@@ -27,7 +21,7 @@ __device__ __forceinline__ f32x16 mfma16(half8 a, half8 b, f32x16 c) {
 // acc1 += hi x hi ; acc2 += hi x lo + lo x hi   over T[:, kcol0 .. kcol0 + KS*16) and packed tile ct0+c.
 // Weight fragments stream from L2 PF k-steps ahead (a k-step is only 12 MFMAs = 384 cycles, less than an L2 round
 // trip under load); the loop is fully unrolled so the PF+1 register sets rotate at compile time.
-template <int KS, int NCT, int PF = 2, bool APF = true>
+template <int KS, int NCT, int PF = 2>
 __device__ __forceinline__ void gemm_stage(const _Float16* __restrict__ Th, const _Float16* __restrict__ Tl, int kcol0,
                                            const float* __restrict__ wp, int ct0, int lane, f32x16 (&acc1)[2][NCT],
                                            f32x16 (&acc2)[2][NCT]) {
@@ -72,10 +66,9 @@ __device__ __forceinline__ void gemm_stage(const _Float16* __restrict__ Th, cons
         an[1][0] = *reinterpret_cast<const half8*>(Tl + off);
         an[1][1] = *reinterpret_cast<const half8*>(Tl + off + 32 * LD);
     };
-    if (APF) load_a(0);
+    load_a(0);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-        if (!APF) load_a(ks);
         half8 ah[2] = {an[0][0], an[0][1]}, al[2] = {an[1][0], an[1][1]};
         if (ks + PF < KS) {
 #pragma unroll
@@ -84,7 +77,7 @@ __device__ __forceinline__ void gemm_stage(const _Float16* __restrict__ Th, cons
                 bq[(ks + PF) % (PF + 1)][c][1] = load_b(c, ks + PF, 1);
             }
         }
-        if (APF && ks + 1 < KS) load_a(ks + 1);
+        if (ks + 1 < KS) load_a(ks + 1);
         half8 bh[NCT], bl[NCT];
 #pragma unroll
         for (int c = 0; c < NCT; ++c) {
@@ -279,19 +272,9 @@ __device__ __forceinline__ void publish_absmax(float mx, float* wave_entry) {
 __global__ void absmax_reduce_kernel(const float* __restrict__ table, int64_t n, float* __restrict__ slot);
 int absmax_reduce_launch(const float* table, int64_t n, float* slot, hipStream_t stream);
 
-// 4 consecutive points (one accumulator quad) of one feature -> one 16-byte piece {hi x4, lo x4} of an ST array;
-// `index` = st_half_index of the quad's first point, plane 0
+// 4 consecutive points (one accumulator quad) of one feature = one 16-byte piece {hi x4, lo x4} of an ST array
 struct Quad16 { _Float16 v[4]; };
 struct Quad16x2 { Quad16 hi, lo; };
-__device__ __forceinline__ void st_store_quad(_Float16* __restrict__ base, int64_t index, const float (&v)[4]) {
-    Quad16x2 q;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        q.hi.v[j] = (_Float16)v[j];
-        q.lo.v[j] = (_Float16)((v[j] - (float)q.hi.v[j]) * LO_SCALE);
-    }
-    *reinterpret_cast<uint4*>(base + index) = __builtin_bit_cast(uint4, q);
-}
 
 // f32 scratch inside the planes' PE columns [256,320): 64 floats per row, floats [0,32) in the hi plane, [32,64)
 // in the lo plane (slot 32 + i/4 of the plane, swizzled like everything else).
