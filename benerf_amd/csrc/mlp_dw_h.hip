@@ -33,7 +33,7 @@ struct DwArgs {
 
 struct Src {
     const u32x4* y;    // ST array of width N (16-byte units)
-    const u32x4* x;    // ST array of width XW
+    const u32x4* x;    // ST array of width K ... or, for the thin instances (XROWS), f32 rows [Mp][K]
     bool bias;
 };
 
@@ -47,9 +47,9 @@ __device__ __forceinline__ Src inst_src(const DwArgs& a, int inst) {
             return {U(D + sdact_h(Mp, 1 + (inst - DW_L1))), U(A + sact_h(Mp, inst - DW_L1)), true};
         case DW_FEAT: return {U(D + sdact_feat(Mp)), U(A + sact_h(Mp, 7)), true};
         case DW_VIEWSF: return {U(D + sdact_hv(Mp)), U(A + sact_feat(Mp)), true};
-        case DW_L0: return {U(D + sdact_h(Mp, 0)), U(A + sact_pe(Mp)), true};
-        case DW_L5P: return {U(D + sdact_h(Mp, 5)), U(A + sact_pe(Mp)), false};
-        default: return {U(D + sdact_hv(Mp)), U(A + sact_ped(Mp)), false};   // DW_VIEWSP
+        case DW_L0: return {U(D + sdact_h(Mp, 0)), U(A + sact_pe32(Mp)), true};       // X = PE as f32 rows
+        case DW_L5P: return {U(D + sdact_h(Mp, 5)), U(A + sact_pe32(Mp)), false};
+        default: return {U(D + sdact_hv(Mp)), U(A + sact_ped32(Mp)), false};          // DW_VIEWSP: PE(dir) rows
     }
 }
 
@@ -57,11 +57,12 @@ __device__ __forceinline__ Src inst_src(const DwArgs& a, int inst) {
 // tiles in ONE accumulator set: per 16-point chunk (= one MFMA k-step) acc += Yh Xh + Yh Xl + Yl Xh with unscaled
 // lo parts (mlp_split.h, 'dW operand formats').  Three chunks are in flight in registers (sets A, B, C) and the LDS
 // image is triple-buffered, so there is one LDS-only barrier per chunk and every operand byte is read once.
-template <int N, int K, int WN, int TR, int TC, bool ALPHA>
+template <int N, int K, int WN, int TR, int TC, bool ALPHA, bool XROWS = false>
 __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int kY, int kX, int64_t chunk_begin, int64_t chunk_end,
                                         float* __restrict__ part, u32x4* __restrict__ smem) {
     static_assert(WN * TR * 32 == N, "row tiling");
     constexpr int YU = 4 * N, XU = 4 * K;                      // 16-byte units per chunk (2 blocks x width x 2 halves)
+    static_assert(!XROWS || (CHP * K / 4 <= DWT), "one float4 of the f32 rows per thread");
     constexpr int NY = (YU + DWT - 1) / DWT, NX = (XU + DWT - 1) / DWT;
     constexpr bool YFULL = YU % DWT == 0, XFULL = XU % DWT == 0;
     constexpr int BUF = YU + XU + 4;                           // + 16 floats of d_sigma
@@ -116,8 +117,13 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int kY, 
         const u32x4* px = src.x + cc * XU + tid;                                                          \
         _Pragma("unroll") for (int j = 0; j < NY; ++j)                                                    \
             if (YFULL || tid + j * DWT < YU) RY[j] = py[j * DWT];                                         \
-        _Pragma("unroll") for (int j = 0; j < NX; ++j)                                                    \
-            if (XFULL || tid + j * DWT < XU) RX[j] = px[j * DWT];                                         \
+        if (XROWS) {   /* f32 rows [point][K]: one float4 (4 features of a point) per thread */                \
+            if (tid < CHP * K / 4)                                                                        \
+                RX[0] = reinterpret_cast<const u32x4*>(reinterpret_cast<const float*>(src.x) + cc * (CHP * K))[tid]; \
+        } else {                                                                                          \
+            _Pragma("unroll") for (int j = 0; j < NX; ++j)                                                \
+                if (XFULL || tid + j * DWT < XU) RX[j] = px[j * DWT];                                     \
+        }                                                                                                 \
         if (ALPHA) {                                                                                      \
             const int64_t row = cc * CHP + (tid & (CHP - 1));                                             \
             RDA = a.d_raw[(row < M ? row : M - 1) * (a.C + 1) + a.C];                                     \
@@ -140,6 +146,19 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int kY, 
                 d[2 * N] = u32x2{q.z, q.w};                                                               \
             }                                                                                             \
         }                                                                                                 \
+        if (XROWS) {   /* split x * 2^kX directly (unscaled lo) and scatter the 4 features into their fragments */ \
+            if (tid < CHP * K / 4) {                                                                      \
+                const int p = tid / (K / 4), w0 = (tid % (K / 4)) * 4;                                    \
+                _Float16* img = reinterpret_cast<_Float16*>(Xs_);                                         \
+                const float xs = exp2i(kX);                                                               \
+                _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
+                    const float v = __uint_as_float(RX[0][i]) * xs;                                       \
+                    const _Float16 hi = (_Float16)v;                                                      \
+                    img[(((p >> 3) * 2 + 0) * K + w0 + i) * 8 + (p & 7)] = hi;                            \
+                    img[(((p >> 3) * 2 + 1) * K + w0 + i) * 8 + (p & 7)] = (_Float16)(v - (float)hi);     \
+                }                                                                                         \
+            }                                                                                             \
+        } else                                                                                            \
         _Pragma("unroll") for (int j = 0; j < NX; ++j) {                                                  \
             const int u = tid + j * DWT, mb = u / (2 * K), rem = u % (2 * K);                             \
             if (XFULL || u < XU) {                                                                        \
@@ -399,8 +418,8 @@ __global__ __launch_bounds__(DWT, 2) void mlp_dw_split_small_kernel(DwArgs a) {
     const Src src = inst_src(a, inst);
     int kY, kX;
     operand_scales(a, inst, kY, kX);
-    if (inst == DW_VIEWSP) dw_gemm<128, 32, 4, 1, 1, false>(a, src, kY, kX, cb, ce, part, smem_u);
-    else dw_gemm<256, 64, 4, 2, 1, false>(a, src, kY, kX, cb, ce, part, smem_u);   // DW_L0, DW_L5P
+    if (inst == DW_VIEWSP) dw_gemm<128, 32, 4, 1, 1, false, true>(a, src, kY, kX, cb, ce, part, smem_u);
+    else dw_gemm<256, 64, 4, 2, 1, false, true>(a, src, kY, kX, cb, ce, part, smem_u);   // DW_L0, DW_L5P
 }
 
 }  // namespace

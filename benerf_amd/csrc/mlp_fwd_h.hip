@@ -121,9 +121,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_split_kernel(FwdArgs a) {
         float x[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) x[c] = __fadd_rn(a.rays_o[ray * 3 + c], __fmul_rn(a.rays_d[ray * 3 + c], zz));
-        // training: PE as f32 rows (dX kernel, sin/cos derivatives) and as an ST array (dW operand), all Mp rows
+        // training: PE as f32 rows (sin/cos derivatives in dX; dW operand of the thin instances), all Mp rows
         float* ape = SAVE ? acts + sact_pe32(Mp) + m * ACT_PE_W : nullptr;
-        _Float16* spe = SAVE ? reinterpret_cast<_Float16*>(acts + sact_pe(Mp)) : nullptr;
         auto put = [&](int col, float v) {
             const _Float16 hi = (_Float16)v;
             const _Float16 lo = (_Float16)((v - (float)hi) * LO_SCALE);
@@ -132,8 +131,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_split_kernel(FwdArgs a) {
             Tl[idx] = lo;
             if (SAVE) {
                 ape[col] = v;
-                spe[st_half_index(m, ACT_PE_W, col, 0)] = hi;
-                spe[st_half_index(m, ACT_PE_W, col, 1)] = lo;
                 amax = fmaxf(amax, fabsf(v));
             }
         };
@@ -205,7 +202,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_split_kernel(FwdArgs a) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) vd[c] = a.viewdirs[ray * 3 + c];
         float* aped = SAVE ? acts + sact_ped32(Mp) + m * ACT_PED_W : nullptr;
-        _Float16* sped = SAVE ? reinterpret_cast<_Float16*>(acts + sact_ped(Mp)) : nullptr;
         auto put = [&](int col, float v) {
             const _Float16 hi = (_Float16)v;
             const _Float16 lo = (_Float16)((v - (float)hi) * LO_SCALE);
@@ -214,8 +210,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_split_kernel(FwdArgs a) {
             Tl[idx] = lo;
             if (SAVE) {
                 aped[col] = v;
-                sped[st_half_index(m, ACT_PED_W, col, 0)] = hi;
-                sped[st_half_index(m, ACT_PED_W, col, 1)] = lo;
             }
         };
         if (grp == 0) {

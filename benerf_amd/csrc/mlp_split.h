@@ -191,9 +191,7 @@ __host__ __device__ inline int64_t m_pad(int64_t M) { return n_tiles(M) * TM; }
 constexpr int SACT_MASK_LAYERS = 9;                                       // h0..h7 + hv
 __host__ __device__ inline int64_t sact_pe32(int64_t Mp) { (void)Mp; return 0; }                 // f32 [Mp][64]  (dX: sin/cos)
 __host__ __device__ inline int64_t sact_ped32(int64_t Mp) { return Mp * ACT_PE_W; }               // f32 [Mp][32]
-__host__ __device__ inline int64_t sact_pe(int64_t Mp) { return sact_ped32(Mp) + Mp * ACT_PED_W; }   // ST W = 64
-__host__ __device__ inline int64_t sact_ped(int64_t Mp) { return sact_pe(Mp) + Mp * ACT_PE_W; }      // ST W = 32
-__host__ __device__ inline int64_t sact_h(int64_t Mp, int l) { return sact_ped(Mp) + Mp * ACT_PED_W + (int64_t)l * Mp * 256; }
+__host__ __device__ inline int64_t sact_h(int64_t Mp, int l) { return sact_ped32(Mp) + Mp * ACT_PED_W + (int64_t)l * Mp * 256; }
 __host__ __device__ inline int64_t sact_feat(int64_t Mp) { return sact_h(Mp, 8); }                // ST W = 256
 __host__ __device__ inline int64_t sact_hv(int64_t Mp) { return sact_feat(Mp) + Mp * 256; }       // ST W = 128
 __host__ __device__ inline int64_t sact_mask(int64_t Mp) { return sact_hv(Mp) + Mp * ACT_HV_W; }  // uint64 [9][tiles][256]

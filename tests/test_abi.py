@@ -28,9 +28,9 @@ def test_header_symbols_exported(lib):
 
 def test_size_queries(lib):
     assert lib.benerf_version() >= 100
-    # sized for either arithmetic mode: the split mode pads to whole 64-point tiles, keeps PE / PE(dir) twice
-    # (f32 rows + ST operand copy) and 9 layers of ReLU sign-bit words
-    per_point = 2 * (64 + 32) + 8 * 256 + 256 + 128
+    # sized for either arithmetic mode: the split mode pads to whole 64-point tiles and keeps 9 layers of ReLU sign-bit
+    # words
+    per_point = (64 + 32) + 8 * 256 + 256 + 128
     # + ReLU sign-bit words + 16 absmax slots + per-wave absmax table [tiles][4]
     assert lib.benerf_mlp_act_floats(640) == 640 * per_point + 9 * 10 * 256 * 2 + 16 + 10 * 4
     assert lib.benerf_mlp_act_floats(641) == 704 * per_point + 9 * 11 * 256 * 2 + 16 + 11 * 4
