@@ -46,14 +46,10 @@ _SIGNATURES = {
     "benerf_mlp_dact_floats_per_point": (c_size_t, []),
     "benerf_mlp_dact_floats": (c_size_t, [c_int64]),
     "benerf_mlp_dw_workspace_floats": (c_size_t, [c_int64]),
-    "benerf_mlp_fwd": (c_int, [POINTER(MlpParams), P, c_int, c_int, c_int, P, P, P, P, P, P, P]),
-    "benerf_mlp_fwd_split": (c_int, [POINTER(MlpParams), P, c_int, c_int, c_int, P, P, P, P, P, P, P]),
-    "benerf_set_mlp_precision": (c_int, [c_int]),
-    "benerf_get_mlp_precision": (c_int, []),
-    "benerf_mlp_bwd": (c_int, [POINTER(MlpParams), P, c_int, c_int, c_int, P, P, P, P, c_size_t, POINTER(MlpGrads),
-                               c_int, P, P, P]),
-    "benerf_mlp_bwd_dx": (c_int, [POINTER(MlpParams), P, c_int, c_int, c_int, P, P, P, P, P, P]),
-    "benerf_mlp_bwd_dw": (c_int, [c_int, c_int, c_int, P, P, P, P, c_size_t, POINTER(MlpGrads), c_int, P]),
+    "benerf_mlp_fwd": (c_int, [POINTER(MlpParams), P, c_int, c_int, c_int, P, P, P, P, P, P, c_int, P, P]),
+    "benerf_mlp_status_check": (c_int, [P, P]),
+    "benerf_mlp_bwd_dx": (c_int, [POINTER(MlpParams), P, c_int, c_int, c_int, P, P, P, P, P, c_int, P, P]),
+    "benerf_mlp_bwd_dw": (c_int, [c_int, c_int, c_int, P, P, P, P, c_size_t, POINTER(MlpGrads), c_int, c_int, P]),
     "benerf_composite_fwd": (c_int, [P, P, P, P, c_float, c_uint64, c_uint64, c_int, c_int, c_int, P, P, P, P, P, P, P]),
     "benerf_composite_bwd": (c_int, [P, P, P, P, c_float, c_uint64, c_uint64, c_int, c_int, c_int, P, P, P, P, P, P,
                                      c_int, P]),
@@ -70,7 +66,7 @@ _SIGNATURES = {
     "benerf_event_window_accumulate": (c_int, [P, P, P, P, c_int64, c_double, c_double, c_int, c_int, P, P]),
     "benerf_gather_rows": (c_int, [P, P, c_int64, c_int, P, P]),
     "benerf_sample_pixels": (c_int, [c_int64, c_int64, ctypes.c_uint64, ctypes.c_uint64, P, P]),
-    "benerf_adam_step": (c_int, [P, P, P, P, c_int64, c_double, c_double, c_double, c_double, c_int, c_double, P]),
+    "benerf_adam_step": (c_int, [P, P, P, P, c_int64, c_double, c_double, c_double, c_double, c_int, c_double, P, P]),
 }
 
 EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))
@@ -97,15 +93,18 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
-    mode = os.environ.get("BENERF_MLP_PRECISION")          # "f32" | "split": process-wide MFMA arithmetic of the MLP kernels
-    if mode:
-        if mode not in ("f32", "split"):
-            raise BenerfHipError("BENERF_MLP_PRECISION must be 'f32' or 'split', not %r" % mode)
-        lib.benerf_set_mlp_precision(1 if mode == "split" else 0)
     return lib
+
+
+class BenerfRangeError(BenerfHipError):
+    """BENERF_ERANGE: a value left the range of the split-f16 MLP mode (include/benerf_hip.h, K3 `status`)."""
+
+
+ERANGE = -4
 
 
 def check(rc, what):
     if rc != 0:
         msg = load().benerf_last_error()
-        raise BenerfHipError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else ""))
+        cls = BenerfRangeError if rc == ERANGE else BenerfHipError
+        raise cls("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else ""))

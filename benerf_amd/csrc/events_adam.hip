@@ -55,7 +55,10 @@ __global__ void gather_rows_kernel(const float* __restrict__ src, const int64_t*
 
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, int64_t n, float step_size, float omb1, float beta2, float omb2,
-                            float eps, float bc2_sqrt, float grad_scale) {
+                            float eps, float bc2_sqrt, float grad_scale, const uint32_t* __restrict__ skip_if_range) {
+    // status words of the split-f16 MLP mode (include/benerf_hip.h): a step whose activations or scaled gradients left
+    // the f16 range carries inf / NaN gradients - leave parameters and moments untouched, the host reports it
+    if (skip_if_range && (skip_if_range[0] >= 0x477fe000u || skip_if_range[1] >= 0x477fe000u)) return;   // 65504.f
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         float gi = g[i] * grad_scale;
@@ -151,7 +154,7 @@ extern "C" int benerf_gather_rows(const float* src, const int64_t* idx, int64_t 
 
 extern "C" int benerf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr,
                                 double beta1, double beta2, double eps, int step, double grad_scale,
-                                benerf_stream_t stream) {
+                                const uint32_t* skip_if_range, benerf_stream_t stream) {
     BENERF_REQUIRE(param && grad && exp_avg && exp_avg_sq && n >= 0 && step >= 1, "adam_step: bad args");
     if (n == 0) return BENERF_OK;
     double bc1 = 1.0 - pow(beta1, (double)step);
@@ -162,7 +165,7 @@ extern "C" int benerf_adam_step(float* param, const float* grad, float* exp_avg,
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq, n,
                        step_size, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, bc2_sqrt,
-                       (float)grad_scale);
+                       (float)grad_scale, skip_if_range);
     BENERF_LAUNCH_CHECK("adam_step");
     return BENERF_OK;
 }

@@ -334,18 +334,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_kernel(BwdArgs a) {
 }  // namespace
 
 // part 2 (mlp_dw.hip)
-int benerf_mlp_dw_launch(const BenerfMlpParams* params, int channels, int64_t M, const float* d_raw, const float* acts,
-                         const float* dacts, float* dw_ws, const BenerfMlpGrads* grads, int accumulate,
-                         hipStream_t stream);
+int benerf_mlp_dw_launch(int precision, int channels, int64_t M, const float* d_raw, const float* acts, const float* dacts,
+                         float* dw_ws, const BenerfMlpGrads* grads, int accumulate, hipStream_t stream);
 
-// split-f16 variant (mlp_bwd_h.hip)
+// f16 variant (mlp_bwd_h.hip)
 int benerf_mlp_dx_split_launch(const BenerfMlpParams* params, const float* packed, int channels, int64_t M, const float* d_raw,
-                               const float* acts, float* dacts, float* d_pts, float* d_vdir_pts, hipStream_t stream);
+                               const float* acts, float* dacts, float* d_pts, float* d_vdir_pts, uint32_t* status, hipStream_t stream);
 
 static int launch_dx(const BenerfMlpParams* params, const float* packed, int channels, int64_t M, const float* d_raw,
                      const float* acts, float* dacts, float* d_pts, float* d_vdir_pts, hipStream_t stream) {
-    if (benerf_get_mlp_precision() == BENERF_MLP_SPLIT)
-        return benerf_mlp_dx_split_launch(params, packed, channels, M, d_raw, acts, dacts, d_pts, d_vdir_pts, stream);
     BwdArgs a;
     a.d_raw = d_raw;
     a.acts = acts;
@@ -360,11 +357,10 @@ static int launch_dx(const BenerfMlpParams* params, const float* packed, int cha
     BENERF_REQUIRE(tiles < (1ll << 31), "mlp_bwd: too many points");
     dim3 grid((unsigned)tiles), block(mlp::NTHREADS);
     const int smem = (int)mlp::TILE_SMEM;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)mlp_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        (void)hipFuncSetAttribute((const void*)mlp_bwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr_done = true;
+    const void* fn = channels == 1 ? (const void*)mlp_bwd_kernel<1> : (const void*)mlp_bwd_kernel<3>;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
+        benerf_set_error("mlp_bwd(dx): cannot reserve %d bytes of LDS", smem);
+        return BENERF_EHIP;
     }
     if (channels == 1) hipLaunchKernelGGL((mlp_bwd_kernel<1>), grid, block, smem, stream, a);
     else hipLaunchKernelGGL((mlp_bwd_kernel<3>), grid, block, smem, stream, a);
@@ -374,35 +370,30 @@ static int launch_dx(const BenerfMlpParams* params, const float* packed, int cha
 
 extern "C" int benerf_mlp_bwd_dx(const BenerfMlpParams* params, const float* packed, int channels, int n_rays,
                                  int n_samples, const float* d_raw, const float* acts, float* dacts, float* d_pts,
-                                 float* d_vdir_pts, benerf_stream_t stream) {
+                                 float* d_vdir_pts, int precision, uint32_t* status, benerf_stream_t stream) {
     BENERF_REQUIRE(params && packed && d_raw && acts && dacts && d_pts && d_vdir_pts, "mlp_bwd_dx: null pointer");
     BENERF_REQUIRE(channels == 1 || channels == 3, "mlp_bwd_dx: channels must be 1 or 3");
     BENERF_REQUIRE(n_rays > 0 && n_samples > 0, "mlp_bwd_dx: bad sizes");
+    BENERF_REQUIRE(precision == BENERF_MLP_F32 || precision == BENERF_MLP_SPLIT, "mlp_bwd_dx: precision must be BENERF_MLP_F32 or BENERF_MLP_SPLIT");
     for (int l = 0; l < BENERF_NLAYERS; ++l) BENERF_REQUIRE(params->w[l], "mlp_bwd_dx: null parameter %d", l);
-    return launch_dx(params, packed, channels, (int64_t)n_rays * n_samples, d_raw, acts, dacts, d_pts, d_vdir_pts,
-                     as_stream(stream));
+    const int64_t M = (int64_t)n_rays * n_samples;
+    if (precision == BENERF_MLP_SPLIT)
+        return benerf_mlp_dx_split_launch(params, packed, channels, M, d_raw, acts, dacts, d_pts, d_vdir_pts, status, as_stream(stream));
+    return launch_dx(params, packed, channels, M, d_raw, acts, dacts, d_pts, d_vdir_pts, as_stream(stream));
 }
 
 extern "C" int benerf_mlp_bwd_dw(int channels, int n_rays, int n_samples, const float* d_raw, const float* acts,
                                  const float* dacts, float* dw_ws, size_t dw_ws_floats, const BenerfMlpGrads* grads,
-                                 int accumulate, benerf_stream_t stream) {
+                                 int accumulate, int precision, benerf_stream_t stream) {
     BENERF_REQUIRE(d_raw && acts && dacts && dw_ws && grads, "mlp_bwd_dw: null pointer");
     BENERF_REQUIRE(channels == 1 || channels == 3, "mlp_bwd_dw: channels must be 1 or 3");
     BENERF_REQUIRE(n_rays > 0 && n_samples > 0, "mlp_bwd_dw: bad sizes");
+    BENERF_REQUIRE(precision == BENERF_MLP_F32 || precision == BENERF_MLP_SPLIT, "mlp_bwd_dw: precision must be BENERF_MLP_F32 or BENERF_MLP_SPLIT");
     if (dw_ws_floats < (size_t)mlp::DW_WS_FLOATS) {
         benerf_set_error("mlp_bwd_dw: dw workspace too small (%zu < %lld floats)", dw_ws_floats, (long long)mlp::DW_WS_FLOATS);
         return BENERF_EWORKSPACE;
     }
     for (int l = 0; l < BENERF_NLAYERS; ++l) BENERF_REQUIRE(grads->w[l] && grads->b[l], "mlp_bwd_dw: null grad %d", l);
-    return benerf_mlp_dw_launch(nullptr, channels, (int64_t)n_rays * n_samples, d_raw, acts, dacts, dw_ws, grads, accumulate,
+    return benerf_mlp_dw_launch(precision, channels, (int64_t)n_rays * n_samples, d_raw, acts, dacts, dw_ws, grads, accumulate,
                                 as_stream(stream));
-}
-
-extern "C" int benerf_mlp_bwd(const BenerfMlpParams* params, const float* packed, int channels, int n_rays,
-                              int n_samples, const float* d_raw, const float* acts, float* dacts, float* dw_ws,
-                              size_t dw_ws_floats, const BenerfMlpGrads* grads, int accumulate, float* d_pts,
-                              float* d_vdir_pts, benerf_stream_t stream) {
-    int rc = benerf_mlp_bwd_dx(params, packed, channels, n_rays, n_samples, d_raw, acts, dacts, d_pts, d_vdir_pts, stream);
-    if (rc != BENERF_OK) return rc;
-    return benerf_mlp_bwd_dw(channels, n_rays, n_samples, d_raw, acts, dacts, dw_ws, dw_ws_floats, grads, accumulate, stream);
 }

@@ -27,6 +27,7 @@ struct BwdArgs {
     const float* w_rgb;     // [C][128]
     float* d_pts;           // [M][3]
     float* d_vdir;          // [M][3]
+    uint32_t* status;       // [1]: max |stored gradient| bits once >= 2^15, [2]: acts buffer written by another mode (may be null)
     int64_t M;
 };
 
@@ -61,24 +62,14 @@ __device__ __forceinline__ f32x16 gemm_one(const _Float16* __restrict__ Th, cons
     return a1;
 }
 
-// {hi x4, lo x4} * s (packed f16)
-__device__ __forceinline__ uint4 scale_quad(const Quad16x2& q, _Float16 s) {
-    const half8 v = __builtin_bit_cast(half8, q) * half8{s, s, s, s, s, s, s, s};
-    return __builtin_bit_cast(uint4, v);
-}
-
-// dY = (acc1 + acc2 * 2^-11) masked by the forward pass' ReLU sign bits -> both planes (tile scale) and, as the SAME
-// hi / lo halfs times gf = 2^8 s_g / s_tile (a power of two <= 2^8: four packed-f16 multiplies per quad, exact unless the
-// result is subnormal, i.e. 2^-18 below the call's largest gradient), the ST gradient array `st` (W = 256; m0 = first
-// point of the tile).
+// dY = (acc1 + acc2 * 2^-11) masked by the forward pass' ReLU sign bits -> both planes (tile scale) and, rescaled by
+// gf = s_call / s_tile (a power of two <= 1) and rounded to f16, the SH gradient array `st` (W = 256; m0 = first point
+// of the tile).
 template <bool MASK>
 __device__ __forceinline__ void epilogue(f32x16 (&acc1)[2][2], f32x16 (&acc2)[2][2], uint64_t bits, _Float16* __restrict__ Th,
                                          _Float16* __restrict__ Tl, int ct0, int lane, _Float16* __restrict__ st, int64_t m0,
-                                         float gf, float* __restrict__ absmax_entry) {
+                                         float gf, float& amax) {
     const int lr = lane & 31, r4 = 4 * (lane >> 5);
-    const _Float16 gfh = (_Float16)gf;
-    float amax = 0.f;          // max |value| of this stage (live only inside the epilogue: the kernel is at the
-                               // register limit, a running maximum across the GEMMs cost 35 extra spills)
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         const int n = (ct0 + c) * 32 + lr;
@@ -86,30 +77,29 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc1)[2][2], f32x16 (&acc2)[2]
         int base[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) base[q] = r4 * LD + ((((ns ^ ((q & 1) | ((q >> 1) << 2)))) << 3) | (n & 7));
-        _Float16* st_lane = st + st_half_index(m0 + r4, 256, n, 0);
+        _Float16* st_lane = st + sh_half_index(m0 + r4, 256, n);
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
             for (int eq = 0; eq < 4; ++eq) {
-                Quad16x2 q;
+                Quad16 q;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int e = eq * 4 + j;
                     float v = acc1[r][c][e] + acc2[r][c][e] * LO_INV;
                     if (MASK) v = ((bits >> ((c * 2 + r) * 16 + e)) & 1ull) ? v : 0.f;
-                    amax = fmaxf(amax, fabsf(v));
                     const _Float16 hi = (_Float16)v;
                     const _Float16 lo = (_Float16)((v - (float)hi) * LO_SCALE);
                     const int idx = base[((e >> 1) & 1) | (((e >> 2) & 1) << 1)] + (r * 32 + (e & 3) + 8 * (e >> 2)) * LD;
                     Th[idx] = hi;
                     Tl[idx] = lo;
-                    q.hi.v[j] = hi;
-                    q.lo.v[j] = lo;
+                    const float sv = v * gf;
+                    amax = fmaxf(amax, fabsf(sv));
+                    q.v[j] = (_Float16)sv;
                 }
-                *reinterpret_cast<uint4*>(st_lane + (int64_t)(r * 4 + eq) * 256 * 16) = scale_quad(q, gfh);
+                *reinterpret_cast<uint2*>(st_lane + (int64_t)(r * 4 + eq) * 256 * 8) = __builtin_bit_cast(uint2, q);
             }
     }
-    publish_absmax(amax * gf, absmax_entry);
 }
 
 template <int C>
@@ -132,12 +122,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_split_kernel(BwdArgs a) {
     const int ct0 = wave * 2;
     const int64_t Mp = m_pad(M);
     const uint64_t* mask_in = reinterpret_cast<const uint64_t*>(acts + sact_mask(Mp)) + (int64_t)blockIdx.x * NTHREADS + tid;
-    const int64_t mask_stride = n_tiles(M) * NTHREADS;
-    _Float16* st_dyh = reinterpret_cast<_Float16*>(dacts + sdact_h(Mp, 0));      // layer l: + l * Mp * 512 halfs
-    const float* absmax_y = dacts + sdact_scale(Mp);                              // [0] max|d_raw| (pre-kernel)
-    float* absmax_row = dacts + sdact_absmax_table(Mp) + ((int64_t)blockIdx.x * 4 + wave) * 16;   // max |stored gradient| per stage of this wave
+    const int64_t mask_stride = (Mp / TM) * NTHREADS;
+    _Float16* st_dyh = reinterpret_cast<_Float16*>(dacts + sdact_h(Mp, 0));      // layer l: + l * Mp * 256 halfs
     float s_g, inv_s_g;
-    pow2_scale(absmax_y[AY_DRAW], s_g, inv_s_g);                                  // global scale of this call
+    pow2_scale6(dacts[sdact_info(Mp) + SD_DRAW], s_g, inv_s_g);                   // scale of the dY arrays of this call
+    if (a.status && blockIdx.x == 0 && tid == 0 && reinterpret_cast<const uint32_t*>(acts + sact_info(Mp))[SI_TAG] != SACT_TAG_SPLIT)
+        a.status[2] = 1u;
+    float amax = 0.f;          // max |stored gradient| of this thread (range guard)
     const int prow = pt * LD;
 
     // ---- P0: d_raw tile, its power-of-two scale, scaled values -> scratch floats [60, 60+C] of each row ------
@@ -152,14 +143,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_split_kernel(BwdArgs a) {
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
         float s, inv;
-        pow2_scale(mx, s, inv);                                             // 2^(-4 - exponent(max)), exact inverse
+        pow2_scale6(mx, s, inv);                                            // 2^(6 - exponent(max)), exact inverse
 #pragma unroll
         for (int c = 0; c <= C; ++c) *fscr(Th, Tl, pt, 60 + c) = dr[c] * s;
         if (tid == 0) *fscr(Th, Tl, 0, 56) = inv;
     }
     lds_barrier();
     const float inv_s = *fscr(Th, Tl, 0, 56);
-    const float gf = s_g * inv_s * DY_STORE_BOOST;   // tile scale -> scale of the stored dY (power of two <= 2^8)
+    const float gf = s_g * inv_s;   // tile scale -> scale of the stored dY (power of two <= 1)
 
     // ---- P1: rgb layer backward + ReLU mask of the views layer -> dYv in planes[:,0:128), accumulator layout ----
     // thread <-> (column wave*32 + lane&31, rows r*32 + acc_row(e)): the hv sign bits the forward pass saved for
@@ -170,13 +161,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_split_kernel(BwdArgs a) {
         float wr[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) wr[c] = a.w_rgb[c * 128 + col];
-        _Float16* st_lane = reinterpret_cast<_Float16*>(dacts + sdact_hv(Mp)) + st_half_index(m0 + r4, ACT_HV_W, col, 0);
-        float amax = 0.f;
+        _Float16* st_lane = reinterpret_cast<_Float16*>(dacts + sdact_hv(Mp)) + sh_half_index(m0 + r4, ACT_HV_W, col);
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
             for (int eq = 0; eq < 4; ++eq) {
-                Quad16x2 q;
+                Quad16 q;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int e = eq * 4 + j;
@@ -187,18 +177,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_split_kernel(BwdArgs a) {
 #pragma unroll
                     for (int c = 0; c < C; ++c) g += drv[c] * wr[c];
                     const float v = ((hvbits >> (r * 16 + e)) & 1ull) ? g : 0.f;
-                    amax = fmaxf(amax, fabsf(v));
                     const _Float16 hi = (_Float16)v;
                     const _Float16 lo = (_Float16)((v - (float)hi) * LO_SCALE);
                     const int idx = hidx(p, col);
                     Th[idx] = hi;
                     Tl[idx] = lo;
-                    q.hi.v[j] = hi;
-                    q.lo.v[j] = lo;
+                    const float sv = v * gf;
+                    amax = fmaxf(amax, fabsf(sv));
+                    q.v[j] = (_Float16)sv;
                 }
-                *reinterpret_cast<uint4*>(st_lane + (int64_t)(r * 4 + eq) * ACT_HV_W * 16) = scale_quad(q, (_Float16)gf);
+                *reinterpret_cast<uint2*>(st_lane + (int64_t)(r * 4 + eq) * ACT_HV_W * 8) = __builtin_bit_cast(uint2, q);
             }
-        publish_absmax(amax * gf, absmax_row + 9);
     }
     lds_barrier();
 
@@ -214,7 +203,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_split_kernel(BwdArgs a) {
         for (int e = 0; e < 16; ++e) *fscr(Th, Tl, wave * 32 + acc_row(e, lane), lane & 31) = ap[e];
     }
     lds_barrier();   // dYv fully consumed; dPE(dir) visible
-    epilogue<false>(acc1, acc2, 0ull, Th, Tl, ct0, lane, reinterpret_cast<_Float16*>(dacts + sdact_feat(Mp)), m0, gf, absmax_row + 8);
+    epilogue<false>(acc1, acc2, 0ull, Th, Tl, ct0, lane, reinterpret_cast<_Float16*>(dacts + sdact_feat(Mp)), m0, gf, amax);
     if (grp == 0 && m < M) {   // d viewdirs (per point) through PE(dir)
         const float* ped = acts + sact_ped32(Mp) + m * ACT_PED_W;
 #pragma unroll
@@ -249,7 +238,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_split_kernel(BwdArgs a) {
             }
     }
     lds_barrier();
-    epilogue<true>(acc1, acc2, bits, Th, Tl, ct0, lane, st_dyh + 7 * Mp * 512, m0, gf, absmax_row + 7);
+    epilogue<true>(acc1, acc2, bits, Th, Tl, ct0, lane, st_dyh + 7 * Mp * 256, m0, gf, amax);
     lds_barrier();
 
     // ---- P4: L7 .. L1: dY_l x W_l, mask h_{l-1} -> dY_{l-1} ----------------------------------------------
@@ -267,11 +256,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_split_kernel(BwdArgs a) {
             for (int e = 0; e < 16; ++e) *fscr(Th, Tl, (wave >> 1) * 32 + acc_row(e, lane), col) = ap[e];
         }
         lds_barrier();
-        epilogue<true>(acc1, acc2, bits, Th, Tl, ct0, lane, st_dyh + (int64_t)(l - 1) * Mp * 512, m0, gf, absmax_row + (l - 1));
+        epilogue<true>(acc1, acc2, bits, Th, Tl, ct0, lane, st_dyh + (int64_t)(l - 1) * Mp * 256, m0, gf, amax);
         lds_barrier();
     }
 
-    if (lane < 6) absmax_row[10 + lane] = 0.f;     // unused entries of the row
+    if (a.status) {   // range guard of the stored f16 gradients: one atomic per wave, only near f16's maximum
+        const float wmax = wave_max_nonneg(amax);
+        if (lane == 63 && !(wmax < 32768.f)) atomicMax(a.status + 1, __float_as_uint(wmax == wmax ? wmax : __builtin_inff()));
+    }
 
     // ---- P5: L0^T: dPE += dY0 x W0 -----------------------------------------------------------------------
     {
@@ -324,7 +316,7 @@ __global__ void grad_absmax_kernel(const float* __restrict__ d_raw, int64_t n, f
 }  // namespace
 
 int benerf_mlp_dx_split_launch(const BenerfMlpParams* params, const float* packed, int channels, int64_t M, const float* d_raw,
-                               const float* acts, float* dacts, float* d_pts, float* d_vdir_pts, hipStream_t stream) {
+                               const float* acts, float* dacts, float* d_pts, float* d_vdir_pts, uint32_t* status, hipStream_t stream) {
     BwdArgs a;
     a.d_raw = d_raw;
     a.acts = acts;
@@ -334,25 +326,25 @@ int benerf_mlp_dx_split_launch(const BenerfMlpParams* params, const float* packe
     a.w_rgb = params->w[BENERF_L_RGB];
     a.d_pts = d_pts;
     a.d_vdir = d_vdir_pts;
+    a.status = status;
     a.M = M;
-    const int64_t tiles = (M + mlp::TM - 1) / mlp::TM;
+    const int64_t tiles = mlp::sn_tiles(M);
     BENERF_REQUIRE(tiles < (1ll << 31), "mlp_bwd: too many points");
-    float* absmax = dacts + mlp::sdact_scale(mlp::m_pad(M));
-    if (hipMemsetAsync(absmax, 0, mlp::AY_COUNT * sizeof(float), stream) != hipSuccess) {
+    float* info = dacts + mlp::sdact_info(mlp::m_pad(M));
+    if (hipMemsetAsync(info, 0, mlp::SD_COUNT * sizeof(float), stream) != hipSuccess) {
         benerf_set_error("mlp_bwd: memset failed");
         return BENERF_EHIP;
     }
-    hipLaunchKernelGGL(grad_absmax_kernel, dim3(256), dim3(256), 0, stream, d_raw, M * (channels + 1), absmax);
+    hipLaunchKernelGGL(grad_absmax_kernel, dim3(256), dim3(256), 0, stream, d_raw, M * (channels + 1), info + mlp::SD_DRAW);
     dim3 grid((unsigned)tiles), block(mlp::NTHREADS);
     const int smem = (int)mlp::TILE_SMEM;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)mlp_bwd_split_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        (void)hipFuncSetAttribute((const void*)mlp_bwd_split_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr_done = true;
+    const void* fn = channels == 1 ? (const void*)mlp_bwd_split_kernel<1> : (const void*)mlp_bwd_split_kernel<3>;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
+        benerf_set_error("mlp_bwd(dx, split): cannot reserve %d bytes of LDS", smem);
+        return BENERF_EHIP;
     }
     if (channels == 1) hipLaunchKernelGGL((mlp_bwd_split_kernel<1>), grid, block, smem, stream, a);
     else hipLaunchKernelGGL((mlp_bwd_split_kernel<3>), grid, block, smem, stream, a);
     BENERF_LAUNCH_CHECK("mlp_bwd(dx, split)");
-    return mlp::absmax_reduce_launch(dacts + mlp::sdact_absmax_table(mlp::m_pad(M)), tiles * 64, absmax + mlp::AY_ALL, stream);
+    return BENERF_OK;
 }

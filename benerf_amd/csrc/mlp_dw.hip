@@ -267,9 +267,8 @@ struct ReduceArgs {
     float* gb[BENERF_NLAYERS];
     int C;
     int accumulate;
-    int split_mode;          // partials written by mlp_dw_h.hip: other split table; dY-derived sums carry the factor s_g
-    const float* absmax_y;   // split mode: absmax slots of the dY arrays ([0] = max |d_raw|, s_g derives from it) ...
-    const float* absmax_x;   // ... and of the activation arrays: the per-array rescale exponents of mlp_dw_h.hip
+    int split_mode;          // partials written by mlp_dw_h.hip: other split table; dY-derived sums carry the factor s_s
+    const float* grad_info;  // split mode: info words of the dY arrays ([SD_DRAW] = max |d_raw|, s_s derives from it)
 };
 
 template <bool SPLIT>
@@ -282,18 +281,17 @@ __device__ __forceinline__ float sum_splits_t(const float* ws, int inst, int64_t
     for (int sp = 0; sp < n; ++sp) s += p[sp * stride];
     return s;
 }
-// split mode: a weight block of instance `inst` carries s_g * 2^(kY + kX), its bias sums s_g * 2^kY (mlp_split.h,
-// 'dW operand formats'); the alpha / rgb heads are written unscaled
+// split mode: weight blocks and bias sums carry the gradient scale s_s of the call (mlp_split.h, pow2_scale6); the
+// alpha / rgb heads are computed from the unscaled d_raw
 template <bool SPLIT>
-__device__ __forceinline__ float unscale_of(const float* absmax_y, const float* absmax_x, int inst, bool bias) {
+__device__ __forceinline__ float unscale_of(const float* grad_info, int inst) {
     if (!SPLIT || inst == DW_RGB) return 1.f;
-    float s_g, inv_s_g;
-    pow2_scale(absmax_y[AY_DRAW], s_g, inv_s_g);
-    const int k = rescale_exp(absmax_y[AY_ALL]) + (bias ? 0 : rescale_exp(absmax_x[AX_ALL]));
-    return inv_s_g * (1.f / DY_STORE_BOOST) * exp2i(-k);
+    float s_s, inv_s_s;
+    pow2_scale6(grad_info[SD_DRAW], s_s, inv_s_s);
+    return inv_s_s;
 }
-#define sum_splits(ws, inst, elem) (sum_splits_t<SPLIT>(ws, inst, elem) * unscale_of<SPLIT>(a.absmax_y, a.absmax_x, inst, false))
-#define sum_bias(ws, inst, elem) (sum_splits_t<SPLIT>(ws, inst, elem) * unscale_of<SPLIT>(a.absmax_y, a.absmax_x, inst, true))
+#define sum_splits(ws, inst, elem) (sum_splits_t<SPLIT>(ws, inst, elem) * unscale_of<SPLIT>(a.grad_info, inst))
+#define sum_bias(ws, inst, elem) (sum_splits_t<SPLIT>(ws, inst, elem) * unscale_of<SPLIT>(a.grad_info, inst))
 #define sum_raw(ws, inst, elem) sum_splits_t<SPLIT>(ws, inst, elem)
 
 __device__ __forceinline__ int layer_inst(int l) {   // instance holding the bias / main block of layer l
@@ -348,7 +346,7 @@ __global__ void dw_reduce_kernel(ReduceArgs a) {
 }  // namespace
 
 int benerf_mlp_dw_reduce_launch(const float* ws, const BenerfMlpGrads* grads, int channels, int accumulate, int split_mode,
-                                const float* absmax_y, const float* absmax_x, hipStream_t stream) {
+                                const float* grad_info, hipStream_t stream) {
     ReduceArgs r;
     r.ws = ws;
     for (int l = 0; l < BENERF_NLAYERS; ++l) {
@@ -358,8 +356,7 @@ int benerf_mlp_dw_reduce_launch(const float* ws, const BenerfMlpGrads* grads, in
     r.C = channels;
     r.accumulate = accumulate;
     r.split_mode = split_mode;
-    r.absmax_y = absmax_y;
-    r.absmax_x = absmax_x;
+    r.grad_info = grad_info;
     if (split_mode) hipLaunchKernelGGL(dw_reduce_kernel<true>, dim3(64, BENERF_NLAYERS), dim3(256), 0, stream, r);
     else hipLaunchKernelGGL(dw_reduce_kernel<false>, dim3(64, BENERF_NLAYERS), dim3(256), 0, stream, r);
     BENERF_LAUNCH_CHECK("mlp_bwd(reduce)");
@@ -370,11 +367,10 @@ int benerf_mlp_dw_reduce_launch(const float* ws, const BenerfMlpGrads* grads, in
 int benerf_mlp_dw_split_launch(int channels, int64_t M, const float* d_raw, const float* acts, const float* dacts, float* dw_ws,
                                const BenerfMlpGrads* grads, int accumulate, hipStream_t stream);
 
-int benerf_mlp_dw_launch(const BenerfMlpParams* params, int channels, int64_t M, const float* d_raw, const float* acts,
+int benerf_mlp_dw_launch(int precision, int channels, int64_t M, const float* d_raw, const float* acts,
                          const float* dacts, float* dw_ws, const BenerfMlpGrads* grads, int accumulate,
                          hipStream_t stream) {
-    (void)params;
-    if (benerf_get_mlp_precision() == BENERF_MLP_SPLIT)
+    if (precision == BENERF_MLP_SPLIT)
         return benerf_mlp_dw_split_launch(channels, M, d_raw, acts, dacts, dw_ws, grads, accumulate, stream);
     DwArgs a;
     a.d_raw = d_raw;
@@ -383,12 +379,11 @@ int benerf_mlp_dw_launch(const BenerfMlpParams* params, int channels, int64_t M,
     a.ws = dw_ws;
     a.M = M;
     a.C = channels;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)mlp_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DW_SMEM);
-        attr_done = true;
+    if (hipFuncSetAttribute((const void*)mlp_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DW_SMEM) != hipSuccess) {
+        benerf_set_error("mlp_bwd(dw): cannot reserve LDS");
+        return BENERF_EHIP;
     }
     hipLaunchKernelGGL(mlp_dw_kernel, dim3(mlp::DW_TOTAL_BLOCKS), dim3(DWT), DW_SMEM, stream, a);
     BENERF_LAUNCH_CHECK("mlp_bwd(dw)");
-    return benerf_mlp_dw_reduce_launch(dw_ws, grads, channels, accumulate, 0, nullptr, nullptr, stream);
+    return benerf_mlp_dw_reduce_launch(dw_ws, grads, channels, accumulate, 0, nullptr, stream);
 }

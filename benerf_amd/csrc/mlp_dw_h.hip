@@ -1,26 +1,25 @@
-// K3 backward part 2, split-f16 variant of mlp_dw.hip: dW_l = dY_l^T X_l over all sample points as three f16 MFMAs
-// per product block, f32 accumulation, + bias sums and the alpha / rgb heads on the VALU.
+// K3 backward part 2, f16 variant of mlp_dw.hip: dW_l = dY_l^T X_l over all sample points with f16 operands (the SH
+// arrays the split forward / f16 dX kernels save, mlp_split.h), one v_mfma_f32_32x32x16_f16 per product block, f32
+// accumulation, + bias sums and the alpha / rgb heads on the VALU.
 //
-// Operands arrive in the ST layout the split forward / dX kernels write (mlp_split.h): blocks of 8 points,
-// feature-major, 16-byte units {hi x4, lo x4} - one split away from the MFMA fragment order for a contraction over
-// points.  A workgroup (8 waves, one per CU) copies 16-point chunks (one MFMA k-step) into a triple-buffered LDS
-// image [block][plane][feature][8 points] (each unit lands as two 8-byte quads; conflict-free fragment reads, no
-// transposition pass) with three chunks in flight in registers and one LDS-only barrier per chunk.
-// The three products of a block go into ONE accumulator set: while staging, every operand unit is rescaled by its
-// launch-wide power of two so that its lo part can be used UNSCALED ('dW operand formats', mlp_split.h).
-// With one set a workgroup holds a whole 256 x 256 output block (128 accumulator registers x 8 waves), so every
-// operand byte is read exactly once: HBM traffic = the algorithmic bytes.  (With two accumulator sets the block was
-// 256 x 128 and dY was streamed twice: 13.3 GB against 9.4 GB of operands per launch at M = 522k.)
+// An SH array is blocks of 8 points, feature-major, one 16-byte unit per (block, feature) = exactly the MFMA fragment
+// of a contraction over points, so a workgroup (8 waves, one per CU) copies 32-point chunks (two MFMA k-steps)
+// verbatim into a triple-buffered LDS image [block][feature][8 points] with three chunks in flight in registers and
+// one LDS-only barrier per chunk.  A workgroup holds a whole 256 x 256 output block (128 accumulator registers x 8
+// waves), so every operand byte is read exactly once: HBM traffic = the algorithmic bytes, 2 bytes per element.
+// The kernel is HBM-bound (9.9 KB per point against 16 MFMAs per wave and chunk).
+// Gradient operands carry the per-call power-of-two scale s_s of the dX kernel (exact; divided out by the reduce
+// kernel); activations are stored unscaled (f16 subnormals keep an absolute floor of 3e-8).
 #include "mlp_split.h"
 
 namespace {
 using namespace mlp;
 
 constexpr int DWT = 512;
-constexpr int CHP = 16;             // points per chunk = 2 blocks of 8 = one MFMA k-step
+constexpr int CHP = 32;             // points per chunk = 4 blocks of 8 = two MFMA k-steps
+constexpr int CHB = CHP / 8;
 // 16-byte unit as a first-class vector (arrays of HIP's uint4 struct were left in scratch memory by the compiler)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 struct DwArgs {
     const float* d_raw;
@@ -32,8 +31,8 @@ struct DwArgs {
 };
 
 struct Src {
-    const u32x4* y;    // ST array of width N (16-byte units)
-    const u32x4* x;    // ST array of width K ... or, for the thin instances (XROWS), f32 rows [Mp][K]
+    const u32x4* y;    // SH array of width N (16-byte units)
+    const u32x4* x;    // SH array of width K ... or, for the thin instances (XROWS), f32 rows [Mp][K]
     bool bias;
 };
 
@@ -54,18 +53,21 @@ __device__ __forceinline__ Src inst_src(const DwArgs& a, int inst) {
 }
 
 // Output block N x K (the whole instance: K = width of X).  Waves form a WN x (8/WN) grid; each owns TR x TC MFMA
-// tiles in ONE accumulator set: per 16-point chunk (= one MFMA k-step) acc += Yh Xh + Yh Xl + Yl Xh with unscaled
-// lo parts (mlp_split.h, 'dW operand formats').  Three chunks are in flight in registers (sets A, B, C) and the LDS
-// image is triple-buffered, so there is one LDS-only barrier per chunk and every operand byte is read once.
+// tiles: per 32-point chunk (= two MFMA k-steps) acc += Y^T X.  Three chunks are in flight in registers (sets A, B,
+// C) and the LDS image is triple-buffered, so there is one LDS-only barrier per chunk.
 template <int N, int K, int WN, int TR, int TC, bool ALPHA, bool XROWS = false>
-__device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int kY, int kX, int64_t chunk_begin, int64_t chunk_end,
+__device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int64_t chunk_begin, int64_t chunk_end,
                                         float* __restrict__ part, u32x4* __restrict__ smem) {
     static_assert(WN * TR * 32 == N, "row tiling");
-    constexpr int YU = 4 * N, XU = 4 * K;                      // 16-byte units per chunk (2 blocks x width x 2 halves)
+    constexpr int YU = CHB * N, XU = CHB * K;                  // 16-byte units per chunk
     static_assert(!XROWS || (CHP * K / 4 <= DWT), "one float4 of the f32 rows per thread");
     constexpr int NY = (YU + DWT - 1) / DWT, NX = (XU + DWT - 1) / DWT;
     constexpr bool YFULL = YU % DWT == 0, XFULL = XU % DWT == 0;
-    constexpr int BUF = YU + XU + 4;                           // + 16 floats of d_sigma
+    // thin instances: X = PE / PE(dir) rows, whose values repeat along a ray (PE(dir)) or across the whole batch (the
+    // raw direction components): their f16 rounding error would be COHERENT over the sum, so they are staged as hi + lo
+    // (two MFMAs per block, 22-bit operand; the rows are f32 anyway)
+    constexpr int XPL = XROWS ? 2 : 1;
+    constexpr int BUF = YU + XPL * XU + CHP / 4;               // + CHP floats of d_sigma
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 31, lh = lane >> 5;
     const int wn = wave % WN, wk = wave / WN;
@@ -80,30 +82,6 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int kY, 
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[r][c][e] = 0.f;
     float bsum = 0.f, asum = 0.f, absum = 0.f;
-
-    // stored (hi, lo * 2^11)  ->  (hi * 2^k, lo * 2^(k-11)): the array's largest element lands in [2^14, 2^15) and lo is
-    // unscaled.  2^k as a product of two f16-representable powers of two (packed-f16 multiplies, all exact).
-    // a unit is {hi x4, lo x4} = words {hi, hi, lo, lo}: per operand four packed-f16 multipliers (2^k = m1 * m2 for the
-    // hi words, 2^(k-11) for the lo words), kept as wave-uniform 32-bit patterns so they live in SGPRs
-    typedef _Float16 half2 __attribute__((ext_vector_type(2)));
-    struct Mul4 { unsigned int h1, h2, l1, l2; };
-    auto mul4 = [](int k) -> Mul4 {
-        const int kl = k - 11;
-        const int h1 = k < -14 ? -14 : (k > 15 ? 15 : k), l1 = kl < -14 ? -14 : (kl > 15 ? 15 : kl);
-        auto pat = [](int e) -> unsigned int {                       // {2^e, 2^e} as packed f16, e in [-14, 15]
-            const unsigned int b = (unsigned int)((e + 15) << 10);
-            return (unsigned int)__builtin_amdgcn_readfirstlane((int)(b | (b << 16)));
-        };
-        return Mul4{pat(h1), pat(k - h1), pat(l1), pat(kl - l1)};
-    };
-    const Mul4 ym = mul4(kY), xm = mul4(kX);
-    auto mulw = [](unsigned int w, unsigned int m1, unsigned int m2) -> unsigned int {
-        const half2 t = (__builtin_bit_cast(half2, w) * __builtin_bit_cast(half2, m1)) * __builtin_bit_cast(half2, m2);
-        return __builtin_bit_cast(unsigned int, t);
-    };
-    auto rescale = [&](u32x4 unit, const Mul4& m) -> u32x4 {
-        return u32x4{mulw(unit.x, m.h1, m.h2), mulw(unit.y, m.h1, m.h2), mulw(unit.z, m.l1, m.l2), mulw(unit.w, m.l1, m.l2)};
-    };
 
     u32x4 ryA[NY], rxA[NX], ryB[NY], rxB[NX], ryC[NY], rxC[NX];
     float rdaA = 0.f, rdaB = 0.f, rdaC = 0.f;
@@ -130,45 +108,32 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int kY, 
             if (row >= M) RDA = 0.f;                                                                      \
         }                                                                                                 \
     }
-    // global unit u = ((block * W + w) * 2 + half) holds {hi x4, lo x4} of 4 points: the two quads go to the hi / lo
-    // fragment planes of the LDS image [block][plane][w][8 points] (8-byte writes, conflict free)
+    // global unit u = block * W + w of the chunk is unit u of the LDS image [block][w] (16-byte writes, conflict free)
 #define DW_STAGE(RY, RX, RDA, B, VALID)                                                                   \
     {                                                                                                     \
         u32x4* Ys_ = smem + (B) * BUF;                                                                    \
         u32x4* Xs_ = Ys_ + YU;                                                                            \
         _Pragma("unroll") for (int j = 0; j < NY; ++j) {                                                  \
-            const int u = tid + j * DWT, mb = u / (2 * N), rem = u % (2 * N);                             \
-            if (YFULL || u < YU) {                                                                        \
-                u32x2* d = reinterpret_cast<u32x2*>(Ys_) + ((mb * 2) * N + (rem >> 1)) * 2 + (rem & 1);   \
-                u32x4 q = rescale(RY[j], ym);                                                       \
-                if (!(VALID)) q = u32x4{0u, 0u, 0u, 0u};       /* past the range: contributes nothing */ \
-                d[0] = u32x2{q.x, q.y};                                                                   \
-                d[2 * N] = u32x2{q.z, q.w};                                                               \
-            }                                                                                             \
+            const int u = tid + j * DWT;                                                                  \
+            if (YFULL || u < YU) Ys_[u] = (VALID) ? RY[j] : u32x4{0u, 0u, 0u, 0u};   /* past the range: contributes nothing */ \
         }                                                                                                 \
-        if (XROWS) {   /* split x * 2^kX directly (unscaled lo) and scatter the 4 features into their fragments */ \
+        if (XROWS) {   /* round to f16 and scatter the 4 features of this thread's point into their fragments */ \
             if (tid < CHP * K / 4) {                                                                      \
                 const int p = tid / (K / 4), w0 = (tid % (K / 4)) * 4;                                    \
                 _Float16* img = reinterpret_cast<_Float16*>(Xs_);                                         \
-                const float xs = exp2i(kX);                                                               \
                 _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
-                    const float v = __uint_as_float(RX[0][i]) * xs;                                       \
+                    const float v = __uint_as_float(RX[0][i]);                                            \
                     const _Float16 hi = (_Float16)v;                                                      \
-                    img[(((p >> 3) * 2 + 0) * K + w0 + i) * 8 + (p & 7)] = hi;                            \
-                    img[(((p >> 3) * 2 + 1) * K + w0 + i) * 8 + (p & 7)] = (_Float16)(v - (float)hi);     \
+                    img[((p >> 3) * K + w0 + i) * 8 + (p & 7)] = hi;                                      \
+                    img[XU * 8 + ((p >> 3) * K + w0 + i) * 8 + (p & 7)] = (_Float16)(v - (float)hi);      \
                 }                                                                                         \
             }                                                                                             \
         } else                                                                                            \
         _Pragma("unroll") for (int j = 0; j < NX; ++j) {                                                  \
-            const int u = tid + j * DWT, mb = u / (2 * K), rem = u % (2 * K);                             \
-            if (XFULL || u < XU) {                                                                        \
-                u32x2* d = reinterpret_cast<u32x2*>(Xs_) + ((mb * 2) * K + (rem >> 1)) * 2 + (rem & 1);   \
-                const u32x4 q = rescale(RX[j], xm);                                                 \
-                d[0] = u32x2{q.x, q.y};                                                                   \
-                d[2 * K] = u32x2{q.z, q.w};                                                               \
-            }                                                                                             \
+            const int u = tid + j * DWT;                                                                  \
+            if (XFULL || u < XU) Xs_[u] = RX[j];                                                          \
         }                                                                                                 \
-        if (ALPHA && tid < CHP) reinterpret_cast<float*>(Xs_ + XU)[tid] = (VALID) ? RDA : 0.f;            \
+        if (ALPHA && tid < CHP) reinterpret_cast<float*>(Xs_ + XPL * XU)[tid] = (VALID) ? RDA : 0.f;      \
         /* buffer B was last read three chunks ago, and every wave has passed two barriers in between */ \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");                                   \
         __builtin_amdgcn_s_barrier();                                                                     \
@@ -177,59 +142,48 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int kY, 
     auto compute = [&](int b) {
         const u32x4* Yl = smem + b * BUF;
         const u32x4* Xl = Yl + YU;
-        const float* da = reinterpret_cast<const float*>(Xl + XU);
+        const float* da = reinterpret_cast<const float*>(Xl + XPL * XU);
         if (mma_wave) {
-            half8 ah[TR], al[TR];
 #pragma unroll
-            for (int r = 0; r < TR; ++r) {
-                ah[r] = __builtin_bit_cast(half8, Yl[(lh * 2 + 0) * N + (wn * TR + r) * 32 + lr]);
-                al[r] = __builtin_bit_cast(half8, Yl[(lh * 2 + 1) * N + (wn * TR + r) * 32 + lr]);
-            }
-            // column tiles in groups of two (fragment registers: 16 + 16 instead of 16 + 32); inside a group all tiles
-            // per product kind, so an accumulator is touched again only after TR*2 other MFMAs
-            constexpr int CG = TC >= 2 ? 2 : 1;
+            for (int ks = 0; ks < CHP / 16; ++ks) {
+                half8 ay[TR], bx[TC];
 #pragma unroll
-            for (int c0 = 0; c0 < TC; c0 += CG) {
-                half8 bh[CG], bl[CG];
+                for (int r = 0; r < TR; ++r) ay[r] = __builtin_bit_cast(half8, Yl[(ks * 2 + lh) * N + (wn * TR + r) * 32 + lr]);
 #pragma unroll
-                for (int c = 0; c < CG; ++c) {
-                    bh[c] = __builtin_bit_cast(half8, Xl[(lh * 2 + 0) * K + (wk * TC + c0 + c) * 32 + lr]);
-                    bl[c] = __builtin_bit_cast(half8, Xl[(lh * 2 + 1) * K + (wk * TC + c0 + c) * 32 + lr]);
+                for (int c = 0; c < TC; ++c) bx[c] = __builtin_bit_cast(half8, Xl[(ks * 2 + lh) * K + (wk * TC + c) * 32 + lr]);
+#pragma unroll
+                for (int r = 0; r < TR; ++r)
+#pragma unroll
+                    for (int c = 0; c < TC; ++c) acc[r][c] = mfma16(ay[r], bx[c], acc[r][c]);
+                if (XROWS) {
+#pragma unroll
+                    for (int c = 0; c < TC; ++c) bx[c] = __builtin_bit_cast(half8, Xl[XU + (ks * 2 + lh) * K + (wk * TC + c) * 32 + lr]);
+#pragma unroll
+                    for (int r = 0; r < TR; ++r)
+#pragma unroll
+                        for (int c = 0; c < TC; ++c) acc[r][c] = mfma16(ay[r], bx[c], acc[r][c]);
                 }
-#pragma unroll
-                for (int r = 0; r < TR; ++r)
-#pragma unroll
-                    for (int c = 0; c < CG; ++c) acc[r][c0 + c] = mfma16(ah[r], bh[c], acc[r][c0 + c]);
-#pragma unroll
-                for (int r = 0; r < TR; ++r)
-#pragma unroll
-                    for (int c = 0; c < CG; ++c) acc[r][c0 + c] = mfma16(ah[r], bl[c], acc[r][c0 + c]);
-#pragma unroll
-                for (int r = 0; r < TR; ++r)
-#pragma unroll
-                    for (int c = 0; c < CG; ++c) acc[r][c0 + c] = mfma16(al[r], bh[c], acc[r][c0 + c]);
             }
         }
         if (src.bias && tid < N) {
             float s = 0.f;
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-                const half8 h = __builtin_bit_cast(half8, Yl[(mb * 2) * N + tid]), l = __builtin_bit_cast(half8, Yl[(mb * 2 + 1) * N + tid]);
+            for (int mb = 0; mb < CHB; ++mb) {
+                const half8 h = __builtin_bit_cast(half8, Yl[mb * N + tid]);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) s += (float)h[j] + (float)l[j];
+                for (int j = 0; j < 8; ++j) s += (float)h[j];
             }
             bsum += s;
         }
         if (ALPHA && tid < K) {
             float s = 0.f, sb = 0.f;
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-                const half8 h = __builtin_bit_cast(half8, Xl[(mb * 2) * K + tid]);
-                const half8 l = __builtin_bit_cast(half8, Xl[(mb * 2 + 1) * K + tid]);
+            for (int mb = 0; mb < CHB; ++mb) {
+                const half8 h = __builtin_bit_cast(half8, Xl[mb * K + tid]);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float d = da[mb * 8 + j];
-                    s += d * ((float)h[j] + (float)l[j]);
+                    s += d * (float)h[j];
                     sb += d;
                 }
             }
@@ -262,7 +216,7 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int kY, 
 #undef DW_STAGE
 
     // partial block -> workspace: [N][K] then bias [N] (then alpha row [256] + alpha bias).  Block and bias stay at
-    // the operand scales (the reduce kernel divides them out); the alpha row only carries the activation scale
+    // the gradient scale s_s (the reduce kernel divides it out); the alpha row is unscaled (d_raw is)
     if (mma_wave) {
 #pragma unroll
         for (int r = 0; r < TR; ++r)
@@ -276,7 +230,7 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int kY, 
     }
     if (tid < N) part[(int64_t)N * K + tid] = src.bias ? bsum : 0.f;
     if (ALPHA && tid < K) {
-        part[(int64_t)N * K + N + tid] = asum * exp2i(-kX);
+        part[(int64_t)N * K + N + tid] = asum;
         if (tid == 0) part[(int64_t)N * K + N + 256] = absum;
     }
 }
@@ -307,23 +261,19 @@ __device__ __forceinline__ void dw_rgb(const DwArgs& a, int64_t blk_begin, int64
             reinterpret_cast<float4*>(dr)[tid] = g;
         }
         __syncthreads();
-        u32x4 hh[BB / 4], hl[BB / 4];
+        u32x4 hh[BB / 4];
 #pragma unroll
         for (int i = 0; i < BB / 4; ++i) {
             const int64_t mb = b0 + ph + 4 * i;
-            hh[i] = hl[i] = u32x4{0u, 0u, 0u, 0u};
-            if (mb < blk_end) {
-                hh[i] = hv[(mb * ACT_HV_W + j) * 2];          // points 0-3: {hi x4, lo x4}
-                hl[i] = hv[(mb * ACT_HV_W + j) * 2 + 1];      // points 4-7
-            }
+            hh[i] = u32x4{0u, 0u, 0u, 0u};
+            if (mb < blk_end) hh[i] = hv[mb * ACT_HV_W + j];     // 8 points of column j
         }
 #pragma unroll
         for (int i = 0; i < BB / 4; ++i) {
-            const half8 p0 = __builtin_bit_cast(half8, hh[i]), p1 = __builtin_bit_cast(half8, hl[i]);
+            const half8 pq = __builtin_bit_cast(half8, hh[i]);
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const half8& pq = q < 4 ? p0 : p1;
-                const float x = (float)pq[q & 3] + (float)pq[4 + (q & 3)] * LO_INV;
+                const float x = (float)pq[q];
                 const float4 g = reinterpret_cast<const float4*>(dr)[(ph + 4 * i) * 8 + q];   // zero beyond the range
                 s[0] += g.x * x;
                 s[1] += g.y * x;
@@ -362,15 +312,8 @@ __device__ __forceinline__ void dw_rgb(const DwArgs& a, int64_t blk_begin, int64
     }
 }
 
-constexpr size_t DWH_SMEM = 3 * (size_t)(4 * 256 + 4 * 256 + 4) * 16;       // three chunk images of the 256 x 256 block: 98 496 B
-constexpr size_t DWH_SMEM_SMALL = 3 * (size_t)(4 * 256 + 4 * 64 + 4) * 16;  // 256 x 64 block: 61 632 B
-
-// rescale exponents of the operands from the absmax slots the forward / dX launches published
-__device__ __forceinline__ void operand_scales(const DwArgs& a, int inst, int& kY, int& kX) {
-    (void)inst;
-    kY = __builtin_amdgcn_readfirstlane(rescale_exp(a.dacts[sdact_scale(m_pad(a.M)) + AY_ALL]));
-    kX = __builtin_amdgcn_readfirstlane(rescale_exp(a.acts[sact_absmax(a.M) + AX_ALL]));
-}
+constexpr size_t DWH_SMEM = 3 * (size_t)(CHB * 256 + CHB * 256 + CHP / 4) * 16;       // three chunk images of the 256 x 256 block: 98 688 B
+constexpr size_t DWH_SMEM_SMALL = 3 * (size_t)(CHB * 256 + 2 * CHB * 64 + CHP / 4) * 16;  // 256 x 64 block, X as hi + lo: 74 112 B
 
 __device__ __forceinline__ void chunk_range(const DwArgs& a, int inst, int split, int64_t& cb, int64_t& ce) {
     const int64_t nchunks = m_pad(a.M) / CHP;
@@ -382,7 +325,7 @@ __device__ __forceinline__ void chunk_range(const DwArgs& a, int inst, int split
 }
 
 // the eight 256x256 instances + the 128x256 views block: one workgroup per CU, every operand byte read once
-__global__ __launch_bounds__(DWT, 2) void mlp_dw_split_big_kernel(DwArgs a) {
+__global__ __launch_bounds__(DWT, 2) void mlp_dw_f16_big_kernel(DwArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32x4 smem_u[];
     const int id = blockIdx.x;
     int inst, split;
@@ -397,35 +340,31 @@ __global__ __launch_bounds__(DWT, 2) void mlp_dw_split_big_kernel(DwArgs a) {
     chunk_range(a, inst, split, cb, ce);
     float* part = a.ws + dwh_inst_offset(inst) + (int64_t)split * dw_inst_floats(inst);
     const Src src = inst_src(a, inst);
-    int kY, kX;
-    operand_scales(a, inst, kY, kX);
-    if (inst == DW_FEAT) dw_gemm<256, 256, 4, 2, 4, true>(a, src, kY, kX, cb, ce, part, smem_u);
-    else if (inst <= DW_L7) dw_gemm<256, 256, 4, 2, 4, false>(a, src, kY, kX, cb, ce, part, smem_u);
-    else dw_gemm<128, 256, 2, 2, 2, false>(a, src, kY, kX, cb, ce, part, smem_u);
+    if (inst == DW_FEAT) dw_gemm<256, 256, 4, 2, 4, true>(a, src, cb, ce, part, smem_u);
+    else if (inst <= DW_L7) dw_gemm<256, 256, 4, 2, 4, false>(a, src, cb, ce, part, smem_u);
+    else dw_gemm<128, 256, 2, 2, 2, false>(a, src, cb, ce, part, smem_u);
 }
 
 // the thin instances: L0 and L5P (256 x 64, X = PE), VIEWSP (128 x 32, X = PE(dir)), rgb head (VALU)
-__global__ __launch_bounds__(DWT, 2) void mlp_dw_split_small_kernel(DwArgs a) {
+__global__ __launch_bounds__(DWT, 2) void mlp_dw_f16_small_kernel(DwArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32x4 smem_u[];
     const int inst = DW_L0 + blockIdx.x / 64, split = blockIdx.x % 64;
     int64_t cb, ce;
     chunk_range(a, inst, split, cb, ce);
     float* part = a.ws + dwh_inst_offset(inst) + (int64_t)split * dw_inst_floats(inst);
     if (inst == DW_RGB) {
-        dw_rgb(a, cb * 2, ce * 2, part, reinterpret_cast<float*>(smem_u));
+        dw_rgb(a, cb * CHB, ce * CHB, part, reinterpret_cast<float*>(smem_u));
         return;
     }
     const Src src = inst_src(a, inst);
-    int kY, kX;
-    operand_scales(a, inst, kY, kX);
-    if (inst == DW_VIEWSP) dw_gemm<128, 32, 4, 1, 1, false, true>(a, src, kY, kX, cb, ce, part, smem_u);
-    else dw_gemm<256, 64, 4, 2, 1, false, true>(a, src, kY, kX, cb, ce, part, smem_u);   // DW_L0, DW_L5P
+    if (inst == DW_VIEWSP) dw_gemm<128, 32, 4, 1, 1, false, true>(a, src, cb, ce, part, smem_u);
+    else dw_gemm<256, 64, 4, 2, 1, false, true>(a, src, cb, ce, part, smem_u);   // DW_L0, DW_L5P
 }
 
 }  // namespace
 
 int benerf_mlp_dw_reduce_launch(const float* ws, const BenerfMlpGrads* grads, int channels, int accumulate, int split_mode,
-                                const float* absmax_y, const float* absmax_x, hipStream_t stream);
+                                const float* grad_info, hipStream_t stream);
 
 int benerf_mlp_dw_split_launch(int channels, int64_t M, const float* d_raw, const float* acts, const float* dacts, float* dw_ws,
                                const BenerfMlpGrads* grads, int accumulate, hipStream_t stream) {
@@ -437,17 +376,15 @@ int benerf_mlp_dw_split_launch(int channels, int64_t M, const float* d_raw, cons
     a.M = M;
     a.C = channels;
     static_assert(DW_L0 + 1 == DW_L5P && DW_L5P + 1 == DW_VIEWSP && DW_VIEWSP + 1 == DW_RGB, "small-kernel instance order");
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)mlp_dw_split_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DWH_SMEM);
-        (void)hipFuncSetAttribute((const void*)mlp_dw_split_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)DWH_SMEM_SMALL);
-        attr_done = true;
+    if (hipFuncSetAttribute((const void*)mlp_dw_f16_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DWH_SMEM) != hipSuccess ||
+        hipFuncSetAttribute((const void*)mlp_dw_f16_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DWH_SMEM_SMALL) !=
+            hipSuccess) {
+        benerf_set_error("mlp_bwd(dw, f16): cannot reserve LDS");
+        return BENERF_EHIP;
     }
-    hipLaunchKernelGGL(mlp_dw_split_small_kernel, dim3(mlp::DWH_SMALL_BLOCKS), dim3(DWT), DWH_SMEM_SMALL, stream, a);
-    BENERF_LAUNCH_CHECK("mlp_bwd(dw small, split)");
-    hipLaunchKernelGGL(mlp_dw_split_big_kernel, dim3(mlp::DWH_BIG_BLOCKS), dim3(DWT), DWH_SMEM, stream, a);
-    BENERF_LAUNCH_CHECK("mlp_bwd(dw, split)");
-    return benerf_mlp_dw_reduce_launch(dw_ws, grads, channels, accumulate, 1, dacts + mlp::sdact_scale(mlp::m_pad(M)),
-                                       acts + mlp::sact_absmax(M), stream);
+    hipLaunchKernelGGL(mlp_dw_f16_small_kernel, dim3(mlp::DWH_SMALL_BLOCKS), dim3(DWT), DWH_SMEM_SMALL, stream, a);
+    BENERF_LAUNCH_CHECK("mlp_bwd(dw small, f16)");
+    hipLaunchKernelGGL(mlp_dw_f16_big_kernel, dim3(mlp::DWH_BIG_BLOCKS), dim3(DWT), DWH_SMEM, stream, a);
+    BENERF_LAUNCH_CHECK("mlp_bwd(dw, f16)");
+    return benerf_mlp_dw_reduce_launch(dw_ws, grads, channels, accumulate, 1, dacts + mlp::sdact_info(mlp::m_pad(M)), stream);
 }

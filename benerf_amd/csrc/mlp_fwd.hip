@@ -18,7 +18,7 @@
 // kernel is bound by the f32 matrix pipe.  The tile is exactly 80 KiB and the kernel fits 256
 // registers, so TWO workgroups share a CU: while one is in an epilogue (bias/ReLU, LDS writes,
 // activation stores for the backward pass, barriers) the other keeps the matrix pipe busy.
-#include "mlp_common.h"
+#include "mlp_split.h"
 
 namespace {
 using namespace mlp;
@@ -36,6 +36,7 @@ struct FwdArgs {
     const float* b_rgb;
     float* raw;
     float* acts;
+    const uint32_t* gate;    // BENERF_MLP_AUTO re-run: workgroups exit unless *gate (max |activation| of the split launch, f32 bits) left f16's range
     int64_t M;
     int S;
 };
@@ -170,6 +171,7 @@ __device__ __forceinline__ uint64_t epilogue(f32x16 (&acc)[2][NCT], float* __res
 template <int C, bool SAVE>
 __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_kernel(FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float T[];   // [TM][LD], swizzled (mlp_common.h)
+    if (a.gate && __builtin_amdgcn_readfirstlane((int)(*a.gate < __float_as_uint(F16_RANGE_LIMIT)))) return;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -346,14 +348,36 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_kernel(FwdArgs a) {
 
 }  // namespace
 
+// split-f16 variant (mlp_fwd_h.hip)
+int benerf_mlp_fwd_split_launch(const BenerfMlpParams* params, const float* packed, int channels, int n_rays, int n_samples,
+                                const float* rays_o, const float* rays_d, const float* viewdirs, const float* z, float* raw,
+                                float* acts, uint32_t* status, hipStream_t stream);
+
 extern "C" int benerf_mlp_fwd(const BenerfMlpParams* params, const float* packed, int channels, int n_rays,
                               int n_samples, const float* rays_o, const float* rays_d, const float* viewdirs,
-                              const float* z, float* raw, float* acts, benerf_stream_t stream) {
-    if (benerf_get_mlp_precision() == BENERF_MLP_SPLIT)
-        return benerf_mlp_fwd_split(params, packed, channels, n_rays, n_samples, rays_o, rays_d, viewdirs, z, raw, acts, stream);
+                              const float* z, float* raw, float* acts, int precision, uint32_t* status,
+                              benerf_stream_t stream) {
     BENERF_REQUIRE(params && packed && rays_o && rays_d && viewdirs && z && raw, "mlp_fwd: null pointer");
     BENERF_REQUIRE(channels == 1 || channels == 3, "mlp_fwd: channels must be 1 or 3");
     BENERF_REQUIRE(n_rays > 0 && n_samples > 0, "mlp_fwd: bad sizes");
+    BENERF_REQUIRE(precision == BENERF_MLP_F32 || precision == BENERF_MLP_SPLIT || precision == BENERF_MLP_AUTO,
+                   "mlp_fwd: unknown precision %d", precision);
+    BENERF_REQUIRE(precision != BENERF_MLP_AUTO || (status && !acts),
+                   "mlp_fwd: BENERF_MLP_AUTO is the inference mode (acts == NULL) and needs a status word");
+    for (int l = 0; l < BENERF_NLAYERS; ++l) BENERF_REQUIRE(params->b[l] && params->w[l], "mlp_fwd: null parameter %d", l);
+    const uint32_t* gate = nullptr;
+    if (precision != BENERF_MLP_F32) {
+        if (precision == BENERF_MLP_AUTO) {   // per-call maximum in status[3]; the f32 launch below runs only if it left the range
+            if (hipMemsetAsync(status + 3, 0, sizeof(uint32_t), as_stream(stream)) != hipSuccess) {
+                benerf_set_error("mlp_fwd: memset failed");
+                return BENERF_EHIP;
+            }
+            gate = status + 3;
+        }
+        const int rc = benerf_mlp_fwd_split_launch(params, packed, channels, n_rays, n_samples, rays_o, rays_d, viewdirs, z, raw, acts,
+                                                   status, as_stream(stream));
+        if (rc != BENERF_OK || precision == BENERF_MLP_SPLIT) return rc;
+    }
     FwdArgs a;
     a.rays_o = rays_o;
     a.rays_d = rays_d;
@@ -367,30 +391,32 @@ extern "C" int benerf_mlp_fwd(const BenerfMlpParams* params, const float* packed
     a.b_alpha = params->b[BENERF_L_ALPHA];
     a.w_rgb = params->w[BENERF_L_RGB];
     a.b_rgb = params->b[BENERF_L_RGB];
-    for (int l = 0; l < BENERF_NLAYERS; ++l) BENERF_REQUIRE(params->b[l] && params->w[l], "mlp_fwd: null parameter %d", l);
     a.raw = raw;
     a.acts = acts;
+    a.gate = gate;
     a.M = (int64_t)n_rays * n_samples;
     a.S = n_samples;
     const int64_t tiles = (a.M + mlp::TM - 1) / mlp::TM;
     BENERF_REQUIRE(tiles < (1ll << 31), "mlp_fwd: too many points");
     dim3 grid((unsigned)tiles), block(mlp::NTHREADS);
     const int smem = (int)mlp::TILE_SMEM;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)mlp_fwd_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        (void)hipFuncSetAttribute((const void*)mlp_fwd_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        (void)hipFuncSetAttribute((const void*)mlp_fwd_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        (void)hipFuncSetAttribute((const void*)mlp_fwd_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr_done = true;
-    }
+#define BENERF_FWD_LAUNCH(CH, SV)                                                                                  \
+    do {                                                                                                           \
+        if (hipFuncSetAttribute((const void*)mlp_fwd_kernel<CH, SV>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                smem) != hipSuccess) {                                                             \
+            benerf_set_error("mlp_fwd: cannot reserve %d bytes of LDS", smem);                                     \
+            return BENERF_EHIP;                                                                                    \
+        }                                                                                                          \
+        hipLaunchKernelGGL((mlp_fwd_kernel<CH, SV>), grid, block, smem, as_stream(stream), a);                     \
+    } while (0)
     if (channels == 1) {
-        if (acts) hipLaunchKernelGGL((mlp_fwd_kernel<1, true>), grid, block, smem, as_stream(stream), a);
-        else hipLaunchKernelGGL((mlp_fwd_kernel<1, false>), grid, block, smem, as_stream(stream), a);
+        if (acts) BENERF_FWD_LAUNCH(1, true);
+        else BENERF_FWD_LAUNCH(1, false);
     } else {
-        if (acts) hipLaunchKernelGGL((mlp_fwd_kernel<3, true>), grid, block, smem, as_stream(stream), a);
-        else hipLaunchKernelGGL((mlp_fwd_kernel<3, false>), grid, block, smem, as_stream(stream), a);
+        if (acts) BENERF_FWD_LAUNCH(3, true);
+        else BENERF_FWD_LAUNCH(3, false);
     }
+#undef BENERF_FWD_LAUNCH
     BENERF_LAUNCH_CHECK("mlp_fwd");
     return BENERF_OK;
 }

@@ -9,8 +9,10 @@
 //
 // LDS: two f16 planes Th/Tl[64][320] (hi / scaled lo) = 80 KiB, so two workgroups still share a CU.
 // 16-byte slots (8 halfs) are XOR-swizzled: element (row, col) lives in slot (col>>3) ^ ((row>>1)&7).
-// Range: |x| must stay below 65504 (f16 max) - NeRF activations are O(1..100).
-// Training mode saves the activations as ST arrays (mlp_split.h) + ReLU sign-bit words for the split dX / dW kernels.
+// Range: |x| must stay below 65504 (f16 max) - NeRF activations are O(1..100); every launch folds max|activation|
+// into the caller's status word once it passes 2^15 (mlp_split.h, 'Range guard'), so a violation is never silent.
+// Training mode saves the f16 (hi) halves of the activations as SH arrays (mlp_split.h) + ReLU sign-bit words for the
+// f16 dX / dW kernels.
 #include "mlp_split.h"
 
 namespace {
@@ -29,13 +31,14 @@ struct FwdArgs {
     const float* b_rgb;
     float* raw;
     float* acts;
+    uint32_t* status;        // [0] sticky / [3] per-call max |activation| bits, written only when >= 2^15 (may be null)
     int64_t M;
     int S;
 };
 
-// combine the two accumulators, bias (+ReLU) -> both LDS planes and, in training mode, the ST activation array `st`
-// of width W (mlp_split.h; m0 = first point of the tile).  Returns the ReLU sign bits in the accumulator-layout
-// convention of mlp_common.h, so the mask words are shared with the f32 kernels.
+// combine the two accumulators, bias (+ReLU) -> both LDS planes and, in training mode, the f16 value into the SH
+// activation array `st` of width W (mlp_split.h; m0 = first point of the tile).  Returns the ReLU sign bits in the
+// accumulator-layout convention of mlp_common.h, so the mask words are shared with the f32 kernels.
 template <int NCT, bool RELU, bool SAVE, int W>
 __device__ __forceinline__ uint64_t epilogue(f32x16 (&acc1)[2][NCT], f32x16 (&acc2)[2][NCT], _Float16* __restrict__ Th,
                                              _Float16* __restrict__ Tl, int ct0, int lane, const float* __restrict__ bias,
@@ -52,12 +55,12 @@ __device__ __forceinline__ uint64_t epilogue(f32x16 (&acc1)[2][NCT], f32x16 (&ac
         int base[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) base[q] = r4 * LD + ((((ns ^ ((q & 1) | ((q >> 1) << 2)))) << 3) | (n & 7));
-        _Float16* st_lane = SAVE ? st + st_half_index(m0 + r4, W, n, 0) : nullptr;    // + (r*4 + eq) * W*16 per quad
+        _Float16* st_lane = SAVE ? st + sh_half_index(m0 + r4, W, n) : nullptr;    // + (r*4 + eq) * W*8 per quad
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
 #pragma unroll
             for (int eq = 0; eq < 4; ++eq) {
-                Quad16 qh, ql;
+                Quad16 qh;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int e = eq * 4 + j;
@@ -66,19 +69,15 @@ __device__ __forceinline__ uint64_t epilogue(f32x16 (&acc1)[2][NCT], f32x16 (&ac
                         v = fmaxf(v, 0.f);
                         bits |= (uint64_t)(v > 0.f) << ((c * 2 + r) * 16 + e);
                     }
-                    if (SAVE) amax = fmaxf(amax, RELU ? v : fabsf(v));      // for the dW kernel's per-array rescale
+                    amax = fmaxf(amax, RELU ? v : fabsf(v));                // range guard
                     const _Float16 hi = (_Float16)v;
                     const _Float16 lo = (_Float16)((v - (float)hi) * LO_SCALE);
                     const int idx = base[((e >> 1) & 1) | (((e >> 2) & 1) << 1)] + (r * 32 + (e & 3) + 8 * (e >> 2)) * LD;
                     Th[idx] = hi;
                     Tl[idx] = lo;
                     qh.v[j] = hi;
-                    ql.v[j] = lo;
                 }
-                if (SAVE) {
-                    const Quad16x2 q = {qh, ql};
-                    *reinterpret_cast<uint4*>(st_lane + (int64_t)(r * 4 + eq) * W * 16) = __builtin_bit_cast(uint4, q);
-                }
+                if (SAVE) *reinterpret_cast<uint2*>(st_lane + (int64_t)(r * 4 + eq) * W * 8) = __builtin_bit_cast(uint2, qh);
             }
         }
     }
@@ -103,14 +102,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_split_kernel(FwdArgs a) {
     const int64_t ray = mc / a.S;
     float* acts = a.acts;
     const int64_t Mp = m_pad(M);
-    _Float16* st_h = SAVE ? reinterpret_cast<_Float16*>(acts + sact_h(Mp, 0)) : nullptr;     // layer l: + l * Mp * 256 * 2 halfs
+    _Float16* st_h = SAVE ? reinterpret_cast<_Float16*>(acts + sact_h(Mp, 0)) : nullptr;     // layer l: + l * Mp * 256 halfs
     uint64_t* mask_out = SAVE ? reinterpret_cast<uint64_t*>(acts + sact_mask(Mp)) + (int64_t)blockIdx.x * NTHREADS + tid
                               : nullptr;
-    const int64_t mask_stride = n_tiles(M) * NTHREADS;
+    const int64_t mask_stride = (Mp / TM) * NTHREADS;
     const bool live = m < M;
-    // running max |value| over everything this wave saves (-> the dW kernel's operand rescale; table entry per wave)
-    float* absmax = SAVE ? acts + sact_absmax_table(M) + (int64_t)blockIdx.x * 4 + wave : nullptr;
-    float amax = 0.f;
+    if (SAVE && blockIdx.x == 0 && tid == 0) reinterpret_cast<uint32_t*>(acts + sact_info(Mp))[SI_TAG] = SACT_TAG_SPLIT;
+    float amax = 0.f;        // running max |activation| of this thread (range guard)
     // f32 scratch in the dead PE columns [288,320) of the lo plane: logical slot 36 + j of this thread's row
     const int psw = hsw(pt);
     auto scratch = [&](int j) { return reinterpret_cast<float*>(Tl + pt * LD + (((36 + j) ^ psw) << 3)); };
@@ -129,27 +127,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_split_kernel(FwdArgs a) {
             const int idx = hidx(pt, COL_PE + col);
             Th[idx] = hi;
             Tl[idx] = lo;
-            if (SAVE) {
-                ape[col] = v;
-                amax = fmaxf(amax, fabsf(v));
-            }
+            if (SAVE) ape[col] = v;
         };
         if (grp == 0) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) put(c, x[c]);
+            for (int c = 0; c < 3; ++c) {
+                put(c, x[c]);
+                amax = fmaxf(amax, fabsf(x[c]));
+            }
             put(63, 0.f);
         }
         for (int p = grp; p < 30; p += 4) {                    // model/embedder.py:13-28
             const int f = p / 3, d = p - 3 * f;
             const float v = x[d] * (float)(1 << f);
             float s, c;
-            sincosf(v, &s, &c);
+            pe_sincos(v, s, c);
             put(3 + f * 6 + d, s);
             put(3 + f * 6 + 3 + d, c);
         }
-    }
-    if (SAVE) {
-        amax = fmaxf(amax, 1.f);                                    // PE(dir): |sin|, |cos|, |viewdir| <= 1
     }
     lds_barrier();
 
@@ -177,7 +172,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_split_kernel(FwdArgs a) {
         else gemm_stage<16, 2>(Th, Tl, 0, a.packed + pack_offset(PF_L0 + l), ct0, lane, acc1, acc2);
         lds_barrier();
         const uint64_t bits = epilogue<2, true, SAVE, 256>(acc1, acc2, Th, Tl, ct0, lane, a.bias[l],
-                                                           SAVE ? st_h + (int64_t)l * Mp * 512 : nullptr, m0, amax);
+                                                           SAVE ? st_h + (int64_t)l * Mp * 256 : nullptr, m0, amax);
         if (SAVE) {
             mask_out[l * mask_stride] = bits;
         }
@@ -224,7 +219,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_split_kernel(FwdArgs a) {
             const int f = p / 3, d = p - 3 * f;
             const float v = vd[d] * (float)(1 << f);
             float sn, cs;
-            sincosf(v, &sn, &cs);
+            pe_sincos(v, sn, cs);
             put(3 + f * 6 + d, sn);
             put(3 + f * 6 + 3 + d, cs);
         }
@@ -278,7 +273,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_split_kernel(FwdArgs a) {
 #pragma unroll
         for (int c = 0; c < C; ++c) scratch(1 + c)[grp] = s[c];
     }
-    if (SAVE) publish_absmax(amax, absmax);
+    // range guard: one atomic per wave, only when something came within a factor of two of f16's maximum
+    if (a.status) {
+        const float wmax = wave_max_nonneg(amax);
+        if (lane == 63 && !(wmax < 32768.f)) {
+            const uint32_t bits = __float_as_uint(wmax == wmax ? wmax : __builtin_inff());
+            atomicMax(a.status, bits);          // sticky maximum (benerf_mlp_status_check)
+            atomicMax(a.status + 3, bits);      // maximum of this call (BENERF_MLP_AUTO gate)
+        }
+    }
     lds_barrier();
     if (tid < 64 && live) {
 #pragma unroll
@@ -291,12 +294,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_split_kernel(FwdArgs a) {
 
 }  // namespace
 
-extern "C" int benerf_mlp_fwd_split(const BenerfMlpParams* params, const float* packed, int channels, int n_rays,
-                                    int n_samples, const float* rays_o, const float* rays_d, const float* viewdirs,
-                                    const float* z, float* raw, float* acts, benerf_stream_t stream) {
-    BENERF_REQUIRE(params && packed && rays_o && rays_d && viewdirs && z && raw, "mlp_fwd_split: null pointer");
-    BENERF_REQUIRE(channels == 1 || channels == 3, "mlp_fwd_split: channels must be 1 or 3");
-    BENERF_REQUIRE(n_rays > 0 && n_samples > 0, "mlp_fwd_split: bad sizes");
+int benerf_mlp_fwd_split_launch(const BenerfMlpParams* params, const float* packed, int channels, int n_rays, int n_samples,
+                                const float* rays_o, const float* rays_d, const float* viewdirs, const float* z, float* raw,
+                                float* acts, uint32_t* status, hipStream_t stream) {
     FwdArgs a;
     a.rays_o = rays_o;
     a.rays_d = rays_d;
@@ -310,36 +310,33 @@ extern "C" int benerf_mlp_fwd_split(const BenerfMlpParams* params, const float* 
     a.b_alpha = params->b[BENERF_L_ALPHA];
     a.w_rgb = params->w[BENERF_L_RGB];
     a.b_rgb = params->b[BENERF_L_RGB];
-    for (int l = 0; l < BENERF_NLAYERS; ++l) BENERF_REQUIRE(params->b[l] && params->w[l], "mlp_fwd_split: null parameter %d", l);
     a.raw = raw;
     a.acts = acts;
+    a.status = status;
     a.M = (int64_t)n_rays * n_samples;
     a.S = n_samples;
-    const int64_t tiles = (a.M + mlp::TM - 1) / mlp::TM;
-    BENERF_REQUIRE(tiles < (1ll << 31), "mlp_fwd_split: too many points");
-    if (acts && hipMemsetAsync(acts + mlp::sact_absmax(a.M), 0, mlp::AX_COUNT * sizeof(float), as_stream(stream)) != hipSuccess) {
-        benerf_set_error("mlp_fwd_split: memset failed");
-        return BENERF_EHIP;
-    }
-
+    // training launches cover the padded point range (whole 128-point dX tiles), inference the live tiles only
+    const int64_t tiles = acts ? mlp::sn_tiles(a.M) : (a.M + mlp::TM - 1) / mlp::TM;
+    BENERF_REQUIRE(tiles < (1ll << 31), "mlp_fwd(split): too many points");
     dim3 grid((unsigned)tiles), block(mlp::NTHREADS);
     const int smem = (int)mlp::TILE_SMEM;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)mlp_fwd_split_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        (void)hipFuncSetAttribute((const void*)mlp_fwd_split_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        (void)hipFuncSetAttribute((const void*)mlp_fwd_split_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        (void)hipFuncSetAttribute((const void*)mlp_fwd_split_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr_done = true;
-    }
+#define BENERF_FWD_LAUNCH(CH, SV)                                                                                        \
+    do {                                                                                                                 \
+        if (hipFuncSetAttribute((const void*)mlp_fwd_split_kernel<CH, SV>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                smem) != hipSuccess) {                                                                   \
+            benerf_set_error("mlp_fwd(split): cannot reserve %d bytes of LDS", smem);                                    \
+            return BENERF_EHIP;                                                                                          \
+        }                                                                                                                \
+        hipLaunchKernelGGL((mlp_fwd_split_kernel<CH, SV>), grid, block, smem, stream, a);                                \
+    } while (0)
     if (channels == 1) {
-        if (acts) hipLaunchKernelGGL((mlp_fwd_split_kernel<1, true>), grid, block, smem, as_stream(stream), a);
-        else hipLaunchKernelGGL((mlp_fwd_split_kernel<1, false>), grid, block, smem, as_stream(stream), a);
+        if (acts) BENERF_FWD_LAUNCH(1, true);
+        else BENERF_FWD_LAUNCH(1, false);
     } else {
-        if (acts) hipLaunchKernelGGL((mlp_fwd_split_kernel<3, true>), grid, block, smem, as_stream(stream), a);
-        else hipLaunchKernelGGL((mlp_fwd_split_kernel<3, false>), grid, block, smem, as_stream(stream), a);
+        if (acts) BENERF_FWD_LAUNCH(3, true);
+        else BENERF_FWD_LAUNCH(3, false);
     }
-    BENERF_LAUNCH_CHECK("mlp_fwd_split");
-    if (acts) return mlp::absmax_reduce_launch(acts + mlp::sact_absmax_table(a.M), tiles * 4, acts + mlp::sact_absmax(a.M) + mlp::AX_ALL, as_stream(stream));
+#undef BENERF_FWD_LAUNCH
+    BENERF_LAUNCH_CHECK("mlp_fwd(split)");
     return BENERF_OK;
 }

@@ -111,29 +111,8 @@ __global__ void pack_kernel(PackArgs a) {
 
 }  // namespace
 
-namespace mlp {
-// slot = max(slot, max over the table): 64 blocks, one atomicMax each; the launcher zeroes the slot first
-__global__ void absmax_reduce_kernel(const float* __restrict__ table, int64_t n, float* __restrict__ slot) {
-    __shared__ float red[4];
-    float mx = 0.f;
-    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x)
-        mx = fmaxf(mx, table[r]);
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
-    __syncthreads();
-    if (threadIdx.x == 0)
-        atomicMax(reinterpret_cast<unsigned int*>(slot), __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
-}
-int absmax_reduce_launch(const float* table, int64_t n, float* slot, hipStream_t stream) {
-    hipLaunchKernelGGL(absmax_reduce_kernel, dim3(64), dim3(256), 0, stream, table, n, slot);
-    BENERF_LAUNCH_CHECK("absmax_reduce");
-    return BENERF_OK;
-}
-}  // namespace mlp
-
 extern "C" size_t benerf_mlp_packed_floats(void) { return (size_t)(2 * mlp::PACKED_FLOATS); }   // f32 blocks | split-f16 blocks
-// buffers are sized for either arithmetic mode (the split mode pads the point count to whole 64-point tiles)
+// buffers are sized for either arithmetic mode (the split mode pads the point count to whole 128-point tiles)
 extern "C" size_t benerf_mlp_act_floats(int64_t n_points) {
     const int64_t a = mlp::act_total_floats(n_points), b = mlp::sact_total_floats(n_points);
     return (size_t)(a > b ? a : b);

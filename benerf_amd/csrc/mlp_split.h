@@ -1,7 +1,8 @@
-// Shared pieces of the split-f16 MLP kernels (mlp_fwd_h.hip, mlp_bwd_h.hip, mlp_dw_h.hip): an f32 value x is
-// carried as two f16 numbers x = hi + lo * 2^-11 and a product block is three f16 MFMAs (hi*hi, hi*lo, lo*hi)
-// with f32 accumulation.  LDS holds two f16 planes Th/Tl[64][LD]; 16-byte slots (8 halfs) are XOR-swizzled:
-// element (row, col) lives in slot (col>>3) ^ ((row>>1)&7) of its row.
+// Shared pieces of the split-f16 MLP kernels (mlp_fwd_h.hip, mlp_bwd_h.hip, mlp_dw_h.hip).  Forward: an f32 value x
+// is carried as two f16 numbers x = hi + lo * 2^-11 and a product block is three f16 MFMAs (hi*hi, hi*lo, lo*hi)
+// with f32 accumulation; LDS holds two f16 planes Th/Tl[64][LD].  Backward (dX chain, dW): f16 operands, one MFMA
+// per product block, f32 accumulation.  16-byte LDS slots (8 halfs) are XOR-swizzled: element (row, col) lives in
+// slot (col>>3) ^ ((row>>1)&7) of its row.
 #pragma once
 #include "mlp_common.h"
 
@@ -173,77 +174,57 @@ __device__ __forceinline__ void load8(const _Float16* __restrict__ Th, const _Fl
 }
 
 
-// ---- saved activations / activation gradients in split mode ("ST" arrays) -------------------------------------
-// An ST array of width W over Mp = 64 * n_tiles points stores the split value of (m, w) as two halfs at
-//   half index  ((m >> 3) * W + w) * 16 + ((m >> 2) & 1) * 8 + plane * 4 + (m & 3)        plane 0 = hi, 1 = lo * 2^11
-// i.e. blocks of 8 points, feature-major; per (block, feature) 32 bytes = [points 0-3: hi x4, lo x4][points 4-7:
-// hi x4, lo x4].  A lane of the forward / dX epilogue holds 4 consecutive points of one feature, so it writes its
-// hi and lo quads as ONE 16-byte store and a wave covers 1 KiB contiguous.  The dW kernel copies chunks into LDS
-// 16 bytes at a time and splits each unit into its two 8-byte quads there, which yields the MFMA fragment order
-// (8 points of a feature contiguous per plane) without a transposition pass.  Same bytes per element (4) as the f32
-// arrays.  Rows m >= M of the last tile are written too (duplicates of the last point for activations, exact
-// zeros for gradients), so no store is masked and no dW chunk is ragged.
-__host__ __device__ inline int64_t st_half_index(int64_t m, int W, int w, int plane) {
-    return ((m >> 3) * W + w) * 16 + ((m >> 2) & 1) * 8 + plane * 4 + (m & 3);
-}
-__host__ __device__ inline int64_t m_pad(int64_t M) { return n_tiles(M) * TM; }
+// ---- saved activations / activation gradients in split mode ("SH" arrays) -------------------------------------
+// The backward GEMMs (dX chain, dW) take f16 operands with f32 accumulation (one MFMA per product block; the forward
+// pass keeps the hi/lo split).  What the forward / dX kernels save for them is therefore the f16 value (the hi half)
+// only: an SH array of width W over Mp points stores element (m, w) at
+//   half index  ((m >> 3) * W + w) * 8 + (m & 7)
+// i.e. blocks of 8 points, feature-major, one 16-byte unit per (block, feature) = the MFMA A/B fragment of a
+// contraction over points (dW = dY^T X), so the dW kernel copies chunks straight into LDS.  A lane of the forward /
+// dX epilogue holds 4 consecutive points of one feature = one 8-byte store; a wave covers 512 B contiguous.
+// Mp = M rounded up to 128 points (rows m >= M: copies of the last point for activations, exact zeros for gradients),
+// so no store is masked and no dW chunk is ragged.  2 bytes per element: 5.5 KB (activations + masks) + 4.9 KB
+// (gradients) per point, half of the f32 layout.
+constexpr int SM_PAD = 128;
+__host__ __device__ inline int64_t sh_half_index(int64_t m, int W, int w) { return ((m >> 3) * W + w) * 8 + (m & 7); }
+__host__ __device__ inline int64_t m_pad(int64_t M) { return (M + SM_PAD - 1) / SM_PAD * SM_PAD; }
+__host__ __device__ inline int64_t sn_tiles(int64_t M) { return m_pad(M) / TM; }                 // 64-point tiles, even
 // float (4-byte) offsets inside the split-mode activation buffer
 constexpr int SACT_MASK_LAYERS = 9;                                       // h0..h7 + hv
 __host__ __device__ inline int64_t sact_pe32(int64_t Mp) { (void)Mp; return 0; }                 // f32 [Mp][64]  (dX: sin/cos)
 __host__ __device__ inline int64_t sact_ped32(int64_t Mp) { return Mp * ACT_PE_W; }               // f32 [Mp][32]
-__host__ __device__ inline int64_t sact_h(int64_t Mp, int l) { return sact_ped32(Mp) + Mp * ACT_PED_W + (int64_t)l * Mp * 256; }
-__host__ __device__ inline int64_t sact_feat(int64_t Mp) { return sact_h(Mp, 8); }                // ST W = 256
-__host__ __device__ inline int64_t sact_hv(int64_t Mp) { return sact_feat(Mp) + Mp * 256; }       // ST W = 128
-__host__ __device__ inline int64_t sact_mask(int64_t Mp) { return sact_hv(Mp) + Mp * ACT_HV_W; }  // uint64 [9][tiles][256]
-__host__ __device__ inline int64_t sact_total_floats(int64_t M) {
-    return sact_mask(m_pad(M)) + (int64_t)SACT_MASK_LAYERS * n_tiles(M) * NTHREADS * 2 + 16 + n_tiles(M) * 4;   // + absmax slots + per-wave table
-}
-// activation gradients: ST arrays holding dY * s_g (s_g = power-of-two scale of this backward call from max|d_raw|),
-// then 16 absmax slots: [0] max|d_raw|, [1..10] max|dY * s_g| of every array (see 'dW operand formats')
-__host__ __device__ inline int64_t sdact_h(int64_t Mp, int l) { return (int64_t)l * Mp * 256; }
-__host__ __device__ inline int64_t sdact_feat(int64_t Mp) { return 8 * Mp * 256; }
-__host__ __device__ inline int64_t sdact_hv(int64_t Mp) { return 9 * Mp * 256; }
-__host__ __device__ inline int64_t sdact_scale(int64_t Mp) { return 9 * Mp * 256 + Mp * ACT_HV_W; }
-__host__ __device__ inline int64_t sdact_absmax_table(int64_t Mp) { return sdact_scale(Mp) + 16; }                      // [tiles][4 waves][16 stages]
-__host__ __device__ inline int64_t sdact_total_floats(int64_t M) { return sdact_scale(m_pad(M)) + 16 + n_tiles(M) * 64; }
+__host__ __device__ inline int64_t sact_h(int64_t Mp, int l) { return sact_ped32(Mp) + Mp * ACT_PED_W + (int64_t)l * Mp * 128; }   // SH W = 256
+__host__ __device__ inline int64_t sact_feat(int64_t Mp) { return sact_h(Mp, 8); }                // SH W = 256
+__host__ __device__ inline int64_t sact_hv(int64_t Mp) { return sact_feat(Mp) + Mp * 128; }       // SH W = 128
+__host__ __device__ inline int64_t sact_mask(int64_t Mp) { return sact_hv(Mp) + Mp * (ACT_HV_W / 2); }   // uint64 [9][tiles][256]
+__host__ __device__ inline int64_t sact_info(int64_t Mp) { return sact_mask(Mp) + (int64_t)SACT_MASK_LAYERS * (Mp / TM) * NTHREADS * 2; }
+__host__ __device__ inline int64_t sact_total_floats(int64_t M) { return sact_info(m_pad(M)) + 16; }
+// info words (uint32) at sact_info: [SI_TAG] arithmetic mode that wrote the buffer (the backward launches check it)
+enum { SI_TAG = 0, SI_COUNT = 16 };
+constexpr uint32_t SACT_TAG_SPLIT = 0x53504c54u;   // 'SPLT'
+// activation gradients: SH arrays holding dY * s_s (s_s = power-of-two scale of this backward call from max|d_raw|,
+// pow2_scale6), then 16 info words: [SD_DRAW] max|d_raw| (float bits, grad_absmax_kernel)
+__host__ __device__ inline int64_t sdact_h(int64_t Mp, int l) { return (int64_t)l * Mp * 128; }
+__host__ __device__ inline int64_t sdact_feat(int64_t Mp) { return 8 * Mp * 128; }
+__host__ __device__ inline int64_t sdact_hv(int64_t Mp) { return 9 * Mp * 128; }
+__host__ __device__ inline int64_t sdact_info(int64_t Mp) { return 9 * Mp * 128 + Mp * (ACT_HV_W / 2); }
+__host__ __device__ inline int64_t sdact_total_floats(int64_t M) { return sdact_info(m_pad(M)) + 16; }
+enum { SD_DRAW = 0, SD_COUNT = 16 };
 
-// power-of-two scale s = 2^(-4 - exponent(mx)) that brings values of magnitude <= mx to <= 2^-3, and its inverse
-__device__ __forceinline__ void pow2_scale(float mx, float& s, float& inv_s) {
+// Gradients are far outside f16's range (d_raw ~ 1/n_rays) but the backward chain is LINEAR in d_raw: power-of-two
+// scale s = 2^(6 - exponent(mx)) brings values of magnitude <= mx to < 2^7 (2^9 of head room below f16's maximum
+// for growth through the layers, full 11-bit precision down to 2^-20 of mx, absolute floor 2^-31 of mx).  The dX
+// kernel scales each 128-point tile by its own maximum; the dY arrays it stores for dW carry ONE scale per call.
+__device__ __forceinline__ void pow2_scale6(float mx, float& s, float& inv_s) {
     int be = (int)((__float_as_uint(mx) >> 23) & 0xffu);
-    be = be < 4 ? 4 : (be > 246 ? 246 : be);
-    s = __uint_as_float((uint32_t)(250 - be) << 23);
-    inv_s = __uint_as_float((uint32_t)(be + 4) << 23);
+    be = be < 8 ? 8 : (be > 250 ? 250 : be);
+    s = __uint_as_float((uint32_t)(260 - be) << 23);
+    inv_s = __uint_as_float((uint32_t)(be - 6) << 23);
 }
-// The dX chain works at 2^-4 (head room for growth through the layers); the dY arrays it STORES sit 2^8 higher
-// (max|d_raw| in [2^4, 2^5)): the tile -> call factor is then a power of two <= 2^8 applied to the f16 halfs, which
-// stays exact for every element down to 2^-18 of the call's largest gradient.
-constexpr float DY_STORE_BOOST = 256.f;
-// ---- dW operand formats ---------------------------------------------------------------------------------------
-// The dW kernels add the three products of a block (hi*hi, hi*lo, lo*hi) into ONE accumulator set - that is what lets
-// a workgroup hold a whole 256x256 output block and read every operand byte once.  It needs the lo parts UNSCALED
-// (x = hi + lo), i.e. operands scaled so that lo stays inside f16's range for every element that matters.  The
-// stored ST arrays keep the robust (hi, lo * 2^11) form; the forward / dX kernels also publish max|value| of every
-// value they save (one running maximum per wave -> table -> absmax_reduce_kernel -> absmax slot), and the dW kernel
-// rescales each unit while staging it into LDS:  hi' = hi * 2^k,  lo' = lo * 2^(k-11)  with k = 14 - exponent(absmax),
-// one k for all activation arrays of the forward launch and one for all gradient arrays of the backward launch
-// (they are all of one order of magnitude), so the largest stored element lands in [2^14, 2^15).  Both are exact powers of two (two packed-f16 multiplies each,
-// every factor inside f16's range); elements down to 2^-17 of the maximum keep a normal lo', smaller ones an
-// absolute floor of 2^-38 of the maximum.  The reduce kernel multiplies by 2^-(kY + kX) (and 1/s_g for dY).
-// absmax slots: acts buffer [AX_ALL] = max |saved activation|; dacts buffer [AY_DRAW] = max|d_raw|, [AY_ALL] = max
-// |stored gradient| (at the stored scale dY * s_g)
-enum { AX_ALL = 0, AX_COUNT = 16 };
-enum { AY_DRAW = 0, AY_ALL = 1, AY_COUNT = 16 };
-__host__ __device__ inline int64_t sact_absmax(int64_t M) {
-    return sact_mask(m_pad(M)) + (int64_t)SACT_MASK_LAYERS * n_tiles(M) * NTHREADS * 2;
-}
-__host__ __device__ inline int64_t sact_absmax_table(int64_t M) { return sact_absmax(M) + AX_COUNT; }   // [tiles][4 waves]
-// k = 14 - exponent(mx), clamped so that 2^k and 2^(k-11) are products of two f16-representable powers of two
-__device__ __forceinline__ int rescale_exp(float mx) {
-    const int be = (int)((__float_as_uint(mx) >> 23) & 0xffu);
-    if (be == 0) return 0;
-    int k = 14 - (be - 127);
-    return k < -14 ? -14 : (k > 30 ? 30 : k);
-}
+// Range guard of the split forward pass: an activation of magnitude >= 65520 rounds to inf in its f16 hi half.  Every
+// forward launch folds max|activation| into a caller-owned device word (f32 bit pattern, atomicMax; non-negative
+// floats order like their bit patterns) - see benerf_mlp_status in include/benerf_hip.h.
+constexpr float F16_RANGE_LIMIT = 65504.f;
 __device__ __forceinline__ float exp2i(int k) { return __uint_as_float((uint32_t)(127 + k) << 23); }   // 2^k, |k| <= 126
 // wave-wide max of non-negative values on the VALU (DPP row shifts + broadcasts, no LDS traffic); result in lane 63
 template <int CTRL, int ROW_MASK>
@@ -260,19 +241,32 @@ __device__ __forceinline__ float wave_max_nonneg(float v) {
     v = dpp_max_step<0x143, 0xc>(v);   // row_bcast:31 -> rows 2, 3
     return v;
 }
-// one plain store per wave into a [tile][wave] table (no atomics: thousands of workgroups hammering one address
-// serialise in L2; no read-compare: it would make the wave wait for all its outstanding stores).
-// absmax_reduce_kernel folds the table into the slot after the kernel.
-__device__ __forceinline__ void publish_absmax(float mx, float* wave_entry) {
-    mx = wave_max_nonneg(mx);
-    if ((threadIdx.x & 63) == 63) *wave_entry = mx;
-}
-__global__ void absmax_reduce_kernel(const float* __restrict__ table, int64_t n, float* __restrict__ slot);
-int absmax_reduce_launch(const float* table, int64_t n, float* slot, hipStream_t stream);
 
-// 4 consecutive points (one accumulator quad) of one feature = one 16-byte piece {hi x4, lo x4} of an ST array
+// sin and cos of v = x * 2^f for the positional encoding (model/embedder.py:13-28): three-term Cody-Waite reduction
+// by pi/2 with FMAs (exact product, so |v| up to ~1e5 reduces to < 1 ulp of the reduced argument) + the cephes
+// minimax polynomials on [-pi/4, pi/4]; absolute error <= 1.2e-7 (ocml's sincosf takes ~4x the instructions).
+// Arguments beyond 1e5 (never reached by NDC / scene-scale coordinates times 2^9) take the library path.
+__device__ __forceinline__ void pe_sincos(float v, float& sn, float& cs) {
+    if (__builtin_expect(fabsf(v) > 1.0e5f, 0)) {
+        sincosf(v, &sn, &cs);
+        return;
+    }
+    const float k = rintf(v * 0x1.45f306p-1f);
+    float r = __builtin_fmaf(-k, 0x1.921fb6p+0f, v);
+    r = __builtin_fmaf(-k, -0x1.777a5cp-25f, r);
+    r = __builtin_fmaf(-k, -0x1.ee59dap-50f, r);
+    const float z = r * r;
+    const float ps = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+    const float pc = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f) * z, z,
+                                    __builtin_fmaf(-0.5f, z, 1.f));
+    const int q = (int)k;
+    const float s0 = (q & 1) ? pc : ps, c0 = (q & 1) ? ps : pc;
+    sn = (q & 2) ? -s0 : s0;
+    cs = ((q + 1) & 2) ? -c0 : c0;
+}
+
+// 4 consecutive points (one accumulator quad) of one feature = one 8-byte piece of an SH array
 struct Quad16 { _Float16 v[4]; };
-struct Quad16x2 { Quad16 hi, lo; };
 
 // f32 scratch inside the planes' PE columns [256,320): 64 floats per row, floats [0,32) in the hi plane, [32,64)
 // in the lo plane (slot 32 + i/4 of the plane, swizzled like everything else).

@@ -3,6 +3,7 @@ include/benerf_hip.h).  PyTorch is plumbing only: device memory, streams, autogr
 Every wrapper validates dtype / device / contiguity and raises on any non-zero return code.
 """
 import ctypes
+import os
 
 import torch
 
@@ -160,16 +161,56 @@ def _param_struct(cls, tensors_w, tensors_b):
 
 
 MLP_PRECISIONS = {"f32": 0, "split": 1}
+_MLP_AUTO = 2
+_default_precision = os.environ.get("BENERF_MLP_PRECISION", "split")
+if _default_precision not in MLP_PRECISIONS:
+    raise _lib.BenerfHipError("BENERF_MLP_PRECISION must be 'f32' or 'split', not %r" % _default_precision)
 
 
 def set_mlp_precision(mode):
-    """'f32': exact f32 MFMA;  'split': 3 x f16 MFMA on hi/lo-split operands, f32 accumulate (include/benerf_hip.h)."""
-    _lib.check(_lib.load().benerf_set_mlp_precision(MLP_PRECISIONS[mode]), "set_mlp_precision")
+    """Default arithmetic of the MLP launches issued through this module (the C ABI takes it per call):
+    'f32': exact f32 MFMA;  'split': forward 3 x f16 MFMA on hi/lo-split operands, backward f16 operands, f32
+    accumulate (include/benerf_hip.h)."""
+    global _default_precision
+    if mode not in MLP_PRECISIONS:
+        raise ValueError("unknown MLP precision %r" % (mode,))
+    _default_precision = mode
 
 
 def get_mlp_precision():
-    m = _lib.load().benerf_get_mlp_precision()
-    return [k for k, v in MLP_PRECISIONS.items() if v == m][0]
+    return _default_precision
+
+
+_status = {}
+
+
+def mlp_status(device):
+    """The device's status words of the split-f16 mode (uint32[4], include/benerf_hip.h K3)."""
+    key = str(torch.device(device))
+    t = _status.get(key)
+    if t is None:
+        t = torch.zeros(4, dtype=torch.int32, device=device)
+        _status[key] = t
+    return t
+
+
+def check_mlp_status(device, reset=True):
+    """Synchronises.  Raises BenerfRangeError if a split-mode launch since the last reset saw an activation or a
+    scaled gradient outside the f16 range (the affected Adam steps were skipped on the device)."""
+    st = mlp_status(device)
+    rc = _lib.load().benerf_mlp_status_check(st.data_ptr(), _stream())
+    if rc != 0 and reset:
+        st.zero_()
+    _lib.check(rc, "mlp_status_check")
+
+
+_param_generation = 0
+
+
+def params_changed():
+    """Tell every PackedMlp that parameter storage was rewritten behind autograd's back (fused Adam, checkpoint load)."""
+    global _param_generation
+    _param_generation += 1
 
 
 class PackedMlp:
@@ -186,32 +227,42 @@ class PackedMlp:
     def struct(self):
         return _param_struct(MlpParams, self.weights, self.biases)
 
+    def _key(self):
+        return (_param_generation,) + tuple((t._version, t.data_ptr()) for t in self.weights + self.biases)
+
     def pack(self):
         lib = _lib.load()
         s = self.struct()
         _lib.check(lib.benerf_mlp_pack_weights(ctypes.byref(s), self.channels, self.packed.data_ptr(), _stream()),
                    "mlp_pack_weights")
+        self.version = self._key()
 
     def pack_if_stale(self):
-        v = tuple((w._version, w.data_ptr()) for w in self.weights)
-        if v != self.version:
+        # torch updates bump ._version; updates through the raw Adam kernel / in-place loads bump the generation
+        if self._key() != self.version:
             self.pack()
-            self.version = v
 
 
-def mlp_fwd(net, rays_o, rays_d, viewdirs, z, save_acts):
+def mlp_fwd(net, rays_o, rays_d, viewdirs, z, save_acts, precision=None):
+    """Returns (raw, acts).  Inference launches (save_acts False) in split mode run as BENERF_MLP_AUTO: the output is
+    valid even if an activation leaves the f16 range (include/benerf_hip.h)."""
     lib = _lib.load()
     n_rays, n_samples = z.shape
     C = net.channels
+    mode = precision or _default_precision
     raw = _new((n_rays, n_samples, C + 1), z)
     acts = None
     if save_acts:
         acts = torch.empty(lib.benerf_mlp_act_floats(n_rays * n_samples), dtype=torch.float32, device=z.device)
+        acts.benerf_precision = mode
     s = net.struct()
+    code = MLP_PRECISIONS[mode]
+    if code == 1 and not save_acts:
+        code = _MLP_AUTO
     _timer("mlp_fwd", n_rays * n_samples)
     _lib.check(lib.benerf_mlp_fwd(ctypes.byref(s), net.packed.data_ptr(), C, n_rays, n_samples, _chk(rays_o),
-                                  _chk(rays_d), _chk(viewdirs), _chk(z), raw.data_ptr(), _chk(acts), _stream()),
-               "mlp_fwd")
+                                  _chk(rays_d), _chk(viewdirs), _chk(z), raw.data_ptr(), _chk(acts), code,
+                                  mlp_status(z.device).data_ptr(), _stream()), "mlp_fwd")
     _timer(None, 0)
     return raw, acts
 
@@ -221,6 +272,7 @@ def mlp_bwd(net, d_raw, acts, n_rays, n_samples, grad_w, grad_b, accumulate):
     lib = _lib.load()
     M = n_rays * n_samples
     dev = d_raw.device
+    code = MLP_PRECISIONS[getattr(acts, "benerf_precision", _default_precision)]
     dacts = scratch("dacts", lib.benerf_mlp_dact_floats(M), dev)
     ws_floats = lib.benerf_mlp_dw_workspace_floats(M)
     ws = scratch("dw_ws", ws_floats, dev)
@@ -231,10 +283,10 @@ def mlp_bwd(net, d_raw, acts, n_rays, n_samples, grad_w, grad_b, accumulate):
     _timer("mlp_bwd_dx", M)
     _lib.check(lib.benerf_mlp_bwd_dx(ctypes.byref(s), net.packed.data_ptr(), net.channels, n_rays, n_samples,
                                      _chk(d_raw, name="d_raw"), _chk(acts), dacts.data_ptr(), d_pts.data_ptr(),
-                                     d_vd.data_ptr(), _stream()), "mlp_bwd_dx")
+                                     d_vd.data_ptr(), code, mlp_status(dev).data_ptr(), _stream()), "mlp_bwd_dx")
     _timer("mlp_bwd_dw", M)
     _lib.check(lib.benerf_mlp_bwd_dw(net.channels, n_rays, n_samples, _chk(d_raw), _chk(acts), dacts.data_ptr(),
-                                     ws.data_ptr(), ws_floats, ctypes.byref(g), int(bool(accumulate)), _stream()),
+                                     ws.data_ptr(), ws_floats, ctypes.byref(g), int(bool(accumulate)), code, _stream()),
                "mlp_bwd_dw")
     _timer(None, 0)
     return d_pts, d_vd
@@ -365,10 +417,14 @@ def sample_pixels(n_total, count, seed, offset, device):
 
 
 # ----------------------------------------------------------------------------- K8 optimiser
-def adam_step(param, grad, exp_avg, exp_avg_sq, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0,
+              guard_range=True):
+    """guard_range: skip the update on the device when the split-mode status words show a range violation."""
     lib = _lib.load()
+    st = mlp_status(param.device).data_ptr() if guard_range else None
     _lib.check(lib.benerf_adam_step(_chk(param), _chk(grad), _chk(exp_avg), _chk(exp_avg_sq), param.numel(), lr, beta1,
-                                    beta2, eps, step, grad_scale, _stream()), "adam_step")
+                                    beta2, eps, step, grad_scale, st, _stream()), "adam_step")
+    params_changed()
 
 
 # ----------------------------------------------------------------------------- stand-alone helpers

@@ -13,9 +13,11 @@
  *     as the torch tensors on the reference side;
  *   - the caller owns every buffer and the stream (pass
  *     torch.cuda.current_stream().cuda_stream); no allocation, no implicit
- *     synchronisation, nothing is thrown across the ABI;
+ *     synchronisation (one documented exception: benerf_mlp_status_check), nothing is thrown
+ *     across the ABI;
  *   - return 0 on success, BENERF_EBADARG (-1) bad argument, BENERF_EWORKSPACE (-2)
- *     workspace too small, BENERF_EHIP (-3) HIP error; text via benerf_last_error();
+ *     workspace too small, BENERF_EHIP (-3) HIP error, BENERF_ERANGE (-4) value outside the arithmetic
+ *     mode's range (benerf_mlp_status_check only); text via benerf_last_error();
  *   - thread-compatible: no global mutable state except the thread-local last error.
  */
 #ifndef BENERF_HIP_H
@@ -32,6 +34,7 @@ extern "C" {
 #define BENERF_EBADARG (-1)
 #define BENERF_EWORKSPACE (-2)
 #define BENERF_EHIP (-3)
+#define BENERF_ERANGE (-4)
 
 typedef void* benerf_stream_t; /* hipStream_t */
 
@@ -117,6 +120,32 @@ size_t benerf_mlp_dact_floats(int64_t n_points);
 /* floats of the weight-gradient partial-sum workspace for n_points */
 size_t benerf_mlp_dw_workspace_floats(int64_t n_points);
 
+/* MFMA arithmetic of the fused MLP kernels - a PER-CALL argument (the library keeps no mode state):
+ *   BENERF_MLP_F32    exact f32 MFMA (v_mfma_f32_32x32x2_f32) in forward and backward, bit-for-bit f32 products;
+ *   BENERF_MLP_SPLIT  forward: every f32 operand as two f16 numbers (hi + lo*2^-11), three f16 MFMAs per product
+ *                     block, f32 accumulation - 22-bit operands, measured error equal to the f32 path;
+ *                     backward (dX chain and dW): f16 operands (11-bit; gradients rescaled by exact powers of
+ *                     two), one f16 MFMA per product block, f32 accumulation - the deviation of the gradients stays
+ *                     inside the spread f32 itself shows against f64 (tools/experiments/lowprec_backward.py; every
+ *                     parity test runs in both modes with the same tolerances).  Activations must stay below 65504
+ *                     in magnitude (f16 range): see `status`;
+ *   BENERF_MLP_AUTO   inference only (acts == NULL): BENERF_MLP_SPLIT, followed by a BENERF_MLP_F32 launch whose
+ *                     workgroups exit at once unless the split launch reported an activation outside the f16 range
+ *                     - the output is always valid, at the price of one (normally empty) extra launch.
+ * The saved-activation / gradient buffers have a mode-specific layout: forward and backward of one step must
+ * use the same mode (the buffers are tagged; a mismatch is reported through status[2]).
+ *
+ * status: caller-owned DEVICE uint32[4], zeroed by the caller, may be NULL for BENERF_MLP_F32:
+ *   [0] max |activation| seen by split forward launches (f32 bit pattern; written only once it passes 2^15; sticky)
+ *   [1] max |scaled gradient| stored by split dX launches (same convention)
+ *   [2] != 0: a backward launch got activation buffers of another mode
+ *   [3] scratch of BENERF_MLP_AUTO (maximum of the current call)
+ * Nothing here synchronises; benerf_mlp_status_check does (copy + stream sync) and returns BENERF_ERANGE when
+ * [0] or [1] reached 65504, BENERF_EBADARG for [2].  benerf_adam_step takes the same pointer and leaves the
+ * parameters untouched for a step whose status shows a range violation. */
+enum { BENERF_MLP_F32 = 0, BENERF_MLP_SPLIT = 1, BENERF_MLP_AUTO = 2 };
+int benerf_mlp_status_check(const uint32_t* status, benerf_stream_t stream);
+
 /* Fused positional encoding + 8x256 MLP + view branch, forward.
  * Replaces Embedder.embed (model/embedder.py:9-34) and NeRF.forward
  * (model/nerf.py:67-116) incl. pts = o + d*z (model/nerf.py:308,327).
@@ -126,44 +155,21 @@ size_t benerf_mlp_dw_workspace_floats(int64_t n_points);
 int benerf_mlp_fwd(const BenerfMlpParams* params, const float* packed, int channels,
                    int n_rays, int n_samples, const float* rays_o, const float* rays_d,
                    const float* viewdirs, const float* z, float* raw, float* acts,
-                   benerf_stream_t stream);
-/* MFMA arithmetic of the fused MLP kernels (process-wide; default BENERF_MLP_SPLIT):
- *   BENERF_MLP_F32    exact f32 MFMA (v_mfma_f32_32x32x2_f32), bit-for-bit f32 products;
- *   BENERF_MLP_SPLIT  every f32 operand as two f16 numbers (hi + lo*2^-11), three f16 MFMAs per product
- *                     block, f32 accumulation: 22-bit operands, measured error equal to the f32 path (every
- *                     parity test runs in both modes with the same tolerances).  Activations must stay below
- *                     65504 in magnitude (f16 range); gradients are rescaled by exact powers of two.
- * The saved-activation / gradient buffers have a mode-specific layout: forward and backward of one step must
- * run in the same mode.
- * benerf_mlp_fwd / _bwd dispatch on it; the explicit *_split entry points ignore it.  Returns -1 on a
- * bad mode. */
-enum { BENERF_MLP_F32 = 0, BENERF_MLP_SPLIT = 1 };
-int benerf_set_mlp_precision(int mode);
-int benerf_get_mlp_precision(void);
-/* Split-f16 variant of benerf_mlp_fwd: same arguments, outputs and saved-activation layout. */
-int benerf_mlp_fwd_split(const BenerfMlpParams* params, const float* packed, int channels,
-                         int n_rays, int n_samples, const float* rays_o, const float* rays_d,
-                         const float* viewdirs, const float* z, float* raw, float* acts,
-                         benerf_stream_t stream);
-/* Backward of the above.  d_raw [n_points,channels+1].
- *   dacts scratch [benerf_mlp_dact_floats(n_points)]; dw_ws scratch
- *   [benerf_mlp_dw_workspace_floats(n_points)]; grads: overwritten when accumulate == 0,
- *   added to otherwise; d_pts [n_points,3], d_vdir_pts [n_points,3] out (per point; reduce
- *   with benerf_ray_grad_reduce). */
-int benerf_mlp_bwd(const BenerfMlpParams* params, const float* packed, int channels,
-                   int n_rays, int n_samples, const float* d_raw, const float* acts,
-                   float* dacts, float* dw_ws, size_t dw_ws_floats,
-                   const BenerfMlpGrads* grads, int accumulate, float* d_pts,
-                   float* d_vdir_pts, benerf_stream_t stream);
-
-/* The two launches of benerf_mlp_bwd, separately callable (profiling / overlap):
- *   _dx: activation-gradient chain -> dacts, d_pts, d_vdir_pts;  _dw: weight gradients. */
+                   int precision, uint32_t* status, benerf_stream_t stream);
+/* Backward of the above (autograd of model/nerf.py:67-116), two launches so that a caller can time / overlap them.
+ * d_raw [n_points,channels+1].
+ *   _dx: activation-gradient chain -> dacts scratch [benerf_mlp_dact_floats(n_points)], d_pts [n_points,3],
+ *        d_vdir_pts [n_points,3] (per point; reduce with benerf_ray_grad_reduce);
+ *   _dw: weight gradients from acts + dacts; dw_ws scratch [benerf_mlp_dw_workspace_floats(n_points)];
+ *        grads: overwritten when accumulate == 0, added to otherwise.
+ * precision: BENERF_MLP_F32 or BENERF_MLP_SPLIT, the mode of the forward launch that wrote acts. */
 int benerf_mlp_bwd_dx(const BenerfMlpParams* params, const float* packed, int channels,
                       int n_rays, int n_samples, const float* d_raw, const float* acts,
-                      float* dacts, float* d_pts, float* d_vdir_pts, benerf_stream_t stream);
+                      float* dacts, float* d_pts, float* d_vdir_pts, int precision, uint32_t* status,
+                      benerf_stream_t stream);
 int benerf_mlp_bwd_dw(int channels, int n_rays, int n_samples, const float* d_raw,
                       const float* acts, const float* dacts, float* dw_ws, size_t dw_ws_floats,
-                      const BenerfMlpGrads* grads, int accumulate, benerf_stream_t stream);
+                      const BenerfMlpGrads* grads, int accumulate, int precision, benerf_stream_t stream);
 
 /* ---------------------------------------------------------------- K4: compositing -- */
 /* Alpha compositing, one wavefront per ray.  Replaces NeRF.raw2output
@@ -278,10 +284,11 @@ int benerf_gather_rows(const float* src, const int64_t* idx, int64_t n_idx, int 
 /* torch.optim.Adam (defaults beta 0.9/0.999, eps 1e-8) on a flat fp32 buffer; step counts
  * from 1.  Replaces train.py:343-352 (+ model/optimize.py:36-55); the caller applies the
  * exponential LR decay of train.py:355-394 to `lr`.  grad_scale multiplies g first
- * (1/world_size after a sum all-reduce). */
+ * (1/world_size after a sum all-reduce).  skip_if_range: NULL, or the MLP status words (K3): the update is
+ * skipped on the device when they show a range violation of the split-f16 mode. */
 int benerf_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                      int64_t n, double lr, double beta1, double beta2, double eps, int step,
-                     double grad_scale, benerf_stream_t stream);
+                     double grad_scale, const uint32_t* skip_if_range, benerf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -174,7 +174,7 @@ def _run_mlp_on_points(K, net, pts, vd, save):
 
 
 def _act_views(acts, M, mode="f32"):
-    """Decode the saved-activation buffer: f32 rows (mlp_common.h) or, in split mode, ST arrays (mlp_split.h)."""
+    """Decode the saved-activation buffer: f32 rows (mlp_common.h) or, in split mode, SH arrays (mlp_split.h)."""
     a = acts.cpu()
     out = {}
     if mode == "f32":
@@ -190,20 +190,19 @@ def _act_views(acts, M, mode="f32"):
         off += M * 128
         out["ped"] = a[off:off + M * 32].reshape(M, 32)
         return out
-    Mp = (M + 63) // 64 * 64
+    Mp = (M + 127) // 128 * 128
     halfs = a.numpy().view(np.float16)
 
-    def st(off, W):   # [block of 8 points][feature][points 0-3 | 4-7][hi x4, lo x4]
-        blk = halfs[off * 2: off * 2 + Mp * W * 2].reshape(Mp // 8, W, 2, 2, 4).astype(np.float32)
-        val = blk[:, :, :, 0] + blk[:, :, :, 1] / 2048.0            # [Mp/8, W, 2, 4]
-        return torch.from_numpy(np.ascontiguousarray(val.reshape(Mp // 8, W, 8).transpose(0, 2, 1)).reshape(Mp, W)[:M])
+    def sh(off, W):   # f16 values, [block of 8 points][feature][8 points]
+        blk = halfs[off * 2: off * 2 + Mp * W].reshape(Mp // 8, W, 8).astype(np.float32)
+        return torch.from_numpy(np.ascontiguousarray(blk.transpose(0, 2, 1)).reshape(Mp, W)[:M])
 
     out["pe"] = a[0:Mp * 64].reshape(Mp, 64)[:M]
     out["ped"] = a[Mp * 64:Mp * 96].reshape(Mp, 32)[:M]
     for l in range(8):
-        out["h%d" % l] = st(Mp * 96 + l * Mp * 256, 256)
-    out["feat"] = st(Mp * 96 + 8 * Mp * 256, 256)
-    out["hv"] = st(Mp * 96 + 9 * Mp * 256, 128)
+        out["h%d" % l] = sh(Mp * 96 + l * Mp * 128, 256)
+    out["feat"] = sh(Mp * 96 + 8 * Mp * 128, 256)
+    out["hv"] = sh(Mp * 96 + 9 * Mp * 128, 128)
     return out
 
 
@@ -220,9 +219,12 @@ def test_mlp_fwd_golden(K, mlp_mode, golden, C, variant, S):
         av = _act_views(acts, M, mlp_mode)
         report("K3 PE " + tag, av["pe"][:, :63], g[tag + "_pe"], atol=2e-6)
         assert float(av["pe"][:, 63].abs().max()) == 0.0
+        # split mode saves the f16 operand of the backward GEMMs (11-bit significand: 2^-11 relative); the full-precision
+        # forward path is what `raw` checks below
+        rt = 1e-4 if mlp_mode == "f32" else 2.0 ** -11
         for name in ("h0", "h4", "h7", "feat", "hv"):
             r = g[tag + "_" + name]
-            report("K3 act %s %s" % (name, tag), av[name], r, atol=2e-5 * float(np.abs(r).max()), rtol=1e-4)
+            report("K3 act %s %s" % (name, tag), av[name], r, atol=2e-5 * float(np.abs(r).max()), rtol=rt)
     report("K3 raw " + tag, raw, ref, atol=1e-5 * max(sc, 1.0), rtol=1e-5)
     raw2, _, _ = _run_mlp_on_points(K, net, pts, vd, False)
     assert torch.equal(raw2, raw), "inference and training forward must agree bit for bit"
@@ -305,13 +307,17 @@ def test_mlp_bwd_vs_oracle_tail_and_determinism(K, mlp_mode):
     d_d = torch.zeros(N, 3, device=DEV)
     d_v = torch.zeros(N, 3, device=DEV)
     K.ray_grad_reduce(dev(z), d_pts, d_vd, d_o, d_d, d_v, False)
+    # entries within the contract's 1e-3 of the largest; the exact-f32 mode is held to round-off.  The split
+    # mode's backward GEMMs take f16 operands: ~3e-4 of the largest entry on these noise-like sums
+    # (tools/experiments/f16_dw_error.py), random and unbiased
+    at = 2e-5 if mlp_mode == "f32" else 1e-3
     for nm, got, ref in (("d_rays_o", d_o, ro_o.grad), ("d_rays_d", d_d, rd_o.grad), ("d_viewdirs", d_v, vd_o.grad)):
-        report("K3 %s (tail)" % nm, got, ref, atol=2e-5 * float(ref.abs().max()), rtol=1e-3)
+        report("K3 %s (tail)" % nm, got, ref, atol=at * float(ref.abs().max()), rtol=1e-3)
     for i, name in enumerate(K.LAYER_NAMES):
         r = po[name + ".weight"].grad
-        report("K3 d%s.weight (tail)" % name, gw[i], r, atol=2e-5 * float(r.abs().max()), rtol=1e-3)
+        report("K3 d%s.weight (tail)" % name, gw[i], r, atol=at * float(r.abs().max()), rtol=1e-3)
         r = po[name + ".bias"].grad
-        report("K3 d%s.bias (tail)" % name, gb[i], r, atol=2e-5 * float(r.abs().max()), rtol=1e-3)
+        report("K3 d%s.bias (tail)" % name, gb[i], r, atol=at * float(r.abs().max()), rtol=1e-3)
     gw2 = [torch.zeros_like(w) for w in net.weights]
     gb2 = [torch.zeros_like(b) for b in net.biases]
     K.mlp_bwd(net, dev(G.reshape(-1, C + 1)), acts, N, S, gw2, gb2, False)
@@ -381,11 +387,12 @@ def test_mlp_modes_agree_at_full_size(K):
         print("K3 full size, split vs f32: %s  points beyond round-off: %.2e of %d, relative L2 distance %.2e"
               % (nm, float(bad), y.shape[0], rel_l2))
         assert float(bad) < 2e-4 and rel_l2 < 2e-3, nm
-    # weight gradients: sums over all points; the few hundred flipped units move an entry by ~sqrt(flips) terms out
-    # of ~sqrt(N) (about 1e-3 of the largest entry for the cancelling early layers), everything else by round-off
+    # weight gradients: sums over all points of noise-like terms (G is random).  The few hundred flipped units move an
+    # entry by ~sqrt(flips) terms out of ~sqrt(N) (1e-3 .. 4e-3 of the largest entry, layer and seed dependent); the f16
+    # operands of the split mode's backward GEMMs add 3e-4 (tools/experiments/f16_dw_error.py); everything else round-off
     for i, name in enumerate(K.LAYER_NAMES):
         for kind, x, y in (("weight", b[3][i], a[3][i]), ("bias", b[4][i], a[4][i])):
-            report("K3 full size, split vs f32: d%s.%s" % (name, kind), x, y, atol=3e-3 * float(y.abs().max()), rtol=1e-3)
+            report("K3 full size, split vs f32: d%s.%s" % (name, kind), x, y, atol=5e-3 * float(y.abs().max()), rtol=1e-3)
             assert float((x - y).norm() / y.norm()) < 3e-3
 
 
