@@ -10,11 +10,13 @@ of the BASELINE.json workload (default C2: benerf_unreal/livingroom_gray camera,
 trajectory spline -> rays -> PE + coarse MLP -> compositing -> sample_pdf -> PE + fine MLP ->
 compositing -> event + blur loss -> full backward (both MLPs, rays, spline) -> gradient
 all-reduce (N > 1) -> Adam with LR decay -> weight re-pack.  Inputs are resident in HBM when
-the timed region starts.  Data-parallel = weak scaling: every rank renders its own 4081 rays.
+the timed region starts.  Data-parallel: --scaling weak (default; every rank renders its own 4081
+rays) or --scaling strong (the global batch of the workload is split over the ranks).
 
-Prints ONE JSON line (rank 0) with the metric, the roofline of the dominant kernel (HIP-event
-timed inside the run) and a CPU baseline (the oracle's op-for-op torch-CPU step on a bounded
-sample of the same workload, host cores stated).
+Prints ONE JSON line (rank 0) with the metric, the roofline of the dominant kernel (the
+fused MLP against the MFMA roof with the algorithmic 1 186 304 FLOP per point, HIP-event timed
+inside the run; HBM figures of the bandwidth-bound dW launch under `hbm`) and a CPU baseline (the
+oracle's op-for-op torch-CPU step, host cores and CPU model stated: full C2 step + C1).
 """
 import argparse
 import json
@@ -31,22 +33,45 @@ sys.path.insert(0, ROOT)
 F32_MFMA_PEAK_TFLOPS = 157.3    # MI355X f32 matrix peak (MI355X_MICROARCH.md)
 F16_MFMA_PEAK_TFLOPS = 2516.6   # dense f16 matrix peak: 256 CUs x 4 SIMDs x 1024 flop/clk x 2.4 GHz
 HBM_PEAK_GBS = 8000.0
-# dW in split mode streams every saved activation and activation gradient once (DESIGN.md, K3 dW): bytes per point
-DW_SPLIT_BYTES_PER_POINT = 4 * ((64 + 32 + 8 * 256 + 256 + 128) + (8 * 256 + 256 + 128)) + 8
+# f16 MFMAs the split-mode kernels execute per algorithmic product block: forward 3 (hi/lo-split
+# operands), dX chain 2 (f16 gradient x hi/lo weight), dW 1 (f16 x f16); exact-f32 mode: 1 f32 MFMA chain everywhere
+EXECUTED_PER_PRODUCT = {"mlp_fwd": 3, "mlp_bwd_dx": 2, "mlp_bwd_dw": 1}
+# bytes per sample point the split-mode dW launch streams once (f16 saved activations h0..h7, feature, hv
+# and as many gradients, f32 PE / PE(dir) rows, one d_raw row)
+DW_SPLIT_BYTES_PER_POINT = 2 * ((8 * 256 + 256 + 128) + (8 * 256 + 256 + 128)) + 4 * (64 + 32) + 8
+# what a saved-activation design moves per point and network pass besides that: forward writes (f16 arrays, PE rows, ReLU
+# sign-bit words), dX reads (PE rows, sign bits) and writes (f16 gradients)
+FWD_SPLIT_WRITE_BYTES_PER_POINT = 2 * (8 * 256 + 256 + 128) + 4 * (64 + 32) + 9 * 256 * 8 // 64
+
+
+def algorithmic_bytes_per_step(wl, C):
+    """SURVEY 8d 'Algorithmic bytes': what ANY implementation must move per step - weights read in forward and
+    backward, gradients written, Adam state read + written, per-ray inputs and outputs.  Saved activations are design
+    traffic, not algorithmic."""
+    n_w = sum(o * i + o for o, i in ((256, 63), (256, 256), (256, 256), (256, 256), (256, 256), (256, 319), (256, 256),
+                                     (256, 256), (128, 283), (256, 256), (1, 256), (C, 128)))
+    weights = 2 * n_w * 4 * (2 + 1 + 6)                       # fwd read + bwd read, grad write, m/v/p read + write
+    rays = 2 * wl["Re"] + wl["n"] * wl["Rr"]
+    per_ray = 8 + (2 * C + 4) * 4                               # pixel index in, rgb_map/rgb0 + disp/acc x 2 out (sigma skipped in training)
+    return weights + rays * per_ray
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="C2")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank renders the workload's batch; strong: the workload's batch is the GLOBAL batch")
+    ap.add_argument("--batch-fraction", type=int, default=1,
+                    help="render 1/F of the workload's pixels per rank (F = 8 on one GPU: the per-rank step of a strong-scaled 8-GPU run)")
     ap.add_argument("--n-events", type=int, default=2_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--primary-only", action="store_true", help="timed training steps only (profiling runs): no secondary legs")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--mlp-precision", default="split", choices=["f32", "split"],
-                    help="MFMA arithmetic of the fused MLP kernels (include/benerf_hip.h: benerf_set_mlp_precision)")
+                    help="arithmetic of the fused MLP kernels (include/benerf_hip.h, K3 `precision`)")
     return ap.parse_args()
 
 
@@ -55,39 +80,38 @@ def split_mode(a):
 
 
 def build_graph(args_ns, device, seed):
-    """Reference-shaped graph with Xavier-uniform weights drawn from numpy."""
+    """Reference-shaped graph with the reference's own initialisation: Xavier-uniform weights, zero biases
+    (run_nerf_helpers.init_nerf, applied at iteration 0 by train.py:154-157), knots rand * 0.01 (model/optimize.py:22-24)."""
     from benerf_amd.model import optimize
-    from benerf_amd import kernels as K
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import benerf_oracle as O   # parameter initialiser only (xavier_params); not on the timed path
-    rng = np.random.default_rng(seed)
+    from benerf_amd import run_nerf_helpers
     torch.manual_seed(seed)
     model = optimize.Model(args_ns)
     model.graph.to(device)
     g = model.build_network(args_ns)
-    for net in (g.nerf, g.nerf_fine):
-        p = O.xavier_params(rng, args_ns.channels)
-        with torch.no_grad():
-            for name in K.LAYER_NAMES:
-                lin = net
-                for part in name.split("."):
-                    lin = lin[int(part)] if part.isdigit() else getattr(lin, part)
-                lin.weight.copy_(p[name + ".weight"])
-                lin.bias.copy_(p[name + ".bias"])
-    with torch.no_grad():
-        g.evt_knot_pose_se3.params.weight.copy_(torch.from_numpy(rng.uniform(0, 0.01, (4, 6)).astype(np.float32)))
+    run_nerf_helpers.init_nerf(g.nerf)
+    run_nerf_helpers.init_nerf(g.nerf_fine)
     return g
 
 
-def cpu_baseline(wl, seed):
-    """Oracle training step (torch CPU, all host cores) on a bounded 1/8 sample of the workload."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(wl, seed, n_steps, warm_fraction=1):
+    """Oracle training step (torch CPU) at the FULL size of workload `wl`: `n_steps` timed steps after one warm-up step
+    (the warm-up runs on 1/warm_fraction of the pixels when a full step takes many seconds)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import benerf_oracle as O
     import golden_inputs as GI
     from benerf_amd import workloads as WL
     w = WL.WORKLOADS[wl]
     cam = WL.CAMERAS[w["cam"]]
-    Re, Rr = max(w["Re"] // 8, 8), max(w["Rr"] // 8, 1)
     C, S, Ni, P = w["channels"], w["S"], w["Ni"], w["n"]
     rng = np.random.default_rng(seed)
     cfg = O.StepConfig(H=cam["H"], W=cam["W"], fx=cam["fx"], fy=cam["fy"], cx=cam["cx"], cy=cam["cy"], channels=C,
@@ -102,10 +126,11 @@ def cpu_baseline(wl, seed):
     ev = GI.synthetic_events(rng, cam, 200000)
     img = torch.from_numpy(rng.random((cam["H"] * cam["W"], C)).astype(np.float32))
     times = []
-    n_steps = 3
     # many small ops: a moderate thread count beats one thread per core of a 128-core host
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     for it in range(n_steps + 1):
+        frac = warm_fraction if it == 0 else 1
+        Re, Rr = max(w["Re"] // frac, 8), max(w["Rr"] // frac, 1)
         t0 = time.perf_counter()
         low_t = float(rng.random() * (1 - w["window"]))
         sel, up = O.event_window(ev["ts"], low_t, w["window"])
@@ -123,10 +148,10 @@ def cpu_baseline(wl, seed):
                 O.adam_update(p, p.grad, m, v, it + 1, 5e-4)
         if it > 0:
             times.append(time.perf_counter() - t0)
-    rays = 2 * Re + P * Rr
+    rays = 2 * w["Re"] + P * w["Rr"]
     return {"value": round(rays / (sum(times) / len(times)), 1), "unit": "rays/s", "cores": torch.get_num_threads(),
-            "kind": "port",
-            "sample": "%d steps of 1/8 of %s (%d rays/step, %d+%d samples), oracle torch-CPU step incl. backward + Adam"
+            "host_cores": os.cpu_count(), "cpu": cpu_model(), "kind": "port", "s_per_step": round(sum(times) / len(times), 3),
+            "sample": "%d full-size step(s) of %s (%d rays/step, %d+%d samples), oracle torch-CPU step incl. backward + Adam"
                       % (n_steps, wl, rays, S, S + Ni)}
 
 
@@ -205,14 +230,16 @@ def main():
 
     from benerf_amd import engine, workloads as WL, kernels as K
     K.set_mlp_precision(a.mlp_precision)
-    wl = WL.WORKLOADS[a.workload]
+    wl = dict(WL.WORKLOADS[a.workload])
+    # per-rank pixel counts.  weak: the workload's batch per rank (global = world x that); strong: the workload's batch IS
+    # the global batch (C4 / C5 are 8192 rays in total), every rank renders 1/world of it
+    div = a.batch_fraction * (world if a.scaling == "strong" else 1)
+    wl["Re"], wl["Rr"] = max(wl["Re"] // div, 1), max(wl["Rr"] // div, 1)
     cam = WL.CAMERAS[wl["cam"]]
-    args_ns = WL.make_args(a.workload)
+    args_ns = WL.make_args(wl)
     g = build_graph(args_ns, device, a.seed)     # identical on every rank (same seed)
     cam_o = engine.Camera(cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"])
-    # weak scaling: every rank renders a full per-GPU batch; the global batch is world x that
-    glob = WL.make_args(a.workload)
-    step = engine.TrainStep(g, glob, cam_o, cam_o, device, world_size=world, rank=rank, process_group=pg, seed=a.seed)
+    step = engine.TrainStep(g, args_ns, cam_o, cam_o, device, world_size=world, rank=rank, process_group=pg, seed=a.seed)
 
     # ---- synthetic inputs, resident in HBM ------------------------------------------------------------
     rng = np.random.default_rng(a.seed)
@@ -250,15 +277,22 @@ def main():
 
     for _ in range(a.warmup):
         one_step()
+    K.check_mlp_status(device)                   # warm-up steps stayed inside the f16 range (synchronises; untimed)
     K.TIMERS.enabled = True
     K.TIMERS.records.clear()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     sync()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    marks[0].record()
+    for i in range(a.steps):
         losses = one_step()
+        marks[i + 1].record()
     sync()
     dt = time.perf_counter() - t0
     K.TIMERS.enabled = False
+    K.check_mlp_status(device)
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
+    median_ms = step_ms[len(step_ms) // 2]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -270,7 +304,7 @@ def main():
         with torch.no_grad():
             idx_e = torch.randperm(HW, device=device, generator=gen)[:wl["Re"]]
             poses = K.spline_poses_fwd(step.knots, None, torch.tensor([0.2, 0.3], device=device), 2, 0)
-            idx_all = torch.randperm(HW, device=device, generator=gen)[:WL.rays_per_step(a.workload) // 2]
+            idx_all = torch.randperm(HW, device=device, generator=gen)[:WL.rays_per_step(wl) // 2]
             d_inf = engine.Draws(seed=a.seed, offset=12345)
             for i in range(a.steps + 2):
                 if i == 2:
@@ -293,72 +327,97 @@ def main():
         for _ in range(n_other):
             one_step()
         torch.cuda.synchronize()
-        other = round(WL.rays_per_step(a.workload) / ((time.perf_counter() - to) / n_other), 1)
+        other = round(WL.rays_per_step(wl) / ((time.perf_counter() - to) / n_other), 1)
         K.set_mlp_precision(a.mlp_precision)
 
-    rays_step = WL.rays_per_step(a.workload) * world
+    rays_step = WL.rays_per_step(wl) * world
     ms_step = dt / a.steps * 1e3
     value = rays_step / (dt / a.steps)
 
-    # ---- roofline of the dominant kernel, from the HIP-event brackets of the timed region ---------------------
+    # ---- roofline: the fused MLP (K3) against the MFMA roof, algorithmic FLOPs / HIP-event-timed duration --
     fpp = WL.mlp_flops_per_point(wl["channels"])
     summ = K.TIMERS.summary()
     split = a.mlp_precision == "split"
+    peak = F16_MFMA_PEAK_TFLOPS if split else F32_MFMA_PEAK_TFLOPS
     roof = None
     kern = {}
     for name, (n, ms, pts) in summ.items():
         # algorithmic flops: fwd = fpp/point; dx chain = fpp/point; dW = fpp/point (training = 3 x fwd)
         tf = pts * fpp / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        kern[name] = {"launches": n, "avg_ms": round(ms / n, 4), "tflops": round(tf, 2)}
-        if split:   # three f16 MFMAs per algorithmic product block: executed matrix flops = 3 x algorithmic
-            kern[name]["mfma_frac_f16_peak"] = round(3 * tf / F16_MFMA_PEAK_TFLOPS, 4)
-    if kern:
-        dom = max(summ.items(), key=lambda kv: kv[1][1])[0]
-        n_dom, ms_dom, pts_dom = summ[dom]
-        if split and dom == "mlp_bwd_dw":
-            # HBM-bound: operands streamed once, 3 f16 MFMAs per block leave the matrix pipe two thirds idle
-            gbs = pts_dom * DW_SPLIT_BYTES_PER_POINT / (ms_dom * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": dom, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_ms": kern[dom]["avg_ms"],
-                    "algorithmic_bytes_per_launch": int(pts_dom / n_dom * DW_SPLIT_BYTES_PER_POINT), "per_kernel": kern}
-        else:
-            peak = F16_MFMA_PEAK_TFLOPS if split else F32_MFMA_PEAK_TFLOPS
-            ach = kern[dom]["tflops"] * (3 if split else 1)
-            roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": None, "avg_launch_ms": kern[dom]["avg_ms"], "per_kernel": kern}
-        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (separate runs of this
-        # same command; bench.py cannot collect counters itself) - see profiles/README.md
+        ex = EXECUTED_PER_PRODUCT[name] if split else 1
+        kern[name] = {"launches": n, "avg_ms": round(ms / n, 4), "points_per_launch": int(pts / n), "tflops_algorithmic": round(tf, 2),
+                      "frac_of_mfma_peak": round(tf / peak, 4), "mfma_per_product": ex, "frac_executed": round(ex * tf / peak, 4)}
+    pmc = {}
+    try:    # per-launch PMC figures of the same command from the committed rocprofv3 passes (profiles/README.md)
+        import glob
+        latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc_summary.json" % a.mlp_precision)))[-1]
+        if a.workload == "C2" and world == 1 and a.batch_fraction == 1:
+            pmc = json.load(open(latest))["kernels"]
+            pmc_src = os.path.relpath(latest, ROOT)
+    except (IndexError, KeyError, OSError, ValueError):
+        pmc = {}
+
+    def traffic_of(k):
         try:
-            import glob
-            latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc_summary.json" % a.mlp_precision)))[-1]
-            pk = json.load(open(latest))["kernels"][dom]
-            if a.workload == "C2" and world == 1:
-                roof["traffic"] = int(pk["hbm_read_bytes_per_launch"] + pk["hbm_write_bytes_per_launch"])
-                roof["traffic_source"] = os.path.relpath(latest, ROOT)
-                if "mfma_util" in pk:
-                    roof["mfma_util_profiled"] = round(pk["mfma_util"], 4)
-        except (IndexError, KeyError, OSError, ValueError):
-            pass
+            return int(pmc[k]["hbm_read_bytes_per_launch"] + pmc[k]["hbm_write_bytes_per_launch"])
+        except KeyError:
+            return None
+
+    if kern:
+        dom = max(summ.items(), key=lambda kv: kv[1][1])[0]          # largest share of the timed region
+        n_dom, ms_dom, pts_dom = summ[dom]
+        roof = {"bound": "mfma", "kernel": dom, "achieved": kern[dom]["tflops_algorithmic"], "peak": peak, "unit": "TFLOP/s",
+                "frac": kern[dom]["frac_of_mfma_peak"], "frac_executed": kern[dom]["frac_executed"],
+                "traffic": traffic_of(dom), "avg_launch_ms": kern[dom]["avg_ms"],
+                "flops_per_point": fpp, "points_per_launch": kern[dom]["points_per_launch"],
+                "peak_note": "dense %s MFMA peak at 2.4 GHz; under this load the chip sustains 1.5-1.7 GHz (power), "
+                             "tools/hwprobe/kloop_bound.hip" % ("f16" if split else "f32"),
+                "per_kernel": kern}
+        if pmc:
+            roof["traffic_source"] = pmc_src
+            if "mfma_util" in pmc.get(dom, {}):
+                roof["mfma_util_profiled"] = round(pmc[dom]["mfma_util"], 4)
+        # whole training step against the same roof: 3 x forward FLOPs per point
+        pts_step = rays_step / world * (wl["S"] + wl["S"] + wl["Ni"])
+        roof["step_tflops_algorithmic"] = round(pts_step * fpp * 3 / (dt / a.steps) / 1e12, 2)
+        roof["step_frac_of_mfma_peak"] = round(roof["step_tflops_algorithmic"] / peak, 4)
+        if split and "mlp_bwd_dw" in summ:
+            # the bandwidth-bound launch (dW) and the step's HBM traffic: design bytes (saved activations) vs the bytes any
+            # implementation must move
+            n_dw, ms_dw, pts_dw = summ["mlp_bwd_dw"]
+            gbs = pts_dw * DW_SPLIT_BYTES_PER_POINT / (ms_dw * 1e-3) / 1e9
+            hbm = {"kernel": "mlp_bwd_dw", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": round(gbs / HBM_PEAK_GBS, 4), "design_bytes_per_launch": int(pts_dw / n_dw * DW_SPLIT_BYTES_PER_POINT),
+                   "traffic": traffic_of("mlp_bwd_dw"),
+                   "algorithmic_bytes_per_step": algorithmic_bytes_per_step(wl, wl["channels"])}
+            tr = [traffic_of(k) for k in ("mlp_fwd", "mlp_bwd_dx", "mlp_bwd_dw")]
+            if all(t is not None for t in tr):
+                hbm["k3_traffic_per_step"] = 2 * sum(tr)                  # coarse + fine launches of each kernel
+            roof["hbm"] = hbm
     mlp_ms = sum(v[1] for v in summ.values()) / a.steps if summ else None
 
     out = {
         "metric": "training rays/s", "value": round(value, 1), "unit": "rays/s", "n_gpus": world, "steps": a.steps,
-        "warmup": a.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
+        "warmup": a.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": a.scaling,
         "vs_baseline": None,
-        "dtype": "f32 (MLP products as 3 f16 MFMAs on hi/lo-split operands, f32 accumulate)" if split else "f32",
+        "dtype": ("f32 storage; MLP GEMMs on f16 MFMA with f32 accumulate: forward 3 MFMAs on hi/lo-split operands (22-bit), "
+                  "backward f16 gradient x hi/lo weight (dX) and f16 x f16 (dW)") if split else "f32",
         "data": "synthetic",
-        "config": {"workload": "%s: %s" % (a.workload, wl["name"]), "rays_per_step_per_gpu": WL.rays_per_step(a.workload),
+        "config": {"workload": "%s: %s" % (a.workload, wl["name"]), "rays_per_step_per_gpu": WL.rays_per_step(wl),
                    "samples": "%d+%d" % (wl["S"], wl["S"] + wl["Ni"]), "channels": wl["channels"],
-                   "parallelism": "dp%d" % world, "mlp_ms_per_step": None if mlp_ms is None else round(mlp_ms, 3),
-                   "step_tflops_algorithmic": round(rays_step / world * (wl["S"] + wl["S"] + wl["Ni"]) * fpp * 3 /
-                                                    (dt / a.steps) / 1e12, 2),
+                   "parallelism": "dp%d" % world, "batch_fraction": a.batch_fraction,
+                   "median_ms_per_step": round(median_ms, 3), "median_rays_per_s": round(rays_step / world / (median_ms * 1e-3) * world, 1),
+                   "mlp_ms_per_step": None if mlp_ms is None else round(mlp_ms, 3),
                    "final_loss": float(losses[0]), "inference_rays_per_s": infer, "mlp_precision": a.mlp_precision,
                    "exact_f32_mfma_rays_per_s": other},
         "roofline": roof,
     }
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline and not a.primary_only:
-            out["cpu_baseline"] = cpu_baseline(a.workload, a.seed)
+            # the workload the metric is quoted on, full size (one step is ~10-20 s of CPU work), and C1, the reference's
+            # own CPU-runnable case (BASELINE.json configs[0])
+            out["cpu_baseline"] = cpu_baseline(a.workload, a.seed, n_steps=1, warm_fraction=16)
+            out["cpu_baseline_c1"] = cpu_baseline("C1", a.seed, n_steps=3)
             try:
                 del step, g
                 torch.cuda.empty_cache()

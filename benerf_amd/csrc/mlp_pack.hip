@@ -85,6 +85,9 @@ __global__ void pack_kernel(PackArgs a) {
     // split-f16 section (mlp_split.h): [tile pair][kstep of 16][tile in pair][plane hi|lo][64 lanes][8 halfs]; lane l
     // holds col = tile*32 + (l&31), k = kstep*16 + 8*(l>>5) + j.  The four fragments a wave needs per k-step (two
     // column tiles x hi/lo) are one contiguous 4 KiB.  Same float count as the f32 block.
+    // Forward blocks: lo = (w - hi) * 2^11 (the forward kernel keeps a second accumulator set for the cross terms).
+    // Backward blocks: lo = w - hi UNSCALED (the f16 dX kernel adds dY*hi and dY*lo into one accumulator; |w| ~ 0.1
+    // puts lo into f16's subnormals, absolute floor 2^-25, i.e. the weight still carries ~20 bits).
     typedef _Float16 half8 __attribute__((ext_vector_type(8)));
     half8* dsth = reinterpret_cast<half8*>(a.packed + PACKED_FLOATS + pack_offset(id));
     const int ksteps = sh.kblocks / 2;
@@ -101,7 +104,7 @@ __global__ void pack_kernel(PackArgs a) {
         for (int j = 0; j < 8; ++j) {
             const float w = pack_source(a, id, col, k0 + j);
             hi[j] = (_Float16)w;
-            lo[j] = (_Float16)((w - (float)hi[j]) * 2048.f);
+            lo[j] = (_Float16)((w - (float)hi[j]) * (id <= PF_VIEWS ? 2048.f : 1.f));
         }
         const int64_t frag = (((int64_t)(tile >> 1) * ksteps + ks) * 2 + (tile & 1)) * 2;   // 1 KiB fragments
         dsth[frag * 64 + lane] = hi;

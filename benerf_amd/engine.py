@@ -243,6 +243,16 @@ class TrainStep:
     """
 
     def __init__(self, graph, cfg, cam_rgb, cam_evt, device, world_size=1, rank=0, process_group=None, seed=0):
+        # switches of train.py:180-352 this fused sequence does not implement are refused, not ignored
+        if getattr(cfg, "optimize_rgb_crf", False) or getattr(cfg, "optimize_event_crf", False):
+            raise NotImplementedError("TrainStep: CRF tone-mappers (optimize_rgb_crf / optimize_event_crf, train.py:180-192) are "
+                                      "not part of the fused step; use the autograd path (graph.render + torch.optim)")
+        if cfg.N_importance <= 0 or not hasattr(graph, "nerf_fine"):
+            raise NotImplementedError("TrainStep needs the fine network (N_importance > 0), as in every shipped config")
+        if getattr(cfg, "use_barf_c2f", False) or cfg.dataset == "TUM_VIE":
+            raise NotImplementedError("TrainStep: use_barf_c2f / TUM_VIE are not implemented (SURVEY 8f4)")
+        if not (getattr(cfg, "event_loss", True) or getattr(cfg, "rgb_loss", True)):
+            raise ValueError("TrainStep: event_loss and rgb_loss are both off - nothing to optimise")
         self.g, self.cfg, self.cam_rgb, self.cam_evt = graph, cfg, cam_rgb, cam_evt
         self.dev, self.world, self.rank, self.pg = device, world_size, rank, process_group
         self.seed = seed
@@ -372,12 +382,16 @@ class TrainStep:
         lcfg = K.make_loss_cfg(C, cfg.dataset.startswith("E2NeRF"), Re, Rr, P, cfg.event_threshold,
                                cfg.event_coeff_syn if syn else cfg.event_coeff_real, cfg.rgb_coeff,
                                Re * self.world, Rr * self.world)
-        largs = (rgb_map[:Ne], rgb0[:Ne], target_acc, rgb_map[Ne:], rgb0[Ne:], target_rgb)
+        # args.event_loss / args.rgb_loss (train.py:201,299): a disabled term contributes neither loss nor gradient
+        use_e, use_r = getattr(cfg, "event_loss", True), getattr(cfg, "rgb_loss", True)
+        largs = ((rgb_map[:Ne], rgb0[:Ne], target_acc) if use_e else (None, None, None)) + \
+                ((rgb_map[Ne:], rgb0[Ne:], target_rgb) if use_r else (None, None, None))
         stats = K.loss_stats(lcfg, *largs)
         dist.allreduce_sum_(stats, self.world, self.pg)
-        g_rgb = torch.empty_like(rgb_map)
-        g_rgb0 = torch.empty_like(rgb0)
-        losses, _ = K.loss_grads(lcfg, stats, *largs, out=(g_rgb[:Ne], g_rgb0[:Ne], g_rgb[Ne:], g_rgb0[Ne:]))
+        g_rgb = torch.empty_like(rgb_map) if (use_e and use_r) else torch.zeros_like(rgb_map)
+        g_rgb0 = torch.empty_like(rgb0) if (use_e and use_r) else torch.zeros_like(rgb0)
+        losses, _ = K.loss_grads(lcfg, stats, *largs, out=((g_rgb[:Ne], g_rgb0[:Ne]) if use_e else (None, None)) +
+                                 ((g_rgb[Ne:], g_rgb0[Ne:]) if use_r else (None, None)))
 
         # ---- backward -------------------------------------------------------------------------------
         d_o = torch.zeros_like(ro)

@@ -8,7 +8,7 @@ then trained for N steps with the reference's recipe.  Both the oracle and the H
 SAME step sequence (pixels, windows and all four RNG draws per render come from one numpy stream),
 so their loss curves and final PSNR can be compared directly.
 
-    python oracle/curve_scene.py            # oracle run -> tests/golden/g11_curve.npz (about 2 min on 8 cores)
+    python oracle/gen_golden.py g11         # reference + oracle runs -> tests/golden/g11_curve.npz (about 15 min on 8 cores)
 """
 import os
 import sys
@@ -21,10 +21,12 @@ sys.path.insert(0, HERE)
 import benerf_oracle as O  # noqa: E402
 import golden_inputs as GI  # noqa: E402
 
-H, W, FOCAL = 24, 32, 40.0
-C, S, NI, P = 1, 24, 24, 9
-RE, RR = 48, 6            # event pixels / blur pixels per step
+# C1-shaped steps (503 rays, 32 + 64 samples, 19 virtual poses) on a 48 x 64 image
+H, W, FOCAL = 48, 64, 80.0
+C, S, NI, P = 1, 32, 64, 19
+RE, RR = 128, 13          # event pixels / blur pixels per step: 2*128 + 19*13 = 503 rays
 N_STEPS = 300
+STREAM_SEEDS = (4242, 4243, 4244)   # input streams (pixels, windows, the four draws per render) of the golden runs
 GRID = 33                 # sharp teacher frames at t = k / (GRID-1)
 WINDOW = 4                # event window = 4 grid steps (0.125)
 THRESHOLD = 0.1
@@ -93,9 +95,10 @@ def eval_psnr(pc, pf, knots, frames):
     return O.psnr(ret["rgb_map"], frames[(GRID - 1) // 2]), ret["rgb_map"]
 
 
-def run_oracle(n_steps=N_STEPS, log=None):
+def run_oracle(n_steps=N_STEPS, log=None, stream_seed=STREAM_SEEDS[0], frames=None):
     torch.set_num_threads(8)
-    frames = teacher_frames()
+    if frames is None:
+        frames = teacher_frames()
     blurry = frames.mean(0)                                  # [H*W, C]
     cam = camera()
     cfg = O.StepConfig(H=H, W=W, fx=cam["fx"], fy=cam["fy"], cx=cam["cx"], cy=cam["cy"], channels=C, n_samples=S,
@@ -106,7 +109,7 @@ def run_oracle(n_steps=N_STEPS, log=None):
     tr = torch.zeros(1, 6)
     params = list(pc.values()) + list(pf.values()) + [knots]
     state = [(torch.zeros_like(p), torch.zeros_like(p)) for p in params]
-    rng = np.random.default_rng(4242)
+    rng = np.random.default_rng(stream_seed)
     losses = []
     for it in range(n_steps):
         (t0, t1), accu, idx_e, idx_r, d_e, d_r = step_inputs(rng, frames)
@@ -130,7 +133,3 @@ def run_oracle(n_steps=N_STEPS, log=None):
 if __name__ == "__main__":
     losses, ps, img, frames = run_oracle(log=print)
     print("final PSNR %.3f dB" % ps)
-    out = os.path.join(os.path.dirname(HERE), "tests", "golden", "g11_curve.npz")
-    np.savez_compressed(out, losses=losses.astype(np.float32), psnr=np.array(ps), image=img.astype(np.float32),
-                        frames_mid=frames[(GRID - 1) // 2].numpy().astype(np.float32))
-    print("wrote", out)

@@ -260,18 +260,25 @@ def test_mlp_bwd_golden(K, mlp_mode, golden, C, variant, S):
     d_pts, d_vd = K.mlp_bwd(net, dev(G.reshape(M, C + 1)), acts, M, 1, gw, gb, False)
     # with o = 0, z = 1: pts = d  =>  d_pts is the reference's d(pts)
     ref_dpts = g[tag + "_dpts"].reshape(M, 3)
-    report("K3 d_pts " + tag, d_pts, ref_dpts, atol=2e-5 * float(np.abs(ref_dpts).max()), rtol=1e-3)
+    # exact-f32 mode: round-off.  split mode: f16 operands in the backward chain, one 11-bit rounding per layer - the
+    # contract's 1e-3 of the largest entry is the bound, ~8e-4 observed
+    at = 2e-5 if mlp_mode == "f32" else 1e-3
+    report("K3 d_pts " + tag, d_pts, ref_dpts, atol=at * float(np.abs(ref_dpts).max()), rtol=1e-3)
     N = pts.shape[0]
     ref_dvd = g[tag + "_dviewdirs"]
     got_dvd = d_vd.reshape(N, S, 3).sum(1)
-    report("K3 d_viewdirs " + tag, got_dvd, ref_dvd, atol=2e-5 * float(np.abs(ref_dvd).max()), rtol=1e-3)
+    report("K3 d_viewdirs " + tag, got_dvd, ref_dvd, atol=at * float(np.abs(ref_dvd).max()), rtol=1e-3)
     for i, name in enumerate(K.LAYER_NAMES):
         for kind, got in (("weight", gw[i]), ("bias", gb[i])):
             key = "%s_g_%s.%s" % (tag, name, kind)
             flat = got.reshape(-1).cpu().numpy()
             nrm = float(np.linalg.norm(flat.astype(np.float64)))
             ref_n = float(g[key + "__norm"])
-            report("K3 |d%s.%s| %s" % (name, kind, tag), np.array(nrm), np.array(ref_n), atol=1e-9, rtol=1e-4)
+            # split mode: the backward chain rounds the gradient to f16 once per layer (random, unbiased); on these
+            # 1k-4k-point batches the heavily cancelling early-layer bias sums keep up to 1.2e-4 of that in their norm.
+            # (test_mlp_modes_agree_at_full_size compares the norms of the two modes at benchmark size)
+            report("K3 |d%s.%s| %s" % (name, kind, tag), np.array(nrm), np.array(ref_n), atol=1e-9,
+                   rtol=1e-4 if mlp_mode == "f32" else 2e-4)
             idx = g[key + "__idx"]
             ref_v = g[key + "__val"]
             report("K3 d%s.%s[64] %s" % (name, kind, tag), flat[idx], ref_v, atol=1e-3 * float(np.abs(ref_v).max()) + 1e-9,
@@ -376,15 +383,17 @@ def test_mlp_modes_agree_at_full_size(K):
     K.set_mlp_precision("split")
     a, b = out["f32"], out["split"]
     report("K3 full size, split vs f32: raw", b[0], a[0], atol=2e-6 * float(a[0].abs().max()), rtol=1e-5)
-    # Per-point gradients are discontinuous where a pre-activation crosses zero: among ~1e9 ReLU units a few hundred
-    # sit within the 1e-7 by which the two modes' activations differ, and their masks flip (the oracle shows the same
-    # sensitivity to a 1-ulp input change, test_path_gpu.test_fine_pass_gradients_with_forced_samples).  So: the
-    # bulk agrees to round-off, the flipped points are a vanishing fraction, and the L2 distance is negligible.
+    # Per-point gradients: the split mode's backward chain takes f16 operands (one rounding to 11 bits per layer, random
+    # and unbiased: ~5e-4 of the largest entry after nine layers, the contract's bound is 1e-3).  On top,
+    # gradients are discontinuous where a pre-activation crosses zero: among ~1e9 ReLU units a few hundred sit within
+    # the 1e-7 by which the two modes' activations differ, and their masks flip (the oracle shows the same sensitivity to a
+    # 1-ulp input change, test_path_gpu.test_fine_pass_gradients_with_forced_samples).  So: every point within 1e-3 of
+    # the largest entry except a vanishing fraction, and a small L2 distance.
     for nm, x, y in (("d_pts", b[1], a[1]), ("d_viewdirs", b[2], a[2])):
-        tol = 1e-5 * float(y.abs().max()) + 1e-3 * y.abs()
+        tol = 1e-3 * float(y.abs().max()) + 1e-3 * y.abs()
         bad = ((x - y).abs() > tol).any(dim=-1).float().mean()
         rel_l2 = float((x - y).norm() / y.norm())
-        print("K3 full size, split vs f32: %s  points beyond round-off: %.2e of %d, relative L2 distance %.2e"
+        print("K3 full size, split vs f32: %s  points beyond 1e-3 of the largest entry: %.2e of %d, relative L2 distance %.2e"
               % (nm, float(bad), y.shape[0], rel_l2))
         assert float(bad) < 2e-4 and rel_l2 < 2e-3, nm
     # weight gradients: sums over all points of noise-like terms (G is random).  The few hundred flipped units move an
@@ -394,6 +403,8 @@ def test_mlp_modes_agree_at_full_size(K):
         for kind, x, y in (("weight", b[3][i], a[3][i]), ("bias", b[4][i], a[4][i])):
             report("K3 full size, split vs f32: d%s.%s" % (name, kind), x, y, atol=5e-3 * float(y.abs().max()), rtol=1e-3)
             assert float((x - y).norm() / y.norm()) < 3e-3
+            # norms: mask flips (any two forward arithmetics) + the split mode's f16 gradient operands, on noise-like sums
+            report("K3 full size, split vs f32: |d%s.%s|" % (name, kind), x.norm().reshape(1), y.norm().reshape(1), rtol=3e-4)
 
 
 @pytest.mark.parametrize("wscale,gscale", [(3.0, 1.0), (0.35, 1e-12), (1.0, 1e6)])

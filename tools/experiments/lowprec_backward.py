@@ -124,9 +124,18 @@ def main():
         l64, g64 = run(seed, torch.float64, "exact", cfg, sizes)
         torch.set_default_dtype(old_default)
         print("seed %d  loss(f64) %.6f" % (seed, l64))
+        g32 = None
         for mode in ("exact", "C", "B", "A"):
             ZCACHE["i"] = 0
             l, g = run(seed, torch.float32, mode, cfg, sizes)
+            if mode == "exact":
+                g32 = g
+            else:   # against the exact-f32 backward of the SAME forward pass (same masks): the arithmetic's own error
+                keys = [k for k in g if k.endswith("bias") or k in ("knots", "transform")] + [k for k in g if k.endswith("weight")]
+                worst = sorted(((float((g[k] - g32[k]).abs().max() / g32[k].abs().max()), k) for k in keys), reverse=True)[:4]
+                print(" mode %-5s vs exact-f32 backward, worst max-relative errors: %s" % (mode, ", ".join("%s %.1e" % (k, e) for e, k in worst)))
+                print("            knots %.1e transform %.1e" % (float((g["knots"] - g32["knots"]).abs().max() / g32["knots"].abs().max()),
+                                                                 float((g["transform"] - g32["transform"]).abs().max() / g32["transform"].abs().max())))
             rows = []
             for k in ("knots", "transform", "c.pts_linears.0.weight", "c.pts_linears.0.bias", "c.pts_linears.4.weight",
                       "c.pts_linears.7.bias", "f.pts_linears.0.weight", "f.pts_linears.0.bias", "f.pts_linears.5.weight",
