@@ -8,7 +8,8 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbenerf_hip.so")
+# BENERF_HIP_LIB: development override (kernel variants built next to the shipped library)
+LIB_PATH = os.environ.get("BENERF_HIP_LIB") or os.path.join(_HERE, "libbenerf_hip.so")
 
 NLAYERS = 12
 L_VIEWS, L_FEAT, L_ALPHA, L_RGB = 8, 9, 10, 11

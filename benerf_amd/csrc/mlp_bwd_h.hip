@@ -167,24 +167,26 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[4][2], const uint64_t (&b
         int base[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) base[q] = r4 * LD + ((((ns ^ ((q & 1) | ((q >> 1) << 2)))) << 3) | (n & 7));
-        _Float16* st_lane = st + sh_half_index(m0 + r4, 256, n);
+        _Float16* st_lane = st + (((m0 >> 3) + (lane >> 5)) * 256 + n) * 8;   // unit (block, n); lanes 32-63: the odd block of a pair
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-            for (int eq = 0; eq < 4; ++eq) {
-                Quad16 q;
+            for (int ep = 0; ep < 2; ++ep) {
+                Quad16 q[2];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int e = eq * 4 + j;
-                    float v = acc[rt][c][e];
-                    if (MASK) v = ((bits[rt >> 1] >> ((c * 2 + (rt & 1)) * 16 + e)) & 1ull) ? v : 0.f;
-                    const int idx = base[((e >> 1) & 1) | (((e >> 2) & 1) << 1)] + (rt * 32 + (e & 3) + 8 * (e >> 2)) * LD;
-                    T[idx] = (_Float16)v;
-                    const float sv = v * gf;
-                    amax = fmaxf(amax, fabsf(sv));
-                    q.v[j] = (_Float16)sv;
-                }
-                *reinterpret_cast<uint2*>(st_lane + (int64_t)(rt * 4 + eq) * 256 * 8) = __builtin_bit_cast(uint2, q);
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int e = (ep * 2 + h) * 4 + j;
+                        float v = acc[rt][c][e];
+                        if (MASK) v = ((bits[rt >> 1] >> ((c * 2 + (rt & 1)) * 16 + e)) & 1ull) ? v : 0.f;
+                        const int idx = base[((e >> 1) & 1) | (((e >> 2) & 1) << 1)] + (rt * 32 + (e & 3) + 8 * (e >> 2)) * LD;
+                        T[idx] = (_Float16)v;
+                        const float sv = v * gf;
+                        amax = fmaxf(amax, fabsf(sv));
+                        q[h].v[j] = (_Float16)sv;
+                    }
+                *reinterpret_cast<uint4*>(st_lane + (int64_t)(rt * 4 + ep * 2) * 256 * 8) = sh_pair_unit(q[0], q[1]);
             }
     }
 }
@@ -245,28 +247,30 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_f16_kernel(BwdArgs a) {
         float wr[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) wr[c] = a.w_rgb[c * 128 + col];
-        _Float16* st_lane = reinterpret_cast<_Float16*>(dacts + sdact_hv(Mp)) + sh_half_index(m0 + r4, ACT_HV_W, col);
+        _Float16* st_lane = reinterpret_cast<_Float16*>(dacts + sdact_hv(Mp)) + (((m0 >> 3) + (lane >> 5)) * ACT_HV_W + col) * 8;
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-            for (int eq = 0; eq < 4; ++eq) {
-                Quad16 q;
+            for (int ep = 0; ep < 2; ++ep) {
+                Quad16 q[2];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int e = eq * 4 + j;
-                    const int p = rt * 32 + (e & 3) + 8 * (e >> 2) + r4;
-                    const float4 dr = *reinterpret_cast<const float4*>(fscr1(T, p, 28));
-                    const float drv[4] = {dr.x, dr.y, dr.z, dr.w};
-                    float g = 0.f;
+                for (int h = 0; h < 2; ++h)
 #pragma unroll
-                    for (int c = 0; c < C; ++c) g += drv[c] * wr[c];
-                    const float v = ((hvbits[rt >> 1] >> ((rt & 1) * 16 + e)) & 1ull) ? g : 0.f;
-                    T[hidx(p, col)] = (_Float16)v;
-                    const float sv = v * gf;
-                    amax = fmaxf(amax, fabsf(sv));
-                    q.v[j] = (_Float16)sv;
-                }
-                *reinterpret_cast<uint2*>(st_lane + (int64_t)(rt * 4 + eq) * ACT_HV_W * 8) = __builtin_bit_cast(uint2, q);
+                    for (int j = 0; j < 4; ++j) {
+                        const int e = (ep * 2 + h) * 4 + j;
+                        const int p = rt * 32 + (e & 3) + 8 * (e >> 2) + r4;
+                        const float4 dr = *reinterpret_cast<const float4*>(fscr1(T, p, 28));
+                        const float drv[4] = {dr.x, dr.y, dr.z, dr.w};
+                        float g = 0.f;
+#pragma unroll
+                        for (int c = 0; c < C; ++c) g += drv[c] * wr[c];
+                        const float v = ((hvbits[rt >> 1] >> ((rt & 1) * 16 + e)) & 1ull) ? g : 0.f;
+                        T[hidx(p, col)] = (_Float16)v;
+                        const float sv = v * gf;
+                        amax = fmaxf(amax, fabsf(sv));
+                        q[h].v[j] = (_Float16)sv;
+                    }
+                *reinterpret_cast<uint4*>(st_lane + (int64_t)(rt * 4 + ep * 2) * ACT_HV_W * 8) = sh_pair_unit(q[0], q[1]);
             }
     }
     lds_barrier();

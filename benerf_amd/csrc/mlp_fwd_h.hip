@@ -55,29 +55,33 @@ __device__ __forceinline__ uint64_t epilogue(f32x16 (&acc1)[2][NCT], f32x16 (&ac
         int base[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) base[q] = r4 * LD + ((((ns ^ ((q & 1) | ((q >> 1) << 2)))) << 3) | (n & 7));
-        _Float16* st_lane = SAVE ? st + sh_half_index(m0 + r4, W, n) : nullptr;    // + (r*4 + eq) * W*8 per quad
+        // 16-byte unit (block, feature n) of the SH array; lanes 32-63 store the odd block of each block pair
+        _Float16* st_lane = SAVE ? st + (((m0 >> 3) + (lane >> 5)) * W + n) * 8 : nullptr;
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
 #pragma unroll
-            for (int eq = 0; eq < 4; ++eq) {
-                Quad16 qh;
+            for (int ep = 0; ep < 2; ++ep) {
+                Quad16 qh[2];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int e = eq * 4 + j;
-                    float v = (acc1[r][c][e] + acc2[r][c][e] * LO_INV) + bv;
-                    if (RELU) {
-                        v = fmaxf(v, 0.f);
-                        bits |= (uint64_t)(v > 0.f) << ((c * 2 + r) * 16 + e);
+                for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int e = (ep * 2 + h) * 4 + j;
+                        float v = (acc1[r][c][e] + acc2[r][c][e] * LO_INV) + bv;
+                        if (RELU) {
+                            v = fmaxf(v, 0.f);
+                            bits |= (uint64_t)(v > 0.f) << ((c * 2 + r) * 16 + e);
+                        }
+                        amax = fmaxf(amax, RELU ? v : fabsf(v));                // range guard
+                        const _Float16 hi = (_Float16)v;
+                        const _Float16 lo = (_Float16)((v - (float)hi) * LO_SCALE);
+                        const int idx = base[((e >> 1) & 1) | (((e >> 2) & 1) << 1)] + (r * 32 + (e & 3) + 8 * (e >> 2)) * LD;
+                        Th[idx] = hi;
+                        Tl[idx] = lo;
+                        qh[h].v[j] = hi;
                     }
-                    amax = fmaxf(amax, RELU ? v : fabsf(v));                // range guard
-                    const _Float16 hi = (_Float16)v;
-                    const _Float16 lo = (_Float16)((v - (float)hi) * LO_SCALE);
-                    const int idx = base[((e >> 1) & 1) | (((e >> 2) & 1) << 1)] + (r * 32 + (e & 3) + 8 * (e >> 2)) * LD;
-                    Th[idx] = hi;
-                    Tl[idx] = lo;
-                    qh.v[j] = hi;
                 }
-                if (SAVE) *reinterpret_cast<uint2*>(st_lane + (int64_t)(r * 4 + eq) * W * 8) = __builtin_bit_cast(uint2, qh);
+                if (SAVE) *reinterpret_cast<uint4*>(st_lane + (int64_t)(r * 4 + ep * 2) * W * 8) = sh_pair_unit(qh[0], qh[1]);
             }
         }
     }

@@ -101,60 +101,6 @@ __device__ __forceinline__ void gemm_stage(const _Float16* __restrict__ Th, cons
     }
 }
 
-// Rolled variant (weights one k-step ahead, plain pointers): same result as gemm_stage; the dX kernel keeps it
-// because the unrolled, descriptor-based version drives that kernel into heavy register spilling.
-template <int KS, int NCT>
-__device__ __forceinline__ void gemm_stage_rolled(const _Float16* __restrict__ Th, const _Float16* __restrict__ Tl, int kcol0,
-                                           const float* __restrict__ wp, int ct0, int lane, f32x16 (&acc1)[2][NCT],
-                                           f32x16 (&acc2)[2][NCT]) {
-    const int row = lane & 31, lh = lane >> 5;
-    const int sw = hsw(row);                        // rows row and row + 32 share the swizzle
-    const int rbase = row * LD;
-    const uint4* bp[NCT];
-    uint4 bhn[NCT], bln[NCT];
-#pragma unroll
-    for (int c = 0; c < NCT; ++c) {
-        bp[c] = reinterpret_cast<const uint4*>(wp) + ((int64_t)((ct0 + c) >> 1) * KS * 4 + ((ct0 + c) & 1) * 2) * 64 + lane;
-        bhn[c] = bp[c][0];
-        bln[c] = bp[c][64];
-    }
-    const int slot0 = kcol0 >> 3;
-#pragma unroll 2
-    for (int ks = 0; ks < KS; ++ks) {
-        half8 bh[NCT], bl[NCT];
-#pragma unroll
-        for (int c = 0; c < NCT; ++c) {
-            bh[c] = __builtin_bit_cast(half8, bhn[c]);
-            bl[c] = __builtin_bit_cast(half8, bln[c]);
-        }
-        if (ks + 1 < KS) {
-#pragma unroll
-            for (int c = 0; c < NCT; ++c) {
-                bhn[c] = bp[c][(ks + 1) * 256];
-                bln[c] = bp[c][(ks + 1) * 256 + 64];
-            }
-        }
-        const int off = rbase + (((slot0 + ks * 2 + lh) ^ sw) << 3);
-        half8 ah[2], al[2];
-        ah[0] = *reinterpret_cast<const half8*>(Th + off);
-        ah[1] = *reinterpret_cast<const half8*>(Th + off + 32 * LD);
-        al[0] = *reinterpret_cast<const half8*>(Tl + off);
-        al[1] = *reinterpret_cast<const half8*>(Tl + off + 32 * LD);
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int c = 0; c < NCT; ++c) acc1[r][c] = mfma16(ah[r], bh[c], acc1[r][c]);
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int c = 0; c < NCT; ++c) acc2[r][c] = mfma16(ah[r], bl[c], acc2[r][c]);
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
-            for (int c = 0; c < NCT; ++c) acc2[r][c] = mfma16(al[r], bh[c], acc2[r][c]);
-    }
-}
-
 template <int NCT>
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][NCT]) {
 #pragma unroll
@@ -267,6 +213,17 @@ __device__ __forceinline__ void pe_sincos(float v, float& sn, float& cs) {
 
 // 4 consecutive points (one accumulator quad) of one feature = one 8-byte piece of an SH array
 struct Quad16 { _Float16 v[4]; };
+// Two quads of one feature, from consecutive 8-point blocks A and B: this lane holds points r4..r4+3 of each (r4 = 0
+// for lanes 0-31, 4 for lanes 32-63).  v_permlane32_swap hands lanes 0-31 the other half of block A and lanes 32-63
+// the other half of block B, so every lane stores ONE whole 16-byte unit (block A + (lane >> 5)) instead of two
+// 8-byte pieces: half the store instructions of an epilogue (the vector-memory queue is shared with the weight
+// prefetch, and 8-byte stores are issue-bound).
+__device__ __forceinline__ uint4 sh_pair_unit(const Quad16& qa, const Quad16& qb) {
+    const uint2 a = __builtin_bit_cast(uint2, qa), b = __builtin_bit_cast(uint2, qb);
+    const auto w0 = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
+    const auto w1 = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
+    return uint4{w0[0], w1[0], w0[1], w1[1]};
+}
 
 // f32 scratch inside the planes' PE columns [256,320): 64 floats per row, floats [0,32) in the hi plane, [32,64)
 // in the lo plane (slot 32 + i/4 of the plane, swizzled like everything else).

@@ -1,8 +1,6 @@
 set -x
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests -q -m gpu -x 2>&1 | tail -4
-timeout 600 python bench.py 2>&1 | tail -1 > gpurun_out/bench_split.json; cat gpurun_out/bench_split.json
-for MODE in split f32; do O=gpurun_out/prof_r1_$MODE; mkdir -p $O; B="python bench.py --primary-only --mlp-precision $MODE"
+for MODE in split f32; do O=gpurun_out/prof_${ROUND:-r02}_$MODE; mkdir -p $O; B="python bench.py --primary-only --mlp-precision $MODE"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- $B --steps 6 --warmup 2 2>/dev/null | tail -1 > $O.bench.json
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o p -- $B --steps 2 --warmup 1 > /dev/null 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o p -- $B --steps 2 --warmup 1 > /dev/null 2>&1

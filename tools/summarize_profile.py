@@ -17,12 +17,11 @@ import sys
 PARTS = [
     ("mlp_fwd_split_kernel", "mlp_fwd", "fwd"),
     ("mlp_fwd_kernel", "mlp_fwd", "fwd"),
-    ("mlp_bwd_split_kernel", "mlp_bwd_dx", "dx"),
+    ("mlp_bwd_f16_kernel", "mlp_bwd_dx", "dx"),
     ("grad_absmax_kernel", "mlp_bwd_dx", "absmax"),
-    ("absmax_reduce_kernel", "mlp_bwd_dx", "absmax_fold"),   # also runs after the forward launch; ~10 us, booked here
     ("mlp_bwd_kernel", "mlp_bwd_dx", "dx"),
-    ("mlp_dw_split_big_kernel", "mlp_bwd_dw", "big"),
-    ("mlp_dw_split_small_kernel", "mlp_bwd_dw", "small"),
+    ("mlp_dw_f16_big_kernel", "mlp_bwd_dw", "big"),
+    ("mlp_dw_f16_small_kernel", "mlp_bwd_dw", "small"),
     ("mlp_dw_kernel", "mlp_bwd_dw", "dw"),
     ("dw_reduce_kernel", "mlp_bwd_dw", "reduce"),
 ]
