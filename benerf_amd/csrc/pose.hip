@@ -191,23 +191,40 @@ __device__ __forceinline__ float nudge(float u) {   // spline.py:249-252
     return u;
 }
 
-template <class T>
-__device__ void cubic_pose(const T k[4][6], float u, T out[12]) {   // spline.py:247-303
+// BEZIER = false: uniform cubic B-spline, spline.py:247-303.  BEZIER = true: cubic Bezier with the same cumulative
+// construction - translation by the Bernstein basis C(3,k)(1-u)^(3-k)u^k (bezier.py:7-20), rotation
+// q0 (x) exp(b1 log(q0^-1 q1)) (x) exp(b2 log(q1^-1 q2)) (x) exp(b3 log(q2^-1 q3)) with the cumulative Bernstein basis
+// b_i = sum_{k>=i} B_k.  The reference's bezier.py:22-74 is an unfinished draft of this (it indexes a size-1 dimension and
+// raises IndexError on every call, and would use B_1 for all three increments); this is its evident intent.
+template <bool BEZIER, class T>
+__device__ void cubic_pose(const T k[4][6], float u, T out[12]) {
     T q[4][4], t[4][3];
 #pragma unroll
     for (int i = 0; i < 4; ++i) se3_to_qt(k[i], q[i], t[i]);
     float uu = u * u, uuu = u * u * u;
     const float sixth = 1.0f / 6.0f, half = 0.5f;
-    float c0 = sixth - half * u + half * uu - sixth * uuu;
-    float c1 = 4 * sixth - uu + half * uuu;
-    float c2 = sixth + half * u + half * uu - half * uuu;
-    float c3 = sixth * uuu;
+    float c0, c1, c2, c3, r1, r2, r3;
+    if (BEZIER) {
+        const float v = 1.0f - u;
+        c0 = v * v * v;
+        c1 = 3.0f * v * v * u;
+        c2 = 3.0f * v * uu;
+        c3 = uuu;
+        r1 = c1 + c2 + c3;
+        r2 = c2 + c3;
+        r3 = c3;
+    } else {
+        c0 = sixth - half * u + half * uu - sixth * uuu;
+        c1 = 4 * sixth - uu + half * uuu;
+        c2 = sixth + half * u + half * uu - half * uuu;
+        c3 = sixth * uuu;
+        r1 = 5 * sixth + half * u - half * uu + sixth * uuu;
+        r2 = sixth + half * u + half * uu - 2 * sixth * uuu;
+        r3 = sixth * uuu;
+    }
     T tr[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) tr[i] = c0 * t[0][i] + c1 * t[1][i] + c2 * t[2][i] + c3 * t[3][i];
-    float r1 = 5 * sixth + half * u - half * uu + sixth * uuu;
-    float r2 = sixth + half * u + half * uu - 2 * sixth * uuu;
-    float r3 = sixth * uuu;
     T cj[4], d01[4], d12[4], d23[4], rv[3], e0[4], e1[4], e2[4];
     quat_conj(q[0], cj);
     quat_mul(cj, q[1], d01);
@@ -263,8 +280,10 @@ __global__ void spline_fwd_kernel(const float* __restrict__ knots, const float* 
     float out[12];
     if (traj == 1)
         linear_pose(k[0], k[3], u, out);
+    else if (traj == 2)
+        cubic_pose<true>(k, u, out);
     else
-        cubic_pose(k, u, out);
+        cubic_pose<false>(k, u, out);
 #pragma unroll
     for (int i = 0; i < 12; ++i) poses[p * 12 + i] = out[i];
 }
@@ -287,8 +306,10 @@ __device__ __forceinline__ void spline_bwd_body(const float* __restrict__ knots,
         Dual out[12];
         if (traj == 1)
             linear_pose(k[0], k[3], u, out);
+        else if (traj == 2)
+            cubic_pose<true>(k, u, out);
         else
-            cubic_pose(k, u, out);
+            cubic_pose<false>(k, u, out);
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < 12; ++i) s += d_poses[p * 12 + i] * out[i].d;
@@ -332,12 +353,81 @@ __global__ void spline_bwd_pair_kernel(const float* __restrict__ knots, const fl
                     b ? d_transform_b : nullptr, contrib);
 }
 
+// ---- the reference's public spline helpers as single-op kernels (spline.py:16-192), same device functions ------------
+enum SplineOp { OP_SE3_2_QT = 0, OP_EXP_R2Q, OP_LOG_Q2R, OP_Q_TO_R, OP_TAYLOR_B, OP_TAYLOR_C, OP_SKEW, OP_Q_TO_Q, OP_Q_CONJ, OP_COUNT };
+__host__ __device__ constexpr int op_in(int op) {
+    return op == OP_SE3_2_QT ? 6 : op == OP_EXP_R2Q || op == OP_SKEW ? 3 : op == OP_TAYLOR_B || op == OP_TAYLOR_C ? 1 : 4;
+}
+__host__ __device__ constexpr int op_out(int op) {
+    return op == OP_SE3_2_QT ? 7 : op == OP_EXP_R2Q || op == OP_Q_CONJ ? 4 : op == OP_LOG_Q2R ? 3 : op == OP_Q_TO_R || op == OP_SKEW ? 9
+           : op == OP_Q_TO_Q ? 16 : 1;
+}
+template <class T>
+__device__ void apply_op(int op, const T* x, T* y) {
+    switch (op) {
+        case OP_SE3_2_QT: se3_to_qt(x, y, y + 4); break;          // [q xyzw | t]
+        case OP_EXP_R2Q: rotvec_to_quat(x, y); break;
+        case OP_LOG_Q2R: quat_to_rotvec(x, y); break;
+        case OP_Q_TO_R: {
+            T tz[3] = {lift<T>(0.f), lift<T>(0.f), lift<T>(0.f)}, o[12];
+            quat_to_pose(x, tz, o);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) y[i * 3 + j] = o[i * 4 + j];
+            break;
+        }
+        case OP_TAYLOR_B: y[0] = taylor_series(x[0], 1); break;
+        case OP_TAYLOR_C: y[0] = taylor_series(x[0], 2); break;
+        case OP_SKEW: {                                           // spline.py:28-34
+            T z = lift<T>(0.f);
+            y[0] = z; y[1] = -x[2]; y[2] = x[1];
+            y[3] = x[2]; y[4] = z; y[5] = -x[0];
+            y[6] = -x[1]; y[7] = x[0]; y[8] = z;
+            break;
+        }
+        case OP_Q_TO_Q: {                                         // left-product matrix, spline.py:130-138
+            T qx = x[0], qy = x[1], qz = x[2], qw = x[3];
+            y[0] = qw; y[1] = -qz; y[2] = qy; y[3] = qx;
+            y[4] = qz; y[5] = qw; y[6] = -qx; y[7] = qy;
+            y[8] = -qy; y[9] = qx; y[10] = qw; y[11] = qz;
+            y[12] = -qx; y[13] = -qy; y[14] = -qz; y[15] = qw;
+            break;
+        }
+        default: quat_conj(x, y); break;                          // OP_Q_CONJ
+    }
+}
+__global__ void spline_op_fwd_kernel(int op, const float* __restrict__ in, int64_t n, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int di = op_in(op), dout = op_out(op);
+    float x[6], y[16];
+    for (int c = 0; c < di; ++c) x[c] = in[i * di + c];
+    apply_op<float>(op, x, y);
+    for (int c = 0; c < dout; ++c) out[i * dout + c] = y[c];
+}
+// d_in[i][j] = <d_out[i], d y / d x_j>: one thread per (item, input component), forward-mode dual on that component
+__global__ void spline_op_bwd_kernel(int op, const float* __restrict__ in, int64_t n, const float* __restrict__ d_out,
+                                     float* __restrict__ d_in) {
+    const int di = op_in(op), dout = op_out(op);
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n * di) return;
+    const int64_t i = w / di;
+    const int j = (int)(w % di);
+    Dual x[6], y[16];
+    for (int c = 0; c < di; ++c) x[c] = Dual{in[i * di + c], c == j ? 1.f : 0.f};
+    apply_op<Dual>(op, x, y);
+    float s = 0.f;
+    for (int c = 0; c < dout; ++c) s += d_out[i * dout + c] * y[c].d;
+    d_in[w] = s;
+}
+
 }  // namespace
 
 extern "C" int benerf_spline_poses_fwd(const float* knots, const float* transform, const float* ts2, int n_poses,
                                        int traj, int explicit_ts, float* poses, benerf_stream_t stream) {
     BENERF_REQUIRE(knots && ts2 && poses, "spline_poses_fwd: null pointer");
-    BENERF_REQUIRE(n_poses > 0 && (traj == 0 || traj == 1), "spline_poses_fwd: bad n_poses/traj");
+    BENERF_REQUIRE(n_poses > 0 && (traj >= 0 && traj <= 2), "spline_poses_fwd: bad n_poses/traj");
     int threads = 64, blocks = (n_poses + threads - 1) / threads;
     hipLaunchKernelGGL(spline_fwd_kernel, dim3(blocks), dim3(threads), 0, as_stream(stream), knots, transform, ts2,
                        n_poses, traj, explicit_ts, poses);
@@ -349,7 +439,7 @@ extern "C" int benerf_spline_poses_bwd(const float* knots, const float* transfor
                                        int traj, int explicit_ts, const float* d_poses, float* d_knots,
                                        float* d_transform, benerf_stream_t stream) {
     BENERF_REQUIRE(knots && ts2 && d_poses && d_knots, "spline_poses_bwd: null pointer");
-    BENERF_REQUIRE(n_poses > 0 && n_poses <= 512 && (traj == 0 || traj == 1), "spline_poses_bwd: n_poses must be in [1,512]");
+    BENERF_REQUIRE(n_poses > 0 && n_poses <= 512 && (traj >= 0 && traj <= 2), "spline_poses_bwd: n_poses must be in [1,512]");
     size_t smem = (size_t)n_poses * 24 * sizeof(float);
     // one (pose, tangent) evaluation per thread where possible: the dual-number evaluation is a long serial
     // chain, so width beats depth (19 poses x 24 tangents = 456 threads in one block)
@@ -367,7 +457,7 @@ extern "C" int benerf_spline_poses_bwd_pair(const float* knots, const float* tra
                                             benerf_stream_t stream) {
     BENERF_REQUIRE(knots && transform_b && ts_a && ts_b && d_poses_a && d_poses_b && d_knots_a && d_knots_b && d_transform_b,
                    "spline_poses_bwd_pair: null pointer");
-    BENERF_REQUIRE(n_a > 0 && n_a <= 512 && n_b > 0 && n_b <= 512 && (traj == 0 || traj == 1), "spline_poses_bwd_pair: bad sizes");
+    BENERF_REQUIRE(n_a > 0 && n_a <= 512 && n_b > 0 && n_b <= 512 && (traj >= 0 && traj <= 2), "spline_poses_bwd_pair: bad sizes");
     const int n_max = n_a > n_b ? n_a : n_b;
     int threads = ((n_max * 24 + 63) / 64) * 64;
     if (threads > 1024) threads = 1024;
@@ -379,5 +469,22 @@ extern "C" int benerf_spline_poses_bwd_pair(const float* knots, const float* tra
     hipLaunchKernelGGL(spline_bwd_pair_kernel, dim3(2), dim3(threads), (size_t)n_max * 24 * sizeof(float), as_stream(stream), knots,
                        transform_b, p, traj, d_transform_b);
     BENERF_LAUNCH_CHECK("spline_poses_bwd_pair");
+    return BENERF_OK;
+}
+
+extern "C" int benerf_spline_op_fwd(int op, const float* in, int64_t n, float* out, benerf_stream_t stream) {
+    BENERF_REQUIRE(in && out && n >= 0 && op >= 0 && op < OP_COUNT, "spline_op_fwd: bad arguments (op %d)", op);
+    if (n == 0) return BENERF_OK;
+    hipLaunchKernelGGL(spline_op_fwd_kernel, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, as_stream(stream), op, in, n, out);
+    BENERF_LAUNCH_CHECK("spline_op_fwd");
+    return BENERF_OK;
+}
+
+extern "C" int benerf_spline_op_bwd(int op, const float* in, int64_t n, const float* d_out, float* d_in, benerf_stream_t stream) {
+    BENERF_REQUIRE(in && d_out && d_in && n >= 0 && op >= 0 && op < OP_COUNT, "spline_op_bwd: bad arguments (op %d)", op);
+    if (n == 0) return BENERF_OK;
+    const int64_t w = n * op_in(op);
+    hipLaunchKernelGGL(spline_op_bwd_kernel, dim3((unsigned)((w + 127) / 128)), dim3(128), 0, as_stream(stream), op, in, n, d_out, d_in);
+    BENERF_LAUNCH_CHECK("spline_op_bwd");
     return BENERF_OK;
 }

@@ -80,6 +80,29 @@ def spline_poses_bwd_pair(knots, transform_b, ts_a, n_a, ts_b, n_b, traj, d_pose
     return dk_a, dk_b, dt_b
 
 
+SPLINE_OPS = {"se3_2_qt": (0, 6, 7), "exp_r2q": (1, 3, 4), "log_q2r": (2, 4, 3), "q_to_R": (3, 4, 9), "taylor_B": (4, 1, 1),
+              "taylor_C": (5, 1, 1), "skew_symmetric": (6, 3, 9), "q_to_Q": (7, 4, 16), "q_to_q_conj": (8, 4, 4)}
+
+
+def spline_op_fwd(name, x):
+    """x [n, in] -> [n, out] (include/benerf_hip.h: benerf_spline_op_fwd)."""
+    lib = _lib.load()
+    op, di, do = SPLINE_OPS[name]
+    n = x.numel() // di
+    out = _new((n, do), x)
+    _lib.check(lib.benerf_spline_op_fwd(op, _chk(x, name=name + " input"), n, out.data_ptr(), _stream()), "spline_op_fwd")
+    return out
+
+
+def spline_op_bwd(name, x, d_out):
+    lib = _lib.load()
+    op, di, do = SPLINE_OPS[name]
+    n = x.numel() // di
+    d_in = _new((n, di), x)
+    _lib.check(lib.benerf_spline_op_bwd(op, _chk(x), n, _chk(d_out, name="d_out"), d_in.data_ptr(), _stream()), "spline_op_bwd")
+    return d_in
+
+
 # ----------------------------------------------------------------------------- K2 rays
 def rays_fwd(poses, ray_idx, H, W, fx, fy, cx, cy, ndc=True, out=None):
     lib = _lib.load()

@@ -50,7 +50,8 @@ const char* benerf_last_error(void);
  *   explicit_ts == 0: ts [2] device floats = (t_start, t_end), pose p is evaluated at
  *   torch.linspace(t0,t1,n)[p] (model/optimize.py:71,102); explicit_ts != 0: ts [n_poses]
  *   sample times as passed to the reference's spline functions;
- *   traj 0 = cubic spline, 1 = linear (knots 0 and 3); poses out [n_poses,3,4]. */
+ *   traj 0 = cubic B-spline, 1 = linear (knots 0 and 3), 2 = cubic Bezier (the evident intent of the reference's
+ *   non-executable bezier.py:22-74: Bernstein translation, cumulative-Bernstein rotation); poses out [n_poses,3,4]. */
 int benerf_spline_poses_fwd(const float* knots, const float* transform, const float* ts,
                             int n_poses, int traj, int explicit_ts, float* poses,
                             benerf_stream_t stream);
@@ -65,6 +66,16 @@ int benerf_spline_poses_bwd_pair(const float* knots, const float* transform_b, c
                                  const float* ts_b, int n_b, int traj, const float* d_poses_a,
                                  const float* d_poses_b, float* d_knots_a, float* d_knots_b,
                                  float* d_transform_b, benerf_stream_t stream);
+
+/* The reference's public single-step helpers (spline.py:16-192) as element-wise kernels over n items, same device
+ * code as the trajectory kernels.  op: 0 se3_2_qt_parallel ([6] -> [q xyzw | t] = [7]), 1 exp_r2q_parallel ([3] -> [4]),
+ * 2 log_q2r_parallel ([4] -> [3]), 3 q_to_R_parallel ([4] -> [3,3]), 4 taylor_B, 5 taylor_C ([1] -> [1]),
+ * 6 skew_symmetric ([3] -> [3,3]), 7 q_to_Q_parallel ([4] -> [4,4]), 8 q_to_q_conj_parallel ([4] -> [4]).
+ * _bwd: d_in [n, in] = J^T d_out.  Branch selection follows the VALUE like torch.where's forward; the derivative is
+ * that of the selected branch (the reference's backward is NaN where its unselected branch divides 0 by 0). */
+int benerf_spline_op_fwd(int op, const float* in, int64_t n, float* out, benerf_stream_t stream);
+int benerf_spline_op_bwd(int op, const float* in, int64_t n, const float* d_out, float* d_in,
+                         benerf_stream_t stream);
 
 /* ---------------------------------------------------------------- K2: rays --------- */
 /* Pinhole ray generation (pose-major, N = n_poses*n_pix), view directions and LLFF NDC.

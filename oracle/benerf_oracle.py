@@ -133,7 +133,13 @@ def nudge_unit_times(ts):
     return ts
 
 
-def cubic_spline_poses(knots, ts):
+def bezier_poses(knots, ts):
+    """Cubic Bezier in SE(3): Bernstein translation (bezier.py:7-20), cumulative-Bernstein rotation - the evident intent
+    of the reference's non-executable bezier.py:22-74 (it raises IndexError on every call; no reference output exists)."""
+    return cubic_spline_poses(knots, ts, bezier=True)
+
+
+def cubic_spline_poses(knots, ts, bezier=False):
     """Uniform cubic B-spline in SE(3), cumulative form for rotation.
 
     knots [4,6] se(3), ts [P] in [0,1] -> poses [P,3,4]      (spline.py:247-303)
@@ -154,10 +160,14 @@ def cubic_spline_poses(knots, ts):
     c1 = 4 * sixth - uu + half * uuu
     c2 = sixth + half * u + half * uu - half * uuu
     c3 = sixth * uuu
-    trans = c0 * t[0] + c1 * t[1] + c2 * t[2] + c3 * t[3]
     r1 = 5 * sixth + half * u - half * uu + sixth * uuu
     r2 = sixth + half * u + half * uu - 2 * sixth * uuu
     r3 = sixth * uuu
+    if bezier:
+        v = 1.0 - u
+        c0, c1, c2, c3 = v * v * v, 3.0 * v * v * u, 3.0 * v * uu, uuu
+        r1, r2, r3 = c1 + c2 + c3, c2 + c3, c3
+    trans = c0 * t[0] + c1 * t[1] + c2 * t[2] + c3 * t[3]
     d01 = quat_mul(quat_conj(q[0]), q[1])
     d12 = quat_mul(quat_conj(q[1]), q[2])
     d23 = quat_mul(quat_conj(q[2]), q[3])

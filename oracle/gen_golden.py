@@ -628,12 +628,83 @@ def g11_curve(R):
          stream_seeds=np.array(CS.STREAM_SEEDS), frames=frames.numpy().astype(np.float32), ref_image=ref_img.numpy().astype(np.float32))
 
 
+# ----------------------------------------------------------------------------------- G12
+def g12_spline_ops(R):
+    """The reference's single-step spline helpers (spline.py:16-192) on random rows plus the rows that reach their
+    special branches, with input gradients for a random cotangent; and whole-trajectory cases with exactly-zero /
+    1e-12 knots.  Where the reference's unselected torch.where branch divides 0 by 0 its BACKWARD is
+    NaN although the forward value is fine - those gradients are stored as they are (NaN)."""
+    rng = np.random.default_rng(1212)
+    out = {}
+
+    def rows(n, d, scale):
+        return GI.f32(rng.uniform(-scale, scale, (n, d)))
+
+    r = rows(24, 3, 2.0)
+    r[0] = 0.0                                   # theta == 0 exactly: series branch, NaN backward in the reference
+    r[1] = torch.tensor([1e-12, -2e-12, 5e-13])  # series branch, finite backward
+    r[2] = torch.tensor([3e-9, 0.0, 0.0])        # just above the threshold (theta = 1.5e-9)
+    q = rows(24, 4, 1.0)
+    q = q / q.norm(dim=-1, keepdim=True)
+    q[0] = torch.tensor([0.0, 0.0, 0.0, 1.0])    # theta == 0: series branch of log, NaN backward in the reference
+    q[1] = torch.tensor([0.6, 0.0, 0.8, 0.0])    # |w| < 1e-10: +pi / theta
+    q[2] = torch.tensor([0.6, 0.0, 0.8, -1e-12])  # |w| < 1e-10, w < 0: -pi / theta
+    q[3] = torch.tensor([1e-12, 0.0, 0.0, 1.0])
+    wu = rows(24, 6, 1.0)
+    wu[0] = 0.0
+    wu[1, :3] = torch.tensor([1e-12, 0.0, -1e-12])
+    th = GI.f32(np.abs(rng.uniform(0, 3.0, (24,))))
+    th[0] = 0.0
+    cases = {
+        "se3_2_qt": (wu.reshape(1, 24, 6), lambda x: torch.cat(R.spline.se3_2_qt_parallel(x), -1)),
+        "exp_r2q": (r.reshape(1, 24, 3), R.spline.exp_r2q_parallel),
+        "log_q2r": (q.reshape(1, 24, 4), R.spline.log_q2r_parallel),
+        "q_to_R": (q.reshape(1, 24, 4), R.spline.q_to_R_parallel),
+        "q_to_Q": (q.reshape(1, 24, 4), R.spline.q_to_Q_parallel),
+        "q_to_q_conj": (q.reshape(1, 24, 4), R.spline.q_to_q_conj_parallel),
+        "skew_symmetric": (r.reshape(1, 24, 3), R.spline.skew_symmetric),
+        "taylor_B": (th.reshape(1, 24), R.spline.taylor_B),
+        "taylor_C": (th.reshape(1, 24), R.spline.taylor_C),
+    }
+    for name, (x, fn) in cases.items():
+        xr = x.clone().requires_grad_(True)
+        y = fn(xr)
+        G = GI.f32(rng.standard_normal(tuple(y.shape)))
+        (y * G).sum().backward()
+        out[name + "_in"] = x
+        out[name + "_out"] = y.detach()
+        out[name + "_G"] = G
+        out[name + "_din"] = xr.grad
+        REPORT.append("G12 %-14s out %s, NaN rows in the reference's input gradient: %s" %
+                      (name, tuple(y.shape), torch.isnan(xr.grad.reshape(24, -1)).any(-1).nonzero().reshape(-1).tolist()))
+    # whole trajectories with degenerate knots
+    for tag, knots in (("zero", torch.zeros(4, 6)), ("tiny", GI.f32(rng.uniform(-1e-12, 1e-12, (4, 6)))),
+                       ("equal", GI.f32(np.tile(rng.uniform(-0.3, 0.3, (1, 6)), (4, 1))))):
+        for traj in ("spline", "linear"):
+            kr = knots.clone().requires_grad_(True)
+            ts = torch.linspace(0.0, 1.0, 5)
+            kk = [kr[i].reshape(1, 1, 6) for i in range(4)]
+            pr = (R.spline.cubic_spline_pose_unit_time(kk[0], kk[1], kk[2], kk[3], ts.clone()) if traj == "spline"
+                  else R.spline.linear_pose_unit_time(kk[0], kk[3], ts.clone()))
+            G = GI.f32(rng.standard_normal((5, 3, 4)))
+            (pr * G).sum().backward()
+            po = O.trajectory_poses(knots.clone(), None, (0.0, 1.0), 5, traj)
+            check("G12 degenerate poses %s %s" % (tag, traj), pr, po)
+            key = "traj_%s_%s" % (tag, traj)
+            out[key + "_knots"] = knots
+            out[key + "_G"] = G
+            out[key + "_poses"] = pr.detach()
+            out[key + "_dknots"] = kr.grad
+            REPORT.append("G12 trajectory %-5s %-6s: reference d_knots has NaN: %s" % (tag, traj, bool(torch.isnan(kr.grad).any())))
+    save("g12_spline_ops.npz", **out)
+
+
 def main():
     torch.set_num_threads(8)
     R = load_reference()
     only = sys.argv[1:]
     for fn in (g1_spline, g2_rays, g3_posenc, g4_mlp, g5_composite, g6_sample_pdf, g7_render, g8_step, g9_events,
-               g10_adam, g11_curve):
+               g10_adam, g11_curve, g12_spline_ops):
         if only and fn.__name__.split("_")[0] not in only:
             continue
         fn(R)

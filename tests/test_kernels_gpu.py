@@ -75,6 +75,67 @@ def test_spline_no_transform(K):
     report("K1 poses (no transform, P=2)", got, ref, atol=2e-6)
 
 
+def test_spline_helper_ops_golden(K, golden):
+    """spline.*_parallel helpers against the reference's outputs, forward and input gradients, incl. the rows
+    that reach the special branches.  Where the reference's BACKWARD is NaN (its unselected torch.where branch is 0/0 at
+    theta == 0) the kernels return the finite derivative of the selected branch - documented deviation."""
+    from benerf_amd import spline as S
+    g = golden("g12_spline_ops")
+    fns = {"se3_2_qt": lambda x: torch.cat(S.se3_2_qt_parallel(x), -1), "exp_r2q": S.exp_r2q_parallel, "log_q2r": S.log_q2r_parallel,
+           "q_to_R": S.q_to_R_parallel, "q_to_Q": S.q_to_Q_parallel, "q_to_q_conj": S.q_to_q_conj_parallel,
+           "skew_symmetric": S.skew_symmetric, "taylor_B": S.taylor_B, "taylor_C": S.taylor_C}
+    for name, fn in fns.items():
+        x = dev(g[name + "_in"]).requires_grad_(True)
+        y = fn(x)
+        assert tuple(y.shape) == g[name + "_out"].shape, name
+        report("K1 helper " + name, y, g[name + "_out"], atol=2e-6, rtol=2e-6)
+        (y * dev(g[name + "_G"])).sum().backward()
+        ref = g[name + "_din"]
+        ok = np.isfinite(ref)
+        got = x.grad.cpu().numpy()
+        assert np.isfinite(got).all(), name + ": kernel gradients must be finite"
+        report("K1 helper d(%s)" % name, np.where(ok, got, 0.0), np.where(ok, ref, 0.0), atol=2e-5 * max(1.0, float(np.abs(ref[ok]).max())),
+               rtol=1e-4)
+
+
+def test_spline_degenerate_knots(K, golden):
+    """Zero, 1e-12 and identical knots: the theta < 1e-9 / theta < 1e-20 branches of exp / log (spline.py:79-100,167-192).
+    Forward identical to the reference; the reference's knot gradients are NaN there, ours stay finite."""
+    g = golden("g12_spline_ops")
+    ts = dev(GI.f32([0.0, 1.0]))
+    for tag in ("zero", "tiny", "equal"):
+        for ti, traj in enumerate(("spline", "linear")):
+            key = "traj_%s_%s" % (tag, traj)
+            knots = dev(g[key + "_knots"])
+            report("K1 poses " + key, K.spline_poses_fwd(knots, None, ts, 5, ti), g[key + "_poses"], atol=2e-6)
+            dk, _ = K.spline_poses_bwd(knots, None, ts, 5, ti, dev(g[key + "_G"]))
+            assert torch.isfinite(dk).all(), key
+            ref = g[key + "_dknots"]
+            if np.isfinite(ref).all():
+                report("K1 dknots " + key, dk, ref, atol=2e-5 * max(1.0, float(np.abs(ref).max())), rtol=1e-3)
+
+
+def test_bezier_vs_restatement(K):
+    """bezier.cubic_bezier_poses_unit_time (kernel traj = 2) against the oracle's restatement of the reference's
+    evident intent (no reference output exists: bezier.py raises IndexError), forward and knot gradients."""
+    from benerf_amd import bezier as B
+    rng = np.random.default_rng(32)
+    for scale in (0.01, 0.4):
+        knots = GI.f32(rng.uniform(-scale, scale, (4, 6)))
+        ts = GI.f32(np.concatenate([[0.0, 1.0], rng.random(9)]))
+        G = GI.f32(rng.standard_normal((11, 3, 4)))
+        ko = knots.clone().requires_grad_(True)
+        ref = O.bezier_poses(ko, ts)
+        (ref * G).sum().backward()
+        kd = dev(knots).requires_grad_(True)
+        got = B.cubic_bezier_poses_unit_time(kd[0], kd[1], kd[2], kd[3], dev(ts))
+        report("K1 bezier poses (scale %g)" % scale, got, ref, atol=2e-6)
+        (got * dev(G)).sum().backward()
+        report("K1 bezier dknots (scale %g)" % scale, kd.grad, ko.grad, atol=2e-5 * max(1.0, float(ko.grad.abs().max())), rtol=1e-3)
+    coef = B.compute_bezier_coefficient_mat(torch.tensor([0.0, 0.5, 1.0]), 3)
+    report("bezier coefficient matrix", coef, torch.tensor([[1.0, 0, 0, 0], [0.125, 0.375, 0.375, 0.125], [0, 0, 0, 1.0]]), atol=1e-7)
+
+
 # ------------------------------------------------------------------------------------ K2
 def test_rays_fwd_golden(K, golden):
     g = golden("g2_rays")

@@ -115,3 +115,40 @@ def test_g10_adam(golden):
         report("G10 adam %d" % step, p, g["p_after_%d" % step], atol=1e-7, rtol=1e-6)
     for s in (0, 1, 1000, 80000):
         assert float(g["lr_%d" % s]) == O.decayed_lr(5e-4, 0.1, s)
+
+
+def test_g12_spline_helpers_and_degenerate_knots(golden):
+    """Oracle helpers vs the reference's single-step spline helpers, incl. the rows that reach their special branches
+    (theta == 0, |w| < 1e-10), and whole trajectories with zero / 1e-12 / identical knots."""
+    g = golden("g12_spline_ops")
+    fns = {"exp_r2q": O.rotvec_to_quat, "log_q2r": O.quat_to_rotvec, "q_to_R": O.quat_to_rot, "q_to_Q": O.quat_left_matrix,
+           "q_to_q_conj": O.quat_conj, "skew_symmetric": O.hat, "taylor_B": lambda x: O._taylor(x, 1),
+           "taylor_C": lambda x: O._taylor(x, 2), "se3_2_qt": lambda x: torch.cat(O.se3_to_quat_trans(x), -1)}
+    for name, fn in fns.items():
+        report("G12 " + name, fn(T(g[name + "_in"])), g[name + "_out"], atol=1e-7)
+    for tag in ("zero", "tiny", "equal"):
+        for traj in ("spline", "linear"):
+            key = "traj_%s_%s" % (tag, traj)
+            report("G12 poses " + key, O.trajectory_poses(T(g[key + "_knots"]), None, (0.0, 1.0), 5, traj), g[key + "_poses"], atol=1e-7)
+    # the reference's backward is NaN exactly where an unselected torch.where branch divides 0 by 0
+    assert np.isnan(g["exp_r2q_din"][0, 0]).all() and np.isfinite(g["exp_r2q_din"][0, 1:]).all()
+    assert np.isnan(g["traj_zero_spline_dknots"]).any()
+
+
+def test_bezier_restatement_properties():
+    """bezier.py of the reference cannot run (IndexError), so its evident intent is pinned by identities: the curve
+    starts at control pose 0 and ends at control pose 3, its translation is the Bernstein combination, and with four
+    identical control poses it is constant."""
+    rng = np.random.default_rng(31)
+    knots = GI.f32(rng.uniform(-0.4, 0.4, (4, 6)))
+    ts = torch.tensor([0.0, 0.25, 0.5, 1.0])
+    poses = O.bezier_poses(knots, ts)
+    ends = [torch.cat([O.quat_to_rot(q), t.unsqueeze(-1)], -1).reshape(3, 4)
+            for q, t in (O.se3_to_quat_trans(knots[k].reshape(1, 1, 6)) for k in (0, 3))]
+    report("bezier start = control pose 0", poses[0], ends[0], atol=2e-5)
+    report("bezier end = control pose 3", poses[3], ends[1], atol=2e-5)
+    tk = torch.stack([O.se3_to_quat_trans(knots[k].reshape(1, 1, 6))[1].reshape(3) for k in range(4)])
+    b = torch.tensor([0.125, 0.375, 0.375, 0.125])
+    report("bezier translation at u = 1/2", poses[2, :, 3], b @ tk, atol=1e-6)
+    same = O.bezier_poses(knots[:1].expand(4, 6), ts)
+    report("bezier of identical control poses is constant", same, ends[0].expand(4, 3, 4), atol=1e-6)
