@@ -336,9 +336,11 @@ class TrainStep:
         return dist.shard_indices(idx, self.rank, self.world)
 
     def step(self, evt_ts2, rgb_ts2, idx_evt_global, idx_rgb_global, events_accu, image, draws_evt=None,
-             draws_rgb=None):
+             draws_rgb=None, z_fine_forced=None):
         """evt_ts2/rgb_ts2: [2] device floats; idx_*_global: int64 device pixel indices (global batch,
-        identical on every rank); events_accu [H_e*W_e] float32 device; image [H*W, C] float32 device."""
+        identical on every rank); events_accu [H_e*W_e] float32 device; image [H*W, C] float32 device.
+        z_fine_forced [N, S+Ni]: parity runs may supply the merged fine depths instead of K5's (sample_pdf is
+        ill-conditioned in the coarse weights: isolates everything behind it)."""
         cfg, C, dev = self.cfg, self.C, self.dev
         P = cfg.num_interpolated_pose
         S, Ni = cfg.N_samples, cfg.N_importance
@@ -369,7 +371,7 @@ class TrainStep:
         nz0 = d.noise_args(0)
         c0 = K.composite_fwd(raw0, z, rd, nz0[0], nz0[1], nz0[2], nz0[3], want=("rgb_map", "weights"))
         u, usd, uoff = d.u_args()
-        z_fine = K.sample_pdf_merge(z, c0["weights"], Ni, u, usd, uoff)
+        z_fine = K.sample_pdf_merge(z, c0["weights"], Ni, u, usd, uoff) if z_fine_forced is None else z_fine_forced.contiguous()
         raw1, acts1 = K.mlp_fwd(self.net_f.packed, ro, rd, vd, z_fine, True)
         nz1 = d.noise_args(1)
         c1 = K.composite_fwd(raw1, z_fine, rd, nz1[0], nz1[1], nz1[2], nz1[3], want=("rgb_map",))

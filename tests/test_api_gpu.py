@@ -252,3 +252,84 @@ def test_two_rank_step_equals_single_rank():
     # the first Adam step is lr * g / (|g| + eps): entries with |g| ~ eps amplify the 1e-7 gradient wobble,
     # bounded by a few percent of lr = 5e-4
     report("DP parameters after Adam (2 ranks vs 1)", p2, p1, atol=2e-5, rtol=1e-5)
+
+
+def test_render_after_fused_steps_uses_current_weights():
+    """Graph.render / render_video between TrainStep.step calls must see the UPDATED weights: the fused Adam kernel
+    rewrites parameter storage without bumping torch's version counters, so the module-level packed copies are
+    invalidated through kernels.params_changed()."""
+    from benerf_amd import engine, kernels as K, workloads as WL
+    wl = dict(WL.WORKLOADS["C1"], S=16, Ni=16, Re=16, Rr=2, n=5)
+    args = WL.make_args(wl, benerf_raw_noise_std=0.0, chunk=2048)
+    cam = WL.CAMERAS["unreal"]
+    model, g = _graph(args)
+    cam_o = engine.Camera(cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+    Kmat = np.array([[cam["fx"], 0, cam["cx"]], [0, cam["fy"], cam["cy"]], [0, 0, 1]], dtype=np.float32)
+    step = engine.TrainStep(g, args, cam_o, cam_o, torch.device(DEV))
+    rng = np.random.default_rng(17)
+    HW = cam["H"] * cam["W"]
+    accu = torch.from_numpy(rng.integers(-3, 4, HW).astype(np.float32)).to(DEV)
+    img = torch.from_numpy(rng.random((HW, 1)).astype(np.float32)).to(DEV)
+    pose = torch.eye(3, 4, device=DEV)[None]
+    idx = torch.arange(0, 512, device=DEV)
+    outs = []
+    for it in range(3):
+        torch.manual_seed(7)     # same draws every time: only the weights change
+        with torch.no_grad():
+            ret = g.render(it, pose, idx, cam["H"], cam["W"], torch.Tensor(Kmat), args, False, None, torch.tensor([]))
+        torch.manual_seed(7)
+        N = idx.shape[0]
+        d = engine.Draws(torch.rand((N, 16), device=DEV), None, torch.rand([N, 16], device=DEV), None, noise_std=0.0)
+        ref, _ = engine._render_forward(cam_o, True, 16, 16, d, pose, idx, step.net_c.packed, step.net_f.packed, False)
+        assert torch.equal(ret["rgb_map"], ref["rgb_map"]), "render() used stale packed weights at iteration %d" % it
+        outs.append(ret["rgb_map"].clone())
+        step.step(torch.tensor([0.2, 0.3], device=DEV), torch.tensor([0.0, 1.0], device=DEV),
+                  torch.from_numpy(rng.permutation(HW)[:16]).to(DEV), torch.from_numpy(rng.permutation(HW)[:2]).to(DEV), accu, img)
+    assert not torch.equal(outs[0], outs[1]) and not torch.equal(outs[1], outs[2]), "training must change the render"
+
+
+def test_f16_range_guard():
+    """Hidden weights x300 drive activations past f16's maximum.  Split mode: the training forward reports it through
+    the status words (BenerfRangeError from check_mlp_status, never a silent inf); inference launches run as
+    BENERF_MLP_AUTO and return the exact-f32 result; the fused Adam step leaves the parameters untouched."""
+    from benerf_amd import _lib, kernels as K
+    if K.get_mlp_precision() != "split":
+        pytest.skip("range guard concerns the split-f16 mode")
+    rng = np.random.default_rng(5)
+    C = 1
+    p = O.xavier_params(rng, C)
+    for k in p:
+        if k.startswith("pts_linears") and k.endswith("weight"):
+            p[k] = p[k] * (300.0 if k.startswith("pts_linears.0") else 3.0)
+    net = K.PackedMlp([p[n + ".weight"].to(DEV) for n in K.LAYER_NAMES], [p[n + ".bias"].to(DEV) for n in K.LAYER_NAMES], C)
+    net.pack()
+    N, S = 64, 32
+    ro = GI.f32(rng.uniform(-0.5, 0.5, (N, 3))).to(DEV)
+    rd = GI.f32(rng.uniform(-1, 1, (N, 3))).to(DEV)
+    vd = torch.nn.functional.normalize(GI.f32(rng.standard_normal((N, 3))), dim=-1).to(DEV)
+    z = GI.f32(np.sort(rng.random((N, S)), -1)).to(DEV)
+    K.check_mlp_status(torch.device(DEV))                         # clean slate
+    raw_f32, _ = K.mlp_fwd(net, ro, rd, vd, z, False, precision="f32")
+    assert torch.isfinite(raw_f32).all() and float(raw_f32.abs().max()) > 0
+    # inference (AUTO): valid output although the split launch overflowed
+    raw_auto, _ = K.mlp_fwd(net, ro, rd, vd, z, False, precision="split")
+    assert torch.equal(raw_auto, raw_f32), "BENERF_MLP_AUTO must fall back to the exact-f32 kernels"
+    with pytest.raises(_lib.BenerfRangeError):
+        K.check_mlp_status(torch.device(DEV))                     # ... and the violation is still reported (then reset)
+    K.check_mlp_status(torch.device(DEV))
+    # training forward: no silent inf - the status check raises
+    raw_s, acts = K.mlp_fwd(net, ro, rd, vd, z, True, precision="split")
+    prm = torch.ones(1000, device=DEV)
+    before = prm.clone()
+    K.adam_step(prm, torch.ones_like(prm), torch.zeros_like(prm), torch.zeros_like(prm), 1e-3, 1)
+    assert torch.equal(prm, before), "Adam must skip a step whose status shows a range violation"
+    with pytest.raises(_lib.BenerfRangeError):
+        K.check_mlp_status(torch.device(DEV))
+    K.adam_step(prm, torch.ones_like(prm), torch.zeros_like(prm), torch.zeros_like(prm), 1e-3, 1)
+    assert not torch.equal(prm, before)
+    # well-scaled weights: nothing reported
+    p2 = O.xavier_params(rng, C)
+    net2 = K.PackedMlp([p2[n + ".weight"].to(DEV) for n in K.LAYER_NAMES], [p2[n + ".bias"].to(DEV) for n in K.LAYER_NAMES], C)
+    net2.pack()
+    K.mlp_fwd(net2, ro, rd, vd, z, True, precision="split")
+    K.check_mlp_status(torch.device(DEV))

@@ -577,10 +577,21 @@ def test_sample_pdf_bit_exact(K, golden):
             assert np.array_equal(zs.cpu().numpy(), g[tag + "_samples_exact"]), "K5 samples not bit-exact " + tag
             ref_sorted, _ = torch.sort(torch.cat([z, torch.from_numpy(g[tag + "_samples_exact"])], -1), -1)
             assert torch.equal(z_fine.cpu(), ref_sorted), "K5 merged depths not bit-exact " + tag
-            # vs the reference itself: identical indices except at 1-ulp cdf ties
-            mism = int((inds.cpu().numpy() != g[tag + "_inds"]).sum())
-            report("K5 index mismatches vs reference (of %d) %s" % (inds.numel(), tag), np.array(float(mism)),
-                   np.array(0.0), atol=2.0)
+            # vs the reference itself: torch leaves the float order of its `sum` unspecified, so its cdf can differ from
+            # the fully specified one by an ulp; an index may differ ONLY where u sits within 2 ulp of the cdf knot that
+            # separates the two answers (SURVEY hard part 4) - asserted for every differing index
+            z_mid = 0.5 * (z[:, 1:] + z[:, :-1])
+            _, _, cdf = O.sample_pdf_exact(z_mid.numpy(), w_mid.numpy(), u.numpy())
+            got, ref = inds.cpu().numpy(), g[tag + "_inds"]
+            rows, cols = np.nonzero(got != ref)
+            for r, c in zip(rows, cols):
+                lo, hi = sorted((int(got[r, c]), int(ref[r, c])))
+                assert hi - lo == 1, "K5 index differs by more than one bin at a tie " + tag
+                knot, uu = cdf[r, lo], u.numpy()[r, c]                       # inds = first k with cdf[k] > u: the knot between them
+                assert abs(float(uu) - float(knot)) <= 2 * float(np.spacing(np.float32(max(abs(knot), 1e-30)))), \
+                    "K5 index differs from the reference away from a cdf tie: %s ray %d draw %d u=%r cdf=%r" % (tag, r, c, uu, knot)
+            report("K5 index differences vs reference, all at <= 2-ulp cdf ties (of %d) %s" % (inds.numel(), tag),
+                   np.array(float(len(rows))), np.array(0.0), atol=float(len(rows)))
 
 
 # ------------------------------------------------------------------------------------ K6

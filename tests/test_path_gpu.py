@@ -131,7 +131,7 @@ def _g8_inputs(si, spec):
                 img=img, d_e=d_e, d_r=d_r)
 
 
-def _check_grads(g8, tag, named, knots_g, tr_g, who):
+def _check_grads(g8, tag, named, knots_g, tr_g, who, fine_entry_tol=2e-2, fine_norm_tol=1e-3, coarse_entry_tol=5e-3):
     # Pose gradients (and bias gradients of the early layers) are sums over every sample point with
     # heavy cancellation (|sum| << sum|.|): f32 round-off of ANY summation order is ~1e-3 of the
     # largest entry, so tolerances are relative to that entry (1e-3 on entries).
@@ -146,10 +146,11 @@ def _check_grads(g8, tag, named, knots_g, tr_g, who):
         # cdf differs by one ulp), so its gradient norms carry a ~1e-4 relative wobble on tiny batches.
         loose = key.endswith(".bias") or key.startswith("nerf_fine.")
         report("%s |d%s| %s" % (who, key, tag), np.array(np.linalg.norm(flat.astype(np.float64))),
-               g8[base + "__norm"], atol=1e-12, rtol=1e-3 if loose else 2e-4)
+               g8[base + "__norm"], atol=1e-12,
+               rtol=(fine_norm_tol if key.startswith("nerf_fine.") else 1e-3) if loose else 2e-4)
         ref_v = g8[base + "__val"]
         report("%s d%s[64] %s" % (who, key, tag), flat[g8[base + "__idx"]], ref_v,
-               atol=(2e-2 if key.startswith("nerf_fine.") else 5e-3) * float(np.abs(ref_v).max()) + 1e-12, rtol=2e-3)
+               atol=(fine_entry_tol if key.startswith("nerf_fine.") else coarse_entry_tol) * float(np.abs(ref_v).max()) + 1e-12, rtol=2e-3)
 
 
 @pytest.mark.parametrize("si", range(len(G8_SPECS)))
@@ -389,6 +390,54 @@ def test_full_size_properties():
     dp2, _ = K.mlp_bwd(net_f, (2 * graw).contiguous(), saved["acts1"], N, 128, gw2, gb2, False)
     report("full-size linearity d_pts", dp2, 2 * dp1, atol=1e-5 * float(dp1.abs().max()), rtol=1e-5)
     report("full-size linearity dW4", gw2[4], 2 * gw1[4], atol=1e-5 * float(gw1[4].abs().max()), rtol=1e-5)
+
+
+@pytest.mark.parametrize("si", range(len(G8_SPECS)))
+def test_training_iteration_golden_g8_forced_fine_depths(golden, si):
+    """G8 again, with sample_pdf's conditioning taken out: the fused step is handed the fine depths the REFERENCE used
+    (the oracle's op-for-op sample_pdf_torch on its own coarse weights - bit-identical to the reference's on the CPU,
+    tests/golden/PINNING_REPORT.txt), so the fine network is evaluated at the same points as in the golden run and its
+    gradients are held to the same tolerances as the coarse network's."""
+    from benerf_amd import engine, kernels as K, workloads as WL
+    g8 = golden("g8_step")
+    spec = G8_SPECS[si]
+    tag, cname, C, dataset, thr, P, S, Ni, Re, Rr = spec
+    x = _g8_inputs(si, spec)
+    cam = x["cam"]
+    Kmat = GI.cam_K(cam)
+    args = WL.make_args("C2", channels=C, N_samples=S, N_importance=Ni, num_interpolated_pose=P, dataset=dataset,
+                        event_threshold=thr, event_height=cam["H"], event_width=cam["W"], optimize_trans=True)
+    _, g = build_graph(args, x["pc"], x["pf"], x["knots"], x["tr"])
+    cam_o = engine.Camera(cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+    step = engine.TrainStep(g, args, cam_o, cam_o, torch.device(DEV))
+    sel, upper_t = O.event_window(x["ev"]["ts"], x["low_t"], x["window"])
+    ref_accu = O.accumulate_events(cam["H"], cam["W"], x["ev"]["x"][sel], x["ev"]["y"][sel], x["ev"]["pol"][sel])
+    img = torch.Tensor(x["img"][0].numpy()).reshape(cam["H"] * cam["W"], C).to(DEV)
+    evt_ts = torch.tensor(np.stack((x["low_t"], upper_t)).reshape(2), dtype=torch.float32)
+    with torch.no_grad():   # the reference's fine depths of both renders
+        pe = O.trajectory_poses(x["knots"], None, evt_ts, 2, "spline")
+        pr = O.trajectory_poses(x["knots"], x["tr"], torch.tensor([0.0, 1.0]), P, "spline")
+        _, ex_e = O.render(x["pc"], x["pf"], pe, x["idx_e"], cam["H"], cam["W"], Kmat, C, S, Ni, x["d_e"], want_extras=True)
+        _, ex_r = O.render(x["pc"], x["pf"], pr, x["idx_r"], cam["H"], cam["W"], Kmat, C, S, Ni, x["d_r"], want_extras=True)
+    z_fine = torch.cat([ex_e["z_fine"], ex_r["z_fine"]]).to(DEV)
+
+    def dd(d):
+        return engine.Draws(*(d[k].to(DEV) for k in ("t_rand", "noise0", "u", "noise1")))
+
+    losses = step.step(evt_ts.to(DEV), torch.tensor([0.0, 1.0], device=DEV), x["idx_e"].to(DEV), x["idx_r"].to(DEV),
+                       ref_accu.float().reshape(-1).to(DEV), img, dd(x["d_e"]), dd(x["d_r"]), z_fine_forced=z_fine)
+    report("step(forced z) loss " + tag, losses[0:1], np.array([g8[tag + "_loss"]], np.float32), atol=1e-6, rtol=2e-5)
+    named = {}
+    for nn_, fn in (("nerf", step.net_c), ("nerf_fine", step.net_f)):
+        for i, name in enumerate(K.LAYER_NAMES):
+            named["%s.%s.weight" % (nn_, name)] = fn.gviews_w[i]
+            named["%s.%s.bias" % (nn_, name)] = fn.gviews_b[i]
+    # SURVEY 8c: 1e-3 on sampled entries, 1e-4 on norms - met by the exact-f32 mode.  The split mode's backward GEMMs
+    # take the gradient as f16 (random, unbiased rounding per layer): on these 24-pixel batches up to 1.2e-3 / 1.4e-4
+    # remain (at benchmark size the sums average it away, test_kernels_gpu.test_mlp_modes_agree_at_full_size)
+    f32 = K.get_mlp_precision() == "f32"
+    _check_grads(g8, tag, named, step.g_knots, step.g_transform, "step(forced z)", fine_entry_tol=1e-3 if f32 else 1.5e-3,
+                 fine_norm_tol=1e-4 if f32 else 2e-4, coarse_entry_tol=1e-3 if f32 else 1.5e-3)
 
 
 def test_fine_pass_gradients_with_forced_samples():
