@@ -35,7 +35,32 @@ def allreduce_sum_(t, world, group=None):
     return t
 
 
+class _Done:
+    def wait(self):
+        return True
+
+
+def allreduce_sum_async_(t, world, group=None):
+    """Starts the in-place sum over ranks and returns a handle whose wait() makes the CURRENT stream wait for it.
+    With nccl (= RCCL) the collective runs on the communicator's own stream behind everything already queued on the
+    current stream, so kernels launched after this call overlap with it: TrainStep issues the fine network's bucket
+    as soon as its weight gradients are complete and computes the coarse backward meanwhile.  gloo (CPU
+    tests / several ranks on one GPU) has no device path: reduced synchronously through host memory."""
+    if world <= 1:
+        return _Done()
+    if t.is_cuda and torch.distributed.get_backend(group) == "gloo":
+        allreduce_sum_(t, world, group)
+        return _Done()
+    return torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM, group=group, async_op=True)
+
+
 def broadcast_(t, world, src=0, group=None):
+    """Rank `src`'s values everywhere (parameters + optimiser state at start-up: replicas must not rely on seeds)."""
     if world > 1:
-        torch.distributed.broadcast(t, src=src, group=group)
+        if t.is_cuda and torch.distributed.get_backend(group) == "gloo":
+            h = t.cpu()
+            torch.distributed.broadcast(h, src=src, group=group)
+            t.copy_(h)
+        else:
+            torch.distributed.broadcast(t, src=src, group=group)
     return t

@@ -281,6 +281,9 @@ class TrainStep:
         self.g_transform = self.flat_g[o + 24:o + 30].view(1, 6)
         self.off_pose = o
         self.global_step = 0
+        # replicas start from rank 0's parameters (and its - zero - Adam state), whatever their local initialisation was
+        for buf in (self.flat_p, self.flat_m, self.flat_v):
+            dist.broadcast_(buf, self.world, 0, self.pg)
         self.net_c.packed.pack()
         self.net_f.packed.pack()
         self.last_losses = None
@@ -402,10 +405,15 @@ class TrainStep:
         d_raw1, _ = K.composite_bwd(raw1, z_fine, rd, nz1[0], nz1[1], nz1[2], nz1[3], g_rgb, d_rays_d=d_d)
         d_pts, d_vp = K.mlp_bwd(self.net_f.packed, d_raw1.view(-1, C + 1), acts1, N, S + Ni, self.net_f.gviews_w,
                                 self.net_f.gviews_b, False)
+        # gradient exchange, bucket 1 of 3: the fine network's gradients are final - their all-reduce (RCCL over xGMI) runs
+        # on the communicator's stream while the coarse backward below computes
+        n = self.n_net
+        pending = [dist.allreduce_sum_async_(self.flat_g[n:2 * n], self.world, self.pg)]
         K.ray_grad_reduce(z_fine, d_pts, d_vp, d_o, d_d, d_v, True)
         d_raw0, _ = K.composite_bwd(raw0, z, rd, nz0[0], nz0[1], nz0[2], nz0[3], g_rgb0, d_rays_d=d_d, accumulate=True)
         d_pts, d_vp = K.mlp_bwd(self.net_c.packed, d_raw0.view(-1, C + 1), acts0, N, S, self.net_c.gviews_w,
                                 self.net_c.gviews_b, False)
+        pending.append(dist.allreduce_sum_async_(self.flat_g[:n], self.world, self.pg))      # bucket 2: coarse network
         K.ray_grad_reduce(z, d_pts, d_vp, d_o, d_d, d_v, True)
         dp_e = K.rays_bwd(poses_e, idx_e, ce.H, ce.W, ce.fx, ce.fy, ce.cx, ce.cy, cfg.ndc, d_o[:Ne], d_d[:Ne], d_v[:Ne])
         dp_r = K.rays_bwd(poses_r, idx_r, cr.H, cr.W, cr.fx, cr.fy, cr.cx, cr.cy, cfg.ndc, d_o[Ne:], d_d[Ne:], d_v[Ne:])
@@ -413,8 +421,10 @@ class TrainStep:
         torch.add(dk_e, dk_r, out=self.g_knots)
         self.g_transform.copy_(dt_r)
 
-        # ---- gradient exchange: one all-reduce of the flat buffer over RCCL/xGMI ------------------------------
-        dist.allreduce_sum_(self.flat_g, self.world, self.pg)
+        # ---- gradient exchange, bucket 3: the 30 trajectory gradients; then every bucket must have landed ------------
+        pending.append(dist.allreduce_sum_async_(self.flat_g[2 * n:], self.world, self.pg))
+        for w in pending:
+            w.wait()
 
         # ---- Adam (K8) with the reference's per-group switches and LR schedule ---------------------------------
         t = self.global_step + 1

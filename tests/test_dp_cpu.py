@@ -60,7 +60,7 @@ def _worker(rank, world, port, thr, q):
     torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
     rng = np.random.default_rng(0)           # identical on every rank
-    C, P, Re_g, Rr_g, dataset = 3, 5, 16, 6, "E2NeRF_Real" if thr <= 0 else "BeNeRF_Unreal"
+    C, P, Re_g, Rr_g, dataset = 3, 5, 16, 8, "E2NeRF_Real" if thr <= 0 else "BeNeRF_Unreal"
     W = torch.from_numpy(rng.standard_normal((C, 8)).astype(np.float32)).requires_grad_(True)   # stand-in "network"
     feat_e = torch.from_numpy(rng.standard_normal((2, Re_g, 8)).astype(np.float32))
     feat_r = torch.from_numpy(rng.standard_normal((P, Rr_g, 8)).astype(np.float32))
@@ -92,10 +92,11 @@ def _worker(rank, world, port, thr, q):
 
 
 @pytest.mark.parametrize("thr", [0.1, -1.0])
-def test_two_rank_gradient_equals_single_rank(thr):
+def test_sharded_gradient_equals_single_rank(thr):
+    """world sizes 2 and 4 against the single process (C4 / C5 run on 8 ranks the same way)."""
     ctx = mp.get_context("spawn")
     out = {}
-    for world in (1, 2):
+    for world in (1, 2, 4):
         q = ctx.Queue()
         port = 29500 + int(abs(thr) * 10) + world * 7 + (os.getpid() % 200)
         procs = [ctx.Process(target=_worker, args=(r, world, port, thr, q)) for r in range(world)]
@@ -106,6 +107,7 @@ def test_two_rank_gradient_equals_single_rank(thr):
             p.join(timeout=60)
             assert p.exitcode == 0
     np.testing.assert_allclose(out[2], out[1], rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(out[4], out[1], rtol=2e-5, atol=1e-7)
 
 
 def test_shard_indices():
@@ -116,3 +118,13 @@ def test_shard_indices():
     assert torch.equal(torch.cat(parts), idx)
     with pytest.raises(ValueError):
         dist.shard_indices(torch.arange(10), 0, 4)
+
+
+def test_async_allreduce_and_broadcast_single_process():
+    """world 1: the asynchronous exchange and the start-up broadcast are no-ops with a waitable handle."""
+    sys.path.insert(0, ROOT)
+    from benerf_amd import dist
+    t = torch.arange(5.0)
+    h = dist.allreduce_sum_async_(t, 1)
+    assert h.wait() and torch.equal(t, torch.arange(5.0))
+    assert dist.broadcast_(t, 1) is t
