@@ -418,12 +418,13 @@ def test_mlp_bwd_gradient_scale_invariance(K, mlp_mode):
         report("K3 dW scale invariance", b, a, atol=1e-6 * float(a.abs().max()), rtol=1e-5)
 
 
-def test_mlp_modes_agree_at_full_size(K):
-    """BASELINE.json size (C2 fine pass: 4081 rays x 128 samples = 522 368 points): the split-f16 mode and the
-    exact-f32 mode, forward and backward, on the same inputs.  Outputs agree to f32 round-off; the weight gradients
-    (sums over half a million points) agree to the f32 accumulation noise both modes carry."""
+@pytest.mark.parametrize("C,N,S", [(1, 4081, 128), (3, 4081, 128), (3, 8188, 192)])
+def test_mlp_modes_agree_at_full_size(K, C, N, S):
+    """BASELINE.json sizes - the fine pass of C2 (gray, 4081 rays x 128 samples = 522 368 points), of C3 / C4's per-GPU
+    shape (colour) and of C5 (colour, 8188 rays x 192 samples = 1.57 M points): the split-f16 mode and the exact-f32
+    mode, forward and backward, on the same inputs.  Outputs agree to f32 round-off; the weight gradients (sums over
+    all points) agree to the noise described below."""
     rng = np.random.default_rng(80)
-    C, N, S = 1, 4081, 128
     p = _params_for(rng, C, "trained")
     net = _packed(K, p, C)
     ro = dev(GI.f32(rng.uniform(-0.5, 0.5, (N, 3))))

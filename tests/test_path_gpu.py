@@ -351,25 +351,30 @@ def test_helper_mirrors(golden):
     report("helpers linear_pose_unit_time", lin, g1[tagl + "_poses"], atol=2e-6)
 
 
-def test_full_size_properties():
-    """C2-size checks that need no oracle run: compositing weights sum to acc <= 1, merged
-    depths sorted and a superset of the coarse depths, MLP linear in d_raw (backward),
-    Philox reproducibility of the whole render."""
+@pytest.mark.parametrize("wl_name", ["C2", "C3", "C4", "C5"])
+def test_full_size_properties(wl_name):
+    """Checks at the full size of every BASELINE.json GPU configuration (C2: gray; C3: colour; C4: 800 x 800 camera, linlog,
+    8181 rays; C5: 31 poses, 64 + 192 samples) that need no oracle run: compositing weights sum to acc <= 1, merged depths
+    sorted and a superset of the coarse depths, MLP linear in d_raw (backward), Philox reproducibility of the whole
+    render - the blur batch of one step (n poses x Rr pixels)."""
     from benerf_amd import engine, kernels as K, workloads as WL
-    args = WL.make_args("C2")
+    wl = WL.WORKLOADS[wl_name]
+    args = WL.make_args(wl_name)
+    C, S, Ni = wl["channels"], wl["S"], wl["Ni"]
     rng = np.random.default_rng(11)
-    pc, pf = O.xavier_params(rng, 1), O.xavier_params(rng, 1)
+    pc, pf = O.xavier_params(rng, C), O.xavier_params(rng, C)
     _, g = build_graph(args, pc, pf, GI.knots_init(rng), torch.zeros(1, 6))
-    cam = WL.CAMERAS["unreal"]
+    cam = WL.CAMERAS[wl["cam"]]
     cam_o = engine.Camera(cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"])
     poses = g.get_pose_rgb(args, torch.tensor([0.0, 1.0])).detach()
-    idx = torch.from_numpy(rng.permutation(cam["H"] * cam["W"])[:215]).to(DEV)
+    assert poses.shape[0] == wl["n"]
+    idx = torch.from_numpy(rng.permutation(cam["H"] * cam["W"])[:wl["Rr"]]).to(DEV)
     net_c, net_f = g.nerf.packed(), g.nerf_fine.packed()
     net_c.pack_if_stale()
     net_f.pack_if_stale()
     d = engine.Draws(seed=5, offset=3)
-    out, saved = engine._render_forward(cam_o, True, 64, 64, d, poses, idx, net_c, net_f, True)
-    out2, _ = engine._render_forward(cam_o, True, 64, 64, d, poses, idx, net_c, net_f, False)
+    out, saved = engine._render_forward(cam_o, True, S, Ni, d, poses, idx, net_c, net_f, True)
+    out2, _ = engine._render_forward(cam_o, True, S, Ni, d, poses, idx, net_c, net_f, False)
     assert torch.equal(out["rgb_map"], out2["rgb_map"]), "same Philox stream => identical render"
     zf, zc = saved["z_fine"], saved["z"]
     assert bool((zf[:, 1:] >= zf[:, :-1]).all()), "merged depths must be sorted"
@@ -380,16 +385,69 @@ def test_full_size_properties():
     assert float(out["rgb_map"].min()) >= 0.0 and float(out["rgb_map"].max()) <= 1.0 + 1e-5
     # backward is linear in the upstream gradient: bwd(2g) == 2 bwd(g)
     N = zc.shape[0]
-    graw = torch.randn(N * 128, 2, device=DEV)
+    assert out["rgb_map"].shape == (wl["n"] * wl["Rr"], C) and zf.shape == (N, S + Ni)
+    graw = torch.randn(N * (S + Ni), C + 1, device=DEV)
     gw1 = [torch.zeros_like(w) for w in net_f.weights]
     gb1 = [torch.zeros_like(b) for b in net_f.biases]
     gw2 = [torch.zeros_like(w) for w in net_f.weights]
     gb2 = [torch.zeros_like(b) for b in net_f.biases]
-    dp1, _ = K.mlp_bwd(net_f, graw, saved["acts1"], N, 128, gw1, gb1, False)
+    dp1, _ = K.mlp_bwd(net_f, graw, saved["acts1"], N, S + Ni, gw1, gb1, False)
     dp1 = dp1.clone()
-    dp2, _ = K.mlp_bwd(net_f, (2 * graw).contiguous(), saved["acts1"], N, 128, gw2, gb2, False)
+    dp2, _ = K.mlp_bwd(net_f, (2 * graw).contiguous(), saved["acts1"], N, S + Ni, gw2, gb2, False)
     report("full-size linearity d_pts", dp2, 2 * dp1, atol=1e-5 * float(dp1.abs().max()), rtol=1e-5)
     report("full-size linearity dW4", gw2[4], 2 * gw1[4], atol=1e-5 * float(gw1[4].abs().max()), rtol=1e-5)
+
+
+@pytest.mark.parametrize("wl_name", ["C3", "C4", "C5"])
+def test_full_size_step_modes_agree(wl_name):
+    """One full-size fused training step of C3 / C4 / C5 (colour kernels at 0.78 M points, the 800 x 800 camera with
+    the linlog loss, 31 poses with 64 + 192 samples and the globally normalised loss) in both arithmetic modes on the same
+    explicit draws: identical event image, losses to 1e-5, pose gradients within the contract's 1e-3 of the largest."""
+    from benerf_amd import engine, kernels as K, workloads as WL
+    wl = WL.WORKLOADS[wl_name]
+    cam = WL.CAMERAS[wl["cam"]]
+    C, S, Ni, P, Re, Rr = wl["channels"], wl["S"], wl["Ni"], wl["n"], wl["Re"], wl["Rr"]
+    HW = cam["H"] * cam["W"]
+    res = {}
+    prev = K.get_mlp_precision()
+    try:
+        for mode in ("f32", "split"):
+            K.set_mlp_precision(mode)
+            rng = np.random.default_rng(21)
+            args = WL.make_args(wl_name, optimize_trans=True)
+            pc, pf = O.xavier_params(rng, C), O.xavier_params(rng, C)
+            pc["alpha_linear.bias"] += 1.0
+            pf["alpha_linear.bias"] += 1.0
+            _, g = build_graph(args, pc, pf, GI.knots_init(rng) * 3, GI.transform_small(rng) * 0.1)
+            cam_o = engine.Camera(cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+            step = engine.TrainStep(g, args, cam_o, cam_o, torch.device(DEV))
+            idx_e = torch.from_numpy(rng.permutation(HW)[:Re]).to(DEV)
+            idx_r = torch.from_numpy(rng.permutation(HW)[:Rr]).to(DEV)
+            accu = torch.from_numpy(rng.integers(-3, 4, HW).astype(np.float32)).to(DEV)
+            img = torch.from_numpy(rng.random((HW, C)).astype(np.float32)).to(DEV)
+            g_t = torch.Generator(device=DEV)
+            g_t.manual_seed(5)
+
+            def draws(n):
+                return engine.Draws(torch.rand((n, S), device=DEV, generator=g_t), torch.randn((n, S), device=DEV, generator=g_t),
+                                    torch.rand((n, Ni), device=DEV, generator=g_t), torch.randn((n, S + Ni), device=DEV, generator=g_t))
+            losses = step.step(torch.tensor([0.3, 0.3 + wl["window"]], device=DEV), torch.tensor([0.0, 1.0], device=DEV), idx_e, idx_r,
+                               accu, img, draws(2 * Re), draws(P * Rr))
+            K.check_mlp_status(torch.device(DEV))
+            res[mode] = (losses.cpu().numpy(), step.g_knots.cpu().numpy().copy(), step.g_transform.cpu().numpy().copy(),
+                         step.net_f.gviews_w[7].cpu().numpy().copy())
+            del step, g
+            torch.cuda.empty_cache()
+    finally:
+        K.set_mlp_precision(prev)
+    a, b = res["f32"], res["split"]
+    assert np.isfinite(b[0]).all() and np.isfinite(b[1]).all()
+    report("full-size step %s: losses, split vs f32" % wl_name, b[0], a[0], atol=1e-7, rtol=2e-5)
+    sc = float(np.abs(a[1]).max())
+    # 1e-3 of the largest entry (SURVEY 8c) + the ReLU-kink flips any two forward arithmetics show (test_kernels_gpu)
+    report("full-size step %s: d knots, split vs f32" % wl_name, b[1], a[1], atol=2e-3 * sc, rtol=2e-3)
+    report("full-size step %s: d transform, split vs f32" % wl_name, b[2], a[2], atol=2e-3 * sc, rtol=2e-3)
+    assert float(np.linalg.norm(b[3] - a[3]) / np.linalg.norm(a[3])) < 3e-3
 
 
 @pytest.mark.parametrize("si", range(len(G8_SPECS)))

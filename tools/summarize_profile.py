@@ -34,6 +34,47 @@ def classify(name):
     return None
 
 
+# HBM-bound kernels outside K3: name fragment -> (label, algorithmic bytes per launch at C2 as a function of
+# the launch's grid: R = rays of the step (4081), S/F = 64 / 128 samples, C = 1).  Bytes: what the launch must read + write.
+R_, S_, F_, C_ = 4081, 64, 192, 1
+SMALL = [
+    ("spline_fwd_kernel", "K1 spline poses fwd", lambda n: 30 * 4 + 19 * 48),
+    ("spline_bwd_pair_kernel", "K1 spline poses bwd (both trajectories)", lambda n: 30 * 4 + 21 * 48 + 54 * 4),
+    ("rays_fwd_kernel", "K2 rays fwd", lambda n: R_ * (8 + 36) // 2),
+    ("rays_bwd_kernel", "K2 rays bwd", lambda n: R_ * (8 + 36) // 2),
+    ("stratified_z_kernel", "K2 stratified depths", lambda n: R_ * S_ * 4),
+    ("composite_fwd_kernel", "K4 compositing fwd (avg coarse / fine)", lambda n: R_ * ((S_ + F_) // 2) * (8 + 4 + 4) ),
+    ("composite_bwd_kernel", "K4 compositing bwd (avg coarse / fine)", lambda n: R_ * ((S_ + F_) // 2) * (8 + 4 + 8)),
+    ("sample_pdf_merge_kernel", "K5 sample_pdf + merge", lambda n: R_ * (S_ * 8 + F_ * 4)),
+    ("loss_stats_kernel", "K6 loss statistics", lambda n: R_ * 2 * 4),
+    ("loss_grads_kernel", "K6 loss gradients", lambda n: R_ * 4 * 4),
+    ("event_window_accumulate_kernel", "K7 event window accumulate (10% of 2M events)", lambda n: 200000 * 12 + 480 * 768 * 4),
+    ("adam_kernel", "K8 Adam (avg nets / pose)", lambda n: (1191172 + 30) // 2 * 28),
+    ("pack_kernel", "K8 weight re-pack (one network)", lambda n: 595586 * 4 + 2 * 1191936 * 4),
+    ("ray_grad_reduce_kernel", "K2 per-point -> per-ray gradient reduce (avg)", lambda n: R_ * ((S_ + F_) // 2) * 28),
+    ("dw_reduce_kernel", "K3 dW partial-sum reduce", lambda n: 256 * 66000 * 4),
+]
+
+
+def small_kernel_table(trace_csv):
+    """avg duration and achieved GB/s against the algorithmic bytes for the kernels outside the fused MLP (C2 shapes)."""
+    dur = collections.defaultdict(list)
+    for r in csv.DictReader(open(trace_csv)):
+        for frag, label, _ in SMALL:
+            if frag in r["Kernel_Name"]:
+                dur[frag].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+                break
+    out = {}
+    for frag, label, fn in SMALL:
+        d = dur.get(frag)
+        if not d:
+            continue
+        us = sum(d) / len(d)
+        b = fn(0)
+        out[label] = {"dispatches": len(d), "avg_us": round(us, 2), "algorithmic_bytes": b, "achieved_GBps": round(b / us / 1e3, 2)}
+    return out
+
+
 def find(src, sub, leaf):
     hits = glob.glob(os.path.join(src, sub, "**", leaf), recursive=True)
     return hits[0] if hits else None
@@ -83,6 +124,7 @@ def main():
             # GRBM_GUI_ACTIVE is summed over the 8 XCDs; MFMA busy cycles over the 1024 SIMDs
             k["mfma_util"] = tot["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * tot["GRBM_GUI_ACTIVE"] / 8)
         out["kernels"][g] = k
+    out["small_kernels"] = small_kernel_table(find(src, "trace", "t_kernel_trace.csv"))
     json.dump(out, open(os.path.join(dst, "%s_pmc_summary.json" % tag), "w"), indent=1)
     print(json.dumps(out, indent=1)[:3000])
 
