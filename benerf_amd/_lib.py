@@ -90,6 +90,8 @@ def load():
         raise BenerfHipError(
             "libbenerf_hip.so not found at %s - run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C benerf_amd/csrc`).  There is no CPU fallback." % LIB_PATH)
+    import torch  # noqa: F401  - first: the library must share the HIP runtime torch ships (loading /opt/rocm's copy
+    #                              before torch's leaves the process with two runtimes and no visible device)
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing: fail loudly
