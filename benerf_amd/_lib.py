@@ -39,8 +39,8 @@ _SIGNATURES = {
     "benerf_spline_poses_bwd_pair": (c_int, [P, P, P, c_int, P, c_int, c_int, P, P, P, P, P, P]),
     "benerf_spline_op_fwd": (c_int, [c_int, P, c_int64, P, P]),
     "benerf_spline_op_bwd": (c_int, [c_int, P, c_int64, P, P, P]),
-    "benerf_rays_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_int, P, P, P, P]),
-    "benerf_rays_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_int, P, P, P, P, P]),
+    "benerf_rays_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_int, P, P, P, P, P]),
+    "benerf_rays_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_int, P, P, P, P, P, P]),
     "benerf_stratified_z": (c_int, [c_int, c_int, c_float, c_float, P, c_uint64, c_uint64, P, P]),
     "benerf_ray_grad_reduce": (c_int, [c_int, c_int, P, P, P, c_int, P, P, P, P]),
     "benerf_mlp_packed_floats": (c_size_t, []),

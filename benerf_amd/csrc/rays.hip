@@ -41,10 +41,23 @@ struct Cam {
 };
 
 // pose: 12 entries row-major [3][4]; pixel (i = column, j = row).
+// pixel -> (column, row) coordinates of the ray: the integer pixel itself, or - TUM_VIE - the entry of the undistortion
+// look-up table remap [H, W, 2] = (x, y) the reference gathers with `rect = remap[j, i]` (model/nerf.py:247-250,
+// run_nerf_helpers.py:17-23)
+__device__ __forceinline__ void pixel_coords(int64_t idx, const Cam& c, const float* __restrict__ remap, float& fi, float& fj) {
+    if (remap) {
+        fi = remap[idx * 2 + 0];
+        fj = remap[idx * 2 + 1];
+    } else {
+        fj = (float)(int)(idx / c.W);               // model/nerf.py:244-245
+        fi = (float)(int)(idx % c.W);
+    }
+}
+
 template <class T>
-__device__ __forceinline__ void ray_from_pose(const T pose[12], int i, int j, const Cam& c, T o[3], T d[3], T vd[3]) {
-    float dx = ((float)i - c.cx) / c.fx;          // run_nerf_helpers.py:36-38
-    float dy = -((float)j - c.cy) / c.fy;
+__device__ __forceinline__ void ray_from_pose(const T pose[12], float fi, float fj, const Cam& c, T o[3], T d[3], T vd[3]) {
+    float dx = (fi - c.cx) / c.fx;          // run_nerf_helpers.py:36-38
+    float dy = -(fj - c.cy) / c.fy;
     float dz = -1.0f;
     T rd[3], ro[3];
 #pragma unroll
@@ -78,14 +91,14 @@ __device__ __forceinline__ void ray_from_pose(const T pose[12], int i, int j, co
 }
 
 __global__ void rays_fwd_kernel(const float* __restrict__ poses, const int64_t* __restrict__ ray_idx, int n_poses,
-                                int n_pix, Cam cam, float* __restrict__ rays_o, float* __restrict__ rays_d,
-                                float* __restrict__ viewdirs) {
+                                int n_pix, Cam cam, const float* __restrict__ remap, float* __restrict__ rays_o,
+                                float* __restrict__ rays_d, float* __restrict__ viewdirs) {
     int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t N = (int64_t)n_poses * n_pix;
     if (n >= N) return;
     int p = (int)(n / n_pix);
-    int64_t idx = ray_idx[n % n_pix];
-    int j = (int)(idx / cam.W), i = (int)(idx % cam.W);   // model/nerf.py:244-245
+    float i, j;
+    pixel_coords(ray_idx[n % n_pix], cam, remap, i, j);
     float pose[12];
 #pragma unroll
     for (int e = 0; e < 12; ++e) pose[e] = poses[p * 12 + e];
@@ -102,8 +115,8 @@ __global__ void rays_fwd_kernel(const float* __restrict__ poses, const int64_t* 
 // one block (256 threads) per pose; thread handles pixels tid, tid+256, ...; each pixel
 // evaluates 12 dual passes; LDS tree reduction in fixed order.
 __global__ void rays_bwd_kernel(const float* __restrict__ poses, const int64_t* __restrict__ ray_idx, int n_poses,
-                                int n_pix, Cam cam, const float* __restrict__ g_o, const float* __restrict__ g_d,
-                                const float* __restrict__ g_v, float* __restrict__ d_poses) {
+                                int n_pix, Cam cam, const float* __restrict__ remap, const float* __restrict__ g_o,
+                                const float* __restrict__ g_d, const float* __restrict__ g_v, float* __restrict__ d_poses) {
     __shared__ float red[256 * 12];
     int p = blockIdx.x;
     float pose[12];
@@ -114,8 +127,8 @@ __global__ void rays_bwd_kernel(const float* __restrict__ poses, const int64_t* 
     for (int e = 0; e < 12; ++e) acc[e] = 0.f;
     for (int r = threadIdx.x; r < n_pix; r += blockDim.x) {
         int64_t n = (int64_t)p * n_pix + r;
-        int64_t idx = ray_idx[r];
-        int j = (int)(idx / cam.W), i = (int)(idx % cam.W);
+        float i, j;
+        pixel_coords(ray_idx[r], cam, remap, i, j);
         float go[3], gd[3], gv[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -222,8 +235,8 @@ __global__ void ray_grad_reduce_kernel(int n_rays, int S, const float* __restric
 }  // namespace
 
 extern "C" int benerf_rays_fwd(const float* poses, const int64_t* ray_idx, int n_poses, int n_pix, int H, int W,
-                               float fx, float fy, float cx, float cy, int ndc, float* rays_o, float* rays_d,
-                               float* viewdirs, benerf_stream_t stream) {
+                               float fx, float fy, float cx, float cy, int ndc, const float* remap, float* rays_o,
+                               float* rays_d, float* viewdirs, benerf_stream_t stream) {
     BENERF_REQUIRE(poses && ray_idx && rays_o && rays_d && viewdirs, "rays_fwd: null pointer");
     BENERF_REQUIRE(n_poses > 0 && n_pix > 0 && H > 0 && W > 0, "rays_fwd: bad sizes");
     Cam cam{H, W, fx, fy, cx, cy, ndc};
@@ -231,20 +244,20 @@ extern "C" int benerf_rays_fwd(const float* poses, const int64_t* ray_idx, int n
     int threads = 256;
     int blocks = (int)((N + threads - 1) / threads);
     hipLaunchKernelGGL(rays_fwd_kernel, dim3(blocks), dim3(threads), 0, as_stream(stream), poses, ray_idx, n_poses,
-                       n_pix, cam, rays_o, rays_d, viewdirs);
+                       n_pix, cam, remap, rays_o, rays_d, viewdirs);
     BENERF_LAUNCH_CHECK("rays_fwd");
     return BENERF_OK;
 }
 
 extern "C" int benerf_rays_bwd(const float* poses, const int64_t* ray_idx, int n_poses, int n_pix, int H, int W,
-                               float fx, float fy, float cx, float cy, int ndc, const float* d_rays_o,
-                               const float* d_rays_d, const float* d_viewdirs, float* d_poses,
+                               float fx, float fy, float cx, float cy, int ndc, const float* remap,
+                               const float* d_rays_o, const float* d_rays_d, const float* d_viewdirs, float* d_poses,
                                benerf_stream_t stream) {
     BENERF_REQUIRE(poses && ray_idx && d_poses, "rays_bwd: null pointer");
     BENERF_REQUIRE(n_poses > 0 && n_pix > 0, "rays_bwd: bad sizes");
     Cam cam{H, W, fx, fy, cx, cy, ndc};
     hipLaunchKernelGGL(rays_bwd_kernel, dim3(n_poses), dim3(256), 0, as_stream(stream), poses, ray_idx, n_poses, n_pix,
-                       cam, d_rays_o, d_rays_d, d_viewdirs, d_poses);
+                       cam, remap, d_rays_o, d_rays_d, d_viewdirs, d_poses);
     BENERF_LAUNCH_CHECK("rays_bwd");
     return BENERF_OK;
 }

@@ -24,15 +24,17 @@ NOISE_STD_DEFAULT = 1.0   # NeRF.raw2output default, never overridden by the ref
 
 
 class Camera:
-    __slots__ = ("H", "W", "fx", "fy", "cx", "cy")
+    """Pinhole intrinsics (+ the optional TUM_VIE undistortion table [H, W, 2] float32 on the device)."""
+    __slots__ = ("H", "W", "fx", "fy", "cx", "cy", "remap")
 
-    def __init__(self, H, W, fx, fy, cx, cy):
+    def __init__(self, H, W, fx, fy, cx, cy, remap=None):
         self.H, self.W = int(H), int(W)
         self.fx, self.fy, self.cx, self.cy = float(fx), float(fy), float(cx), float(cy)
+        self.remap = remap
 
     @staticmethod
-    def from_K(H, W, Kmat):
-        return Camera(H, W, float(Kmat[0][0]), float(Kmat[1][1]), float(Kmat[0][2]), float(Kmat[1][2]))
+    def from_K(H, W, Kmat, remap=None):
+        return Camera(H, W, float(Kmat[0][0]), float(Kmat[1][1]), float(Kmat[0][2]), float(Kmat[1][2]), remap)
 
 
 class Draws:
@@ -82,7 +84,7 @@ class SplinePoses(torch.autograd.Function):
 
 def _render_forward(cam, ndc, n_samples, n_importance, draws, poses, ray_idx, net_c, net_f, save):
     """Shared forward kernel sequence of Graph.render.  Returns (outputs dict, saved dict)."""
-    ro, rd, vd = K.rays_fwd(poses, ray_idx, cam.H, cam.W, cam.fx, cam.fy, cam.cx, cam.cy, ndc)
+    ro, rd, vd = K.rays_fwd(poses, ray_idx, cam.H, cam.W, cam.fx, cam.fy, cam.cx, cam.cy, ndc, remap=cam.remap)
     n_rays = ro.shape[0]
     t_rand, seed, off = draws.jitter_args()
     z = K.stratified_z(n_rays, n_samples, ro.device, t_rand, seed, off)
@@ -145,7 +147,7 @@ def _render_backward(cam, ndc, draws, poses, ray_idx, net_c, net_f, saved, g, gr
     d_pts, d_vp = K.mlp_bwd(net_c, d_raw0.reshape(-1, d_raw0.shape[-1]), saved["acts0"], n_rays, z.shape[1],
                             grads_c[0], grads_c[1], accumulate)
     K.ray_grad_reduce(z, d_pts, d_vp, d_o, d_d, d_v, True)
-    return K.rays_bwd(poses, ray_idx, cam.H, cam.W, cam.fx, cam.fy, cam.cx, cam.cy, ndc, d_o, d_d, d_v)
+    return K.rays_bwd(poses, ray_idx, cam.H, cam.W, cam.fx, cam.fy, cam.cx, cam.cy, ndc, d_o, d_d, d_v, remap=cam.remap)
 
 
 class RenderRays(torch.autograd.Function):
@@ -249,8 +251,10 @@ class TrainStep:
                                       "not part of the fused step; use the autograd path (graph.render + torch.optim)")
         if cfg.N_importance <= 0 or not hasattr(graph, "nerf_fine"):
             raise NotImplementedError("TrainStep needs the fine network (N_importance > 0), as in every shipped config")
-        if getattr(cfg, "use_barf_c2f", False) or cfg.dataset == "TUM_VIE":
-            raise NotImplementedError("TrainStep: use_barf_c2f / TUM_VIE are not implemented (SURVEY 8f4)")
+        if getattr(cfg, "use_barf_c2f", False):
+            raise NotImplementedError("TrainStep: use_barf_c2f is not implemented (SURVEY 8f4)")
+        if cfg.dataset == "TUM_VIE" and (cam_rgb.remap is None or cam_evt.remap is None):
+            raise ValueError("TrainStep: TUM_VIE needs the undistortion tables (Camera(..., remap=...), model/nerf.py:247-250)")
         if not (getattr(cfg, "event_loss", True) or getattr(cfg, "rgb_loss", True)):
             raise ValueError("TrainStep: event_loss and rgb_loss are both off - nothing to optimise")
         self.g, self.cfg, self.cam_rgb, self.cam_evt = graph, cfg, cam_rgb, cam_evt
@@ -361,8 +365,8 @@ class TrainStep:
         rd = torch.empty_like(ro)
         vd = torch.empty_like(ro)
         ce, cr = self.cam_evt, self.cam_rgb
-        K.rays_fwd(poses_e, idx_e, ce.H, ce.W, ce.fx, ce.fy, ce.cx, ce.cy, cfg.ndc, out=(ro[:Ne], rd[:Ne], vd[:Ne]))
-        K.rays_fwd(poses_r, idx_r, cr.H, cr.W, cr.fx, cr.fy, cr.cx, cr.cy, cfg.ndc, out=(ro[Ne:], rd[Ne:], vd[Ne:]))
+        K.rays_fwd(poses_e, idx_e, ce.H, ce.W, ce.fx, ce.fy, ce.cx, ce.cy, cfg.ndc, out=(ro[:Ne], rd[:Ne], vd[:Ne]), remap=ce.remap)
+        K.rays_fwd(poses_r, idx_r, cr.H, cr.W, cr.fx, cr.fy, cr.cx, cr.cy, cfg.ndc, out=(ro[Ne:], rd[Ne:], vd[Ne:]), remap=cr.remap)
         if draws_evt is not None:   # parity mode: explicit draws for both renders, concatenated
             d = Draws(torch.cat([draws_evt.t_rand, draws_rgb.t_rand]), torch.cat([draws_evt.noise0, draws_rgb.noise0]),
                       torch.cat([draws_evt.u, draws_rgb.u]), torch.cat([draws_evt.noise1, draws_rgb.noise1]))
@@ -415,8 +419,8 @@ class TrainStep:
                                 self.net_c.gviews_b, False)
         pending.append(dist.allreduce_sum_async_(self.flat_g[:n], self.world, self.pg))      # bucket 2: coarse network
         K.ray_grad_reduce(z, d_pts, d_vp, d_o, d_d, d_v, True)
-        dp_e = K.rays_bwd(poses_e, idx_e, ce.H, ce.W, ce.fx, ce.fy, ce.cx, ce.cy, cfg.ndc, d_o[:Ne], d_d[:Ne], d_v[:Ne])
-        dp_r = K.rays_bwd(poses_r, idx_r, cr.H, cr.W, cr.fx, cr.fy, cr.cx, cr.cy, cfg.ndc, d_o[Ne:], d_d[Ne:], d_v[Ne:])
+        dp_e = K.rays_bwd(poses_e, idx_e, ce.H, ce.W, ce.fx, ce.fy, ce.cx, ce.cy, cfg.ndc, d_o[:Ne], d_d[:Ne], d_v[:Ne], remap=ce.remap)
+        dp_r = K.rays_bwd(poses_r, idx_r, cr.H, cr.W, cr.fx, cr.fy, cr.cx, cr.cy, cfg.ndc, d_o[Ne:], d_d[Ne:], d_v[Ne:], remap=cr.remap)
         dk_e, dk_r, dt_r = K.spline_poses_bwd_pair(self.knots, self.transform.view(6), evt_ts2, 2, rgb_ts2, P, traj, dp_e, dp_r)
         torch.add(dk_e, dk_r, out=self.g_knots)
         self.g_transform.copy_(dt_r)

@@ -104,24 +104,25 @@ def spline_op_bwd(name, x, d_out):
 
 
 # ----------------------------------------------------------------------------- K2 rays
-def rays_fwd(poses, ray_idx, H, W, fx, fy, cx, cy, ndc=True, out=None):
+def rays_fwd(poses, ray_idx, H, W, fx, fy, cx, cy, ndc=True, out=None, remap=None):
+    """remap: None or the TUM_VIE undistortion table [H, W, 2] float32 (include/benerf_hip.h)."""
     lib = _lib.load()
     n = poses.shape[0] * ray_idx.shape[0]
     if out is None:
         out = (_new((n, 3), poses), _new((n, 3), poses), _new((n, 3), poses))
     ro, rd, vd = out
     _lib.check(lib.benerf_rays_fwd(_chk(poses, name="poses"), _chk(ray_idx, torch.int64, "ray_idx"), poses.shape[0],
-                                   ray_idx.shape[0], H, W, fx, fy, cx, cy, int(bool(ndc)), _chk(ro), _chk(rd), _chk(vd),
-                                   _stream()), "rays_fwd")
+                                   ray_idx.shape[0], H, W, fx, fy, cx, cy, int(bool(ndc)), _chk(remap, name="remap"), _chk(ro),
+                                   _chk(rd), _chk(vd), _stream()), "rays_fwd")
     return ro, rd, vd
 
 
-def rays_bwd(poses, ray_idx, H, W, fx, fy, cx, cy, ndc, d_rays_o, d_rays_d, d_viewdirs):
+def rays_bwd(poses, ray_idx, H, W, fx, fy, cx, cy, ndc, d_rays_o, d_rays_d, d_viewdirs, remap=None):
     lib = _lib.load()
     d_poses = _new((poses.shape[0], 3, 4), poses)
     _lib.check(lib.benerf_rays_bwd(_chk(poses), _chk(ray_idx, torch.int64), poses.shape[0], ray_idx.shape[0], H, W, fx,
-                                   fy, cx, cy, int(bool(ndc)), _chk(d_rays_o), _chk(d_rays_d), _chk(d_viewdirs),
-                                   d_poses.data_ptr(), _stream()), "rays_bwd")
+                                   fy, cx, cy, int(bool(ndc)), _chk(remap, name="remap"), _chk(d_rays_o), _chk(d_rays_d),
+                                   _chk(d_viewdirs), d_poses.data_ptr(), _stream()), "rays_bwd")
     return d_poses
 
 

@@ -160,7 +160,7 @@ class Graph(nn.Module):
     def _device(self):
         return self.nerf.alpha_linear.weight.device
 
-    def _events_on_device(self, events):
+    def _events_on_device(self, events, tum_vie=False):
         """Upload the event stream once (sorted by ts as recorded) instead of masking it on the
         host every iteration (model/nerf.py:170-178)."""
         key = (id(events["ts"]), len(events["ts"]))
@@ -169,9 +169,12 @@ class Graph(nn.Module):
             ts = np.asarray(events["ts"], dtype=np.float64)
             if ts.size > 1 and not bool(np.all(ts[1:] >= ts[:-1])):
                 raise ValueError("events['ts'] must be ascending")
+            pol = np.asarray(events["pol"]).astype(np.float32)
+            if tum_vie:
+                pol = np.where(pol == 0, np.float32(-1), pol)      # 0: negative polarity in TUM-VIE (model/nerf.py:194-196)
             cache = {"x": torch.as_tensor(np.asarray(events["x"]).astype(np.int32), device=dev),
                      "y": torch.as_tensor(np.asarray(events["y"]).astype(np.int32), device=dev),
-                     "p": torch.as_tensor(np.asarray(events["pol"]).astype(np.float32), device=dev),
+                     "p": torch.as_tensor(pol, device=dev),
                      "ts": torch.as_tensor(ts, device=dev)}
             self._event_cache = (key, cache)
         return self._event_cache[1]
@@ -180,10 +183,8 @@ class Graph(nn.Module):
         """One training iteration's rendering (model/nerf.py:160-234): event-window accumulation,
         two trajectory queries, two renders.  Same return tuple as the reference."""
         dev = self._device()
-        ev = self._events_on_device(events)
+        ev = self._events_on_device(events, args.dataset == "TUM_VIE")
         He, We = args.event_height, args.event_width
-        if args.dataset == "TUM_VIE":
-            raise NotImplementedError("TUM_VIE (polarity remap + fisheye LUT) is out of scope (SURVEY 8f4)")
         if args.event_time_window:
             window_t = args.accumulate_time_length
             if args.random_sampling_window:
@@ -226,15 +227,16 @@ class Graph(nn.Module):
         """rays (pose-major) -> stratified coarse pass -> importance sampling -> fine pass
         (model/nerf.py:236-343).  `training` only selects how the reference builds its rays; both
         branches give the same rays, generated on the fly here."""
-        if args.dataset == "TUM_VIE":
-            raise NotImplementedError("TUM_VIE remap LUT is out of scope (SURVEY 8f4)")
         if not args.use_viewdirs:
             raise NotImplementedError("use_viewdirs=False is not supported")
         if near != 0. or far != 1.:
             raise NotImplementedError("render() supports the reference's near=0, far=1 only")
         dev = self._device()
         poses = poses[:, :3, :4]
-        cam = Camera.from_K(H, W, K)
+        lut = None
+        if args.dataset == "TUM_VIE":      # rect = remap[j, i] (model/nerf.py:247-250; run_nerf_helpers.py:17-23 for inference)
+            lut = torch.as_tensor(remap, dtype=torch.float32, device=dev).reshape(H, W, 2).contiguous()
+        cam = Camera.from_K(H, W, K, lut)
         ray_idx = ray_idx.reshape(-1).to(device=dev, dtype=torch.int64).contiguous()
         N = poses.shape[0] * ray_idx.shape[0]
         S, Ni = args.N_samples, args.N_importance

@@ -22,10 +22,13 @@ def _f(x):
 
 def get_rays(H, W, K_, c2w, args, remap):
     """Full H x W ray grid for one pose (run_nerf_helpers.py:13-32): rays_o, rays_d [H,W,3]."""
-    if getattr(args, "dataset", None) == "TUM_VIE":
-        raise NotImplementedError("TUM_VIE remap LUT is out of scope (SURVEY 8f4)")
     dev = c2w.device if c2w.is_cuda else _dev()
     idx = torch.arange(H * W, device=dev)
+    if getattr(args, "dataset", None) == "TUM_VIE":      # rect = remap[j, i] (run_nerf_helpers.py:17-23)
+        lut = torch.as_tensor(remap, dtype=torch.float32, device=dev).reshape(H, W, 2).contiguous()
+        pose1 = c2w[:3, :4].detach().float().to(dev).reshape(1, 3, 4).contiguous()
+        ro, rd, _ = K.rays_fwd(pose1, idx, H, W, _f(K_[0][0]), _f(K_[1][1]), _f(K_[0][2]), _f(K_[1][2]), ndc=False, remap=lut)
+        return ro.view(H, W, 3), rd.view(H, W, 3)
     i, j = (idx % W).contiguous(), (idx // W).contiguous()
     pose = c2w[:3, :4].detach().float().to(dev).contiguous()
     ro, rd = K.pixel_rays(pose, i, j, _f(K_[0][0]), _f(K_[1][1]), _f(K_[0][2]), _f(K_[1][2]))

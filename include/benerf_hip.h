@@ -82,13 +82,15 @@ int benerf_spline_op_bwd(int op, const float* in, int64_t n, const float* d_out,
  * Replaces run_nerf_helpers.get_specific_rays / get_rays (run_nerf_helpers.py:13-44),
  * ndc_rays (run_nerf_helpers.py:46-71) and Graph.render's ray plumbing
  * (model/nerf.py:241-286).  ray_idx [n_pix] int64 pixel indices (row-major, idx = j*W+i).
+ * remap: NULL, or the TUM_VIE undistortion look-up table [H,W,2] of (x, y) float coordinates
+ * gathered per pixel (model/nerf.py:247-250, run_nerf_helpers.py:17-23).
  * Outputs rays_o, rays_d (NDC'd when ndc != 0), viewdirs: [N,3] each. */
 int benerf_rays_fwd(const float* poses, const int64_t* ray_idx, int n_poses, int n_pix,
-                    int H, int W, float fx, float fy, float cx, float cy, int ndc,
+                    int H, int W, float fx, float fy, float cx, float cy, int ndc, const float* remap,
                     float* rays_o, float* rays_d, float* viewdirs, benerf_stream_t stream);
 /* (d_rays_o, d_rays_d, d_viewdirs) [N,3] -> d_poses [n_poses,3,4] (overwritten). */
 int benerf_rays_bwd(const float* poses, const int64_t* ray_idx, int n_poses, int n_pix,
-                    int H, int W, float fx, float fy, float cx, float cy, int ndc,
+                    int H, int W, float fx, float fy, float cx, float cy, int ndc, const float* remap,
                     const float* d_rays_o, const float* d_rays_d, const float* d_viewdirs,
                     float* d_poses, benerf_stream_t stream);
 /* Stratified coarse depths: z = lower + (upper-lower)*t_rand (model/nerf.py:297-307).

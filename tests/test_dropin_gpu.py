@@ -264,3 +264,33 @@ def test_graph_forward_window_modes(installed, monkeypatch, time_window, random_
     assert accu.dtype == torch.float64 and np.array_equal(accu.cpu().numpy(), ref.numpy())
     report("window timestamps", seen["ts"], ts_ref.astype(np.float32), atol=0)
     assert idx_e.shape == (args.sampling_event_rays,) and idx_r.shape == (args.sampling_rgb_rays // args.num_interpolated_pose,)
+
+
+def test_graph_forward_tum_vie(installed, monkeypatch):
+    """dataset = TUM_VIE (model/nerf.py:194-196, 247-250): polarity 0 means -1 in the accumulated event image, and both
+    renders take their pixel coordinates from the undistortion tables; with identity tables the renders equal the
+    plain dataset's on the same draws."""
+    from model import optimize
+    cam = None
+    rets = {}
+    for dataset in ("BeNeRF_Unreal", "TUM_VIE"):
+        args, cam = _small_args(dataset=dataset)
+        H, W = cam["H"], cam["W"]
+        K = np.array([[cam["fx"], 0, cam["cx"]], [0, cam["fy"], cam["cy"]], [0, 0, 1]], dtype=np.float32)
+        events = GI.synthetic_events(np.random.default_rng(12), cam, 30000)
+        if dataset == "TUM_VIE":
+            events = dict(events, pol=np.where(events["pol"] < 0, 0.0, 1.0).astype(np.float32))     # TUM-VIE stores 0 / 1
+        jj, ii = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+        ident = np.stack([ii, jj], -1).astype(np.float32)
+        torch.manual_seed(1)
+        model = optimize.Model(args)
+        model.graph.to(DEV)
+        g = model.build_network(args)
+        np.random.seed(9)
+        torch.manual_seed(2)
+        remaps = (ident, ident) if dataset == "TUM_VIE" else (np.array([]), np.array([]))
+        ret_e, ret_r, idx_e, idx_r, accu = g.forward(0, events, np.array([0.0, 1.0]), H, W, K, K, args, *remaps)
+        rets[dataset] = (ret_e["rgb_map"].detach().cpu(), ret_r["rgb_map"].detach().cpu(), accu.cpu())
+    a, b = rets["BeNeRF_Unreal"], rets["TUM_VIE"]
+    assert torch.equal(a[2], b[2]), "polarity 0 must accumulate as -1"
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), "identity undistortion tables must not change the renders"

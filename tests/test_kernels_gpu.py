@@ -151,6 +151,41 @@ def test_rays_fwd_golden(K, golden):
         report("K2 rays_d " + cname, rd, g[cname + "_rays_d"], atol=1e-6)
 
 
+def test_rays_tum_vie_remap(K):
+    """TUM_VIE: pixel coordinates come from the undistortion table, rect = remap[j, i] (model/nerf.py:247-250); forward
+    and pose gradients against the reference's lines restated in torch."""
+    rng = np.random.default_rng(23)
+    cam = GI.CAMERAS["e2nerf_real"]
+    H, W = cam["H"], cam["W"]
+    Kmat = GI.cam_K(cam)
+    jj, ii = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    remap = np.stack([ii + 3.0 * np.sin(jj / 40.0) + rng.uniform(-0.3, 0.3, (H, W)),
+                      jj + 2.0 * np.cos(ii / 55.0) + rng.uniform(-0.3, 0.3, (H, W))], -1).astype(np.float32)
+    poses = O.trajectory_poses(GI.knots_stress(rng) * 0.2, None, (0.0, 1.0), 4, "spline").detach()
+    idx = GI.pixel_indices(rng, cam, 200)
+    for ndc in (True, False):
+        p = poses.clone().requires_grad_(True)
+        idx_ = idx.repeat(4)
+        pp = p.unsqueeze(1).repeat(1, 200, 1, 1).reshape(-1, 3, 4)
+        rect = torch.from_numpy(remap)[idx_ // W, idx_ % W]
+        i, j = rect[..., 0], rect[..., 1]
+        dirs = torch.stack([(i - Kmat[0][2]) / Kmat[0][0], -(j - Kmat[1][2]) / Kmat[1][1], -torch.ones_like(i)], -1)   # run_nerf_helpers.py:35-44
+        rd = torch.sum(dirs[..., None, :] * pp[..., :3, :3], -1)
+        ro = pp[..., :3, -1]
+        vd = rd / torch.norm(rd, dim=-1, keepdim=True)
+        if ndc:
+            ro, rd = O.ndc_project(H, W, Kmat[0][0], 1.0, ro, rd)
+        go, gd, gv = (GI.f32(rng.standard_normal((800, 3))) for _ in range(3))
+        ((ro * go).sum() + (rd * gd).sum() + (vd * gv).sum()).backward()
+        lut = dev(torch.from_numpy(remap))
+        o, d, v = K.rays_fwd(dev(poses), dev(idx), H, W, cam["fx"], cam["fy"], cam["cx"], cam["cy"], ndc, remap=lut)
+        report("K2 TUM_VIE rays_o ndc=%d" % ndc, o, ro, atol=2e-6, rtol=2e-6)
+        report("K2 TUM_VIE rays_d ndc=%d" % ndc, d, rd, atol=2e-6, rtol=2e-6)
+        report("K2 TUM_VIE viewdirs ndc=%d" % ndc, v, vd, atol=1e-6)
+        got = K.rays_bwd(dev(poses), dev(idx), H, W, cam["fx"], cam["fy"], cam["cx"], cam["cy"], ndc, dev(go), dev(gd), dev(gv), remap=lut)
+        report("K2 TUM_VIE d_poses ndc=%d" % ndc, got, p.grad, atol=2e-5 * float(p.grad.abs().max()), rtol=1e-4)
+
+
 def test_rays_bwd_vs_oracle(K):
     rng = np.random.default_rng(21)
     cam = GI.CAMERAS["unreal"]
