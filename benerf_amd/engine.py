@@ -246,9 +246,11 @@ class TrainStep:
 
     def __init__(self, graph, cfg, cam_rgb, cam_evt, device, world_size=1, rank=0, process_group=None, seed=0):
         # switches of train.py:180-352 this fused sequence does not implement are refused, not ignored
-        if getattr(cfg, "optimize_rgb_crf", False) or getattr(cfg, "optimize_event_crf", False):
-            raise NotImplementedError("TrainStep: CRF tone-mappers (optimize_rgb_crf / optimize_event_crf, train.py:180-192) are "
-                                      "not part of the fused step; use the autograd path (graph.render + torch.optim)")
+        self.use_rgb_crf = bool(getattr(cfg, "optimize_rgb_crf", False))
+        self.use_evt_crf = bool(getattr(cfg, "optimize_event_crf", False))
+        if (self.use_rgb_crf or self.use_evt_crf) and cfg.channels != 1:
+            raise NotImplementedError("the reference's tone-mappers are built with input_type='Gray' (model/optimize.py:24-26): one "
+                                      "channel; with channels = 3 its own Linear(1, width) cannot take the colours either")
         if cfg.N_importance <= 0 or not hasattr(graph, "nerf_fine"):
             raise NotImplementedError("TrainStep needs the fine network (N_importance > 0), as in every shipped config")
         if getattr(cfg, "use_barf_c2f", False):
@@ -284,6 +286,20 @@ class TrainStep:
         self.g_knots = self.flat_g[o:o + 24].view(4, 6)
         self.g_transform = self.flat_g[o + 24:o + 30].view(1, 6)
         self.off_pose = o
+        # CRF tone-mappers (train.py:180-192; off in every shipped config): 385 parameters each, applied to the rendered colours
+        # between compositing and the loss kernels as torch modules (per-ray work, thousands of rows), their own Adam
+        self.crf_params, self.crf_opts = [], []
+        for on, mod, lr0, dr in ((self.use_rgb_crf, getattr(graph, "rgb_crf", None), getattr(cfg, "rgb_crf_lrate", 5e-4),
+                                  getattr(cfg, "decay_rate_rgb_crf", 0.1)),
+                                 (self.use_evt_crf, getattr(graph, "event_crf", None), getattr(cfg, "event_crf_lrate", 5e-4),
+                                  getattr(cfg, "decay_rate_event_crf", 0.1))):
+            if on:
+                ps = list(mod.parameters())
+                for p_ in ps:
+                    dist.broadcast_(p_.data, self.world, 0, self.pg)
+                self.crf_params += ps
+                self.crf_opts.append((torch.optim.Adam(ps, lr=lr0), lr0, dr))
+        self._crf_slots = [i for i, on in ((3, self.use_rgb_crf), (4, self.use_evt_crf)) if on]   # index in setup_optimizer's tuple
         self.global_step = 0
         # replicas start from rank 0's parameters (and its - zero - Adam state), whatever their local initialisation was
         for buf in (self.flat_p, self.flat_m, self.flat_v):
@@ -312,7 +328,9 @@ class TrainStep:
 
     def export_optimizer_state(self, optimizers):
         """Fills the Adam objects of Model.setup_optimizer (nerf, pose, transform, ...) with this step's moments, step
-        count and current learning rates, ready for checkpoint.save.  The CRF optimisers hold no state on this path."""
+        count and current learning rates, ready for checkpoint.save (the tone-mapper optimisers too, when they are trained)."""
+        for slot, (opt, _, _) in zip(self._crf_slots, self.crf_opts):
+            optimizers[slot].load_state_dict(opt.state_dict())
         for opt, lr in self._trained_optimizers(optimizers):
             for group in opt.param_groups:
                 group["lr"] = lr
@@ -334,6 +352,8 @@ class TrainStep:
                     off, n = self._flat_slice(p)
                     self.flat_m[off:off + n].copy_(st["exp_avg"].reshape(-1))
                     self.flat_v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+        for slot, (opt, _, _) in zip(self._crf_slots, self.crf_opts):
+            opt.load_state_dict(optimizers[slot].state_dict())
         self.global_step = int(global_step)
         self.net_c.packed.pack()
         self.net_f.packed.pack()
@@ -393,6 +413,17 @@ class TrainStep:
                                Re * self.world, Rr * self.world)
         # args.event_loss / args.rgb_loss (train.py:201,299): a disabled term contributes neither loss nor gradient
         use_e, use_r = getattr(cfg, "event_loss", True), getattr(cfg, "rgb_loss", True)
+        crf = self.use_rgb_crf or self.use_evt_crf
+        if crf:   # train.py:180-192: the losses see the tone-mapped colours; the mappers are differentiated by torch autograd
+            leaves = [rgb_map.requires_grad_(True), rgb0.requires_grad_(True)]
+            mapped = []
+            with torch.enable_grad():
+                for t in leaves:
+                    e_part = self.g.event_crf(t[:Ne]) if self.use_evt_crf else t[:Ne]
+                    r_part = self.g.rgb_crf(t[Ne:]) if self.use_rgb_crf else t[Ne:]
+                    mapped.append(torch.cat([e_part, r_part], 0))
+            raw_maps = (rgb_map, rgb0)
+            rgb_map, rgb0 = mapped[0].detach(), mapped[1].detach()
         largs = ((rgb_map[:Ne], rgb0[:Ne], target_acc) if use_e else (None, None, None)) + \
                 ((rgb_map[Ne:], rgb0[Ne:], target_rgb) if use_r else (None, None, None))
         stats = K.loss_stats(lcfg, *largs)
@@ -401,6 +432,13 @@ class TrainStep:
         g_rgb0 = torch.empty_like(rgb0) if (use_e and use_r) else torch.zeros_like(rgb0)
         losses, _ = K.loss_grads(lcfg, stats, *largs, out=((g_rgb[:Ne], g_rgb0[:Ne]) if use_e else (None, None)) +
                                  ((g_rgb[Ne:], g_rgb0[Ne:]) if use_r else (None, None)))
+
+        if crf:   # gradients w.r.t. the tone-mapped colours -> the rendered colours and the tone-mapper parameters
+            for p_ in self.crf_params:
+                p_.grad = None
+            torch.autograd.backward(mapped, [g_rgb, g_rgb0])
+            g_rgb, g_rgb0 = leaves[0].grad.contiguous(), leaves[1].grad.contiguous()
+            rgb_map, rgb0 = raw_maps[0].detach(), raw_maps[1].detach()
 
         # ---- backward -------------------------------------------------------------------------------
         d_o = torch.zeros_like(ro)
@@ -443,6 +481,18 @@ class TrainStep:
             K.adam_step(self.flat_p[o + 24:o + 30], self.flat_g[o + 24:o + 30], self.flat_m[o + 24:o + 30],
                         self.flat_v[o + 24:o + 30],
                         self._lr(cfg.transform_lrate, cfg.decay_rate_transform), t)
+        if self.crf_params:
+            if self.world > 1:
+                flat = torch.cat([p_.grad.reshape(-1) for p_ in self.crf_params])
+                dist.allreduce_sum_(flat, self.world, self.pg)
+                o_ = 0
+                for p_ in self.crf_params:
+                    p_.grad.copy_(flat[o_:o_ + p_.numel()].view_as(p_))
+                    o_ += p_.numel()
+            for opt, lr0, dr in self.crf_opts:
+                for grp in opt.param_groups:
+                    grp["lr"] = self._lr(lr0, dr)
+                opt.step()
         self.net_c.packed.pack()
         self.net_f.packed.pack()
         self.global_step += 1

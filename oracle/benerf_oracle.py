@@ -575,10 +575,18 @@ class StepConfig:
         return torch.tensor([[self.fx, 0, self.cx], [0, self.fy, self.cy], [0, 0, 1]], dtype=torch.float32)
 
 
+def tone_map(p, x):
+    """ColorToneMapper / LuminanceToneMapper with hidden = 0 (model/component.py:38-149): sigmoid(Linear(ReLU(Linear(x)))).
+    p: {"0.weight" [width, 1], "0.bias" [width], "2.weight" [1, width], "2.bias" [1]}; x [N, 1]."""
+    h = torch.relu(torch.nn.functional.linear(x, p["0.weight"], p["0.bias"]))
+    return torch.sigmoid(torch.nn.functional.linear(h, p["2.weight"], p["2.bias"]))
+
+
 def step_loss(cfg, p_coarse, p_fine, knots, transform, evt_ts, rgb_ts, idx_evt, idx_rgb,
-              target_acc, target_rgb, draws_evt, draws_rgb, exact_pdf=False):
+              target_acc, target_rgb, draws_evt, draws_rgb, exact_pdf=False, event_crf=None, rgb_crf=None):
     """Forward of one training iteration (model/nerf.py:208-232 + train.py:163-337) on
-    explicit inputs.  Returns (loss, dict of parts)."""
+    explicit inputs.  event_crf / rgb_crf: tone-mapper parameters applied to the rendered colours as train.py:180-192
+    does when optimize_event_crf / optimize_rgb_crf are set.  Returns (loss, dict of parts)."""
     K = cfg.K()
     poses_e = trajectory_poses(knots, None, evt_ts, 2, cfg.traj)
     poses_r = trajectory_poses(knots, transform, rgb_ts, cfg.n_poses, cfg.traj)
@@ -586,6 +594,10 @@ def step_loss(cfg, p_coarse, p_fine, knots, transform, evt_ts, rgb_ts, idx_evt, 
                    cfg.n_samples, cfg.n_importance, draws_evt, exact_pdf=exact_pdf)
     ret_r = render(p_coarse, p_fine, poses_r, idx_rgb, cfg.H, cfg.W, K, cfg.channels,
                    cfg.n_samples, cfg.n_importance, draws_rgb, exact_pdf=exact_pdf)
+    if event_crf is not None:
+        ret_e = dict(ret_e, rgb_map=tone_map(event_crf, ret_e["rgb_map"]), rgb0=tone_map(event_crf, ret_e["rgb0"]))
+    if rgb_crf is not None:
+        ret_r = dict(ret_r, rgb_map=tone_map(rgb_crf, ret_r["rgb_map"]), rgb0=tone_map(rgb_crf, ret_r["rgb0"]))
     le, le_f, le_c = event_loss(ret_e["rgb_map"], ret_e["rgb0"], idx_evt.shape[0], target_acc,
                                 cfg.channels, cfg.dataset, cfg.threshold, cfg.coeff_syn, cfg.coeff_real)
     lr_, lr_f, lr_c = blur_loss(ret_r["rgb_map"], ret_r["rgb0"], target_rgb, cfg.n_poses, cfg.rgb_coeff)

@@ -699,12 +699,42 @@ def g12_spline_ops(R):
     save("g12_spline_ops.npz", **out)
 
 
+# ----------------------------------------------------------------------------------- G13
+def g13_crf(R):
+    """The reference's tone-mappers (model/component.py:38-149, hidden = 0, Gray) on random colours: outputs and the
+    gradients of a random cotangent w.r.t. input and parameters; pins oracle.tone_map."""
+    rng = np.random.default_rng(1313)
+    out = {}
+    for name, cls, key in (("rgb", R.component.ColorToneMapper, "mlp_gray"), ("event", R.component.LuminanceToneMapper, "mlp_luminance")):
+        m = cls(hidden=0, width=128, input_type="Gray")
+        m.weights_biases_init()
+        with torch.no_grad():
+            for prm in m.parameters():
+                prm.add_(GI.f32(rng.uniform(-0.05, 0.05, tuple(prm.shape))))
+        x = GI.f32(rng.uniform(0.01, 0.99, (96, 1))).requires_grad_(True)
+        y = m(x)
+        G = GI.f32(rng.standard_normal((96, 1)))
+        (y * G).sum().backward()
+        p = {k: v.detach().clone().requires_grad_(True) for k, v in getattr(m, key).state_dict().items()}
+        xo = x.detach().clone().requires_grad_(True)
+        yo = O.tone_map(p, xo)
+        (yo * G).sum().backward()
+        check("G13 %s tone-mapper output" % name, y, yo)
+        check("G13 %s tone-mapper d input" % name, x.grad, xo.grad, atol=1e-7, rtol=1e-5)
+        for k, v in getattr(m, key).named_parameters():
+            check("G13 %s tone-mapper d %s" % (name, k), v.grad, p[k].grad, atol=1e-7, rtol=1e-5)
+            out["%s_p_%s" % (name, k)] = v.detach()
+            out["%s_dp_%s" % (name, k)] = v.grad
+        out[name + "_x"], out[name + "_y"], out[name + "_G"], out[name + "_dx"] = x.detach(), y.detach(), G, x.grad
+    save("g13_crf.npz", **out)
+
+
 def main():
     torch.set_num_threads(8)
     R = load_reference()
     only = sys.argv[1:]
     for fn in (g1_spline, g2_rays, g3_posenc, g4_mlp, g5_composite, g6_sample_pdf, g7_render, g8_step, g9_events,
-               g10_adam, g11_curve, g12_spline_ops):
+               g10_adam, g11_curve, g12_spline_ops, g13_crf):
         if only and fn.__name__.split("_")[0] not in only:
             continue
         fn(R)

@@ -345,3 +345,61 @@ def test_f16_range_guard():
     net2.pack()
     K.mlp_fwd(net2, ro, rd, vd, z, True, precision="split")
     K.check_mlp_status(torch.device(DEV))
+
+
+@pytest.mark.parametrize("which", ["rgb", "event", "both"])
+def test_fused_step_with_crf(which):
+    """optimize_rgb_crf / optimize_event_crf (train.py:180-192) in the fused TrainStep: losses, tone-mapper gradients and the
+    gradients that flow back through the mappers into the networks and the trajectory, against the oracle's autograd."""
+    from benerf_amd import engine, kernels as K, workloads as WL
+    wl = dict(WL.WORKLOADS["C1"], S=16, Ni=16, Re=24, Rr=3, n=5)
+    args = WL.make_args(wl, optimize_rgb_crf=which in ("rgb", "both"), optimize_event_crf=which in ("event", "both"), optimize_trans=True)
+    cam = WL.CAMERAS[wl["cam"]]
+    C, S, Ni, P, Re, Rr = 1, 16, 16, 5, 24, 3
+    model, g = _graph(args, seed=5)
+    rng = np.random.default_rng(77)
+    with torch.no_grad():
+        for m in (g.rgb_crf, g.event_crf):
+            for prm in m.parameters():
+                prm.add_(torch.from_numpy(rng.uniform(-0.05, 0.05, tuple(prm.shape)).astype(np.float32)).to(DEV))
+    def crf_params(mod):
+        return {k: v.detach().cpu().clone().requires_grad_(True) for k, v in mod.state_dict().items()}
+    o_rgb = crf_params(g.rgb_crf.mlp_gray) if args.optimize_rgb_crf else None
+    o_evt = crf_params(g.event_crf.mlp_luminance) if args.optimize_event_crf else None
+    pc = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in g.nerf.state_dict().items()}
+    pf = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in g.nerf_fine.state_dict().items()}
+    ko = g.evt_knot_pose_se3.params.weight.detach().cpu().clone().requires_grad_(True)
+    tro = g.transform.params.weight.detach().cpu().clone().requires_grad_(True)
+    cam_o = engine.Camera(cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+    step = engine.TrainStep(g, args, cam_o, cam_o, torch.device(DEV))
+    HW = cam["H"] * cam["W"]
+    idx_e, idx_r = GI.pixel_indices(rng, cam, Re), GI.pixel_indices(rng, cam, Rr)
+    d_e, d_r = GI.render_draws(rng, 2 * Re, S, Ni), GI.render_draws(rng, P * Rr, S, Ni)
+    acc = torch.from_numpy(rng.integers(-3, 4, (HW,)).astype(np.float32))
+    img = torch.from_numpy(rng.random((HW, C)).astype(np.float32))
+    evt_ts, rgb_ts = torch.tensor([0.31, 0.41]), torch.tensor([0.0, 1.0])
+    cfg = O.StepConfig(H=cam["H"], W=cam["W"], fx=cam["fx"], fy=cam["fy"], cx=cam["cx"], cy=cam["cy"], channels=C, n_samples=S,
+                       n_importance=Ni, n_poses=P, dataset=wl["dataset"], threshold=wl["threshold"])
+    loss_o, _ = O.step_loss(cfg, pc, pf, ko, tro, evt_ts, rgb_ts, idx_e, idx_r, acc.double().reshape(-1, 1)[idx_e], img[idx_r], d_e, d_r,
+                            exact_pdf=True, event_crf=o_evt, rgb_crf=o_rgb)
+    loss_o.backward()
+
+    def dd(d):
+        return engine.Draws(*(d[k].to(DEV) for k in ("t_rand", "noise0", "u", "noise1")))
+    before = {id(p_): p_.detach().clone() for p_ in step.crf_params}
+    losses = step.step(evt_ts.to(DEV), rgb_ts.to(DEV), idx_e.to(DEV), idx_r.to(DEV), acc.to(DEV), img.to(DEV), dd(d_e), dd(d_r))
+    report("crf(%s) loss" % which, losses[0:1], loss_o.detach().float().reshape(1), atol=1e-6, rtol=2e-5)
+    for name, mod, op in (("rgb", g.rgb_crf.mlp_gray, o_rgb), ("event", g.event_crf.mlp_luminance, o_evt)):
+        if op is None:
+            continue
+        for k, v in mod.named_parameters():
+            r = op[k].grad
+            report("crf(%s) d %s_crf.%s" % (which, name, k), v.grad, r, atol=2e-5 * float(r.abs().max()) + 1e-9, rtol=1e-3)
+            assert not torch.equal(v.detach(), before[id(v)]), "the tone-mapper must have taken its Adam step"
+    sc = float(ko.grad.abs().max())
+    report("crf(%s) d knots" % which, step.g_knots, ko.grad, atol=2e-3 * sc, rtol=2e-3)
+    rw = pc["pts_linears.7.weight"].grad
+    report("crf(%s) d nerf.pts_linears.7.weight" % which, step.net_c.gviews_w[7], rw, atol=2e-3 * float(rw.abs().max()), rtol=2e-3)
+    with pytest.raises(NotImplementedError):
+        engine.TrainStep(_graph(WL.make_args(dict(wl, channels=3), optimize_rgb_crf=True), seed=1)[1],
+                         WL.make_args(dict(wl, channels=3), optimize_rgb_crf=True), cam_o, cam_o, torch.device(DEV))

@@ -152,3 +152,17 @@ def test_bezier_restatement_properties():
     report("bezier translation at u = 1/2", poses[2, :, 3], b @ tk, atol=1e-6)
     same = O.bezier_poses(knots[:1].expand(4, 6), ts)
     report("bezier of identical control poses is constant", same, ends[0].expand(4, 3, 4), atol=1e-6)
+
+
+def test_g13_tone_mappers(golden):
+    """oracle.tone_map against the reference's ColorToneMapper / LuminanceToneMapper (model/component.py:38-149)."""
+    g = golden("g13_crf")
+    for name in ("rgb", "event"):
+        p = {k: T(g["%s_p_%s" % (name, k)]).requires_grad_(True) for k in ("0.weight", "0.bias", "2.weight", "2.bias")}
+        x = T(g[name + "_x"]).requires_grad_(True)
+        y = O.tone_map(p, x)
+        (y * T(g[name + "_G"])).sum().backward()
+        report("G13 %s tone-mapper" % name, y, g[name + "_y"], atol=1e-7)
+        report("G13 %s tone-mapper d input" % name, x.grad, g[name + "_dx"], atol=1e-7, rtol=1e-5)
+        for k in p:
+            report("G13 %s tone-mapper d %s" % (name, k), p[k].grad, g["%s_dp_%s" % (name, k)], atol=1e-7, rtol=1e-5)
