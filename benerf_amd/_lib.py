@@ -17,7 +17,7 @@ LOSS_NSTATS = 16
 
 
 class MlpParams(Structure):
-    _fields_ = [("w", c_void_p * NLAYERS), ("b", c_void_p * NLAYERS)]
+    _fields_ = [("w", c_void_p * NLAYERS), ("b", c_void_p * NLAYERS), ("pe_weights", c_void_p)]
 
 
 class MlpGrads(Structure):
@@ -52,7 +52,7 @@ _SIGNATURES = {
     "benerf_mlp_fwd": (c_int, [POINTER(MlpParams), P, c_int, c_int, c_int, P, P, P, P, P, P, c_int, P, P]),
     "benerf_mlp_status_check": (c_int, [P, P]),
     "benerf_mlp_bwd_dx": (c_int, [POINTER(MlpParams), P, c_int, c_int, c_int, P, P, P, P, P, c_int, P, P]),
-    "benerf_mlp_bwd_dw": (c_int, [c_int, c_int, c_int, P, P, P, P, c_size_t, POINTER(MlpGrads), c_int, c_int, P]),
+    "benerf_mlp_bwd_dw": (c_int, [c_int, c_int, c_int, P, P, P, P, c_size_t, POINTER(MlpGrads), c_int, c_int, P, P]),
     "benerf_composite_fwd": (c_int, [P, P, P, P, c_float, c_uint64, c_uint64, c_int, c_int, c_int, P, P, P, P, P, P, P]),
     "benerf_composite_bwd": (c_int, [P, P, P, P, c_float, c_uint64, c_uint64, c_int, c_int, c_int, P, P, P, P, P, P,
                                      c_int, P]),

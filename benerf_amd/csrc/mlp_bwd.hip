@@ -28,6 +28,7 @@ struct BwdArgs {
     const float* packed;
     const float* w_alpha;   // [256]
     const float* w_rgb;     // [C][128]
+    const float* pe_w;      // BARF c2f column weights (include/benerf_hip.h) or null
     float* d_pts;           // [M][3]
     float* d_vdir;          // [M][3]
     int64_t M;
@@ -238,10 +239,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_kernel(BwdArgs a) {
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             float s = trow[(COL_PE + d) ^ psw];
+            if (a.pe_w) s *= a.pe_w[64 + d];
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
-                const float sn = ped[3 + f * 6 + d], cs = ped[3 + f * 6 + 3 + d];
-                s += (float)(1 << f) * (cs * trow[(COL_PE + 3 + f * 6 + d) ^ psw] - sn * trow[(COL_PE + 3 + f * 6 + 3 + d) ^ psw]);
+                const int es = 3 + f * 6 + d, ec = es + 3;
+                const float sn = ped[es], cs = ped[ec];
+                const float ws = a.pe_w ? a.pe_w[64 + es] : 1.f, wc = a.pe_w ? a.pe_w[64 + ec] : 1.f;
+                s += (float)(1 << f) * (cs * (ws * trow[(COL_PE + es) ^ psw]) - sn * (wc * trow[(COL_PE + ec) ^ psw]));
             }
             a.d_vdir[m * 3 + d] = s;
         }
@@ -308,16 +312,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_kernel(BwdArgs a) {
         const int64_t mc = m < M ? m : M - 1;
         const float* pe = acts + act_pe(M) + mc * ACT_PE_W;
         if (grp == 0) {
-            s[0] = trow[(COL_PE + 0) ^ psw];
-            s[1] = trow[(COL_PE + 1) ^ psw];
-            s[2] = trow[(COL_PE + 2) ^ psw];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) s[d] = (a.pe_w ? a.pe_w[d] : 1.f) * trow[(COL_PE + d) ^ psw];
         }
         for (int f = grp; f < 10; f += 4) {
             const float sc = (float)(1 << f);
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
-                const float sn = pe[3 + f * 6 + d], cs = pe[3 + f * 6 + 3 + d];
-                s[d] += sc * (cs * trow[(COL_PE + 3 + f * 6 + d) ^ psw] - sn * trow[(COL_PE + 3 + f * 6 + 3 + d) ^ psw]);
+                const int es = 3 + f * 6 + d, ec = es + 3;
+                const float sn = pe[es], cs = pe[ec];
+                const float ws = a.pe_w ? a.pe_w[es] : 1.f, wc = a.pe_w ? a.pe_w[ec] : 1.f;
+                s[d] += sc * (cs * (ws * trow[(COL_PE + es) ^ psw]) - sn * (wc * trow[(COL_PE + ec) ^ psw]));
             }
         }
 #pragma unroll
@@ -335,7 +340,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_kernel(BwdArgs a) {
 
 // part 2 (mlp_dw.hip)
 int benerf_mlp_dw_launch(int precision, int channels, int64_t M, const float* d_raw, const float* acts, const float* dacts,
-                         float* dw_ws, const BenerfMlpGrads* grads, int accumulate, hipStream_t stream);
+                         float* dw_ws, const BenerfMlpGrads* grads, int accumulate, const float* pe_weights, hipStream_t stream);
 
 // f16 variant (mlp_bwd_h.hip)
 int benerf_mlp_dx_split_launch(const BenerfMlpParams* params, const float* packed, int channels, int64_t M, const float* d_raw,
@@ -350,6 +355,7 @@ static int launch_dx(const BenerfMlpParams* params, const float* packed, int cha
     a.packed = packed;
     a.w_alpha = params->w[BENERF_L_ALPHA];
     a.w_rgb = params->w[BENERF_L_RGB];
+    a.pe_w = params->pe_weights;
     a.d_pts = d_pts;
     a.d_vdir = d_vdir_pts;
     a.M = M;
@@ -384,7 +390,7 @@ extern "C" int benerf_mlp_bwd_dx(const BenerfMlpParams* params, const float* pac
 
 extern "C" int benerf_mlp_bwd_dw(int channels, int n_rays, int n_samples, const float* d_raw, const float* acts,
                                  const float* dacts, float* dw_ws, size_t dw_ws_floats, const BenerfMlpGrads* grads,
-                                 int accumulate, int precision, benerf_stream_t stream) {
+                                 int accumulate, int precision, const float* pe_weights, benerf_stream_t stream) {
     BENERF_REQUIRE(d_raw && acts && dacts && dw_ws && grads, "mlp_bwd_dw: null pointer");
     BENERF_REQUIRE(channels == 1 || channels == 3, "mlp_bwd_dw: channels must be 1 or 3");
     BENERF_REQUIRE(n_rays > 0 && n_samples > 0, "mlp_bwd_dw: bad sizes");
@@ -395,5 +401,5 @@ extern "C" int benerf_mlp_bwd_dw(int channels, int n_rays, int n_samples, const 
     }
     for (int l = 0; l < BENERF_NLAYERS; ++l) BENERF_REQUIRE(grads->w[l] && grads->b[l], "mlp_bwd_dw: null grad %d", l);
     return benerf_mlp_dw_launch(precision, channels, (int64_t)n_rays * n_samples, d_raw, acts, dacts, dw_ws, grads, accumulate,
-                                as_stream(stream));
+                                pe_weights, as_stream(stream));
 }

@@ -35,6 +35,7 @@ struct BwdArgs {
     const float* packed;    // split-f16 section at + PACKED_FLOATS (backward blocks: hi + unscaled lo)
     const float* w_alpha;   // [256]
     const float* w_rgb;     // [C][128]
+    const float* pe_w;      // BARF c2f column weights (include/benerf_hip.h) or null
     float* d_pts;           // [M][3]
     float* d_vdir;          // [M][3]
     uint32_t* status;       // [1]: max |stored gradient| bits once >= 2^15, [2]: acts buffer written by another mode (may be null)
@@ -299,10 +300,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_f16_kernel(BwdArgs a) {
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             float sv = *fscr1(T, tid, d);
+            if (a.pe_w) sv *= a.pe_w[64 + d];
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
-                const float sn = ped[3 + f * 6 + d], cs = ped[3 + f * 6 + 3 + d];
-                sv += (float)(1 << f) * (cs * *fscr1(T, tid, 3 + f * 6 + d) - sn * *fscr1(T, tid, 3 + f * 6 + 3 + d));
+                const int es = 3 + f * 6 + d, ec = es + 3;
+                const float sn = ped[es], cs = ped[ec];
+                const float ws = a.pe_w ? a.pe_w[64 + es] : 1.f, wc = a.pe_w ? a.pe_w[64 + ec] : 1.f;
+                sv += (float)(1 << f) * (cs * (ws * *fscr1(T, tid, es)) - sn * (wc * *fscr1(T, tid, ec)));
             }
             a.d_vdir[m * 3 + d] = sv * inv_s;
         }
@@ -379,16 +383,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_f16_kernel(BwdArgs a) {
         const float* dp = F + pt * FLD;
         float sp[3] = {0.f, 0.f, 0.f};
         if (g == 0) {
-            sp[0] = dp[0];
-            sp[1] = dp[1];
-            sp[2] = dp[2];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) sp[d] = a.pe_w ? a.pe_w[d] * dp[d] : dp[d];
         }
         for (int f = g; f < 10; f += 2) {
             const float sc = (float)(1 << f);
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
-                const float sn = pe[3 + f * 6 + d], cs = pe[3 + f * 6 + 3 + d];
-                sp[d] += sc * (cs * dp[3 + f * 6 + d] - sn * dp[3 + f * 6 + 3 + d]);
+                const int es = 3 + f * 6 + d, ec = es + 3;
+                const float sn = pe[es], cs = pe[ec];
+                const float ws = a.pe_w ? a.pe_w[es] : 1.f, wc = a.pe_w ? a.pe_w[ec] : 1.f;
+                sp[d] += sc * (cs * (ws * dp[es]) - sn * (wc * dp[ec]));
             }
         }
         float* part = F + pt * FLD + 64;                          // floats [64,68) of the row: past the dPE block
@@ -425,6 +430,7 @@ int benerf_mlp_dx_split_launch(const BenerfMlpParams* params, const float* packe
     a.packed = packed;
     a.w_alpha = params->w[BENERF_L_ALPHA];
     a.w_rgb = params->w[BENERF_L_RGB];
+    a.pe_w = params->pe_weights;
     a.d_pts = d_pts;
     a.d_vdir = d_vdir_pts;
     a.status = status;

@@ -269,6 +269,8 @@ struct ReduceArgs {
     int accumulate;
     int split_mode;          // partials written by mlp_dw_h.hip: other split table; dY-derived sums carry the factor s_s
     const float* grad_info;  // split mode: info words of the dY arrays ([SD_DRAW] = max |d_raw|, s_s derives from it)
+    const float* pe_w;       // BARF c2f: the saved encodings are unweighted, so the PE columns of layers 0 / 5 / views are
+                             // scaled here (dW[:, col] = w[col] * sum dY * PE[col]); null = no weighting
 };
 
 template <bool SPLIT>
@@ -326,6 +328,10 @@ __global__ void dw_reduce_kernel(ReduceArgs a) {
             else if (l == BENERF_L_ALPHA) v = sum_raw(a.ws, DW_FEAT, (int64_t)256 * 256 + 256 + j);
             else if (l == BENERF_L_RGB) v = sum_splits(a.ws, DW_RGB, (int64_t)n * 128 + j);
             else v = sum_splits(a.ws, layer_inst(l), (int64_t)n * 256 + j);
+            if (a.pe_w) {
+                if ((l == 0 || l == 5) && j < 63) v *= a.pe_w[j];
+                else if (l == BENERF_L_VIEWS && j >= 256) v *= a.pe_w[64 + (j - 256)];
+            }
         } else {
             const int n = (int)(e - nw);
             dst = a.gb[l] + n;
@@ -346,7 +352,7 @@ __global__ void dw_reduce_kernel(ReduceArgs a) {
 }  // namespace
 
 int benerf_mlp_dw_reduce_launch(const float* ws, const BenerfMlpGrads* grads, int channels, int accumulate, int split_mode,
-                                const float* grad_info, hipStream_t stream) {
+                                const float* grad_info, const float* pe_weights, hipStream_t stream) {
     ReduceArgs r;
     r.ws = ws;
     for (int l = 0; l < BENERF_NLAYERS; ++l) {
@@ -357,6 +363,7 @@ int benerf_mlp_dw_reduce_launch(const float* ws, const BenerfMlpGrads* grads, in
     r.accumulate = accumulate;
     r.split_mode = split_mode;
     r.grad_info = grad_info;
+    r.pe_w = pe_weights;
     if (split_mode) hipLaunchKernelGGL(dw_reduce_kernel<true>, dim3(64, BENERF_NLAYERS), dim3(256), 0, stream, r);
     else hipLaunchKernelGGL(dw_reduce_kernel<false>, dim3(64, BENERF_NLAYERS), dim3(256), 0, stream, r);
     BENERF_LAUNCH_CHECK("mlp_bwd(reduce)");
@@ -365,13 +372,13 @@ int benerf_mlp_dw_reduce_launch(const float* ws, const BenerfMlpGrads* grads, in
 
 // split-f16 variant (mlp_dw_h.hip)
 int benerf_mlp_dw_split_launch(int channels, int64_t M, const float* d_raw, const float* acts, const float* dacts, float* dw_ws,
-                               const BenerfMlpGrads* grads, int accumulate, hipStream_t stream);
+                               const BenerfMlpGrads* grads, int accumulate, const float* pe_weights, hipStream_t stream);
 
 int benerf_mlp_dw_launch(int precision, int channels, int64_t M, const float* d_raw, const float* acts,
                          const float* dacts, float* dw_ws, const BenerfMlpGrads* grads, int accumulate,
-                         hipStream_t stream) {
+                         const float* pe_weights, hipStream_t stream) {
     if (precision == BENERF_MLP_SPLIT)
-        return benerf_mlp_dw_split_launch(channels, M, d_raw, acts, dacts, dw_ws, grads, accumulate, stream);
+        return benerf_mlp_dw_split_launch(channels, M, d_raw, acts, dacts, dw_ws, grads, accumulate, pe_weights, stream);
     DwArgs a;
     a.d_raw = d_raw;
     a.acts = acts;
@@ -385,5 +392,5 @@ int benerf_mlp_dw_launch(int precision, int channels, int64_t M, const float* d_
     }
     hipLaunchKernelGGL(mlp_dw_kernel, dim3(mlp::DW_TOTAL_BLOCKS), dim3(DWT), DW_SMEM, stream, a);
     BENERF_LAUNCH_CHECK("mlp_bwd(dw)");
-    return benerf_mlp_dw_reduce_launch(dw_ws, grads, channels, accumulate, 0, nullptr, stream);
+    return benerf_mlp_dw_reduce_launch(dw_ws, grads, channels, accumulate, 0, nullptr, pe_weights, stream);
 }

@@ -34,6 +34,7 @@ struct FwdArgs {
     const float* b_alpha;
     const float* w_rgb;
     const float* b_rgb;
+    const float* pe_w;       // BARF c2f column weights (include/benerf_hip.h) or null
     float* raw;
     float* acts;
     const uint32_t* gate;    // BENERF_MLP_AUTO re-run: workgroups exit unless *gate (max |activation| of the split launch, f32 bits) left f16's range
@@ -223,6 +224,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_kernel(FwdArgs a) {
             for (int j = 0; j < 4; ++j) dst[j] = *reinterpret_cast<const float4*>(T + tidx(r, COL_PE + q * 16 + 4 * j));
         }
     }
+    if (a.pe_w) {   // BARF c2f: the saved tile stays unweighted (dX needs sin / cos themselves), the GEMM operand is scaled
+        if (SAVE) lds_barrier();
+        for (int col = grp; col < 64; col += 4) trow[(COL_PE + col) ^ psw] *= a.pe_w[col];
+        lds_barrier();
+    }
 
     f32x16 acc[2][2];
     const int ct0 = wave * 2;
@@ -303,6 +309,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_kernel(FwdArgs a) {
             dst[0] = *reinterpret_cast<const float4*>(T + tidx(r, COL_PE + q * 8));
             dst[1] = *reinterpret_cast<const float4*>(T + tidx(r, COL_PE + q * 8 + 4));
         }
+    }
+    if (a.pe_w) {
+        if (SAVE) lds_barrier();
+        for (int col = grp; col < 32; col += 4) trow[(COL_PE + col) ^ psw] *= a.pe_w[64 + col];
     }
     lds_barrier();
     if (SAVE && STAGED) copy_tile<256>(T, acts + act_feat(M) + m0 * 256, rows_valid);
@@ -391,6 +401,7 @@ extern "C" int benerf_mlp_fwd(const BenerfMlpParams* params, const float* packed
     a.b_alpha = params->b[BENERF_L_ALPHA];
     a.w_rgb = params->w[BENERF_L_RGB];
     a.b_rgb = params->b[BENERF_L_RGB];
+    a.pe_w = params->pe_weights;
     a.raw = raw;
     a.acts = acts;
     a.gate = gate;

@@ -29,6 +29,7 @@ struct FwdArgs {
     const float* b_alpha;
     const float* w_rgb;
     const float* b_rgb;
+    const float* pe_w;       // BARF c2f column weights (include/benerf_hip.h) or null
     float* raw;
     float* acts;
     uint32_t* status;        // [0] sticky / [3] per-call max |activation| bits, written only when >= 2^15 (may be null)
@@ -126,12 +127,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_split_kernel(FwdArgs a) {
         // training: PE as f32 rows (sin/cos derivatives in dX; dW operand of the thin instances), all Mp rows
         float* ape = SAVE ? acts + sact_pe32(Mp) + m * ACT_PE_W : nullptr;
         auto put = [&](int col, float v) {
+            if (SAVE) ape[col] = v;                                  // saved UNWEIGHTED (dX needs sin / cos themselves)
+            if (a.pe_w) v *= a.pe_w[col];
             const _Float16 hi = (_Float16)v;
             const _Float16 lo = (_Float16)((v - (float)hi) * LO_SCALE);
             const int idx = hidx(pt, COL_PE + col);
             Th[idx] = hi;
             Tl[idx] = lo;
-            if (SAVE) ape[col] = v;
         };
         if (grp == 0) {
 #pragma unroll
@@ -202,14 +204,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_split_kernel(FwdArgs a) {
         for (int c = 0; c < 3; ++c) vd[c] = a.viewdirs[ray * 3 + c];
         float* aped = SAVE ? acts + sact_ped32(Mp) + m * ACT_PED_W : nullptr;
         auto put = [&](int col, float v) {
+            if (SAVE) {
+                aped[col] = v;
+            }
+            if (a.pe_w) v *= a.pe_w[64 + col];
             const _Float16 hi = (_Float16)v;
             const _Float16 lo = (_Float16)((v - (float)hi) * LO_SCALE);
             const int idx = hidx(pt, COL_PE + col);
             Th[idx] = hi;
             Tl[idx] = lo;
-            if (SAVE) {
-                aped[col] = v;
-            }
         };
         if (grp == 0) {
 #pragma unroll
@@ -314,6 +317,7 @@ int benerf_mlp_fwd_split_launch(const BenerfMlpParams* params, const float* pack
     a.b_alpha = params->b[BENERF_L_ALPHA];
     a.w_rgb = params->w[BENERF_L_RGB];
     a.b_rgb = params->b[BENERF_L_RGB];
+    a.pe_w = params->pe_weights;
     a.raw = raw;
     a.acts = acts;
     a.status = status;

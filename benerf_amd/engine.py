@@ -253,8 +253,6 @@ class TrainStep:
                                       "channel; with channels = 3 its own Linear(1, width) cannot take the colours either")
         if cfg.N_importance <= 0 or not hasattr(graph, "nerf_fine"):
             raise NotImplementedError("TrainStep needs the fine network (N_importance > 0), as in every shipped config")
-        if getattr(cfg, "use_barf_c2f", False):
-            raise NotImplementedError("TrainStep: use_barf_c2f is not implemented (SURVEY 8f4)")
         if cfg.dataset == "TUM_VIE" and (cam_rgb.remap is None or cam_evt.remap is None):
             raise ValueError("TrainStep: TUM_VIE needs the undistortion tables (Camera(..., remap=...), model/nerf.py:247-250)")
         if not (getattr(cfg, "event_loss", True) or getattr(cfg, "rgb_loss", True)):
@@ -394,6 +392,10 @@ class TrainStep:
             d = Draws(seed=self.seed + self.rank * 7919, offset=step_id)
         t_rand, sd, off = d.jitter_args()
         z = K.stratified_z(N, S, dev, t_rand, sd, off)
+        pw = None
+        if getattr(cfg, "use_barf_c2f", False):     # iter_step of graph.forward(i, ...) = the iteration counter (train.py:160)
+            pw = K.barf_pe_weights(step_id, cfg.max_iter, cfg.barf_c2f_start, cfg.barf_c2f_end, dev)
+        self.net_c.packed.pe_weights = self.net_f.packed.pe_weights = pw
         raw0, acts0 = K.mlp_fwd(self.net_c.packed, ro, rd, vd, z, True)
         nz0 = d.noise_args(0)
         c0 = K.composite_fwd(raw0, z, rd, nz0[0], nz0[1], nz0[2], nz0[3], want=("rgb_map", "weights"))

@@ -247,9 +247,12 @@ class PackedMlp:
         lib = _lib.load()
         self.packed = torch.empty(lib.benerf_mlp_packed_floats(), dtype=torch.float32, device=self.weights[0].device)
         self.version = None
+        self.pe_weights = None        # BARF c2f column weights of the current iteration (barf_pe_weights) or None
 
     def struct(self):
-        return _param_struct(MlpParams, self.weights, self.biases)
+        s = _param_struct(MlpParams, self.weights, self.biases)
+        s.pe_weights = _chk(self.pe_weights, name="pe_weights")
+        return s
 
     def _key(self):
         return (_param_generation,) + tuple((t._version, t.data_ptr()) for t in self.weights + self.biases)
@@ -267,6 +270,22 @@ class PackedMlp:
             self.pack()
 
 
+def barf_pe_weights(iter_step, max_iter, start, end, device):
+    """BARF coarse-to-fine weights of the positional-encoding columns (model/nerf.py:16-26,78-89) as the 96-float table of
+    BenerfMlpParams.pe_weights.  The reference computes w_k = (1 - cos(pi * clamp(alpha - k, 0, 1))) / 2, k < L, with
+    alpha = (iter_step / max_iter - start) / (end - start) * L, and applies it through `embedded.view(-1, L) * weight`,
+    i.e. encoding element e (sin / cos interleaved per frequency, input not included) is scaled by w[e % L]; the raw
+    input concatenated in front keeps weight 1.  L = 10 for points, 4 for view directions."""
+    import math
+    tab = [1.0] * 96
+    for base, n_enc, L in ((0, 60, 10), (64, 24, 4)):
+        alpha = (iter_step / max_iter - start) / (end - start) * L
+        w = [(1.0 - math.cos(math.pi * min(max(alpha - k, 0.0), 1.0))) / 2.0 for k in range(L)]
+        for e in range(n_enc):
+            tab[base + 3 + e] = w[e % L]
+    return torch.tensor(tab, dtype=torch.float32, device=device)
+
+
 def mlp_fwd(net, rays_o, rays_d, viewdirs, z, save_acts, precision=None):
     """Returns (raw, acts).  Inference launches (save_acts False) in split mode run as BENERF_MLP_AUTO: the output is
     valid even if an activation leaves the f16 range (include/benerf_hip.h)."""
@@ -279,6 +298,7 @@ def mlp_fwd(net, rays_o, rays_d, viewdirs, z, save_acts, precision=None):
     if save_acts:
         acts = torch.empty(lib.benerf_mlp_act_floats(n_rays * n_samples), dtype=torch.float32, device=z.device)
         acts.benerf_precision = mode
+        acts.benerf_pe_weights = net.pe_weights       # the backward of THIS forward uses the same column weights
     s = net.struct()
     code = MLP_PRECISIONS[mode]
     if code == 1 and not save_acts:
@@ -302,7 +322,9 @@ def mlp_bwd(net, d_raw, acts, n_rays, n_samples, grad_w, grad_b, accumulate):
     ws = scratch("dw_ws", ws_floats, dev)
     d_pts = torch.empty((M, 3), dtype=torch.float32, device=dev)
     d_vd = torch.empty((M, 3), dtype=torch.float32, device=dev)
+    pe_w = getattr(acts, "benerf_pe_weights", net.pe_weights)
     s = net.struct()
+    s.pe_weights = _chk(pe_w, name="pe_weights")
     g = _param_struct(MlpGrads, grad_w, grad_b)
     _timer("mlp_bwd_dx", M)
     _lib.check(lib.benerf_mlp_bwd_dx(ctypes.byref(s), net.packed.data_ptr(), net.channels, n_rays, n_samples,
@@ -310,8 +332,8 @@ def mlp_bwd(net, d_raw, acts, n_rays, n_samples, grad_w, grad_b, accumulate):
                                      d_vd.data_ptr(), code, mlp_status(dev).data_ptr(), _stream()), "mlp_bwd_dx")
     _timer("mlp_bwd_dw", M)
     _lib.check(lib.benerf_mlp_bwd_dw(net.channels, n_rays, n_samples, _chk(d_raw), _chk(acts), dacts.data_ptr(),
-                                     ws.data_ptr(), ws_floats, ctypes.byref(g), int(bool(accumulate)), code, _stream()),
-               "mlp_bwd_dw")
+                                     ws.data_ptr(), ws_floats, ctypes.byref(g), int(bool(accumulate)), code,
+                                     _chk(pe_w, name="pe_weights"), _stream()), "mlp_bwd_dw")
     _timer(None, 0)
     return d_pts, d_vd
 

@@ -93,6 +93,13 @@ class _Composite(torch.autograd.Function):
         return d_raw, None, d_rd, None
 
 
+def barf_weights(iter_step, args, device):
+    """None, or the BARF coarse-to-fine column weights of this iteration (barf_c2f_weight, model/nerf.py:16-26)."""
+    if not getattr(args, "use_barf_c2f", False):
+        return None
+    return K.barf_pe_weights(iter_step, args.max_iter, args.barf_c2f_start, args.barf_c2f_end, device)
+
+
 class NeRF(nn.Module):
     """8x256 ReLU MLP with skip at layer 4 and a 128-wide view branch (model/nerf.py:40-64).
     Same constructor and parameter names as the reference; the HIP kernels implement exactly
@@ -128,11 +135,10 @@ class NeRF(nn.Module):
 
     def forward(self, iter_step, pts, viewdirs, args):
         """pts [N,S,3], viewdirs [N,3] -> [N,S,channels+1] = [rgb..., sigma]  (model/nerf.py:67-116)."""
-        if getattr(args, "use_barf_c2f", False):
-            raise NotImplementedError("use_barf_c2f is off in every shipped config and not implemented (SURVEY 8f4)")
         if viewdirs is None:
             raise NotImplementedError("use_viewdirs=False is not supported")
         net = self.packed()
+        net.pe_weights = barf_weights(iter_step, args, pts.device)
         return _MlpPoints.apply(pts, viewdirs, net, *net.weights, *net.biases)
 
     def raw2output(self, crf_func, enable_crf: bool, sensor_type, raw, z_vals, rays_d, raw_noise_std=1.0):
@@ -252,6 +258,9 @@ class Graph(nn.Module):
             draws = Draws(t_rand, noise0, u, noise1, noise_std=0.0 if std <= 0 else std)
         net_c = self.nerf.packed()
         net_f = self.nerf_fine.packed() if Ni > 0 else None
+        net_c.pe_weights = barf_weights(iter_step, args, dev)
+        if net_f is not None:
+            net_f.pe_weights = net_c.pe_weights
         params = list(net_c.weights) + list(net_c.biases)
         if net_f is not None:
             params += list(net_f.weights) + list(net_f.biases)

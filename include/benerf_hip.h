@@ -112,6 +112,10 @@ enum { BENERF_NLAYERS = 12, BENERF_L_VIEWS = 8, BENERF_L_FEAT = 9, BENERF_L_ALPH
 typedef struct BenerfMlpParams {
     const float* w[BENERF_NLAYERS];
     const float* b[BENERF_NLAYERS];
+    /* NULL, or 96 device floats scaling the positional-encoding columns before the first / skip / view layers
+     * (BARF coarse-to-fine, model/nerf.py:16-26,78-89): [0,64) the 63 PE(pts) columns (+ pad), [64,96) the 27 PE(dir)
+     * columns (+ pad).  The reference's weight of encoding element e is w[e % L] (its view(-1, L)), 1 for the raw input. */
+    const float* pe_weights;
 } BenerfMlpParams;
 typedef struct BenerfMlpGrads {
     float* w[BENERF_NLAYERS];
@@ -174,7 +178,8 @@ int benerf_mlp_fwd(const BenerfMlpParams* params, const float* packed, int chann
  *   _dx: activation-gradient chain -> dacts scratch [benerf_mlp_dact_floats(n_points)], d_pts [n_points,3],
  *        d_vdir_pts [n_points,3] (per point; reduce with benerf_ray_grad_reduce);
  *   _dw: weight gradients from acts + dacts; dw_ws scratch [benerf_mlp_dw_workspace_floats(n_points)];
- *        grads: overwritten when accumulate == 0, added to otherwise.
+ *        grads: overwritten when accumulate == 0, added to otherwise; pe_weights: the forward call's
+ *        BenerfMlpParams.pe_weights (the saved encodings are unweighted; the columns are scaled in the reduce).
  * precision: BENERF_MLP_F32 or BENERF_MLP_SPLIT, the mode of the forward launch that wrote acts. */
 int benerf_mlp_bwd_dx(const BenerfMlpParams* params, const float* packed, int channels,
                       int n_rays, int n_samples, const float* d_raw, const float* acts,
@@ -182,7 +187,8 @@ int benerf_mlp_bwd_dx(const BenerfMlpParams* params, const float* packed, int ch
                       benerf_stream_t stream);
 int benerf_mlp_bwd_dw(int channels, int n_rays, int n_samples, const float* d_raw,
                       const float* acts, const float* dacts, float* dw_ws, size_t dw_ws_floats,
-                      const BenerfMlpGrads* grads, int accumulate, int precision, benerf_stream_t stream);
+                      const BenerfMlpGrads* grads, int accumulate, int precision, const float* pe_weights,
+                      benerf_stream_t stream);
 
 /* ---------------------------------------------------------------- K4: compositing -- */
 /* Alpha compositing, one wavefront per ray.  Replaces NeRF.raw2output

@@ -294,15 +294,31 @@ def xavier_params(rng, channels):
     return p
 
 
-def mlp_forward(p, pts, viewdirs, multires=10, multires_views=4, want_acts=False):
+def barf_c2f(embedded, n_freqs, progress, start, end):
+    """barf_c2f_weight (model/nerf.py:16-26) on an encoding WITHOUT the raw input ([.., 6L]): the reference's
+    `embedded.view(-1, L) * weight` scales element e by weight[e % L]."""
+    L = n_freqs
+    alpha = (progress - start) / (end - start) * L
+    k = torch.arange(L)
+    weight = (1 - (alpha - k).clamp(min=0, max=1).mul(math.pi).cos()) / 2
+    return (embedded.reshape(-1, L) * weight).reshape(embedded.shape)
+
+
+def mlp_forward(p, pts, viewdirs, multires=10, multires_views=4, want_acts=False, barf=None):
     """NeRF.forward (model/nerf.py:67-116).  pts [N,S,3], viewdirs [N,3] -> raw [N,S,C+1].
 
     Layer 5 consumes cat[input_pts, h] (input first).  alpha_linear has no
-    activation; rgb and alpha are concatenated as [rgb..., sigma]."""
+    activation; rgb and alpha are concatenated as [rgb..., sigma].
+    barf = (iter_step, max_iter, c2f_start, c2f_end): use_barf_c2f (model/nerf.py:78-89) - the encodings are built
+    without the raw input, coarse-to-fine weighted, and the raw input is concatenated in front."""
     N, S = pts.shape[0], pts.shape[1]
     x = posenc(pts.reshape(-1, 3), multires)
     dirs = viewdirs[:, None].expand(pts.shape).reshape(-1, 3)
     xd = posenc(dirs, multires_views)
+    if barf is not None:
+        it, max_iter, c0, c1 = barf
+        x = torch.cat([x[:, :3], barf_c2f(x[:, 3:], multires, it / max_iter, c0, c1)], -1)
+        xd = torch.cat([xd[:, :3], barf_c2f(xd[:, 3:], multires_views, it / max_iter, c0, c1)], -1)
     acts = {"pe": x, "ped": xd}
     h = x
     for i in range(8):
@@ -425,7 +441,7 @@ def fine_depths(z, weights, u, exact=False):
 # --------------------------------------------------------------------------------------
 
 def render(p_coarse, p_fine, poses, ray_idx, H, W, K, channels, n_samples, n_importance,
-           draws, ndc=True, exact_pdf=False, want_extras=False):
+           draws, ndc=True, exact_pdf=False, want_extras=False, barf=None):
     """Graph.render.  draws = dict(t_rand [N,S], noise0 [N,S] | None, u [N,Ni],
     noise1 [N,S+Ni] | None) - the four RNG draws in reference order.
     Returns the reference's dict (rgb_map, disp_map, acc_map, rgb0, disp0, acc0, sigma)."""
@@ -433,7 +449,7 @@ def render(p_coarse, p_fine, poses, ray_idx, H, W, K, channels, n_samples, n_imp
     N = rays_o.shape[0]
     z = stratified_z(N, n_samples, draws["t_rand"])
     pts = rays_o[..., None, :] + rays_d[..., None, :] * z[..., :, None]
-    raw0 = mlp_forward(p_coarse, pts, viewdirs)
+    raw0 = mlp_forward(p_coarse, pts, viewdirs, barf=barf)
     rgb0, disp0, acc0, w0, depth0, sigma0 = composite(raw0, z, rays_d, draws.get("noise0"), channels)
     ret = {"rgb_map": rgb0, "disp_map": disp0, "acc_map": acc0}
     extras = {"rays_o": rays_o, "rays_d": rays_d, "viewdirs": viewdirs, "z_coarse": z,
@@ -441,7 +457,7 @@ def render(p_coarse, p_fine, poses, ray_idx, H, W, K, channels, n_samples, n_imp
     if n_importance > 0:
         z_all, z_samples = fine_depths(z, w0, draws["u"], exact=exact_pdf)
         pts = rays_o[..., None, :] + rays_d[..., None, :] * z_all[..., :, None]
-        raw1 = mlp_forward(p_fine, pts, viewdirs)
+        raw1 = mlp_forward(p_fine, pts, viewdirs, barf=barf)
         rgb1, disp1, acc1, w1, depth1, sigma1 = composite(raw1, z_all, rays_d, draws.get("noise1"), channels)
         ret = {"rgb_map": rgb1, "disp_map": disp1, "acc_map": acc1,
                "rgb0": rgb0, "disp0": disp0, "acc0": acc0, "sigma": sigma1}
@@ -583,7 +599,7 @@ def tone_map(p, x):
 
 
 def step_loss(cfg, p_coarse, p_fine, knots, transform, evt_ts, rgb_ts, idx_evt, idx_rgb,
-              target_acc, target_rgb, draws_evt, draws_rgb, exact_pdf=False, event_crf=None, rgb_crf=None):
+              target_acc, target_rgb, draws_evt, draws_rgb, exact_pdf=False, event_crf=None, rgb_crf=None, barf=None):
     """Forward of one training iteration (model/nerf.py:208-232 + train.py:163-337) on
     explicit inputs.  event_crf / rgb_crf: tone-mapper parameters applied to the rendered colours as train.py:180-192
     does when optimize_event_crf / optimize_rgb_crf are set.  Returns (loss, dict of parts)."""
@@ -591,9 +607,9 @@ def step_loss(cfg, p_coarse, p_fine, knots, transform, evt_ts, rgb_ts, idx_evt, 
     poses_e = trajectory_poses(knots, None, evt_ts, 2, cfg.traj)
     poses_r = trajectory_poses(knots, transform, rgb_ts, cfg.n_poses, cfg.traj)
     ret_e = render(p_coarse, p_fine, poses_e, idx_evt, cfg.H, cfg.W, K, cfg.channels,
-                   cfg.n_samples, cfg.n_importance, draws_evt, exact_pdf=exact_pdf)
+                   cfg.n_samples, cfg.n_importance, draws_evt, exact_pdf=exact_pdf, barf=barf)
     ret_r = render(p_coarse, p_fine, poses_r, idx_rgb, cfg.H, cfg.W, K, cfg.channels,
-                   cfg.n_samples, cfg.n_importance, draws_rgb, exact_pdf=exact_pdf)
+                   cfg.n_samples, cfg.n_importance, draws_rgb, exact_pdf=exact_pdf, barf=barf)
     if event_crf is not None:
         ret_e = dict(ret_e, rgb_map=tone_map(event_crf, ret_e["rgb_map"]), rgb0=tone_map(event_crf, ret_e["rgb0"]))
     if rgb_crf is not None:

@@ -729,12 +729,50 @@ def g13_crf(R):
     save("g13_crf.npz", **out)
 
 
+# ----------------------------------------------------------------------------------- G14
+def g14_barf(R):
+    """use_barf_c2f (model/nerf.py:16-26,78-89): the reference's NeRF.forward at iteration counts before, inside and after the
+    coarse-to-fine window, output + gradients w.r.t. points, view directions and two weight matrices."""
+    rng = np.random.default_rng(1414)
+    C, N, S = 1, 12, 8
+    out = {}
+    p = O.xavier_params(rng, C)
+    p["alpha_linear.bias"] += 1.0
+    pts = GI.f32(rng.uniform(-1.2, 1.2, (N, S, 3)))
+    vd = GI.f32(rng.standard_normal((N, 3)))
+    vd = vd / vd.norm(dim=-1, keepdim=True)
+    G = GI.f32(rng.standard_normal((N, S, C + 1)))
+    out["pts"], out["viewdirs"], out["G"] = pts, vd, G
+    for it in (0, 12000, 23000, 60000):
+        args = make_args(channels=C, use_barf_c2f=True, barf_c2f_start=0.1, barf_c2f_end=0.5, max_iter=80000)
+        net = R.nerf.NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=4, skips=[4], use_viewdirs=True, channels=C)
+        with torch.no_grad():
+            net.load_state_dict(p)
+        pr, vr = pts.clone().requires_grad_(True), vd.clone().requires_grad_(True)
+        raw = net.forward(it, pr, vr, args)
+        (raw * G).sum().backward()
+        po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+        p2, v2 = pts.clone().requires_grad_(True), vd.clone().requires_grad_(True)
+        raw_o = O.mlp_forward(po, p2, v2, barf=(it, 80000, 0.1, 0.5))
+        (raw_o * G).sum().backward()
+        check("G14 barf raw it=%d" % it, raw, raw_o, atol=1e-6, rtol=1e-5)
+        check("G14 barf d pts it=%d" % it, pr.grad, p2.grad, atol=1e-5 * float(pr.grad.abs().max()) + 1e-9, rtol=1e-4)
+        check("G14 barf d viewdirs it=%d" % it, vr.grad, v2.grad, atol=1e-5 * float(vr.grad.abs().max()) + 1e-9, rtol=1e-4)
+        tag = "it%d" % it
+        out[tag + "_raw"], out[tag + "_dpts"], out[tag + "_dviewdirs"] = raw.detach(), pr.grad, vr.grad
+        for name in ("pts_linears.0.weight", "pts_linears.5.weight", "views_linears.0.weight", "pts_linears.2.weight"):
+            gr = dict(net.named_parameters())[name].grad
+            check("G14 barf d %s it=%d" % (name, it), gr, po[name].grad, atol=1e-5 * float(gr.abs().max()) + 1e-9, rtol=1e-4)
+            out["%s_g_%s" % (tag, name)] = gr
+    save("g14_barf.npz", **out)
+
+
 def main():
     torch.set_num_threads(8)
     R = load_reference()
     only = sys.argv[1:]
     for fn in (g1_spline, g2_rays, g3_posenc, g4_mlp, g5_composite, g6_sample_pdf, g7_render, g8_step, g9_events,
-               g10_adam, g11_curve, g12_spline_ops, g13_crf):
+               g10_adam, g11_curve, g12_spline_ops, g13_crf, g14_barf):
         if only and fn.__name__.split("_")[0] not in only:
             continue
         fn(R)

@@ -403,3 +403,55 @@ def test_fused_step_with_crf(which):
     with pytest.raises(NotImplementedError):
         engine.TrainStep(_graph(WL.make_args(dict(wl, channels=3), optimize_rgb_crf=True), seed=1)[1],
                          WL.make_args(dict(wl, channels=3), optimize_rgb_crf=True), cam_o, cam_o, torch.device(DEV))
+
+
+def test_barf_c2f_through_render_and_fused_step():
+    """use_barf_c2f on the two paths that carry iter_step: Graph.render (RenderRays) and the fused TrainStep (its
+    global_step), against the oracle with the same coarse-to-fine weights (model/nerf.py:16-26,78-89)."""
+    from benerf_amd import engine, kernels as K, workloads as WL
+    wl = dict(WL.WORKLOADS["C1"], S=16, Ni=16, Re=24, Rr=3, n=5)
+    args = WL.make_args(wl, use_barf_c2f=True, barf_c2f_start=0.1, barf_c2f_end=0.5, max_iter=100)
+    cam = WL.CAMERAS[wl["cam"]]
+    C, S, Ni, P, Re, Rr = 1, 16, 16, 5, 24, 3
+    model, g = _graph(args, seed=6)
+    pc = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in g.nerf.state_dict().items()}
+    pf = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in g.nerf_fine.state_dict().items()}
+    ko = g.evt_knot_pose_se3.params.weight.detach().cpu().clone().requires_grad_(True)
+    rng = np.random.default_rng(78)
+    Kmat = GI.cam_K(cam)
+    idx_e, idx_r = GI.pixel_indices(rng, cam, Re), GI.pixel_indices(rng, cam, Rr)
+    d_e, d_r = GI.render_draws(rng, 2 * Re, S, Ni), GI.render_draws(rng, P * Rr, S, Ni)
+    it = 27                                                    # inside the window: progress 0.27
+    barf = (it, 100, 0.1, 0.5)
+    # Graph.render at iter_step = it, explicit draws through the torch generator replaced by Philox-free Draws: use the engine
+    cam_o = engine.Camera(cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+    poses = O.trajectory_poses(ko.detach(), None, (0.31, 0.41), 2, "spline")
+    ref = O.render(pc, pf, poses, idx_e, cam["H"], cam["W"], Kmat, C, S, Ni, d_e, exact_pdf=True, barf=barf)
+    net_c, net_f = g.nerf.packed(), g.nerf_fine.packed()
+    net_c.pack_if_stale()
+    net_f.pack_if_stale()
+    net_c.pe_weights = net_f.pe_weights = K.barf_pe_weights(it, 100, 0.1, 0.5, torch.device(DEV))
+    dd = engine.Draws(*(d_e[k].to(DEV) for k in ("t_rand", "noise0", "u", "noise1")))
+    out, _ = engine._render_forward(cam_o, True, S, Ni, dd, poses.to(DEV).contiguous(), idx_e.to(DEV), net_c, net_f, False)
+    report("barf render rgb_map", out["rgb_map"], ref["rgb_map"], atol=1e-4)
+    report("barf render rgb0", out["rgb0"], ref["rgb0"], atol=1e-4)
+    # fused step at global_step = it
+    step = engine.TrainStep(g, args, cam_o, cam_o, torch.device(DEV))
+    step.global_step = it
+    HW = cam["H"] * cam["W"]
+    acc = torch.from_numpy(rng.integers(-3, 4, (HW,)).astype(np.float32))
+    img = torch.from_numpy(rng.random((HW, C)).astype(np.float32))
+    evt_ts, rgb_ts = torch.tensor([0.31, 0.41]), torch.tensor([0.0, 1.0])
+    cfg = O.StepConfig(H=cam["H"], W=cam["W"], fx=cam["fx"], fy=cam["fy"], cx=cam["cx"], cy=cam["cy"], channels=C, n_samples=S,
+                       n_importance=Ni, n_poses=P, dataset=wl["dataset"], threshold=wl["threshold"])
+    loss_o, _ = O.step_loss(cfg, pc, pf, ko, torch.zeros(1, 6), evt_ts, rgb_ts, idx_e, idx_r, acc.double().reshape(-1, 1)[idx_e], img[idx_r],
+                            d_e, d_r, exact_pdf=True, barf=barf)
+    loss_o.backward()
+
+    def dr(d):
+        return engine.Draws(*(d[k].to(DEV) for k in ("t_rand", "noise0", "u", "noise1")))
+    losses = step.step(evt_ts.to(DEV), rgb_ts.to(DEV), idx_e.to(DEV), idx_r.to(DEV), acc.to(DEV), img.to(DEV), dr(d_e), dr(d_r))
+    report("barf fused step loss", losses[0:1], loss_o.detach().float().reshape(1), atol=1e-6, rtol=2e-5)
+    report("barf fused step d knots", step.g_knots, ko.grad, atol=2e-3 * float(ko.grad.abs().max()), rtol=2e-3)
+    r0 = pc["pts_linears.0.weight"].grad
+    report("barf fused step d nerf.pts_linears.0.weight", step.net_c.gviews_w[0], r0, atol=2e-3 * float(r0.abs().max()), rtol=2e-3)

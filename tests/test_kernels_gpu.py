@@ -326,6 +326,37 @@ def test_mlp_fwd_golden(K, mlp_mode, golden, C, variant, S):
     assert torch.equal(raw2, raw), "inference and training forward must agree bit for bit"
 
 
+@pytest.mark.parametrize("it", [0, 12000, 23000, 60000])
+def test_mlp_barf_c2f_golden(K, mlp_mode, golden, it):
+    """use_barf_c2f (model/nerf.py:16-26,78-89) through NeRF.forward of the mirror: iteration counts before, inside and
+    after the coarse-to-fine window; raw output and the gradients w.r.t. points, view directions and weights against the
+    reference."""
+    from benerf_amd import workloads as WL
+    from benerf_amd.model.nerf import NeRF
+    g = golden("g14_barf")
+    rng = np.random.default_rng(1414)
+    p = O.xavier_params(rng, 1)
+    p["alpha_linear.bias"] += 1.0
+    args = WL.make_args("C1", use_barf_c2f=True, barf_c2f_start=0.1, barf_c2f_end=0.5, max_iter=80000)
+    net = NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=4, skips=[4], use_viewdirs=True, channels=1).to(DEV)
+    net.load_state_dict({k: v.to(DEV) for k, v in p.items()})
+    pts, vd = dev(g["pts"]).requires_grad_(True), dev(g["viewdirs"]).requires_grad_(True)
+    raw = net.forward(it, pts, vd, args)
+    tag = "it%d" % it
+    ref = g[tag + "_raw"]
+    report("K3 barf raw " + tag, raw, ref, atol=1e-5 * max(1.0, float(np.abs(ref).max())), rtol=1e-5)
+    (raw * dev(g["G"])).sum().backward()
+    at = 2e-5 if mlp_mode == "f32" else 1e-3
+    for nm, got, key in (("d_pts", pts.grad, "_dpts"), ("d_viewdirs", vd.grad, "_dviewdirs")):
+        r = g[tag + key]
+        report("K3 barf %s %s" % (nm, tag), got, r, atol=at * float(np.abs(r).max()) + 1e-9, rtol=1e-3)
+    for name in ("pts_linears.0.weight", "pts_linears.5.weight", "views_linears.0.weight", "pts_linears.2.weight"):
+        r = g["%s_g_%s" % (tag, name)]
+        from benerf_amd import engine
+        got = engine.getattr_path(net, name.rsplit(".", 1)[0]).weight.grad
+        report("K3 barf d%s %s" % (name, tag), got, r, atol=at * float(np.abs(r).max()) + 1e-9, rtol=1e-3)
+
+
 def test_mlp_fwd_rays_and_tail(K, mlp_mode):
     """pts = o + d*z inside the kernel, ragged tile tail (M not a multiple of 64)."""
     rng = np.random.default_rng(77)

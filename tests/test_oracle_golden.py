@@ -166,3 +166,14 @@ def test_g13_tone_mappers(golden):
         report("G13 %s tone-mapper d input" % name, x.grad, g[name + "_dx"], atol=1e-7, rtol=1e-5)
         for k in p:
             report("G13 %s tone-mapper d %s" % (name, k), p[k].grad, g["%s_dp_%s" % (name, k)], atol=1e-7, rtol=1e-5)
+
+
+def test_g14_barf_c2f(golden):
+    """oracle.mlp_forward(barf=...) against the reference's NeRF.forward with use_barf_c2f (model/nerf.py:16-26,78-89)."""
+    g = golden("g14_barf")
+    rng = np.random.default_rng(1414)
+    p = O.xavier_params(rng, 1)
+    p["alpha_linear.bias"] += 1.0
+    for it in (0, 12000, 23000, 60000):
+        raw = O.mlp_forward(p, T(g["pts"]), T(g["viewdirs"]), barf=(it, 80000, 0.1, 0.5))
+        report("G14 raw it=%d" % it, raw, g["it%d_raw" % it], atol=1e-7)
