@@ -152,17 +152,18 @@ constexpr int64_t DW_WS_FLOATS = dw_inst_offset(DW_COUNT);
 //   big kernel, one workgroup per CU: a whole 256x256 instance block per workgroup (one accumulator set), 30 point-
 //     splits for each of the eight instances + 16 for the 128x256 views block: 8*30 + 16 = 256.
 //   small kernel: the thin instances (PE / PE(dir) operands, rgb head) move few bytes per chunk and are latency-
-//     bound per workgroup; 64 point-splits each = 256 light workgroups.
+//     bound per workgroup; 128 point-splits each = 512 light workgroups, two per CU (128 registers).
+constexpr int DWH_THIN_SPLITS = 128;
 __host__ __device__ constexpr int dwh_splits(int inst) {
     switch (inst) {
         case DW_VIEWSF: return 16;
-        case DW_L0: case DW_L5P: case DW_VIEWSP: case DW_RGB: return 64;
+        case DW_L0: case DW_L5P: case DW_VIEWSP: case DW_RGB: return DWH_THIN_SPLITS;
         default: return 30;
     }
 }
 constexpr int DWH_FULL_BLOCKS = 8 * 30;
 constexpr int DWH_BIG_BLOCKS = DWH_FULL_BLOCKS + 16;
-constexpr int DWH_SMALL_BLOCKS = 4 * 64;
+constexpr int DWH_SMALL_BLOCKS = 4 * DWH_THIN_SPLITS;
 __host__ __device__ constexpr int64_t dwh_inst_offset(int inst) {
     int64_t o = 0;
     for (int i = 0; i < inst; ++i) o += dw_inst_floats(i) * dwh_splits(i);

@@ -260,6 +260,7 @@ class TrainStep:
         self.g, self.cfg, self.cam_rgb, self.cam_evt = graph, cfg, cam_rgb, cam_evt
         self.dev, self.world, self.rank, self.pg = device, world_size, rank, process_group
         self.seed = seed
+        self.dw_stream = torch.cuda.Stream(device=device)    # weight-gradient launches (step(): backward)
         self.C = cfg.channels
         wc, bc = nerf_param_lists(graph.nerf)
         wf, bf = nerf_param_lists(graph.nerf_fine)
@@ -446,19 +447,29 @@ class TrainStep:
         d_o = torch.zeros_like(ro)
         d_d = torch.empty_like(ro)
         d_v = torch.zeros_like(ro)
-        d_raw1, _ = K.composite_bwd(raw1, z_fine, rd, nz1[0], nz1[1], nz1[2], nz1[3], g_rgb, d_rays_d=d_d)
-        d_pts, d_vp = K.mlp_bwd(self.net_f.packed, d_raw1.view(-1, C + 1), acts1, N, S + Ni, self.net_f.gviews_w,
-                                self.net_f.gviews_b, False)
-        # gradient exchange, bucket 1 of 3: the fine network's gradients are final - their all-reduce (RCCL over xGMI) runs
-        # on the communicator's stream while the coarse backward below computes
+        # The weight-gradient launches (HBM-bound: they stream the saved activations and activation gradients once) go to
+        # a second stream and run beside the other network's activation-gradient chain and the trajectory tail
+        # (MFMA-bound, little HBM traffic); the two networks keep separate activation-gradient buffers for that.
         n = self.n_net
-        pending = [dist.allreduce_sum_async_(self.flat_g[n:2 * n], self.world, self.pg)]
-        K.ray_grad_reduce(z_fine, d_pts, d_vp, d_o, d_d, d_v, True)
+        main, side = torch.cuda.current_stream(dev), self.dw_stream
+        d_raw1, _ = K.composite_bwd(raw1, z_fine, rd, nz1[0], nz1[1], nz1[2], nz1[3], g_rgb, d_rays_d=d_d)
         d_raw0, _ = K.composite_bwd(raw0, z, rd, nz0[0], nz0[1], nz0[2], nz0[3], g_rgb0, d_rays_d=d_d, accumulate=True)
-        d_pts, d_vp = K.mlp_bwd(self.net_c.packed, d_raw0.view(-1, C + 1), acts0, N, S, self.net_c.gviews_w,
-                                self.net_c.gviews_b, False)
-        pending.append(dist.allreduce_sum_async_(self.flat_g[:n], self.world, self.pg))      # bucket 2: coarse network
-        K.ray_grad_reduce(z, d_pts, d_vp, d_o, d_d, d_v, True)
+        d_pts1, d_vp1, dacts1 = K.mlp_bwd_dx(self.net_f.packed, d_raw1.view(-1, C + 1), acts1, N, S + Ni, slot="_fine")
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            K.mlp_bwd_dw(self.net_f.packed, d_raw1.view(-1, C + 1), acts1, dacts1, N, S + Ni, self.net_f.gviews_w,
+                         self.net_f.gviews_b, False)
+            # gradient exchange, bucket 1 of 3: the fine network's gradients are final - their all-reduce (RCCL over
+            # xGMI) runs on the communicator's stream while the coarse backward computes
+            pending = [dist.allreduce_sum_async_(self.flat_g[n:2 * n], self.world, self.pg)]
+        d_pts0, d_vp0, dacts0 = K.mlp_bwd_dx(self.net_c.packed, d_raw0.view(-1, C + 1), acts0, N, S, slot="_coarse")
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            K.mlp_bwd_dw(self.net_c.packed, d_raw0.view(-1, C + 1), acts0, dacts0, N, S, self.net_c.gviews_w,
+                         self.net_c.gviews_b, False)
+            pending.append(dist.allreduce_sum_async_(self.flat_g[:n], self.world, self.pg))      # bucket 2: coarse network
+        K.ray_grad_reduce(z_fine, d_pts1, d_vp1, d_o, d_d, d_v, True)
+        K.ray_grad_reduce(z, d_pts0, d_vp0, d_o, d_d, d_v, True)
         dp_e = K.rays_bwd(poses_e, idx_e, ce.H, ce.W, ce.fx, ce.fy, ce.cx, ce.cy, cfg.ndc, d_o[:Ne], d_d[:Ne], d_v[:Ne], remap=ce.remap)
         dp_r = K.rays_bwd(poses_r, idx_r, cr.H, cr.W, cr.fx, cr.fy, cr.cx, cr.cy, cfg.ndc, d_o[Ne:], d_d[Ne:], d_v[Ne:], remap=cr.remap)
         dk_e, dk_r, dt_r = K.spline_poses_bwd_pair(self.knots, self.transform.view(6), evt_ts2, 2, rgb_ts2, P, traj, dp_e, dp_r)
@@ -467,8 +478,11 @@ class TrainStep:
 
         # ---- gradient exchange, bucket 3: the 30 trajectory gradients; then every bucket must have landed ------------
         pending.append(dist.allreduce_sum_async_(self.flat_g[2 * n:], self.world, self.pg))
-        for w in pending:
-            w.wait()
+        with torch.cuda.stream(side):
+            for w in pending[:2]:
+                w.wait()
+        main.wait_stream(side)
+        pending[2].wait()
 
         # ---- Adam (K8) with the reference's per-group switches and LR schedule ---------------------------------
         t = self.global_step + 1

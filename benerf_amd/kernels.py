@@ -311,30 +311,48 @@ def mlp_fwd(net, rays_o, rays_d, viewdirs, z, save_acts, precision=None):
     return raw, acts
 
 
-def mlp_bwd(net, d_raw, acts, n_rays, n_samples, grad_w, grad_b, accumulate):
-    """Returns per-point (d_pts [M,3], d_vdir [M,3]); writes/accumulates weight grads."""
+def mlp_bwd_dx(net, d_raw, acts, n_rays, n_samples, slot=""):
+    """Activation-gradient chain of one network: returns per-point (d_pts [M,3], d_vdir [M,3]) and the per-layer
+    activation gradients (scratch buffer `slot`: give the two networks different slots when the weight-gradient launch
+    of one is to overlap the chain of the other)."""
     lib = _lib.load()
     M = n_rays * n_samples
     dev = d_raw.device
     code = MLP_PRECISIONS[getattr(acts, "benerf_precision", _default_precision)]
-    dacts = scratch("dacts", lib.benerf_mlp_dact_floats(M), dev)
-    ws_floats = lib.benerf_mlp_dw_workspace_floats(M)
-    ws = scratch("dw_ws", ws_floats, dev)
+    dacts = scratch("dacts" + slot, lib.benerf_mlp_dact_floats(M), dev)
     d_pts = torch.empty((M, 3), dtype=torch.float32, device=dev)
     d_vd = torch.empty((M, 3), dtype=torch.float32, device=dev)
     pe_w = getattr(acts, "benerf_pe_weights", net.pe_weights)
     s = net.struct()
     s.pe_weights = _chk(pe_w, name="pe_weights")
-    g = _param_struct(MlpGrads, grad_w, grad_b)
     _timer("mlp_bwd_dx", M)
     _lib.check(lib.benerf_mlp_bwd_dx(ctypes.byref(s), net.packed.data_ptr(), net.channels, n_rays, n_samples,
                                      _chk(d_raw, name="d_raw"), _chk(acts), dacts.data_ptr(), d_pts.data_ptr(),
                                      d_vd.data_ptr(), code, mlp_status(dev).data_ptr(), _stream()), "mlp_bwd_dx")
+    _timer(None, 0)
+    return d_pts, d_vd, dacts
+
+
+def mlp_bwd_dw(net, d_raw, acts, dacts, n_rays, n_samples, grad_w, grad_b, accumulate):
+    """Weight / bias gradients of one network from its saved activations and activation gradients (current stream)."""
+    lib = _lib.load()
+    M = n_rays * n_samples
+    code = MLP_PRECISIONS[getattr(acts, "benerf_precision", _default_precision)]
+    ws_floats = lib.benerf_mlp_dw_workspace_floats(M)
+    ws = scratch("dw_ws", ws_floats, d_raw.device)
+    pe_w = getattr(acts, "benerf_pe_weights", net.pe_weights)
+    g = _param_struct(MlpGrads, grad_w, grad_b)
     _timer("mlp_bwd_dw", M)
     _lib.check(lib.benerf_mlp_bwd_dw(net.channels, n_rays, n_samples, _chk(d_raw), _chk(acts), dacts.data_ptr(),
                                      ws.data_ptr(), ws_floats, ctypes.byref(g), int(bool(accumulate)), code,
                                      _chk(pe_w, name="pe_weights"), _stream()), "mlp_bwd_dw")
     _timer(None, 0)
+
+
+def mlp_bwd(net, d_raw, acts, n_rays, n_samples, grad_w, grad_b, accumulate):
+    """Returns per-point (d_pts [M,3], d_vdir [M,3]); writes/accumulates weight grads."""
+    d_pts, d_vd, dacts = mlp_bwd_dx(net, d_raw, acts, n_rays, n_samples)
+    mlp_bwd_dw(net, d_raw, acts, dacts, n_rays, n_samples, grad_w, grad_b, accumulate)
     return d_pts, d_vd
 
 
