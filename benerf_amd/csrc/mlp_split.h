@@ -218,11 +218,13 @@ struct Quad16 { _Float16 v[4]; };
 // the other half of block B, so every lane stores ONE whole 16-byte unit (block A + (lane >> 5)) instead of two
 // 8-byte pieces: half the store instructions of an epilogue (the vector-memory queue is shared with the weight
 // prefetch, and 8-byte stores are issue-bound).
-__device__ __forceinline__ uint4 sh_pair_unit(const Quad16& qa, const Quad16& qb) {
-    const uint2 a = __builtin_bit_cast(uint2, qa), b = __builtin_bit_cast(uint2, qb);
+__device__ __forceinline__ uint4 sh_pair_unit(const uint2 a, const uint2 b) {
     const auto w0 = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
     const auto w1 = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
     return uint4{w0[0], w1[0], w0[1], w1[1]};
+}
+__device__ __forceinline__ uint4 sh_pair_unit(const Quad16& qa, const Quad16& qb) {
+    return sh_pair_unit(__builtin_bit_cast(uint2, qa), __builtin_bit_cast(uint2, qb));
 }
 
 // f32 scratch inside the planes' PE columns [256,320): 64 floats per row, floats [0,32) in the hi plane, [32,64)

@@ -154,7 +154,7 @@ size_t benerf_mlp_dw_workspace_floats(int64_t n_points);
  *
  * status: caller-owned DEVICE uint32[4], zeroed by the caller, may be NULL for BENERF_MLP_F32:
  *   [0] max |activation| seen by split forward launches (f32 bit pattern; written only once it passes 2^15; sticky)
- *   [1] max |scaled gradient| stored by split dX launches (same convention)
+ *   [1] max |gradient| of the tile-scaled split dX chain, taken before its rounding to f16 (same convention)
  *   [2] != 0: a backward launch got activation buffers of another mode
  *   [3] scratch of BENERF_MLP_AUTO (maximum of the current call)
  * Nothing here synchronises; benerf_mlp_status_check does (copy + stream sync) and returns BENERF_ERANGE when

@@ -1,0 +1,46 @@
+"""Decodes the phase timestamps a tracing build of the dX kernel (-DABL=0x10000) leaves in its d_viewdirs output."""
+import os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from benerf_amd import kernels as K
+from benerf_amd import run_nerf_helpers
+from benerf_amd.model import nerf as nerf_mod
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+model = nerf_mod.NeRF(D=8, W=256, input_ch=63, input_ch_views=27, output_ch=2, skips=[4], use_viewdirs=True, channels=1).to(dev)
+run_nerf_helpers.init_nerf(model)
+packed = model.packed(); packed.pack()
+n_rays, n_samples = 4081, 128
+ro = torch.randn(n_rays, 3, device=dev) * 0.1
+rd = torch.nn.functional.normalize(torch.randn(n_rays, 3, device=dev), dim=-1)
+z = torch.sort(torch.rand(n_rays, n_samples, device=dev), dim=-1).values
+raw, acts = K.mlp_fwd(packed, ro, rd, rd, z, True)
+d_raw = torch.randn_like(raw) * 1e-4
+for _ in range(3):
+    d_pts, d_vd, _ = K.mlp_bwd_dx(packed, d_raw.view(-1, 2), acts, n_rays, n_samples)
+torch.cuda.synchronize()
+t = d_vd.view(-1).view(torch.int64)[:2048 * 64].cpu().numpy().reshape(2048, 64)
+np.save("gpurun_out/trace_dx.npy", t)
+hw = t[:, 63]
+t0 = t[:, 0].min()
+print("blk  xcc hw_id(hex)  start(10ns)  phase durations (10 ns units)")
+for b in list(range(0, 8)) + list(range(256, 264)) + list(range(512, 520)):
+    r = t[b]
+    idx = [0, 1, 2, 3, 4, 5, 6, 7] + list(range(10, 24)) + [40, 41, 42]
+    ts = [int(r[i] - t0) for i in idx]
+    print(b, int(hw[b] >> 32) & 0xf, hex(int(hw[b] & 0xffffffff)), ts[0], [ts[i + 1] - ts[i] for i in range(len(ts) - 1)])
+print("k-step timestamps inside the layer-3 K-loop (10 ns units, relative to the barrier before it)")
+for b in list(range(0, 6)) + list(range(256, 262)) + list(range(1024, 1030)):
+    r = t[b]
+    base = int(r[10 + (7 - 3) * 2 - 1])      # end of layer 4's epilogue barrier
+    ks = [int(r[44 + i]) - base for i in range(16)]
+    print(b, "pre", [int(r[44 + i]) - base for i in (16, 17, 18, 19)], "first", ks[0], "steps", [ks[i + 1] - ks[i] for i in range(15)], "-> barrier", int(r[10 + (7 - 3) * 2]) - int(r[44 + 15]))
+# co-residency: same (xcc, cu/se bits) -> group
+key = (hw >> 32 << 32) | (hw & 0xfff00)      # drop wave/simd id bits
+import collections
+g = collections.defaultdict(list)
+for b in range(512):
+    g[int(key[b])].append(b)
+print("distinct CU keys among first 512 blocks:", len(g), "sizes", collections.Counter(len(v) for v in g.values()))
+print("examples", list(g.values())[:6])
