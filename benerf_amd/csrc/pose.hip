@@ -70,15 +70,20 @@ template <>
 __device__ __forceinline__ Dual lift<Dual>(float x) { return {x, 0.f}; }
 
 // sum_i (-1)^i th^(2i) / prod (2j+a)(2j+a+1)            spline.py:46-62
+// th^(2i) by repeated multiplication with th^2 (the reference's th ** (2i) through pow() differs from it by an ulp of terms
+// that are themselves <= th^2 / 6 of the sum; powf made this series, evaluated 8 times per pose, the whole cost of K1)
 template <class T>
 __device__ T taylor_series(T th, int a) {
     T acc = lift<T>(0.f);
+    const T th2 = th * th;
+    T pw = lift<T>(1.f);
     double denom = 1.0;
 #pragma unroll
     for (int i = 0; i <= 10; ++i) {
         denom *= (double)((2 * i + a) * (2 * i + a + 1));
-        T term = t_powi(th, 2 * i) / (float)denom;
+        T term = pw / (float)denom;
         acc = (i & 1) ? acc - term : acc + term;
+        pw = pw * th2;
     }
     return acc;
 }
@@ -197,10 +202,18 @@ __device__ __forceinline__ float nudge(float u) {   // spline.py:249-252
 // b_i = sum_{k>=i} B_k.  The reference's bezier.py:22-74 is an unfinished draft of this (it indexes a size-1 dimension and
 // raises IndexError on every call, and would use B_1 for all three increments); this is its evident intent.
 template <bool BEZIER, class T>
+__device__ void cubic_from_qt(const T q[4][4], const T t[4][3], float u, T out[12]);
+template <bool BEZIER, class T>
 __device__ void cubic_pose(const T k[4][6], float u, T out[12]) {
     T q[4][4], t[4][3];
 #pragma unroll
     for (int i = 0; i < 4; ++i) se3_to_qt(k[i], q[i], t[i]);
+    cubic_from_qt<BEZIER>(q, t, u, out);
+}
+// the part of the curve evaluation that depends on the query time (the knots' (q, t) do not: the backward evaluates
+// them once per launch, not once per pose and tangent)
+template <bool BEZIER, class T>
+__device__ void cubic_from_qt(const T q[4][4], const T t[4][3], float u, T out[12]) {
     float uu = u * u, uuu = u * u * u;
     const float sixth = 1.0f / 6.0f, half = 0.5f;
     float c0, c1, c2, c3, r1, r2, r3;
@@ -249,10 +262,16 @@ __device__ void cubic_pose(const T k[4][6], float u, T out[12]) {
 }
 
 template <class T>
+__device__ void linear_from_qt(const T qs[4], const T ts[3], const T qe[4], const T te[3], float u, T out[12]);
+template <class T>
 __device__ void linear_pose(const T k0[6], const T k3[6], float u, T out[12]) {   // spline.py:305-331
     T qs[4], ts[3], qe[4], te[3];
     se3_to_qt(k0, qs, ts);
     se3_to_qt(k3, qe, te);
+    linear_from_qt(qs, ts, qe, te, u, out);
+}
+template <class T>
+__device__ void linear_from_qt(const T qs[4], const T ts[3], const T qe[4], const T te[3], float u, T out[12]) {
     T tr[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) tr[i] = (1.0f - u) * ts[i] + u * te[i];
@@ -294,22 +313,46 @@ __device__ __forceinline__ void spline_bwd_body(const float* __restrict__ knots,
                                                 const float* __restrict__ ts2, int n_poses, int traj, int explicit_ts,
                                                 const float* __restrict__ d_poses, float* __restrict__ d_knots,
                                                 float* __restrict__ d_transform, float* contrib) {
+    // phase A: (q, t) of knot j/6 with the tangent of coefficient j - independent of the pose, 24 threads
+    float* qt_v = contrib + n_poses * 24;      // [4][7] values
+    float* qt_d = qt_v + 28;                   // [24][7] tangents
+    if (threadIdx.x < 24) {
+        const int j = threadIdx.x, i = j / 6;
+        Dual wu[6], q[4], t[3];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) wu[c] = Dual{knots[i * 6 + c] + (transform ? transform[c] : 0.f), (c == j % 6) ? 1.f : 0.f};
+        se3_to_qt(wu, q, t);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) qt_d[j * 7 + c] = q[c].d;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) qt_d[j * 7 + 4 + c] = t[c].d;
+        if (j % 6 == 0) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) qt_v[i * 7 + c] = q[c].v;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) qt_v[i * 7 + 4 + c] = t[c].v;
+        }
+    }
+    __syncthreads();
     for (int w = threadIdx.x; w < n_poses * 24; w += blockDim.x) {
         int p = w / 24, j = w % 24;
-        Dual k[4][6];
+        Dual q[4][4], t[4][3];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
+            const bool mine = (i == j / 6);
 #pragma unroll
-            for (int c = 0; c < 6; ++c)
-                k[i][c] = Dual{knots[i * 6 + c] + (transform ? transform[c] : 0.f), (i * 6 + c == j) ? 1.f : 0.f};
+            for (int c = 0; c < 4; ++c) q[i][c] = Dual{qt_v[i * 7 + c], mine ? qt_d[j * 7 + c] : 0.f};
+#pragma unroll
+            for (int c = 0; c < 3; ++c) t[i][c] = Dual{qt_v[i * 7 + 4 + c], mine ? qt_d[j * 7 + 4 + c] : 0.f};
+        }
         float u = nudge(explicit_ts ? ts2[p] : linspace_at(ts2[0], ts2[1], n_poses, p));
         Dual out[12];
         if (traj == 1)
-            linear_pose(k[0], k[3], u, out);
+            linear_from_qt(q[0], t[0], q[3], t[3], u, out);
         else if (traj == 2)
-            cubic_pose<true>(k, u, out);
+            cubic_from_qt<true>(q, t, u, out);
         else
-            cubic_pose<false>(k, u, out);
+            cubic_from_qt<false>(q, t, u, out);
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < 12; ++i) s += d_poses[p * 12 + i] * out[i].d;
@@ -440,7 +483,7 @@ extern "C" int benerf_spline_poses_bwd(const float* knots, const float* transfor
                                        float* d_transform, benerf_stream_t stream) {
     BENERF_REQUIRE(knots && ts2 && d_poses && d_knots, "spline_poses_bwd: null pointer");
     BENERF_REQUIRE(n_poses > 0 && n_poses <= 512 && (traj >= 0 && traj <= 2), "spline_poses_bwd: n_poses must be in [1,512]");
-    size_t smem = (size_t)n_poses * 24 * sizeof(float);
+    size_t smem = ((size_t)n_poses * 24 + 28 + 24 * 7) * sizeof(float);
     // one (pose, tangent) evaluation per thread where possible: the dual-number evaluation is a long serial
     // chain, so width beats depth (19 poses x 24 tangents = 456 threads in one block)
     int threads = ((n_poses * 24 + 63) / 64) * 64;
@@ -466,7 +509,7 @@ extern "C" int benerf_spline_poses_bwd_pair(const float* knots, const float* tra
     p.d_poses[0] = d_poses_a; p.d_poses[1] = d_poses_b;
     p.d_knots[0] = d_knots_a; p.d_knots[1] = d_knots_b;
     p.n_poses[0] = n_a; p.n_poses[1] = n_b;
-    hipLaunchKernelGGL(spline_bwd_pair_kernel, dim3(2), dim3(threads), (size_t)n_max * 24 * sizeof(float), as_stream(stream), knots,
+    hipLaunchKernelGGL(spline_bwd_pair_kernel, dim3(2), dim3(threads), ((size_t)n_max * 24 + 28 + 24 * 7) * sizeof(float), as_stream(stream), knots,
                        transform_b, p, traj, d_transform_b);
     BENERF_LAUNCH_CHECK("spline_poses_bwd_pair");
     return BENERF_OK;
