@@ -21,10 +21,9 @@
 // stays in accumulator registers from layer 5 to the end.
 #include "mlp_split.h"
 
-#ifndef ABL
-#define ABL 0
-#endif
-#if (ABL & 0x10000)
+// -DBENERF_TRACE_DX: wave 0 of the first 2048 workgroups stamps the 100 MHz wall clock at every barrier into the d_viewdirs
+// output (which is then not written) - tools/experiments/trace_dx.py decodes the per-phase durations behind DESIGN.md 4.
+#ifdef BENERF_TRACE_DX
 #define TR(i) do { if (tid == 0 && blockIdx.x < 2048) reinterpret_cast<unsigned long long*>(a.d_vdir)[blockIdx.x * 64 + (i)] = wall_clock64(); } while (0)
 #else
 #define TR(i) do { } while (0)
@@ -33,7 +32,7 @@ namespace {
 using namespace mlp;
 
 constexpr int TMB = 128;                                          // points per workgroup
-constexpr size_t BWD_SMEM = (size_t)TMB * LD * sizeof(_Float16) + ((ABL & 16) ? 2048 : 0);  // 81 920 B
+constexpr size_t BWD_SMEM = (size_t)TMB * LD * sizeof(_Float16);  // 81 920 B
 static_assert(TMB == SM_PAD, "the padded point count is a whole number of dX tiles");
 
 struct BwdArgs {
@@ -81,7 +80,6 @@ struct WFrag {
     // fragment of column tile t (wave-uniform), k-step ks of a block with KS k-steps; plane 0 = hi, 1 = lo (unscaled)
     __device__ __forceinline__ u32x4 load(int t_uniform, int ks, int KS, int plane) const {
         int soff = (((t_uniform >> 1) * KS + ks) * 2 + (t_uniform & 1)) * 2048 + plane * 1024;
-        if (ABL & 0x80000) soff &= 0x3fff;
         return __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
     }
 };
@@ -113,7 +111,6 @@ struct WRing { u32x4 q[PF + 1][NCT][2]; };
 // would not be usable before every one of those stores is acknowledged.
 template <int KS, int NCT, int PF>
 __device__ __forceinline__ void gemm16_head(const float* __restrict__ wp, int ct0, int lane, WRing<NCT, PF>& r) {
-    if (ABL & 8) return;
     const WFrag wf(wp, lane);
     const int ct0u = __builtin_amdgcn_readfirstlane(ct0);
 #pragma unroll
@@ -132,7 +129,6 @@ __device__ __forceinline__ void gemm16_body(const _Float16* __restrict__ T, cons
                                             WRing<NCT, PF>& r, f32x16 (&acc)[4][NCT]) {
     lane = stage_local(lane);
     const int row = lane & 31, lh = lane >> 5;
-    if (ABL & 8) return;
     const int sw = hsw(row);                        // rows row + 32 * rt share the swizzle
     const int rbase = row * LD;
     const WFrag wf(wp, lane);
@@ -251,8 +247,6 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[4][2], const uint64_t (&b
                                          const _Float16* __restrict__ st_tile, float gf, float& amax) {
     lane = stage_local(lane);
     const int lr = lane & 31, r4 = 4 * (lane >> 5);
-    if (ABL & 4) { if (gf == 123.f) { float t = 0.f; for (int r = 0; r < 4; ++r) for (int c = 0; c < 2; ++c) for (int e = 0; e < 16; ++e) t += acc[r][c][e]; T[lane] = (_Float16)t; } return; }
-    if (ABL & 0x40000) __builtin_amdgcn_s_setprio(1);
     const __amdgpu_buffer_rsrc_t st_rsrc = uniform_rsrc(st_tile);     // this tile's 16 blocks of the SH array (64 KiB)
     const _Float16 gh = (_Float16)gf;             // a power of two (or 0 below 2^-24: such a tile's gradients are below f16 anyway)
     const half2v g2 = {gh, gh};
@@ -310,7 +304,6 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[4][2], const uint64_t (&b
                 __builtin_amdgcn_raw_buffer_store_b128(o, st_rsrc, st_lane + (rt * 4 + ep * 2) * 256 * 8 * 2, 0, 0);
             }
     }
-    if (ABL & 0x40000) __builtin_amdgcn_s_setprio(0);
 }
 
 template <int C>
@@ -346,15 +339,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_f16_kernel(BwdArgs a) {
     if (a.status && blockIdx.x == 0 && tid == 0 && reinterpret_cast<const uint32_t*>(acts + sact_info(Mp))[SI_TAG] != SACT_TAG_SPLIT)
         a.status[2] = 1u;
     TR(0);
-#if (ABL & 0x10000)
+#ifdef BENERF_TRACE_DX
     if (tid == 0 && blockIdx.x < 2048) { unsigned hw, xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); reinterpret_cast<unsigned long long*>(a.d_vdir)[blockIdx.x * 64 + 63] = ((unsigned long long)xcc << 32) | hw; }
 #endif
     float amax = 0.f;          // max |tile-scaled gradient| of this thread before its f16 rounding (range guard)
-#if (ABL & 0xff00)
-    if (blockIdx.x >= 256 && blockIdx.x < 512) {
-        for (int i = 0; i < ((ABL >> 8) & 0xff); ++i) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
 
     // ---- P0: d_raw tile, its power-of-two scale, scaled values -> scratch floats [28, 28+C] of each row ------
     float dr0[C + 1];
@@ -449,7 +437,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_f16_kernel(BwdArgs a) {
                 const float ws = a.pe_w ? a.pe_w[64 + es] : 1.f, wc = a.pe_w ? a.pe_w[64 + ec] : 1.f;
                 sv += (float)(1 << f) * (cs * (ws * *fscr1(T, tid, es)) - sn * (wc * *fscr1(T, tid, ec)));
             }
-            if (!(ABL & 0x10000)) a.d_vdir[m * 3 + d] = sv * inv_s;
+#ifndef BENERF_TRACE_DX
+            a.d_vdir[m * 3 + d] = sv * inv_s;
+#endif
         }
     }
     load_bits(7, bits);
@@ -476,15 +466,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_f16_kernel(BwdArgs a) {
     // sign bits of the stage after (from HBM: a whole epilogue + K-loop of cover) and the first weight fragments.
     uint64_t bits_n[2];
     WRing<2, 2> ring;
-#if (ABL & 0x1000000)
-    epilogue<true>(acc, bits, T, ct0, lane, st_tile(7), gf, amax);
-    load_bits(6, bits_n);
-    gemm16_head<16, 2, 2>(packed_h + pack_offset(PB_L7), ct0, lane, ring);
-#else
     load_bits(6, bits_n);
     gemm16_head<16, 2, 2>(packed_h + pack_offset(PB_L7), ct0, lane, ring);
     epilogue<true>(acc, bits, T, ct0, lane, st_tile(7), gf, amax);
-#endif
     lds_barrier(); TR(7);
 
     // ---- P4: L7 .. L1: dY_l x W_l, mask h_{l-1} -> dY_{l-1} ----------------------------------------------
@@ -530,28 +514,47 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_f16_kernel(BwdArgs a) {
     }
 
     // ---- P5: L0^T: dPE += dY0 x W0 -----------------------------------------------------------------------
+    // The tile's saved PE rows (f32 [128][64] = 32 KiB, contiguous: the arrays cover all Mp rows) are requested here as
+    // coalesced 16-byte loads, so that their HBM round trip hides under the L0 GEMM; P6 reads them from LDS.
+    float4 per[8];
+    {
+        const float4* pe_tile = reinterpret_cast<const float4*>(acts + sact_pe32(Mp) + m0 * ACT_PE_W);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) per[k] = pe_tile[tid + k * NTHREADS];
+    }
     f32x16 dpe[2];
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int e = 0; e < 16; ++e) dpe[c][e] = (float)T[hidx(wave * 32 + acc_row(e, lane), 256 + c * 32 + (lane & 31))];
     gemm_row<16, 2>(T, packed_h + pack_offset(PB_L0), 0, wave, lane, dpe);
-    lds_barrier(); TR(40);      // every wave is done reading dY0: the plane becomes f32 scratch [128][64] (row stride LD halfs)
+    lds_barrier(); TR(40);      // every wave is done reading dY0: the plane becomes f32 scratch, 133 floats per point:
+    // [0,64) dPE, [64,68) the odd-frequency partial sums, [68,132) PE.  The odd row stride keeps P6's per-point walks
+    // (lane = point, same column) free of bank conflicts.
     float* F = reinterpret_cast<float*>(T);
-    constexpr int FLD = LD / 2;                                   // row stride in floats
+    constexpr int FLD = 133;
+    static_assert((size_t)TMB * FLD * sizeof(float) <= BWD_SMEM, "P6 scratch fits the plane");
 #pragma unroll
     for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int e = 0; e < 16; ++e) F[(wave * 32 + acc_row(e, lane)) * FLD + c * 32 + (lane & 31)] = dpe[c][e];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int u = tid + k * NTHREADS;                         // float4 u of the tile: point u / 16, floats 4 (u % 16) ..
+        float* dst = F + (u >> 4) * FLD + 68 + (u & 15) * 4;
+        dst[0] = per[k].x;
+        dst[1] = per[k].y;
+        dst[2] = per[k].z;
+        dst[3] = per[k].w;
+    }
     lds_barrier(); TR(41);
 
     // ---- P6: dPE -> d_pts through the saved PE values; two threads per point (even / odd frequencies) ------------
     {
         const int pt = tid & (TMB - 1), g = tid >> 7;
         const int64_t m = m0 + pt;
-        const int64_t mc = m < M ? m : M - 1;
-        const float* pe = acts + sact_pe32(Mp) + mc * ACT_PE_W;
         const float* dp = F + pt * FLD;
+        const float* pe = dp + 68;
         float sp[3] = {0.f, 0.f, 0.f};
         if (g == 0) {
 #pragma unroll

@@ -278,9 +278,18 @@ __device__ __forceinline__ float sum_splits_t(const float* ws, int inst, int64_t
     const float* p = ws + (SPLIT ? dwh_inst_offset(inst) : dw_inst_offset(inst)) + elem;
     const int64_t stride = dw_inst_floats(inst);
     const int n = SPLIT ? dwh_splits(inst) : dw_splits(inst);
+    // fixed summation order (run-to-run reproducible); eight loads in flight per step - the partial sums were just
+    // written and sit in L2 / MALL, so this kernel is bound by the length of its dependent load chains
     float s = 0.f;
-#pragma unroll 4
-    for (int sp = 0; sp < n; ++sp) s += p[sp * stride];
+    int sp = 0;
+    for (; sp + 8 <= n; sp += 8) {
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = p[(sp + i) * stride];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += v[i];
+    }
+    for (; sp < n; ++sp) s += p[sp * stride];
     return s;
 }
 // split mode: weight blocks and bias sums carry the gradient scale s_s of the call (mlp_split.h, pow2_scale6); the
@@ -364,8 +373,8 @@ int benerf_mlp_dw_reduce_launch(const float* ws, const BenerfMlpGrads* grads, in
     r.split_mode = split_mode;
     r.grad_info = grad_info;
     r.pe_w = pe_weights;
-    if (split_mode) hipLaunchKernelGGL(dw_reduce_kernel<true>, dim3(64, BENERF_NLAYERS), dim3(256), 0, stream, r);
-    else hipLaunchKernelGGL(dw_reduce_kernel<false>, dim3(64, BENERF_NLAYERS), dim3(256), 0, stream, r);
+    if (split_mode) hipLaunchKernelGGL(dw_reduce_kernel<true>, dim3(128, BENERF_NLAYERS), dim3(256), 0, stream, r);
+    else hipLaunchKernelGGL(dw_reduce_kernel<false>, dim3(128, BENERF_NLAYERS), dim3(256), 0, stream, r);
     BENERF_LAUNCH_CHECK("mlp_bwd(reduce)");
     return BENERF_OK;
 }
