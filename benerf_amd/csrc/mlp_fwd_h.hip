@@ -104,7 +104,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_split_kernel(FwdArgs a) {
     const int grp = tid >> 6;
     const int64_t m = m0 + pt;
     const int64_t mc = m < M ? m : M - 1;
-    const int64_t ray = mc / a.S;
+    const int64_t ray = (int64_t)((uint32_t)mc / (uint32_t)a.S);      // M < 2^31 (launcher): a 32-bit division
     float* acts = a.acts;
     const int64_t Mp = m_pad(M);
     _Float16* st_h = SAVE ? reinterpret_cast<_Float16*>(acts + sact_h(Mp, 0)) : nullptr;     // layer l: + l * Mp * 256 halfs
@@ -124,10 +124,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_split_kernel(FwdArgs a) {
         float x[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) x[c] = __fadd_rn(a.rays_o[ray * 3 + c], __fmul_rn(a.rays_d[ray * 3 + c], zz));
-        // training: PE as f32 rows (sin/cos derivatives in dX; dW operand of the thin instances), all Mp rows
-        float* ape = SAVE ? acts + sact_pe32(Mp) + m * ACT_PE_W : nullptr;
+        // training: PE as f32 rows (sin/cos derivatives in dX; dW operand of the thin instances), all Mp rows.  Staged in
+        // the still unused columns [0,128) of this point's hi-plane row and written out below as whole 16-byte units
+        // (a 4-byte store per thread and column touches 64 cache lines per instruction); the columns are rotated by
+        // 4 * point so that the 64 lanes of a staging write do not all hit one bank.
+        float* stage = reinterpret_cast<float*>(Th) + pt * (LD / 2);
         auto put = [&](int col, float v) {
-            if (SAVE) ape[col] = v;                                  // saved UNWEIGHTED (dX needs sin / cos themselves)
+            if (SAVE) stage[(col + 4 * pt) & 63] = v;                // saved UNWEIGHTED (dX needs sin / cos themselves)
             if (a.pe_w) v *= a.pe_w[col];
             const _Float16 hi = (_Float16)v;
             const _Float16 lo = (_Float16)((v - (float)hi) * LO_SCALE);
@@ -153,6 +156,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_split_kernel(FwdArgs a) {
         }
     }
     lds_barrier();
+    if (SAVE) {
+        float4* pe_tile = reinterpret_cast<float4*>(acts + sact_pe32(Mp) + m0 * ACT_PE_W);
+#pragma unroll
+        for (int k = 0; k < TM * ACT_PE_W / 4 / NTHREADS; ++k) {
+            const int u = tid + k * NTHREADS, row = u >> 4, c4 = u & 15;
+            pe_tile[u] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(Th) + row * (LD / 2) + ((4 * c4 + 4 * row) & 63));
+        }
+        lds_barrier();          // the staging columns are layer 0's output columns
+    }
 
     f32x16 acc1[2][2], acc2[2][2];
     const int ct0 = wave * 2;
@@ -325,7 +337,7 @@ int benerf_mlp_fwd_split_launch(const BenerfMlpParams* params, const float* pack
     a.S = n_samples;
     // training launches cover the padded point range (whole 128-point dX tiles), inference the live tiles only
     const int64_t tiles = acts ? mlp::sn_tiles(a.M) : (a.M + mlp::TM - 1) / mlp::TM;
-    BENERF_REQUIRE(tiles < (1ll << 31), "mlp_fwd(split): too many points");
+    BENERF_REQUIRE(tiles < (1ll << 31) && a.M < (1ll << 31), "mlp_fwd(split): too many points");
     dim3 grid((unsigned)tiles), block(mlp::NTHREADS);
     const int smem = (int)mlp::TILE_SMEM;
 #define BENERF_FWD_LAUNCH(CH, SV)                                                                                        \
