@@ -376,8 +376,12 @@ def main():
                 "frac": kern[dom]["frac_of_mfma_peak"], "frac_executed": kern[dom]["frac_executed"],
                 "traffic": traffic_of(dom), "avg_launch_ms": kern[dom]["avg_ms"],
                 "flops_per_point": fpp, "points_per_launch": kern[dom]["points_per_launch"],
-                "peak_note": "dense %s MFMA peak at 2.4 GHz; under this load the chip sustains 1.5-1.7 GHz (power), "
-                             "tools/hwprobe/kloop_bound.hip" % ("f16" if split else "f32"),
+                "peak_note": "dense %s MFMA peak at 2.4 GHz (the isolated K-loop runs at the pipe's pace and 1.5-1.7 GHz, "
+                             "tools/hwprobe/kloop_bound.hip; the fused kernels are bound by the serial phases of a tile, "
+                             "DESIGN.md 4)" % ("f16" if split else "f32"),
+                "per_kernel_note": "mlp_bwd_dw launches run on a second stream beside mlp_bwd_dx of the other network "
+                                   "(engine.TrainStep): the HIP-event durations of these two include that time slicing; "
+                                   "mlp_fwd, the dominant kernel, runs alone",
                 "per_kernel": kern}
         if pmc:
             roof["traffic_source"] = pmc_src

@@ -1,4 +1,11 @@
-"""Decodes the phase timestamps a tracing build of the dX kernel (-DABL=0x10000) leaves in its d_viewdirs output."""
+"""Decodes the phase timestamps a tracing build of the dX kernel leaves in its d_viewdirs output.
+
+  hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DBENERF_TRACE_DX -c benerf_amd/csrc/mlp_bwd_h.hip -o /tmp/bwd_tr.o
+  hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/libtr.so $(ls benerf_amd/csrc/*.o | grep -v mlp_bwd_h.o) /tmp/bwd_tr.o
+  BENERF_HIP_LIB=/tmp/libtr.so python tools/experiments/trace_dx.py        # on an MI355X
+
+Columns: P0a, P0b, P1 (rgb head), P2 GEMM, P2 epilogue, P3 GEMM, P3 epilogue, then K-loop / epilogue of layers 7..1
+(the layer-5 entry includes the skip connection's row GEMM), P5 (L0 row GEMM, scratch fill), P6; units of 10 ns."""
 import os, sys
 import numpy as np
 import torch
@@ -30,12 +37,6 @@ for b in list(range(0, 8)) + list(range(256, 264)) + list(range(512, 520)):
     idx = [0, 1, 2, 3, 4, 5, 6, 7] + list(range(10, 24)) + [40, 41, 42]
     ts = [int(r[i] - t0) for i in idx]
     print(b, int(hw[b] >> 32) & 0xf, hex(int(hw[b] & 0xffffffff)), ts[0], [ts[i + 1] - ts[i] for i in range(len(ts) - 1)])
-print("k-step timestamps inside the layer-3 K-loop (10 ns units, relative to the barrier before it)")
-for b in list(range(0, 6)) + list(range(256, 262)) + list(range(1024, 1030)):
-    r = t[b]
-    base = int(r[10 + (7 - 3) * 2 - 1])      # end of layer 4's epilogue barrier
-    ks = [int(r[44 + i]) - base for i in range(16)]
-    print(b, "pre", [int(r[44 + i]) - base for i in (16, 17, 18, 19)], "first", ks[0], "steps", [ks[i + 1] - ks[i] for i in range(15)], "-> barrier", int(r[10 + (7 - 3) * 2]) - int(r[44 + 15]))
 # co-residency: same (xcc, cu/se bits) -> group
 key = (hw >> 32 << 32) | (hw & 0xfff00)      # drop wave/simd id bits
 import collections

@@ -91,7 +91,7 @@ def main():
             dur[c].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
     out = {"note": "FETCH_SIZE / WRITE_SIZE are rocprofv3 KB units; on gfx950 FETCH_SIZE counts 64 B per 128-B request for "
                    "wide coalesced streaming reads (MI355X_MICROARCH.md, HBM) => fetch_bytes_corrected = 2 x FETCH_SIZE x 1024. "
-                   "Launches alternate coarse (M = 261 184 points) / fine (M = 783 552 points); per-launch averages over both. "
+                   "Launches alternate coarse (M = 261 184 points) / fine (M = 522 368 points); per-launch averages over both. "
                    "A group's figures are sums over its kernels ('parts').",
            "kernels": {}}
     pm = collections.defaultdict(lambda: collections.defaultdict(list))
