@@ -46,12 +46,17 @@ __device__ __forceinline__ uint64_t epilogue(f32x16 (&acc1)[2][NCT], f32x16 (&ac
                                              _Float16* __restrict__ st, int64_t m0, float& amax) {
     const int lr = lane & 31, r4 = 4 * (lane >> 5);
     uint64_t bits = 0;
+    // all bias values first: a load issued behind the first column tile's activation stores would wait for their
+    // acknowledgement (vector-memory operations retire in order)
+    float bvs[NCT];
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) bvs[c] = bias[(ct0 + c) * 32 + lr];
     // row = R(r,e) + r4 with R = r*32 + (e&3) + 8*(e>>2): its swizzle hsw(row) = e1 | r4bit<<1 | e2<<2, so every
     // LDS store address is one of 4 lane-dependent bases per column tile plus a compile-time row offset.
 #pragma unroll
     for (int c = 0; c < NCT; ++c) {
         const int n = (ct0 + c) * 32 + lr;
-        const float bv = bias[n];
+        const float bv = bvs[c];
         const int ns = (n >> 3) ^ ((lane >> 5) << 1);
         int base[4];
 #pragma unroll

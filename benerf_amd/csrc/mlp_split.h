@@ -19,10 +19,13 @@ __device__ __forceinline__ f32x16 mfma16(half8 a, half8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
+#ifndef FWD_PF
+#define FWD_PF 2
+#endif
 // acc1 += hi x hi ; acc2 += hi x lo + lo x hi   over T[:, kcol0 .. kcol0 + KS*16) and packed tile ct0+c.
 // Weight fragments stream from L2 PF k-steps ahead (a k-step is only 12 MFMAs = 384 cycles, less than an L2 round
 // trip under load); the loop is fully unrolled so the PF+1 register sets rotate at compile time.
-template <int KS, int NCT, int PF = 2>
+template <int KS, int NCT, int PF = FWD_PF>
 __device__ __forceinline__ void gemm_stage(const _Float16* __restrict__ Th, const _Float16* __restrict__ Tl, int kcol0,
                                            const float* __restrict__ wp, int ct0, int lane, f32x16 (&acc1)[2][NCT],
                                            f32x16 (&acc2)[2][NCT]) {
@@ -59,18 +62,17 @@ __device__ __forceinline__ void gemm_stage(const _Float16* __restrict__ Th, cons
     int abase[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) abase[j] = rbase + (((2 * j + lh) ^ sw) << 3);
-    half8 an[2][2];                                  // A fragments (hi, lo) x (row tile) of the NEXT k-step
-    auto load_a = [&](int ks) {
-        const int off = abase[ks & 3] + ((slot0 + ((2 * ks) & ~7)) << 3);
-        an[0][0] = *reinterpret_cast<const half8*>(Th + off);
-        an[0][1] = *reinterpret_cast<const half8*>(Th + off + 32 * LD);
-        an[1][0] = *reinterpret_cast<const half8*>(Tl + off);
-        an[1][1] = *reinterpret_cast<const half8*>(Tl + off + 32 * LD);
-    };
-    load_a(0);
+    // ONE set of activation fragments (hi / lo x row tile): the MFMAs of a fragment are consecutive and its successor is
+    // requested right behind them; the other fragments' MFMAs (>= 8 x 32 cycles) cover the LDS round trip.  The
+    // registers this saves go to a deeper weight-fragment ring (PF).
+    half8 ah[2], al[2];
+    auto a_off = [&](int ks) { return abase[ks & 3] + ((slot0 + ((2 * ks) & ~7)) << 3); };
+    ah[0] = *reinterpret_cast<const half8*>(Th + a_off(0));
+    ah[1] = *reinterpret_cast<const half8*>(Th + a_off(0) + 32 * LD);
+    al[0] = *reinterpret_cast<const half8*>(Tl + a_off(0));
+    al[1] = *reinterpret_cast<const half8*>(Tl + a_off(0) + 32 * LD);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-        half8 ah[2] = {an[0][0], an[0][1]}, al[2] = {an[1][0], an[1][1]};
         if (ks + PF < KS) {
 #pragma unroll
             for (int c = 0; c < NCT; ++c) {
@@ -78,7 +80,6 @@ __device__ __forceinline__ void gemm_stage(const _Float16* __restrict__ Th, cons
                 bq[(ks + PF) % (PF + 1)][c][1] = load_b(c, ks + PF, 1);
             }
         }
-        if (ks + 1 < KS) load_a(ks + 1);
         half8 bh[NCT], bl[NCT];
 #pragma unroll
         for (int c = 0; c < NCT; ++c) {
@@ -86,17 +87,19 @@ __device__ __forceinline__ void gemm_stage(const _Float16* __restrict__ Th, cons
             bl[c] = __builtin_bit_cast(half8, bq[ks % (PF + 1)][c][1]);
         }
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
+        for (int r = 0; r < 2; ++r) {
 #pragma unroll
             for (int c = 0; c < NCT; ++c) acc1[r][c] = mfma16(ah[r], bh[c], acc1[r][c]);
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
-#pragma unroll
             for (int c = 0; c < NCT; ++c) acc2[r][c] = mfma16(ah[r], bl[c], acc2[r][c]);
+            if (ks + 1 < KS) ah[r] = *reinterpret_cast<const half8*>(Th + a_off(ks + 1) + r * 32 * LD);
+        }
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
+        for (int r = 0; r < 2; ++r) {
 #pragma unroll
             for (int c = 0; c < NCT; ++c) acc2[r][c] = mfma16(al[r], bh[c], acc2[r][c]);
+            if (ks + 1 < KS) al[r] = *reinterpret_cast<const half8*>(Tl + a_off(ks + 1) + r * 32 * LD);
+        }
         __builtin_amdgcn_sched_barrier(0);          // one k-step per scheduling region: keeps the prefetch distances as written
     }
 }
