@@ -80,20 +80,33 @@ def sample_pdf(bins, weights, N_samples, det=False, pytest=False):
     return s.view(lead + [N_samples])
 
 
+def _device_frames(iter_step, graph, render_poses, H, W, K_, args, remap):
+    """One full-image render per pose (Graph.render_video, chunked K2-K5 launches), tone-mapped when the colour CRF is
+    trained; yields (index, rgb [H,W,C], disparity [H,W]) as DEVICE tensors - the callers convert once, on the device."""
+    for index, pose in enumerate(tqdm(render_poses)):
+        out = graph.render_video(iter_step, pose[None, :3, :4], H, W, K_, args, remap, type="rgb")
+        rgb = graph.rgb_crf.forward(out["rgb_map"]) if args.optimize_rgb_crf else out["rgb_map"]
+        yield index, rgb, out["disp_map"]
+
+
+def _quantise(t):
+    """utils/img_utils.to8bit on the device: 255 * clip(x, 0, 1), truncated to uint8."""
+    return (t.clamp(0.0, 1.0) * 255.0).to(torch.uint8)
+
+
 @torch.no_grad()
 def render_video_test(iter_step, graph, render_poses, H, W, K_, args, remap):
-    """(run_nerf_helpers.py:117-140) -> (rgbs [n,H,W,C], disps [n,H,W]) numpy."""
-    rgbs, disps = [], []
-    for i, pose in enumerate(tqdm(render_poses)):
-        pose = pose[None, :3, :4]
-        ret = graph.render_video(iter_step, pose[:3, :4], H, W, K_, args, remap, type="rgb")
-        if args.optimize_rgb_crf:
-            ret["rgb_map"] = graph.rgb_crf.forward(ret["rgb_map"])
-        rgbs.append(ret["rgb_map"].cpu().numpy())
-        disps.append(ret["disp_map"].cpu().numpy())
-        if i == 0:
-            print(ret["rgb_map"].shape, ret["disp_map"].shape)
-    return np.stack(rgbs, 0), np.stack(disps, 0)
+    """(run_nerf_helpers.py:117-140) -> (rgbs [n,H,W,C], disps [n,H,W]) float32 numpy; the frames are collected in two
+    device buffers and cross PCIe once."""
+    rgb_all = disp_all = None
+    for k, rgb, disp in _device_frames(iter_step, graph, render_poses, H, W, K_, args, remap):
+        if rgb_all is None:
+            n = len(render_poses)
+            rgb_all = torch.empty((n,) + tuple(rgb.shape), dtype=rgb.dtype, device=rgb.device)
+            disp_all = torch.empty((n,) + tuple(disp.shape), dtype=disp.dtype, device=disp.device)
+            print(rgb.shape, disp.shape)        # the reference reports the frame shapes once
+        rgb_all[k], disp_all[k] = rgb, disp
+    return rgb_all.cpu().numpy(), disp_all.cpu().numpy()
 
 
 def _imwrite(path, img, mode):
@@ -104,26 +117,23 @@ def _imwrite(path, img, mode):
         np.save(os.path.splitext(path)[0] + ".npy", img)
 
 
+@torch.no_grad()
 def render_image_test(iter_step, graph, render_poses, H, W, K_, args, logdir, remap, dir=None, need_depth=True):
-    """(run_nerf_helpers.py:142-171) -> (imgs, depth) lists of uint8 arrays; PNGs under
-    logdir/dir/img_test_{iter:06d}/."""
-    img_dir = os.path.join(logdir, dir, "img_test_{:06d}".format(iter_step))
-    os.makedirs(img_dir, exist_ok=True)
+    """(run_nerf_helpers.py:142-171) -> (imgs, depth) lists of uint8 arrays; PNGs under logdir/dir/img_test_{iter:06d}/
+    with the reference's file names (frames: dir[11:] + index, depth maps: depth_ + index).  8-bit conversion and the
+    per-frame disparity normalisation run on the device; only bytes are copied back."""
+    target = os.path.join(logdir, dir, "img_test_{:06d}".format(iter_step))
+    os.makedirs(target, exist_ok=True)
+    colour_mode = "L" if args.channels == 1 else "RGB"
     imgs, depth = [], []
-    for j, pose in enumerate(tqdm(render_poses)):
-        pose = pose[None, :3, :4]
-        ret = graph.render_video(iter_step, pose[:3, :4], H, W, K_, args, remap, type="rgb")
-        if args.optimize_rgb_crf:
-            ret["rgb_map"] = graph.rgb_crf.forward(ret["rgb_map"])
-        rgb8 = img_utils.to8bit(ret["rgb_map"].cpu().numpy())
-        _imwrite(os.path.join(img_dir, dir[11:] + "{:03d}.png".format(j)), rgb8.squeeze(),
-                 "L" if args.channels == 1 else "RGB")
-        imgs.append(rgb8)
+    for k, rgb, disp in _device_frames(iter_step, graph, render_poses, H, W, K_, args, remap):
+        frame = _quantise(rgb).cpu().numpy()
+        _imwrite(os.path.join(target, "{}{:03d}.png".format(dir[11:], k)), frame.squeeze(), colour_mode)
+        imgs.append(frame)
         if need_depth:
-            depths = ret["disp_map"].cpu().numpy()
-            depth8 = img_utils.to8bit(depths / np.max(depths))
-            _imwrite(os.path.join(img_dir, "depth_{:03d}.png".format(j)), depth8, "L")
-            depth.append(depth8)
+            dmap = _quantise(disp / disp.max()).cpu().numpy()
+            _imwrite(os.path.join(target, "depth_{:03d}.png".format(k)), dmap, "L")
+            depth.append(dmap)
     return imgs, depth
 
 

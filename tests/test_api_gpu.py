@@ -134,7 +134,13 @@ def test_render_video_and_image_test(tmp_path):
                                       need_depth=True)
     assert len(imgs) == 3 and imgs[0].dtype == np.uint8 and imgs[0].shape == (Hh, Ww, 1) and len(depth) == 3
     rgbs, disps = H.render_video_test(5, g, poses, Hh, Ww, K, args, np.array([]))
-    assert rgbs.shape == (3, Hh, Ww, 1) and disps.shape == (3, Hh, Ww)
+    assert rgbs.shape == (3, Hh, Ww, 1) and disps.shape == (3, Hh, Ww) and rgbs.dtype == np.float32
+    # the device-side 8-bit conversion is utils/img_utils.to8bit (255 * clip(x, 0, 1) truncated), bit for bit
+    from benerf_amd.utils import img_utils
+    x = np.concatenate([np.random.default_rng(0).uniform(-0.2, 1.2, 4096), [0.0, 1.0, 1.0 / 255, 254.999 / 255, 0.5]]).astype(np.float32)
+    assert np.array_equal(H._quantise(torch.from_numpy(x).to(DEV)).cpu().numpy(), img_utils.to8bit(x))
+    for d8, d in zip(depth, depth):
+        assert d8.max() == 255            # per-frame disparity normalisation
 
 
 def test_checkpoint_resume_equals_uninterrupted(tmp_path):
