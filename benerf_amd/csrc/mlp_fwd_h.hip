@@ -37,58 +37,110 @@ struct FwdArgs {
     int S;
 };
 
-// combine the two accumulators, bias (+ReLU) -> both LDS planes and, in training mode, the f16 value into the SH
-// activation array `st` of width W (mlp_split.h; m0 = first point of the tile).  Returns the ReLU sign bits in the
-// accumulator-layout convention of mlp_common.h, so the mask words are shared with the f32 kernels.
-template <int NCT, bool RELU, bool SAVE, int W>
-__device__ __forceinline__ uint64_t epilogue(f32x16 (&acc1)[2][NCT], f32x16 (&acc2)[2][NCT], _Float16* __restrict__ Th,
-                                             _Float16* __restrict__ Tl, int ct0, int lane, const float* __restrict__ bias,
-                                             _Float16* __restrict__ st, int64_t m0, float& amax) {
-    const int lr = lane & 31, r4 = 4 * (lane >> 5);
-    uint64_t bits = 0;
-    // all bias values first: a load issued behind the first column tile's activation stores would wait for their
-    // acknowledgement (vector-memory operations retire in order)
-    float bvs[NCT];
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef short short4v __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// buffer descriptor on a wave-uniform base address (mlp_bwd_h.hip)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* p) {
+    const uint64_t wa = reinterpret_cast<uint64_t>(p);
+    const uint64_t wau = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(wa >> 32)) << 32) |
+                         (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)wa);
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(wau), 0, 0x7fffffff, 0x00020000);
+}
+
+// The stage GEMMs run as the TRANSPOSED product (gemm_stage<..., SWAP>: weights as the MFMA A operand): a lane of the
+// accumulator holds ONE point (row r*32 + lane&31 of the tile) and, per column tile, 16 features in four quads of
+// consecutive features 8q + 4*(lane>>5) + 0..3.  The lane pair (l, l+32) therefore holds the 8 consecutive features of a
+// 16-byte plane slot: after one v_permlane32_swap per register pair every lane writes whole slots - 16 ds_write_b128 per
+// wave and stage for both planes instead of 256 two-byte writes.
+// combine the two accumulators, bias (+ReLU) -> both LDS planes (hi, scaled lo).
+template <int NCT, bool RELU>
+__device__ __forceinline__ void epilogue_t(f32x16 (&acc1)[2][NCT], f32x16 (&acc2)[2][NCT], _Float16* __restrict__ Th,
+                                           _Float16* __restrict__ Tl, int ct0, int lane, const float* __restrict__ bias, float& amax) {
+    const int pl = lane & 31, hf = lane >> 5;
+    float4 bq[NCT][4];           // bias of this lane's features, requested before anything is stored
 #pragma unroll
-    for (int c = 0; c < NCT; ++c) bvs[c] = bias[(ct0 + c) * 32 + lr];
-    // row = R(r,e) + r4 with R = r*32 + (e&3) + 8*(e>>2): its swizzle hsw(row) = e1 | r4bit<<1 | e2<<2, so every
-    // LDS store address is one of 4 lane-dependent bases per column tile plus a compile-time row offset.
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bq[c][q] = *reinterpret_cast<const float4*>(bias + (ct0 + c) * 32 + 8 * q + 4 * hf);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int row = r * 32 + pl, sw = hsw(row);
+        _Float16* rowh = Th + row * LD;
+        _Float16* rowl = Tl + row * LD;
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+            uint2 qh[4], ql[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float bv[4] = {bq[c][q].x, bq[c][q].y, bq[c][q].z, bq[c][q].w};
+                uint32_t wh[2], wl[2];
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) {
+                    const int e = q * 4 + jp * 2;
+                    float2v v = {(acc1[r][c][e] + acc2[r][c][e] * LO_INV) + bv[jp * 2],
+                                 (acc1[r][c][e + 1] + acc2[r][c][e + 1] * LO_INV) + bv[jp * 2 + 1]};
+                    if (RELU) {
+                        v[0] = fmaxf(v[0], 0.f);
+                        v[1] = fmaxf(v[1], 0.f);
+                        amax = fmaxf(amax, fmaxf(v[0], v[1]));                              // range guard
+                    } else {
+                        amax = fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1])));
+                    }
+                    const half2v hi = __builtin_convertvector(v, half2v);
+                    const float2v res = (v - __builtin_convertvector(hi, float2v)) * LO_SCALE;
+                    wh[jp] = __builtin_bit_cast(uint32_t, hi);
+                    wl[jp] = __builtin_bit_cast(uint32_t, __builtin_convertvector(res, half2v));
+                }
+                qh[q] = uint2{wh[0], wh[1]};
+                ql[q] = uint2{wl[0], wl[1]};
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {   // lanes 0-31 end up with slot 2i, lanes 32-63 with slot 2i + 1 of the column tile
+                const int slot = (ct0 + c) * 4 + 2 * i + hf;
+                *reinterpret_cast<uint4*>(rowh + ((slot ^ sw) << 3)) = sh_pair_unit(qh[2 * i], qh[2 * i + 1]);
+                *reinterpret_cast<uint4*>(rowl + ((slot ^ sw) << 3)) = sh_pair_unit(ql[2 * i], ql[2 * i + 1]);
+            }
+        }
+    }
+}
+
+// Training mode, after the barrier behind epilogue_t: the finished hi plane -> the SH activation array of width W (tile part
+// at `st_tile`) and the ReLU sign-bit word.  ds_read_b64_tr_b16 (tools/hwprobe/tr_read.hip: within a 16-lane group lane t
+// supplies the address of row t >> 2, halfs 4 (t & 3) .. +3 of a 4 x 16 block and receives column t) hands lane l the 4
+// points 4 (l >> 5) .. +3 of an 8-point block for feature l & 31 of the column tile: the lane pair (l, l + 32) again
+// holds one 16-byte SH unit, and the layout of the sign bits is the one the dX kernel reads: bit c*32 + b*4 + j =
+// point 8b + 4 (l >> 5) + j of column tile c (the accumulator layout of the un-transposed product, mlp_common.h).
+template <int NCT, int W, bool MASK>
+__device__ __forceinline__ uint64_t save_tile(const _Float16* __restrict__ Th, int ct0, int lane, const _Float16* __restrict__ st_tile) {
+    const int t = lane & 15, g = lane >> 4, hf = lane >> 5, pl = lane & 31;
+    const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(st_tile);
+    uint64_t bits = 0;
 #pragma unroll
     for (int c = 0; c < NCT; ++c) {
-        const int n = (ct0 + c) * 32 + lr;
-        const float bv = bvs[c];
-        const int ns = (n >> 3) ^ ((lane >> 5) << 1);
-        int base[4];
+        const int n = (ct0 + c) * 32 + pl;
+        const int col = (ct0 + c) * 32 + 16 * (g & 1) + 4 * (t & 3);      // first of the 4 halfs this lane addresses
+        const int rsub = 4 * (g >> 1) + (t >> 2);                         // its row inside an 8-point block
 #pragma unroll
-        for (int q = 0; q < 4; ++q) base[q] = r4 * LD + ((((ns ^ ((q & 1) | ((q >> 1) << 2)))) << 3) | (n & 7));
-        // 16-byte unit (block, feature n) of the SH array; lanes 32-63 store the odd block of each block pair
-        _Float16* st_lane = SAVE ? st + (((m0 >> 3) + (lane >> 5)) * W + n) * 8 : nullptr;
+        for (int bp = 0; bp < TM / 16; ++bp) {
+            uint2 q[2];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+            for (int k = 0; k < 2; ++k) {
+                const int b = 2 * bp + k, row = b * 8 + rsub;
+                const _Float16* src = Th + row * LD + ((((col >> 3) ^ hsw(row)) << 3) | (col & 7));
+                const short4v v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (short4v __attribute__((address_space(3)))*)(reinterpret_cast<const short4v*>(src)));
+                q[k] = __builtin_bit_cast(uint2, v);
+                if (MASK) {
 #pragma unroll
-            for (int ep = 0; ep < 2; ++ep) {
-                Quad16 qh[2];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int e = (ep * 2 + h) * 4 + j;
-                        float v = (acc1[r][c][e] + acc2[r][c][e] * LO_INV) + bv;
-                        if (RELU) {
-                            v = fmaxf(v, 0.f);
-                            bits |= (uint64_t)(v > 0.f) << ((c * 2 + r) * 16 + e);
-                        }
-                        amax = fmaxf(amax, RELU ? v : fabsf(v));                // range guard
-                        const _Float16 hi = (_Float16)v;
-                        const _Float16 lo = (_Float16)((v - (float)hi) * LO_SCALE);
-                        const int idx = base[((e >> 1) & 1) | (((e >> 2) & 1) << 1)] + (r * 32 + (e & 3) + 8 * (e >> 2)) * LD;
-                        Th[idx] = hi;
-                        Tl[idx] = lo;
-                        qh[h].v[j] = hi;
-                    }
+                    for (int j = 0; j < 4; ++j) bits |= (uint64_t)(v[j] != 0) << (c * 32 + b * 4 + j);   // post-ReLU: > 0 <=> != 0
                 }
-                if (SAVE) *reinterpret_cast<uint4*>(st_lane + (int64_t)(r * 4 + ep * 2) * W * 8) = sh_pair_unit(qh[0], qh[1]);
             }
+            const uint4 u = sh_pair_unit(q[0], q[1]);           // lanes 0-31: block 2bp, lanes 32-63: block 2bp + 1
+            // vector offset, zero scalar offset (mlp_bwd_h.hip: the scalar-offset form reads its data late)
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{u.x, u.y, u.z, u.w}, rs, (((2 * bp + hf) * W + n) * 8) * 2, 0, 0);
         }
     }
     return bits;
@@ -177,29 +229,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_split_kernel(FwdArgs a) {
     // ---- L0 ---------------------------------------------------------------------------------
     zero_acc(acc1);
     zero_acc(acc2);
-    gemm_stage<4, 2>(Th, Tl, COL_PE, a.packed + pack_offset(PF_L0), ct0, lane, acc1, acc2);
-    {
-        const uint64_t bits = epilogue<2, true, SAVE, 256>(acc1, acc2, Th, Tl, ct0, lane, a.bias[0], st_h, m0, amax);
-        if (SAVE) {
-            mask_out[0] = bits;
-        }
-    }
+    gemm_stage<4, 2, FWD_PF, true>(Th, Tl, COL_PE, a.packed + pack_offset(PF_L0), ct0, lane, acc1, acc2);
+    epilogue_t<2, true>(acc1, acc2, Th, Tl, ct0, lane, a.bias[0], amax);
     lds_barrier();
+    if (SAVE) mask_out[0] = save_tile<2, 256, true>(Th, ct0, lane, st_h + m0 * 256);
 
     // ---- L1..L7 -------------------------------------------------------------------------------
 #pragma unroll 1
     for (int l = 1; l < 8; ++l) {
         zero_acc(acc1);
         zero_acc(acc2);
-        if (l == 5) gemm_stage<20, 2>(Th, Tl, 0, a.packed + pack_offset(PF_L5), ct0, lane, acc1, acc2);
-        else gemm_stage<16, 2>(Th, Tl, 0, a.packed + pack_offset(PF_L0 + l), ct0, lane, acc1, acc2);
+        if (l == 5) gemm_stage<20, 2, FWD_PF, true>(Th, Tl, 0, a.packed + pack_offset(PF_L5), ct0, lane, acc1, acc2);
+        else gemm_stage<16, 2, FWD_PF, true>(Th, Tl, 0, a.packed + pack_offset(PF_L0 + l), ct0, lane, acc1, acc2);
         lds_barrier();
-        const uint64_t bits = epilogue<2, true, SAVE, 256>(acc1, acc2, Th, Tl, ct0, lane, a.bias[l],
-                                                           SAVE ? st_h + (int64_t)l * Mp * 256 : nullptr, m0, amax);
-        if (SAVE) {
-            mask_out[l * mask_stride] = bits;
-        }
+        epilogue_t<2, true>(acc1, acc2, Th, Tl, ct0, lane, a.bias[l], amax);
         lds_barrier();
+        if (SAVE) mask_out[l * mask_stride] = save_tile<2, 256, true>(Th, ct0, lane, st_h + ((int64_t)l * Mp + m0) * 256);
     }
 
     // ---- alpha partials (reads h7) + PE(viewdir) into columns [256,288) ---------------------------
@@ -252,30 +297,28 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_split_kernel(FwdArgs a) {
     // ---- FEAT (linear) ----------------------------------------------------------------------------
     zero_acc(acc1);
     zero_acc(acc2);
-    gemm_stage<16, 2>(Th, Tl, 0, a.packed + pack_offset(PF_FEAT), ct0, lane, acc1, acc2);
+    gemm_stage<16, 2, FWD_PF, true>(Th, Tl, 0, a.packed + pack_offset(PF_FEAT), ct0, lane, acc1, acc2);
     lds_barrier();
-    epilogue<2, false, SAVE, 256>(acc1, acc2, Th, Tl, ct0, lane, a.bias[BENERF_L_FEAT],
-                                  SAVE ? reinterpret_cast<_Float16*>(acts + sact_feat(Mp)) : nullptr, m0, amax);
+    epilogue_t<2, false>(acc1, acc2, Th, Tl, ct0, lane, a.bias[BENERF_L_FEAT], amax);
     if (tid < 64 && live) {
         const float4 p = *reinterpret_cast<const float4*>(scratch(0));
         a.raw[m * (C + 1) + C] = ((p.x + p.y) + (p.z + p.w)) + a.b_alpha[0];
     }
     lds_barrier();
+    if (SAVE) save_tile<2, 256, false>(Th, ct0, lane, reinterpret_cast<_Float16*>(acts + sact_feat(Mp)) + m0 * 256);
 
     // ---- VIEWS: [feature | PE(dir)] (288) -> 128, one column tile per wave ----------------------------
     {
         f32x16 av1[2][1], av2[2][1];
         zero_acc(av1);
         zero_acc(av2);
-        gemm_stage<18, 1>(Th, Tl, 0, a.packed + pack_offset(PF_VIEWS), wave, lane, av1, av2);
+        gemm_stage<18, 1, FWD_PF, true>(Th, Tl, 0, a.packed + pack_offset(PF_VIEWS), wave, lane, av1, av2);
         lds_barrier();
-        const uint64_t bits = epilogue<1, true, SAVE, ACT_HV_W>(av1, av2, Th, Tl, wave, lane, a.bias[BENERF_L_VIEWS],
-                                                                SAVE ? reinterpret_cast<_Float16*>(acts + sact_hv(Mp)) : nullptr, m0, amax);
-        if (SAVE) {
-            mask_out[8 * mask_stride] = bits;     // bit r*16 + e: element e of row tile r, column tile = wave
-        }
+        epilogue_t<1, true>(av1, av2, Th, Tl, wave, lane, a.bias[BENERF_L_VIEWS], amax);
     }
     lds_barrier();
+    if (SAVE)    // sign bits of hv: bit b*4 + j = point 8b + 4 (lane >> 5) + j, column tile = wave
+        mask_out[8 * mask_stride] = save_tile<1, ACT_HV_W, true>(Th, wave, lane, reinterpret_cast<_Float16*>(acts + sact_hv(Mp)) + m0 * ACT_HV_W);
 
     // ---- rgb: 128 -> C on the VALU; partials of channel c in scratch slot 1 + c ------------------------
     {

@@ -25,7 +25,8 @@ __device__ __forceinline__ f32x16 mfma16(half8 a, half8 b, f32x16 c) {
 // acc1 += hi x hi ; acc2 += hi x lo + lo x hi   over T[:, kcol0 .. kcol0 + KS*16) and packed tile ct0+c.
 // Weight fragments stream from L2 PF k-steps ahead (a k-step is only 12 MFMAs = 384 cycles, less than an L2 round
 // trip under load); the loop is fully unrolled so the PF+1 register sets rotate at compile time.
-template <int KS, int NCT, int PF = FWD_PF>
+// SWAP: the transposed product (weights as the A operand): accumulator lane = point, elements = 16 features in quads of 4.
+template <int KS, int NCT, int PF = FWD_PF, bool SWAP = false>
 __device__ __forceinline__ void gemm_stage(const _Float16* __restrict__ Th, const _Float16* __restrict__ Tl, int kcol0,
                                            const float* __restrict__ wp, int ct0, int lane, f32x16 (&acc1)[2][NCT],
                                            f32x16 (&acc2)[2][NCT]) {
@@ -89,15 +90,15 @@ __device__ __forceinline__ void gemm_stage(const _Float16* __restrict__ Th, cons
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
 #pragma unroll
-            for (int c = 0; c < NCT; ++c) acc1[r][c] = mfma16(ah[r], bh[c], acc1[r][c]);
+            for (int c = 0; c < NCT; ++c) acc1[r][c] = SWAP ? mfma16(bh[c], ah[r], acc1[r][c]) : mfma16(ah[r], bh[c], acc1[r][c]);
 #pragma unroll
-            for (int c = 0; c < NCT; ++c) acc2[r][c] = mfma16(ah[r], bl[c], acc2[r][c]);
+            for (int c = 0; c < NCT; ++c) acc2[r][c] = SWAP ? mfma16(bl[c], ah[r], acc2[r][c]) : mfma16(ah[r], bl[c], acc2[r][c]);
             if (ks + 1 < KS) ah[r] = *reinterpret_cast<const half8*>(Th + a_off(ks + 1) + r * 32 * LD);
         }
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
 #pragma unroll
-            for (int c = 0; c < NCT; ++c) acc2[r][c] = mfma16(al[r], bh[c], acc2[r][c]);
+            for (int c = 0; c < NCT; ++c) acc2[r][c] = SWAP ? mfma16(bh[c], al[r], acc2[r][c]) : mfma16(al[r], bh[c], acc2[r][c]);
             if (ks + 1 < KS) al[r] = *reinterpret_cast<const half8*>(Tl + a_off(ks + 1) + r * 32 * LD);
         }
         __builtin_amdgcn_sched_barrier(0);          // one k-step per scheduling region: keeps the prefetch distances as written
