@@ -56,8 +56,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* p) {
 // 16-byte plane slot: after one v_permlane32_swap per register pair every lane writes whole slots - 16 ds_write_b128 per
 // wave and stage for both planes instead of 256 two-byte writes.
 // combine the two accumulators, bias (+ReLU) -> both LDS planes (hi, scaled lo).
-template <int NCT, bool RELU>
-__device__ __forceinline__ void epilogue_t(f32x16 (&acc1)[2][NCT], f32x16 (&acc2)[2][NCT], _Float16* __restrict__ Th,
+template <int NCT, bool RELU, int NR>
+__device__ __forceinline__ void epilogue_t(f32x16 (&acc1)[NR][NCT], f32x16 (&acc2)[NR][NCT], _Float16* __restrict__ Th,
                                            _Float16* __restrict__ Tl, int ct0, int lane, const float* __restrict__ bias, float& amax) {
     const int pl = lane & 31, hf = lane >> 5;
     float4 bq[NCT][4];           // bias of this lane's features, requested before anything is stored
@@ -66,7 +66,7 @@ __device__ __forceinline__ void epilogue_t(f32x16 (&acc1)[2][NCT], f32x16 (&acc2
 #pragma unroll
         for (int q = 0; q < 4; ++q) bq[c][q] = *reinterpret_cast<const float4*>(bias + (ct0 + c) * 32 + 8 * q + 4 * hf);
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < NR; ++r) {
         const int row = r * 32 + pl, sw = hsw(row);
         _Float16* rowh = Th + row * LD;
         _Float16* rowl = Tl + row * LD;
@@ -111,10 +111,36 @@ __device__ __forceinline__ void epilogue_t(f32x16 (&acc1)[2][NCT], f32x16 (&acc2
 // at `st_tile`) and the ReLU sign-bit word.  ds_read_b64_tr_b16 (tools/hwprobe/tr_read.hip: within a 16-lane group lane t
 // supplies the address of row t >> 2, halfs 4 (t & 3) .. +3 of a 4 x 16 block and receives column t) hands lane l the 4
 // points 4 (l >> 5) .. +3 of an 8-point block for feature l & 31 of the column tile: the lane pair (l, l + 32) again
-// holds one 16-byte SH unit, and the layout of the sign bits is the one the dX kernel reads: bit c*32 + b*4 + j =
-// point 8b + 4 (l >> 5) + j of column tile c (the accumulator layout of the un-transposed product, mlp_common.h).
-template <int NCT, int W, bool MASK>
+// holds one 16-byte SH unit.  Sign bits: bit (c * NBLK + b) * 4 + j = point 8b + 4 (l >> 5) + j of column tile c; with
+// NBLK = 8 that is the accumulator layout of the un-transposed 64-point product the dX kernel reads (mlp_common.h).
+// One block pair (blocks 2bp, 2bp + 1) of column tile ct: the unit of work the layer loop spreads over its k-steps.
+template <int W, bool MASK, int NBLK>
+__device__ __forceinline__ void save_pair(const _Float16* __restrict__ Th, int ct, int bp, int lane, __amdgpu_buffer_rsrc_t rs, uint64_t& bits) {
+    asm volatile("" : "+v"(lane));      // the addresses below are cheap: recomputed per call, not hoisted out of the layer loop and spilled
+    const int t = lane & 15, g = lane >> 4, hf = lane >> 5, pl = lane & 31;
+    const int n = ct * 32 + pl;
+    const int col = ct * 32 + 16 * (g & 1) + 4 * (t & 3);
+    const int rsub = 4 * (g >> 1) + (t >> 2);
+    uint2 q[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int b = 2 * bp + k, row = b * 8 + rsub;
+        const _Float16* src = Th + row * LD + ((((col >> 3) ^ hsw(row)) << 3) | (col & 7));
+        const short4v v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (short4v __attribute__((address_space(3)))*)(reinterpret_cast<const short4v*>(src)));
+        q[k] = __builtin_bit_cast(uint2, v);
+        if (MASK) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bits |= (uint64_t)(v[j] != 0) << (b * 4 + j);
+        }
+    }
+    const uint4 u = sh_pair_unit(q[0], q[1]);
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{u.x, u.y, u.z, u.w}, rs, (((2 * bp + hf) * W + n) * 8) * 2, 0, 0);
+}
+
+template <int NCT, int W, bool MASK, int NBLK>
 __device__ __forceinline__ uint64_t save_tile(const _Float16* __restrict__ Th, int ct0, int lane, const _Float16* __restrict__ st_tile) {
+    static_assert(NCT * NBLK * 4 <= 64, "one sign-bit word per thread");
     const int t = lane & 15, g = lane >> 4, hf = lane >> 5, pl = lane & 31;
     const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(st_tile);
     uint64_t bits = 0;
@@ -124,7 +150,7 @@ __device__ __forceinline__ uint64_t save_tile(const _Float16* __restrict__ Th, i
         const int col = (ct0 + c) * 32 + 16 * (g & 1) + 4 * (t & 3);      // first of the 4 halfs this lane addresses
         const int rsub = 4 * (g >> 1) + (t >> 2);                         // its row inside an 8-point block
 #pragma unroll
-        for (int bp = 0; bp < TM / 16; ++bp) {
+        for (int bp = 0; bp < NBLK / 2; ++bp) {
             uint2 q[2];
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
@@ -135,7 +161,7 @@ __device__ __forceinline__ uint64_t save_tile(const _Float16* __restrict__ Th, i
                 q[k] = __builtin_bit_cast(uint2, v);
                 if (MASK) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) bits |= (uint64_t)(v[j] != 0) << (c * 32 + b * 4 + j);   // post-ReLU: > 0 <=> != 0
+                    for (int j = 0; j < 4; ++j) bits |= (uint64_t)(v[j] != 0) << (c * NBLK * 4 + b * 4 + j);   // post-ReLU: > 0 <=> != 0
                 }
             }
             const uint4 u = sh_pair_unit(q[0], q[1]);           // lanes 0-31: block 2bp, lanes 32-63: block 2bp + 1
@@ -146,28 +172,50 @@ __device__ __forceinline__ uint64_t save_tile(const _Float16* __restrict__ Th, i
     return bits;
 }
 
+// offset of the forward block of hidden layer l (1..7, l != 5 at the call site) without the generic pack_offset() summation,
+// which becomes a scalar loop of branches for a run-time l
+__device__ __forceinline__ int fwd_layer_offset(int l) {
+    return (int)pack_offset(PF_L1) + (l - 1) * (int)pack_floats(PF_L1) + (l > 5 ? (int)(pack_floats(PF_L5) - pack_floats(PF_L1)) : 0);
+}
+static_assert(pack_offset(PF_L1) + 3 * pack_floats(PF_L1) == pack_offset(PF_L4) &&
+              pack_offset(PF_L1) + 5 * pack_floats(PF_L1) + (pack_floats(PF_L5) - pack_floats(PF_L1)) == pack_offset(PF_L6) &&
+              pack_offset(PF_L1) + 6 * pack_floats(PF_L1) + (pack_floats(PF_L5) - pack_floats(PF_L1)) == pack_offset(PF_L7), "fwd_layer_offset");
+
+// One workgroup of 8 waves per 128 points (the whole LDS: two planes [128][320] f16); wave w owns column tile w (32 output
+// features) x all four point tiles: every weight fragment pair (hi, lo: 2 KiB) feeds 12 MFMAs - half the fragment bytes
+// per MFMA of the 64-point / 2 x 2 tiling, and the 8-register ring slot leaves room for a 4-deep prefetch.
+constexpr int FTM = 128, FNT = 512, FPF = 2;
+constexpr size_t FWD_SMEM = (size_t)2 * FTM * LD * sizeof(_Float16);      // 163 840 B
+
 template <int C, bool SAVE>
-__global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_split_kernel(FwdArgs a) {
+__global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) _Float16 Tsm[];   // Th | Tl
     _Float16* Th = Tsm;
-    _Float16* Tl = Tsm + TM * LD;
+    _Float16* Tl = Tsm + FTM * LD;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: weight pointers stay scalar
-    const int64_t m0 = (int64_t)blockIdx.x * TM;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7, wave-uniform: weight pointers stay scalar
+    const int64_t m0 = (int64_t)blockIdx.x * FTM;
     const int64_t M = a.M;
-    const int pt = tid & 63;
-    const int grp = tid >> 6;
+    const int pt = tid & (FTM - 1);
+    const int grp = tid >> 7;                                        // 4 thread groups per point
     const int64_t m = m0 + pt;
     const int64_t mc = m < M ? m : M - 1;
     const int64_t ray = (int64_t)((uint32_t)mc / (uint32_t)a.S);      // M < 2^31 (launcher): a 32-bit division
     float* acts = a.acts;
     const int64_t Mp = m_pad(M);
     _Float16* st_h = SAVE ? reinterpret_cast<_Float16*>(acts + sact_h(Mp, 0)) : nullptr;     // layer l: + l * Mp * 256 halfs
-    uint64_t* mask_out = SAVE ? reinterpret_cast<uint64_t*>(acts + sact_mask(Mp)) + (int64_t)blockIdx.x * NTHREADS + tid
+    // sign-bit words in the dX kernel's layout: uint64 [layer][64-point tile][256 threads = wave' (4) x lane]; this wave
+    // produces the 32 bits of column tile wave & 1 of wave' = wave >> 1 for both 64-point tiles of the workgroup
+    uint32_t* mask_out = SAVE ? reinterpret_cast<uint32_t*>(reinterpret_cast<uint64_t*>(acts + sact_mask(Mp)) +
+                                                            (int64_t)blockIdx.x * 2 * NTHREADS + (wave >> 1) * 64 + lane) + (wave & 1)
                               : nullptr;
-    const int64_t mask_stride = (Mp / TM) * NTHREADS;
+    const int64_t mask_stride = (Mp / TM) * NTHREADS * 2;            // uint32 units between layers
+    auto store_bits = [&](int layer, uint64_t b) {
+        mask_out[layer * mask_stride] = (uint32_t)b;                               // points 0..63
+        mask_out[layer * mask_stride + 2 * NTHREADS] = (uint32_t)(b >> 32);        // points 64..127: the next 64-point tile
+    };
     const bool live = m < M;
     if (SAVE && blockIdx.x == 0 && tid == 0) reinterpret_cast<uint32_t*>(acts + sact_info(Mp))[SI_TAG] = SACT_TAG_SPLIT;
     float amax = 0.f;        // running max |activation| of this thread (range guard)
@@ -216,36 +264,51 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_split_kernel(FwdArgs a) {
     if (SAVE) {
         float4* pe_tile = reinterpret_cast<float4*>(acts + sact_pe32(Mp) + m0 * ACT_PE_W);
 #pragma unroll
-        for (int k = 0; k < TM * ACT_PE_W / 4 / NTHREADS; ++k) {
-            const int u = tid + k * NTHREADS, row = u >> 4, c4 = u & 15;
+        for (int k = 0; k < FTM * ACT_PE_W / 4 / FNT; ++k) {
+            const int u = tid + k * FNT, row = u >> 4, c4 = u & 15;
             pe_tile[u] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(Th) + row * (LD / 2) + ((4 * c4 + 4 * row) & 63));
         }
         lds_barrier();          // the staging columns are layer 0's output columns
     }
 
-    f32x16 acc1[2][2], acc2[2][2];
-    const int ct0 = wave * 2;
+    f32x16 acc1[4][1], acc2[4][1];
 
     // ---- L0 ---------------------------------------------------------------------------------
     zero_acc(acc1);
     zero_acc(acc2);
-    gemm_stage<4, 2, FWD_PF, true>(Th, Tl, COL_PE, a.packed + pack_offset(PF_L0), ct0, lane, acc1, acc2);
-    epilogue_t<2, true>(acc1, acc2, Th, Tl, ct0, lane, a.bias[0], amax);
+    gemm_stage<4, 1, FPF, true, 4>(Th, Tl, COL_PE, a.packed + pack_offset(PF_L0), wave, lane, acc1, acc2);
+    epilogue_t<1, true, 4>(acc1, acc2, Th, Tl, wave, lane, a.bias[0], amax);
     lds_barrier();
-    if (SAVE) mask_out[0] = save_tile<2, 256, true>(Th, ct0, lane, st_h + m0 * 256);
 
     // ---- L1..L7 -------------------------------------------------------------------------------
+    // the previous layer's activations leave for HBM (save_tile: transpose reads of the finished hi plane, 16-byte stores)
+    // right behind this layer's first weight-fragment requests
 #pragma unroll 1
     for (int l = 1; l < 8; ++l) {
+        // The previous layer's activations leave for HBM during this layer's LAST two k-steps (four block pairs each: two
+        // transpose reads of the finished hi plane, the sign bits, one 16-byte store per pair): behind the K-loop's last
+        // weight-fragment request, so that no fragment is queued behind a store (in-order retirement), and in the gaps
+        // between the MFMAs.  The next requests (the following layer's) come an epilogue later.
+        uint64_t pbits = 0;
+        const __amdgpu_buffer_rsrc_t prs = uniform_rsrc(SAVE ? st_h + ((int64_t)(l - 1) * Mp + m0) * 256 : nullptr);
+        auto save_at = [&](int ks, int first) {
+            if (SAVE && ks >= first) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) save_pair<256, true, 16>(Th, wave, (ks - first) * 4 + i, lane, prs, pbits);
+                if (ks == first + 1) store_bits(l - 1, pbits);
+            }
+        };
         zero_acc(acc1);
         zero_acc(acc2);
-        if (l == 5) gemm_stage<20, 2, FWD_PF, true>(Th, Tl, 0, a.packed + pack_offset(PF_L5), ct0, lane, acc1, acc2);
-        else gemm_stage<16, 2, FWD_PF, true>(Th, Tl, 0, a.packed + pack_offset(PF_L0 + l), ct0, lane, acc1, acc2);
+        if (l == 5) gemm_stage<20, 1, FPF, true, 4>(Th, Tl, 0, a.packed + pack_offset(PF_L5), wave, lane, acc1, acc2, NoAfterHead(),
+                                                    [&](int ks) { save_at(ks, 18); });
+        else gemm_stage<16, 1, FPF, true, 4>(Th, Tl, 0, a.packed + fwd_layer_offset(l), wave, lane, acc1, acc2, NoAfterHead(),
+                                             [&](int ks) { save_at(ks, 14); });
         lds_barrier();
-        epilogue_t<2, true>(acc1, acc2, Th, Tl, ct0, lane, a.bias[l], amax);
+        epilogue_t<1, true, 4>(acc1, acc2, Th, Tl, wave, lane, a.bias[l], amax);
         lds_barrier();
-        if (SAVE) mask_out[l * mask_stride] = save_tile<2, 256, true>(Th, ct0, lane, st_h + ((int64_t)l * Mp + m0) * 256);
     }
+    if (SAVE) store_bits(7, save_tile<1, 256, true, 16>(Th, wave, lane, st_h + ((int64_t)7 * Mp + m0) * 256));
 
     // ---- alpha partials (reads h7) + PE(viewdir) into columns [256,288) ---------------------------
     {
@@ -297,28 +360,34 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_split_kernel(FwdArgs a) {
     // ---- FEAT (linear) ----------------------------------------------------------------------------
     zero_acc(acc1);
     zero_acc(acc2);
-    gemm_stage<16, 2, FWD_PF, true>(Th, Tl, 0, a.packed + pack_offset(PF_FEAT), ct0, lane, acc1, acc2);
+    gemm_stage<16, 1, FPF, true, 4>(Th, Tl, 0, a.packed + pack_offset(PF_FEAT), wave, lane, acc1, acc2);
     lds_barrier();
-    epilogue_t<2, false>(acc1, acc2, Th, Tl, ct0, lane, a.bias[BENERF_L_FEAT], amax);
-    if (tid < 64 && live) {
+    epilogue_t<1, false, 4>(acc1, acc2, Th, Tl, wave, lane, a.bias[BENERF_L_FEAT], amax);
+    if (tid < FTM && live) {
         const float4 p = *reinterpret_cast<const float4*>(scratch(0));
         a.raw[m * (C + 1) + C] = ((p.x + p.y) + (p.z + p.w)) + a.b_alpha[0];
     }
     lds_barrier();
-    if (SAVE) save_tile<2, 256, false>(Th, ct0, lane, reinterpret_cast<_Float16*>(acts + sact_feat(Mp)) + m0 * 256);
+    if (SAVE) save_tile<1, 256, false, 16>(Th, wave, lane, reinterpret_cast<_Float16*>(acts + sact_feat(Mp)) + m0 * 256);
 
-    // ---- VIEWS: [feature | PE(dir)] (288) -> 128, one column tile per wave ----------------------------
+    // ---- VIEWS: [feature | PE(dir)] (288) -> 128: wave w computes column tile w & 3 for the point half w >> 2 -------------
     {
+        const int vct = wave & 3, vrh = wave >> 2;
+        _Float16* Thh = Th + vrh * 64 * LD;          // rows + 64: same swizzle
+        _Float16* Tlh = Tl + vrh * 64 * LD;
         f32x16 av1[2][1], av2[2][1];
         zero_acc(av1);
         zero_acc(av2);
-        gemm_stage<18, 1, FWD_PF, true>(Th, Tl, 0, a.packed + pack_offset(PF_VIEWS), wave, lane, av1, av2);
+        gemm_stage<18, 1, FPF, true, 2>(Thh, Tlh, 0, a.packed + pack_offset(PF_VIEWS), vct, lane, av1, av2);
         lds_barrier();
-        epilogue_t<1, true>(av1, av2, Th, Tl, wave, lane, a.bias[BENERF_L_VIEWS], amax);
+        epilogue_t<1, true, 2>(av1, av2, Thh, Tlh, vct, lane, a.bias[BENERF_L_VIEWS], amax);
+        lds_barrier();
+        if (SAVE) {  // sign bits of hv: bit b*4 + j = point 8b + 4 (lane >> 5) + j of this half, column tile = wave & 3
+            const uint64_t bits = save_tile<1, ACT_HV_W, true, 8>(Thh, vct, lane, reinterpret_cast<_Float16*>(acts + sact_hv(Mp)) +
+                                                                                      (m0 + vrh * 64) * ACT_HV_W);
+            reinterpret_cast<uint64_t*>(acts + sact_mask(Mp))[8 * (Mp / TM) * NTHREADS + ((int64_t)blockIdx.x * 2 + vrh) * NTHREADS + vct * 64 + lane] = bits;
+        }
     }
-    lds_barrier();
-    if (SAVE)    // sign bits of hv: bit b*4 + j = point 8b + 4 (lane >> 5) + j, column tile = wave
-        mask_out[8 * mask_stride] = save_tile<1, ACT_HV_W, true>(Th, wave, lane, reinterpret_cast<_Float16*>(acts + sact_hv(Mp)) + m0 * ACT_HV_W);
 
     // ---- rgb: 128 -> C on the VALU; partials of channel c in scratch slot 1 + c ------------------------
     {
@@ -350,7 +419,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_split_kernel(FwdArgs a) {
         }
     }
     lds_barrier();
-    if (tid < 64 && live) {
+    if (tid < FTM && live) {
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const float4 p = *reinterpret_cast<const float4*>(scratch(1 + c));
@@ -383,11 +452,12 @@ int benerf_mlp_fwd_split_launch(const BenerfMlpParams* params, const float* pack
     a.status = status;
     a.M = (int64_t)n_rays * n_samples;
     a.S = n_samples;
-    // training launches cover the padded point range (whole 128-point dX tiles), inference the live tiles only
-    const int64_t tiles = acts ? mlp::sn_tiles(a.M) : (a.M + mlp::TM - 1) / mlp::TM;
+    // training launches cover the padded point range (whole 128-point tiles, the dX kernel's too), inference the live tiles
+    const int64_t tiles = acts ? mlp::m_pad(a.M) / FTM : (a.M + FTM - 1) / FTM;
+    static_assert(mlp::SM_PAD == FTM, "the padded point count is a whole number of forward tiles");
     BENERF_REQUIRE(tiles < (1ll << 31) && a.M < (1ll << 31), "mlp_fwd(split): too many points");
-    dim3 grid((unsigned)tiles), block(mlp::NTHREADS);
-    const int smem = (int)mlp::TILE_SMEM;
+    dim3 grid((unsigned)tiles), block(FNT);
+    const int smem = (int)FWD_SMEM;
 #define BENERF_FWD_LAUNCH(CH, SV)                                                                                        \
     do {                                                                                                                 \
         if (hipFuncSetAttribute((const void*)mlp_fwd_split_kernel<CH, SV>, hipFuncAttributeMaxDynamicSharedMemorySize,   \

@@ -26,10 +26,18 @@ __device__ __forceinline__ f32x16 mfma16(half8 a, half8 b, f32x16 c) {
 // Weight fragments stream from L2 PF k-steps ahead (a k-step is only 12 MFMAs = 384 cycles, less than an L2 round
 // trip under load); the loop is fully unrolled so the PF+1 register sets rotate at compile time.
 // SWAP: the transposed product (weights as the A operand): accumulator lane = point, elements = 16 features in quads of 4.
-template <int KS, int NCT, int PF = FWD_PF, bool SWAP = false>
+// NR: row (point) tiles of 32 per wave.
+// after_head(): caller's work that issues vector-memory STORES (the previous stage's activation save), run right behind the
+// requests for the first PF k-steps' fragments - vector-memory operations retire in order through one counter, so
+// fragments requested behind those stores would not be usable before every store is acknowledged.
+struct NoAfterHead { __device__ __forceinline__ void operator()() const {} };
+// per_kstep(ks): caller's work spread over the k-steps (placed in the k-step's scheduling region, so its VALU / LDS / store
+// instructions issue in the gaps between this wave's MFMAs: an MFMA occupies the issue port for one pass of its eight)
+struct NoPerKstep { __device__ __forceinline__ void operator()(int) const {} };
+template <int KS, int NCT, int PF = FWD_PF, bool SWAP = false, int NR = 2, class AH = NoAfterHead, class PK = NoPerKstep>
 __device__ __forceinline__ void gemm_stage(const _Float16* __restrict__ Th, const _Float16* __restrict__ Tl, int kcol0,
-                                           const float* __restrict__ wp, int ct0, int lane, f32x16 (&acc1)[2][NCT],
-                                           f32x16 (&acc2)[2][NCT]) {
+                                           const float* __restrict__ wp, int ct0, int lane, f32x16 (&acc1)[NR][NCT],
+                                           f32x16 (&acc2)[NR][NCT], AH after_head = AH(), PK per_kstep = PK()) {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const int row = lane & 31, lh = lane >> 5;
     const int sw = hsw(row);                        // rows row and row + 32 share the swizzle
@@ -57,7 +65,10 @@ __device__ __forceinline__ void gemm_stage(const _Float16* __restrict__ Th, cons
                 bq[p][c][0] = load_b(c, p, 0);
                 bq[p][c][1] = load_b(c, p, 1);
             }
+            __builtin_amdgcn_sched_barrier(0);      // in k-step order: the scheduler otherwise requests k-step 0 last
         }
+    after_head();
+    __builtin_amdgcn_sched_barrier(0);
     const int slot0 = kcol0 >> 3;                    // multiple of 8: the swizzle only permutes slots inside 8-slot groups
     // slot (slot0 + 2ks + lh) ^ sw = group base (compile-time) + ((2(ks&3) + lh) ^ sw): four lane-dependent bases
     int abase[4];
@@ -66,12 +77,13 @@ __device__ __forceinline__ void gemm_stage(const _Float16* __restrict__ Th, cons
     // ONE set of activation fragments (hi / lo x row tile): the MFMAs of a fragment are consecutive and its successor is
     // requested right behind them; the other fragments' MFMAs (>= 8 x 32 cycles) cover the LDS round trip.  The
     // registers this saves go to a deeper weight-fragment ring (PF).
-    half8 ah[2], al[2];
+    half8 ah[NR], al[NR];
     auto a_off = [&](int ks) { return abase[ks & 3] + ((slot0 + ((2 * ks) & ~7)) << 3); };
-    ah[0] = *reinterpret_cast<const half8*>(Th + a_off(0));
-    ah[1] = *reinterpret_cast<const half8*>(Th + a_off(0) + 32 * LD);
-    al[0] = *reinterpret_cast<const half8*>(Tl + a_off(0));
-    al[1] = *reinterpret_cast<const half8*>(Tl + a_off(0) + 32 * LD);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        ah[r] = *reinterpret_cast<const half8*>(Th + a_off(0) + r * 32 * LD);
+        al[r] = *reinterpret_cast<const half8*>(Tl + a_off(0) + r * 32 * LD);
+    }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         if (ks + PF < KS) {
@@ -81,6 +93,7 @@ __device__ __forceinline__ void gemm_stage(const _Float16* __restrict__ Th, cons
                 bq[(ks + PF) % (PF + 1)][c][1] = load_b(c, ks + PF, 1);
             }
         }
+        per_kstep(ks);
         half8 bh[NCT], bl[NCT];
 #pragma unroll
         for (int c = 0; c < NCT; ++c) {
@@ -88,7 +101,7 @@ __device__ __forceinline__ void gemm_stage(const _Float16* __restrict__ Th, cons
             bl[c] = __builtin_bit_cast(half8, bq[ks % (PF + 1)][c][1]);
         }
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < NR; ++r) {
 #pragma unroll
             for (int c = 0; c < NCT; ++c) acc1[r][c] = SWAP ? mfma16(bh[c], ah[r], acc1[r][c]) : mfma16(ah[r], bh[c], acc1[r][c]);
 #pragma unroll
@@ -96,7 +109,7 @@ __device__ __forceinline__ void gemm_stage(const _Float16* __restrict__ Th, cons
             if (ks + 1 < KS) ah[r] = *reinterpret_cast<const half8*>(Th + a_off(ks + 1) + r * 32 * LD);
         }
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+        for (int r = 0; r < NR; ++r) {
 #pragma unroll
             for (int c = 0; c < NCT; ++c) acc2[r][c] = SWAP ? mfma16(bh[c], al[r], acc2[r][c]) : mfma16(al[r], bh[c], acc2[r][c]);
             if (ks + 1 < KS) al[r] = *reinterpret_cast<const half8*>(Tl + a_off(ks + 1) + r * 32 * LD);
@@ -105,10 +118,10 @@ __device__ __forceinline__ void gemm_stage(const _Float16* __restrict__ Th, cons
     }
 }
 
-template <int NCT>
-__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][NCT]) {
+template <int NR, int NCT>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[NR][NCT]) {
 #pragma unroll
-    for (int r = 0; r < 2; ++r)
+    for (int r = 0; r < NR; ++r)
 #pragma unroll
         for (int c = 0; c < NCT; ++c)
 #pragma unroll
