@@ -113,6 +113,16 @@ __device__ __forceinline__ void epilogue_t(f32x16 (&acc1)[NR][NCT], f32x16 (&acc
 // points 4 (l >> 5) .. +3 of an 8-point block for feature l & 31 of the column tile: the lane pair (l, l + 32) again
 // holds one 16-byte SH unit.  Sign bits: bit (c * NBLK + b) * 4 + j = point 8b + 4 (l >> 5) + j of column tile c; with
 // NBLK = 8 that is the accumulator layout of the un-transposed 64-point product the dX kernel reads (mlp_common.h).
+// bit j = (half j of the four f16 in q != 0): two v_pk_min_u16 against 1, then three bit operations
+__device__ __forceinline__ uint32_t nonzero4(uint2 q) {
+    typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+    const ushort2v one = {1, 1};
+    const uint32_t t0 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(ushort2v, q.x), one));
+    const uint32_t t1 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(ushort2v, q.y), one));
+    const uint32_t u = t0 | (t1 << 2);            // bits 0, 16, 2, 18
+    return (u | (u >> 15)) & 0xFu;
+}
+
 // One block pair (blocks 2bp, 2bp + 1) of column tile ct: the unit of work the layer loop spreads over its k-steps.
 template <int W, bool MASK, int NBLK>
 __device__ __forceinline__ void save_pair(const _Float16* __restrict__ Th, int ct, int bp, int lane, __amdgpu_buffer_rsrc_t rs, uint64_t& bits) {
@@ -129,10 +139,7 @@ __device__ __forceinline__ void save_pair(const _Float16* __restrict__ Th, int c
         const short4v v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
             (short4v __attribute__((address_space(3)))*)(reinterpret_cast<const short4v*>(src)));
         q[k] = __builtin_bit_cast(uint2, v);
-        if (MASK) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bits |= (uint64_t)(v[j] != 0) << (b * 4 + j);
-        }
+        if (MASK) bits |= (uint64_t)nonzero4(q[k]) << (b * 4);        // post-ReLU: > 0 <=> != 0
     }
     const uint4 u = sh_pair_unit(q[0], q[1]);
     __builtin_amdgcn_raw_buffer_store_b128(u32x4{u.x, u.y, u.z, u.w}, rs, (((2 * bp + hf) * W + n) * 8) * 2, 0, 0);
@@ -159,10 +166,7 @@ __device__ __forceinline__ uint64_t save_tile(const _Float16* __restrict__ Th, i
                 const short4v v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                     (short4v __attribute__((address_space(3)))*)(reinterpret_cast<const short4v*>(src)));
                 q[k] = __builtin_bit_cast(uint2, v);
-                if (MASK) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) bits |= (uint64_t)(v[j] != 0) << (c * NBLK * 4 + b * 4 + j);   // post-ReLU: > 0 <=> != 0
-                }
+                if (MASK) bits |= (uint64_t)nonzero4(q[k]) << (c * NBLK * 4 + b * 4);     // post-ReLU: > 0 <=> != 0
             }
             const uint4 u = sh_pair_unit(q[0], q[1]);           // lanes 0-31: block 2bp, lanes 32-63: block 2bp + 1
             // vector offset, zero scalar offset (mlp_bwd_h.hip: the scalar-offset form reads its data late)
