@@ -55,16 +55,35 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* p) {
 // consecutive features 8q + 4*(lane>>5) + 0..3.  The lane pair (l, l+32) therefore holds the 8 consecutive features of a
 // 16-byte plane slot: after one v_permlane32_swap per register pair every lane writes whole slots - 16 ds_write_b128 per
 // wave and stage for both planes instead of 256 two-byte writes.
-// combine the two accumulators, bias (+ReLU) -> both LDS planes (hi, scaled lo).
-template <int NCT, bool RELU, int NR>
-__device__ __forceinline__ void epilogue_t(f32x16 (&acc1)[NR][NCT], f32x16 (&acc2)[NR][NCT], _Float16* __restrict__ Th,
-                                           _Float16* __restrict__ Tl, int ct0, int lane, const float* __restrict__ bias, float& amax) {
-    const int pl = lane & 31, hf = lane >> 5;
-    float4 bq[NCT][4];           // bias of this lane's features, requested before anything is stored
+// The bias enters as the INITIAL value of the hi x hi accumulator (acc_init_bias; requested one stage ahead, at the top of the
+// previous epilogue), which saves the epilogue an addition per element and a load behind its predecessor's stores.
+template <int NCT>
+__device__ __forceinline__ void load_bias(const float* __restrict__ bias, int ct0, int lane, float4 (&bq)[NCT][4]) {
 #pragma unroll
     for (int c = 0; c < NCT; ++c)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) bq[c][q] = *reinterpret_cast<const float4*>(bias + (ct0 + c) * 32 + 8 * q + 4 * hf);
+        for (int q = 0; q < 4; ++q) bq[c][q] = *reinterpret_cast<const float4*>(bias + (ct0 + c) * 32 + 8 * q + 4 * (lane >> 5));
+}
+template <int NR, int NCT>
+__device__ __forceinline__ void acc_init_bias(f32x16 (&acc1)[NR][NCT], const float4 (&bq)[NCT][4]) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc1[r][c][q * 4 + 0] = bq[c][q].x;
+                acc1[r][c][q * 4 + 1] = bq[c][q].y;
+                acc1[r][c][q * 4 + 2] = bq[c][q].z;
+                acc1[r][c][q * 4 + 3] = bq[c][q].w;
+            }
+}
+
+// combine the two accumulators (+ReLU) -> both LDS planes (hi, scaled lo).
+template <int NCT, bool RELU, int NR>
+__device__ __forceinline__ void epilogue_t(f32x16 (&acc1)[NR][NCT], f32x16 (&acc2)[NR][NCT], _Float16* __restrict__ Th,
+                                           _Float16* __restrict__ Tl, int ct0, int lane, float& amax) {
+    const int pl = lane & 31, hf = lane >> 5;
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const int row = r * 32 + pl, sw = hsw(row);
@@ -75,13 +94,11 @@ __device__ __forceinline__ void epilogue_t(f32x16 (&acc1)[NR][NCT], f32x16 (&acc
             uint2 qh[4], ql[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float bv[4] = {bq[c][q].x, bq[c][q].y, bq[c][q].z, bq[c][q].w};
                 uint32_t wh[2], wl[2];
 #pragma unroll
                 for (int jp = 0; jp < 2; ++jp) {
                     const int e = q * 4 + jp * 2;
-                    float2v v = {(acc1[r][c][e] + acc2[r][c][e] * LO_INV) + bv[jp * 2],
-                                 (acc1[r][c][e + 1] + acc2[r][c][e + 1] * LO_INV) + bv[jp * 2 + 1]};
+                    float2v v = {acc1[r][c][e] + acc2[r][c][e] * LO_INV, acc1[r][c][e + 1] + acc2[r][c][e + 1] * LO_INV};
                     if (RELU) {
                         v[0] = fmaxf(v[0], 0.f);
                         v[1] = fmaxf(v[1], 0.f);
@@ -278,10 +295,13 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
     f32x16 acc1[4][1], acc2[4][1];
 
     // ---- L0 ---------------------------------------------------------------------------------
-    zero_acc(acc1);
+    float4 bq[1][4];
+    load_bias<1>(a.bias[0], wave, lane, bq);
+    acc_init_bias(acc1, bq);
     zero_acc(acc2);
     gemm_stage<4, 1, FPF, true, 4>(Th, Tl, COL_PE, a.packed + pack_offset(PF_L0), wave, lane, acc1, acc2);
-    epilogue_t<1, true, 4>(acc1, acc2, Th, Tl, wave, lane, a.bias[0], amax);
+    load_bias<1>(a.bias[1], wave, lane, bq);
+    epilogue_t<1, true, 4>(acc1, acc2, Th, Tl, wave, lane, amax);
     lds_barrier();
 
     // ---- L1..L7 -------------------------------------------------------------------------------
@@ -302,14 +322,15 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
                 if (ks == first + 1) store_bits(l - 1, pbits);
             }
         };
-        zero_acc(acc1);
+        acc_init_bias(acc1, bq);
         zero_acc(acc2);
         if (l == 5) gemm_stage<20, 1, FPF, true, 4>(Th, Tl, 0, a.packed + pack_offset(PF_L5), wave, lane, acc1, acc2, NoAfterHead(),
                                                     [&](int ks) { save_at(ks, 18); });
         else gemm_stage<16, 1, FPF, true, 4>(Th, Tl, 0, a.packed + fwd_layer_offset(l), wave, lane, acc1, acc2, NoAfterHead(),
                                              [&](int ks) { save_at(ks, 14); });
         lds_barrier();
-        epilogue_t<1, true, 4>(acc1, acc2, Th, Tl, wave, lane, a.bias[l], amax);
+        load_bias<1>(a.bias[l < 7 ? l + 1 : BENERF_L_FEAT], wave, lane, bq);
+        epilogue_t<1, true, 4>(acc1, acc2, Th, Tl, wave, lane, amax);
         lds_barrier();
     }
     if (SAVE) store_bits(7, save_tile<1, 256, true, 16>(Th, wave, lane, st_h + ((int64_t)7 * Mp + m0) * 256));
@@ -362,11 +383,12 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
     }
 
     // ---- FEAT (linear) ----------------------------------------------------------------------------
-    zero_acc(acc1);
+    acc_init_bias(acc1, bq);
     zero_acc(acc2);
     gemm_stage<16, 1, FPF, true, 4>(Th, Tl, 0, a.packed + pack_offset(PF_FEAT), wave, lane, acc1, acc2);
     lds_barrier();
-    epilogue_t<1, false, 4>(acc1, acc2, Th, Tl, wave, lane, a.bias[BENERF_L_FEAT], amax);
+    load_bias<1>(a.bias[BENERF_L_VIEWS], wave & 3, lane, bq);
+    epilogue_t<1, false, 4>(acc1, acc2, Th, Tl, wave, lane, amax);
     if (tid < FTM && live) {
         const float4 p = *reinterpret_cast<const float4*>(scratch(0));
         a.raw[m * (C + 1) + C] = ((p.x + p.y) + (p.z + p.w)) + a.b_alpha[0];
@@ -380,11 +402,11 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
         _Float16* Thh = Th + vrh * 64 * LD;          // rows + 64: same swizzle
         _Float16* Tlh = Tl + vrh * 64 * LD;
         f32x16 av1[2][1], av2[2][1];
-        zero_acc(av1);
+        acc_init_bias(av1, bq);
         zero_acc(av2);
         gemm_stage<18, 1, FPF, true, 2>(Thh, Tlh, 0, a.packed + pack_offset(PF_VIEWS), vct, lane, av1, av2);
         lds_barrier();
-        epilogue_t<1, true, 2>(av1, av2, Thh, Tlh, vct, lane, a.bias[BENERF_L_VIEWS], amax);
+        epilogue_t<1, true, 2>(av1, av2, Thh, Tlh, vct, lane, amax);
         lds_barrier();
         if (SAVE) {  // sign bits of hv: bit b*4 + j = point 8b + 4 (lane >> 5) + j of this half, column tile = wave & 3
             const uint64_t bits = save_tile<1, ACT_HV_W, true, 8>(Thh, vct, lane, reinterpret_cast<_Float16*>(acts + sact_hv(Mp)) +
