@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Training-throughput bench of the BeNeRF hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W            (N = 1)
+    python bench.py --gpus N --steps K --warmup W            (N > 1 without WORLD_SIZE in the environment: spawns its N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one full training iteration (train.py:153-394 semantics) on a synthetic batch
@@ -62,8 +62,13 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="C2")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak: every rank renders the workload's batch; strong: the workload's batch is the GLOBAL batch")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="weak: every rank renders the workload's batch; strong: the workload's batch is the GLOBAL batch.  Default: "
+                         "weak for C1-C3, strong for C4 / C5 (BASELINE.json quotes those as 8192 rays over 8 GPUs, SURVEY 8e)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend: nccl = RCCL over xGMI (the product path); gloo only with --selfcheck-only (CPU test)")
+    ap.add_argument("--selfcheck-only", action="store_true",
+                    help="rendezvous + collective self-check only (ranks seen, all-reduce time), no training step")
     ap.add_argument("--batch-fraction", type=int, default=1,
                     help="render 1/F of the workload's pixels per rank (F = 8 on one GPU: the per-rank step of a strong-scaled 8-GPU run)")
     ap.add_argument("--n-events", type=int, default=2_000_000)
@@ -72,7 +77,62 @@ def parse():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--mlp-precision", default="split", choices=["f32", "split"],
                     help="arithmetic of the fused MLP kernels (include/benerf_hip.h, K3 `precision`)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.scaling is None:
+        a.scaling = "strong" if a.workload in ("C4", "C5") else "weak"
+    return a
+
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher: re-run this script as N ranks under torch.distributed.run
+    (one process per GPU, rendezvous on 127.0.0.1) and pass its exit code on.  Refuses when the node has fewer devices."""
+    import socket
+    import subprocess
+    if a.backend == "nccl" and torch.cuda.device_count() < a.gpus:
+        print("bench.py: --gpus %d but only %d device(s) visible" % (a.gpus, torch.cuda.device_count()), file=sys.stderr)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def collective_selfcheck(world, device, n_net):
+    """Every rank contributes a vector of ones: the sum must equal the world size everywhere (the process group really spans
+    `world` ranks); then the step's three gradient buckets (fine net, coarse net, trajectory) are all-reduced 20 times,
+    timed with events on the stream that waits for them."""
+    ones = torch.ones(64, dtype=torch.float32, device=device)
+    torch.distributed.all_reduce(ones)
+    seen = int(round(float(ones.min().item())))
+    assert float(ones.max().item()) == float(ones.min().item()) == world, "all-reduce of ones gave %r on a world of %d" % (ones.tolist()[:4], world)
+    buckets = [torch.zeros(n, dtype=torch.float32, device=device) for n in (n_net, n_net, 31)]
+    cuda = device.type == "cuda"
+
+    def once():
+        hs = [torch.distributed.all_reduce(b, async_op=True) for b in buckets]
+        for h in hs:
+            h.wait()
+    for _ in range(3):
+        once()
+    if cuda:
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        once()
+    if cuda:
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+    else:
+        ms = (time.perf_counter() - t0) * 1e3 / 20
+    nbytes = sum(b.numel() for b in buckets) * 4
+    return {"rccl_ranks_seen": seen, "allreduce_ms": round(ms, 4), "allreduce_bytes": nbytes,
+            "allreduce_bus_gbs": round(2 * (world - 1) / world * nbytes / (ms * 1e-3) / 1e9, 2)}
 
 
 def split_mode(a):
@@ -214,19 +274,41 @@ def torch_gpu_baseline(wl, seed, device):
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    if world != a.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node == --gpus)" % (a.gpus, world))
+    if a.backend == "gloo":
+        if not a.selfcheck_only:
+            sys.exit("bench.py: --backend gloo is the CPU self-check of the launch path (--selfcheck-only); the product path is nccl")
+        device = torch.device("cpu")
+    else:
+        if torch.cuda.device_count() <= local_rank:
+            sys.exit("bench.py: rank %d has no device (%d visible)" % (local_rank, torch.cuda.device_count()))
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
     pg = None
+    comm = None
     if world > 1:
-        torch.distributed.init_process_group("nccl", device_id=device)   # RCCL over xGMI
+        if a.backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=device)   # RCCL over xGMI
+        else:
+            torch.distributed.init_process_group("gloo")
         pg = torch.distributed.group.WORLD
+        comm = collective_selfcheck(world, device, 595586)
+    if a.selfcheck_only:
+        if rank == 0:
+            print(json.dumps({"metric": "collective self-check", "n_gpus": world, "backend": a.backend, "scaling": a.scaling,
+                              "config": {"workload": a.workload}, **(comm or {"rccl_ranks_seen": 1})}), flush=True)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
 
     from benerf_amd import engine, workloads as WL, kernels as K
     K.set_mlp_precision(a.mlp_precision)
@@ -280,7 +362,7 @@ def main():
     K.TIMERS.enabled = True
     for _ in range(a.warmup):
         one_step()
-    K.check_mlp_status(device)                   # warm-up steps stayed inside the f16 range (synchronises; untimed)
+    step.check_range()                           # warm-up steps stayed inside the f16 range (synchronises; untimed)
     K.TIMERS.records.clear()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     sync()
@@ -292,7 +374,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     K.TIMERS.enabled = False
-    K.check_mlp_status(device)
+    step.check_range()
     step_series = [marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps)]
     if os.environ.get("BENERF_BENCH_DEBUG"):
         print("step ms:", " ".join("%.2f" % t for t in step_series), file=sys.stderr)
@@ -321,20 +403,44 @@ def main():
             n_inf = 2 * idx_all.shape[0]
             infer = round(n_inf / ((time.perf_counter() - ti) / a.steps), 1)
 
-    # ---- secondary: the same training step with exact-f32 MFMA products (the other arithmetic mode) -------------------
-    other = None
+    # ---- secondary: the same training step with exact-f32 MFMA products (the strict arithmetic mode), >= 20 timed steps,
+    # its own per-kernel HIP-event durations -> `exact_f32` + `roofline_f32` in the JSON line --------------------------------
+    summ_main = K.TIMERS.summary()
+    exact = roof_f32 = None
     if world == 1 and split_mode(a) and not a.primary_only:
         K.set_mlp_precision("f32")
-        for _ in range(2):
+        K.TIMERS.records.clear()
+        K.TIMERS.enabled = True
+        for _ in range(3):
             one_step()
+        K.TIMERS.records.clear()
         torch.cuda.synchronize()
         to = time.perf_counter()
-        n_other = max(4, a.steps // 3)
+        n_other = max(20, a.steps)
         for _ in range(n_other):
             one_step()
         torch.cuda.synchronize()
-        other = round(WL.rays_per_step(wl) / ((time.perf_counter() - to) / n_other), 1)
+        dt_o = (time.perf_counter() - to) / n_other
+        K.TIMERS.enabled = False
+        step.check_range()
+        exact = {"value": round(WL.rays_per_step(wl) / dt_o, 1), "unit": "rays/s", "ms_per_step": round(dt_o * 1e3, 3), "steps": n_other,
+                 "dtype": "f32 (v_mfma_f32_32x32x2_f32: bit-exact f32 products, f32 accumulate) in forward and backward"}
+        fpp_ = WL.mlp_flops_per_point(wl["channels"])
+        per = {}
+        for name, (n_, ms_, pts_) in K.TIMERS.summary().items():
+            tf_ = pts_ * fpp_ / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0.0
+            per[name] = {"launches": n_, "avg_ms": round(ms_ / n_, 4), "points_per_launch": int(pts_ / n_), "tflops_algorithmic": round(tf_, 2),
+                         "frac_of_mfma_peak": round(tf_ / F32_MFMA_PEAK_TFLOPS, 4)}
+        if per:
+            dom_ = max(per.items(), key=lambda kv: kv[1]["avg_ms"] * kv[1]["launches"])[0]
+            pts_step_ = WL.rays_per_step(wl) * (wl["S"] + wl["S"] + wl["Ni"])
+            roof_f32 = {"bound": "mfma", "kernel": dom_, "achieved": per[dom_]["tflops_algorithmic"], "peak": F32_MFMA_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": per[dom_]["frac_of_mfma_peak"], "avg_launch_ms": per[dom_]["avg_ms"],
+                        "step_tflops_algorithmic": round(pts_step_ * fpp_ * 3 / dt_o / 1e12, 2),
+                        "step_frac_of_mfma_peak": round(pts_step_ * fpp_ * 3 / dt_o / 1e12 / F32_MFMA_PEAK_TFLOPS, 4), "per_kernel": per}
+        K.TIMERS.records.clear()
         K.set_mlp_precision(a.mlp_precision)
+    other = exact["value"] if exact else None
 
     rays_step = WL.rays_per_step(wl) * world
     ms_step = dt / a.steps * 1e3
@@ -342,7 +448,7 @@ def main():
 
     # ---- roofline: the fused MLP (K3) against the MFMA roof, algorithmic FLOPs / HIP-event-timed duration --
     fpp = WL.mlp_flops_per_point(wl["channels"])
-    summ = K.TIMERS.summary()
+    summ = summ_main
     split = a.mlp_precision == "split"
     peak = F16_MFMA_PEAK_TFLOPS if split else F32_MFMA_PEAK_TFLOPS
     roof = None
@@ -422,6 +528,10 @@ def main():
                    "exact_f32_mfma_rays_per_s": other},
         "roofline": roof,
     }
+    if exact is not None:
+        out["exact_f32"], out["roofline_f32"] = exact, roof_f32
+    if comm is not None:
+        out.update(comm)
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline and not a.primary_only:
             # the workload the metric is quoted on, full size (one step is ~10-20 s of CPU work), and C1, the reference's

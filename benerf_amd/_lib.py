@@ -14,6 +14,8 @@ LIB_PATH = os.environ.get("BENERF_HIP_LIB") or os.path.join(_HERE, "libbenerf_hi
 NLAYERS = 12
 L_VIEWS, L_FEAT, L_ALPHA, L_RGB = 8, 9, 10, 11
 LOSS_NSTATS = 16
+# status words of the split-f16 range guard (include/benerf_hip.h)
+ST_ACT, ST_GRAD, ST_MODE, ST_AUTO, ST_SKIP, ST_SKIPPED, ST_CONSECUTIVE, ST_STEPS, ST_LAST_ACT, ST_LAST_GRAD, ST_WORDS = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 16
 
 
 class MlpParams(Structure):
@@ -51,6 +53,7 @@ _SIGNATURES = {
     "benerf_mlp_dw_workspace_floats": (c_size_t, [c_int64]),
     "benerf_mlp_fwd": (c_int, [POINTER(MlpParams), P, c_int, c_int, c_int, P, P, P, P, P, P, c_int, P, P]),
     "benerf_mlp_status_check": (c_int, [P, P]),
+    "benerf_step_gate": (c_int, [P, P, c_int, P]),
     "benerf_mlp_bwd_dx": (c_int, [POINTER(MlpParams), P, c_int, c_int, c_int, P, P, P, P, P, c_int, P, P]),
     "benerf_mlp_bwd_dw": (c_int, [c_int, c_int, c_int, P, P, P, P, c_size_t, POINTER(MlpGrads), c_int, c_int, P, P]),
     "benerf_composite_fwd": (c_int, [P, P, P, P, c_float, c_uint64, c_uint64, c_int, c_int, c_int, P, P, P, P, P, P, P]),

@@ -18,16 +18,24 @@ extern "C" const char* benerf_last_error(void) { return g_err; }
 // synchronises - it has to, a device-side condition cannot reach a return code otherwise.
 extern "C" int benerf_mlp_status_check(const uint32_t* status, benerf_stream_t stream) {
     BENERF_REQUIRE(status, "mlp_status_check: null pointer");
-    uint32_t h[4] = {0, 0, 0, 0};
+    uint32_t h[BENERF_ST_WORDS] = {0};
     if (hipMemcpyAsync(h, status, sizeof(h), hipMemcpyDeviceToHost, as_stream(stream)) != hipSuccess ||
         hipStreamSynchronize(as_stream(stream)) != hipSuccess) {
         benerf_set_error("mlp_status_check: copy failed: %s", hipGetErrorString(hipGetLastError()));
         return BENERF_EHIP;
     }
     float act, grad;
-    memcpy(&act, &h[0], 4);
-    memcpy(&grad, &h[1], 4);
-    if (h[2]) {
+    memcpy(&act, &h[BENERF_ST_ACT], 4);
+    memcpy(&grad, &h[BENERF_ST_GRAD], 4);
+    if (h[BENERF_ST_SKIPPED] && act < 65504.f && grad < 65504.f) {   // steps gated since the host last cleared the words
+        memcpy(&act, &h[BENERF_ST_LAST_ACT], 4);
+        memcpy(&grad, &h[BENERF_ST_LAST_GRAD], 4);
+        benerf_set_error("mlp(split): %u of %u training steps were skipped (%u in a row at the end) - an activation (max %g) or a scaled "
+                         "gradient (max %g) left the f16 range (65504) on this or another rank; train with BENERF_MLP_F32",
+                         h[BENERF_ST_SKIPPED], h[BENERF_ST_STEPS], h[BENERF_ST_CONSECUTIVE], (double)act, (double)grad);
+        return BENERF_ERANGE;
+    }
+    if (h[BENERF_ST_MODE]) {
         benerf_set_error("mlp: a backward launch was handed activation buffers written in another precision mode");
         return BENERF_EBADARG;
     }

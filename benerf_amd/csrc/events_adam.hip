@@ -58,7 +58,9 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
                             float eps, float bc2_sqrt, float grad_scale, const uint32_t* __restrict__ skip_if_range) {
     // status words of the split-f16 MLP mode (include/benerf_hip.h): a step whose activations or scaled gradients left
     // the f16 range carries inf / NaN gradients - leave parameters and moments untouched, the host reports it
-    if (skip_if_range && (skip_if_range[0] >= 0x477fe000u || skip_if_range[1] >= 0x477fe000u)) return;   // 65504.f
+    // ([4]: the verdict of benerf_step_gate for this step - identical on every data-parallel rank)
+    if (skip_if_range && (skip_if_range[BENERF_ST_SKIP] != 0u || skip_if_range[BENERF_ST_ACT] >= 0x477fe000u ||
+                          skip_if_range[BENERF_ST_GRAD] >= 0x477fe000u)) return;   // 65504.f
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         float gi = g[i] * grad_scale;
@@ -71,7 +73,35 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     }
 }
 
+// Range-guard bookkeeping of one training step (include/benerf_hip.h, benerf_step_gate).  One thread.
+__global__ void step_gate_kernel(uint32_t* __restrict__ st, float* __restrict__ flag, int phase) {
+    const bool local = st[BENERF_ST_ACT] >= 0x477fe000u || st[BENERF_ST_GRAD] >= 0x477fe000u || st[BENERF_ST_MODE] != 0u;
+    if (phase == 0) {          // this rank's verdict as a float, to be SUMMED over the ranks with the gradients
+        flag[0] = local ? 1.f : 0.f;
+        return;
+    }
+    const bool skip = flag ? (flag[0] > 0.f || local) : local;
+    if (local) {               // keep what tripped the guard for the host's message
+        st[BENERF_ST_LAST_ACT] = st[BENERF_ST_ACT];
+        st[BENERF_ST_LAST_GRAD] = st[BENERF_ST_GRAD];
+    }
+    st[BENERF_ST_SKIP] = skip ? 1u : 0u;
+    st[BENERF_ST_SKIPPED] += skip ? 1u : 0u;
+    st[BENERF_ST_CONSECUTIVE] = skip ? st[BENERF_ST_CONSECUTIVE] + 1u : 0u;
+    st[BENERF_ST_STEPS] += 1u;
+    st[BENERF_ST_ACT] = 0u;    // the next step starts clean: one violation does not disable training for good
+    st[BENERF_ST_GRAD] = 0u;
+    st[BENERF_ST_MODE] = 0u;
+}
+
 }  // namespace
+
+extern "C" int benerf_step_gate(uint32_t* status, float* reduce_flag, int phase, benerf_stream_t stream) {
+    BENERF_REQUIRE(status && (phase == 0 || phase == 1) && (phase == 1 || reduce_flag), "step_gate: bad args");
+    hipLaunchKernelGGL(step_gate_kernel, dim3(1), dim3(1), 0, as_stream(stream), status, reduce_flag, phase);
+    BENERF_LAUNCH_CHECK("step_gate");
+    return BENERF_OK;
+}
 
 extern "C" int benerf_event_accumulate(const int32_t* xs, const int32_t* ys, const float* ps, int64_t n, int H, int W,
                                        float* out, benerf_stream_t stream) {

@@ -21,12 +21,19 @@ def shard_indices(idx, rank, world):
     return idx[rank * per:(rank + 1) * per].contiguous()
 
 
+def _through_host(t, group):
+    """True when a device tensor has to be staged through host memory: the group has no device backend.  The backend
+    may be a plain name ("gloo", "nccl") or a per-device map ("cpu:gloo,cuda:nccl"): anything that names nccl (= RCCL
+    on ROCm) reduces device buffers in place; a custom backend that does not is treated like gloo (slow but correct)."""
+    return t.is_cuda and "nccl" not in str(torch.distributed.get_backend(group)).lower()
+
+
 def allreduce_sum_(t, world, group=None):
     """In-place sum over ranks (no-op on one rank).  With the gloo backend (CPU tests, or the
     2-ranks-on-one-GPU equivalence test) device tensors are staged through host memory; the
     production backend is nccl (= RCCL over xGMI), which reduces the device buffer directly."""
     if world > 1:
-        if t.is_cuda and torch.distributed.get_backend(group) == "gloo":
+        if _through_host(t, group):
             h = t.cpu()
             torch.distributed.all_reduce(h, op=torch.distributed.ReduceOp.SUM, group=group)
             t.copy_(h)
@@ -48,7 +55,7 @@ def allreduce_sum_async_(t, world, group=None):
     tests / several ranks on one GPU) has no device path: reduced synchronously through host memory."""
     if world <= 1:
         return _Done()
-    if t.is_cuda and torch.distributed.get_backend(group) == "gloo":
+    if _through_host(t, group):      # blocking round trip through host memory: no overlap with the kernels that follow
         allreduce_sum_(t, world, group)
         return _Done()
     return torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM, group=group, async_op=True)
@@ -57,7 +64,7 @@ def allreduce_sum_async_(t, world, group=None):
 def broadcast_(t, world, src=0, group=None):
     """Rank `src`'s values everywhere (parameters + optimiser state at start-up: replicas must not rely on seeds)."""
     if world > 1:
-        if t.is_cuda and torch.distributed.get_backend(group) == "gloo":
+        if _through_host(t, group):
             h = t.cpu()
             torch.distributed.broadcast(h, src=src, group=group)
             t.copy_(h)

@@ -40,9 +40,11 @@ class Camera:
 class Draws:
     """Random inputs of one render: explicit tensors (parity mode) or Philox (seed, offsets)."""
 
-    def __init__(self, t_rand=None, noise0=None, u=None, noise1=None, seed=0, offset=0, noise_std=NOISE_STD_DEFAULT):
+    def __init__(self, t_rand=None, noise0=None, u=None, noise1=None, seed=0, offset=0, noise_std=NOISE_STD_DEFAULT, near=0.0,
+                 far=1.0):
         self.t_rand, self.noise0, self.u, self.noise1 = t_rand, noise0, u, noise1
         self.seed, self.offset, self.noise_std = int(seed), int(offset), float(noise_std)
+        self.near, self.far = float(near), float(far)      # depth range of the stratified samples (model/nerf.py:297-299)
 
     def noise_args(self, which):
         t = self.noise0 if which == 0 else self.noise1
@@ -87,7 +89,7 @@ def _render_forward(cam, ndc, n_samples, n_importance, draws, poses, ray_idx, ne
     ro, rd, vd = K.rays_fwd(poses, ray_idx, cam.H, cam.W, cam.fx, cam.fy, cam.cx, cam.cy, ndc, remap=cam.remap)
     n_rays = ro.shape[0]
     t_rand, seed, off = draws.jitter_args()
-    z = K.stratified_z(n_rays, n_samples, ro.device, t_rand, seed, off)
+    z = K.stratified_z(n_rays, n_samples, ro.device, t_rand, seed, off, draws.near, draws.far)
     raw0, acts0 = K.mlp_fwd(net_c, ro, rd, vd, z, save)
     nz0 = draws.noise_args(0)
     want0 = ("rgb_map", "disp", "acc", "weights") if n_importance > 0 else ("rgb_map", "disp", "acc", "sigma")
@@ -161,6 +163,10 @@ class RenderRays(torch.autograd.Function):
     def forward(ctx, poses, ray_idx, cam, ndc, n_samples, n_importance, draws, net_c, net_f, *params):
         poses_c = poses.detach().contiguous()
         need_grad = any(ctx.needs_input_grad)
+        if need_grad and K.get_mlp_precision() == "split":
+            # range guard of the autograd path: the previous backward posted the device's status words to pinned host memory;
+            # gradients that left the f16 range (inf / NaN into torch.optim) are reported here, without a synchronisation
+            K.range_guard(poses_c.device).poll()
         net_c.pack_if_stale()
         if net_f is not None:
             net_f.pack_if_stale()
@@ -190,6 +196,8 @@ class RenderRays(torch.autograd.Function):
             gf = ([torch.empty_like(w) for w in net_f.weights], [torch.empty_like(b) for b in net_f.biases])
         d_poses = _render_backward(ctx.cam, ctx.ndc, ctx.draws, ctx.poses, ctx.ray_idx, net_c, net_f, ctx.saved_k, g,
                                    gc, gf, False)
+        if K.get_mlp_precision() == "split":
+            K.range_guard(d_poses.device).post()
         ctx.saved_k = None
         grads = list(gc[0]) + list(gc[1])
         if net_f is not None:
@@ -236,6 +244,9 @@ def getattr_path(obj, dotted):
 
 
 class TrainStep:
+    MAX_SKIPPED_IN_A_ROW = 3     # consecutive range-guard skips after which step() raises (checked without synchronising)
+    GUARD_POST_EVERY = 8         # steps between two copies of the guard's counters to the host
+
     """One full training iteration (train.py:153-394 semantics) as a fixed kernel sequence.
 
     Per rank it renders its shard of the event pixels (2 poses) and blur pixels (n poses) in one
@@ -266,7 +277,14 @@ class TrainStep:
         wf, bf = nerf_param_lists(graph.nerf_fine)
         n_net = sum(t.numel() for t in wc + bc)
         self.n_net = n_net
-        n_total = 2 * n_net + 24 + 6
+        # flat layout: [coarse net | fine net | knots 24 | transform 6 | range-guard verdict 1 | tone-mapper parameters]
+        crf_mods = [(getattr(graph, "rgb_crf", None), getattr(cfg, "rgb_crf_lrate", 5e-4), getattr(cfg, "decay_rate_rgb_crf", 0.1), 3)
+                    if self.use_rgb_crf else None,
+                    (getattr(graph, "event_crf", None), getattr(cfg, "event_crf_lrate", 5e-4), getattr(cfg, "decay_rate_event_crf", 0.1), 4)
+                    if self.use_evt_crf else None]
+        crf_mods = [m for m in crf_mods if m is not None]
+        n_crf = sum(p_.numel() for m in crf_mods for p_ in m[0].parameters())
+        n_total = 2 * n_net + 24 + 6 + 1 + n_crf
         self.flat_p = torch.zeros(n_total, dtype=torch.float32, device=device)
         self.flat_g = torch.zeros(n_total, dtype=torch.float32, device=device)
         self.flat_m = torch.zeros(n_total, dtype=torch.float32, device=device)
@@ -285,20 +303,26 @@ class TrainStep:
         self.g_knots = self.flat_g[o:o + 24].view(4, 6)
         self.g_transform = self.flat_g[o + 24:o + 30].view(1, 6)
         self.off_pose = o
+        # Range guard of the split-f16 mode (include/benerf_hip.h `status`): this step's own words.  flag: this rank's verdict
+        # as a float behind the trajectory gradients - it rides their all-reduce, so every replica skips the same steps.
+        self.guard = K.RangeGuard(device)
+        self.flag = self.flat_g[o + 30:o + 31]
         # CRF tone-mappers (train.py:180-192; off in every shipped config): 385 parameters each, applied to the rendered colours
-        # between compositing and the loss kernels as torch modules (per-ray work, thousands of rows), their own Adam
-        self.crf_params, self.crf_opts = [], []
-        for on, mod, lr0, dr in ((self.use_rgb_crf, getattr(graph, "rgb_crf", None), getattr(cfg, "rgb_crf_lrate", 5e-4),
-                                  getattr(cfg, "decay_rate_rgb_crf", 0.1)),
-                                 (self.use_evt_crf, getattr(graph, "event_crf", None), getattr(cfg, "event_crf_lrate", 5e-4),
-                                  getattr(cfg, "decay_rate_event_crf", 0.1))):
-            if on:
-                ps = list(mod.parameters())
-                for p_ in ps:
-                    dist.broadcast_(p_.data, self.world, 0, self.pg)
-                self.crf_params += ps
-                self.crf_opts.append((torch.optim.Adam(ps, lr=lr0), lr0, dr))
-        self._crf_slots = [i for i, on in ((3, self.use_rgb_crf), (4, self.use_evt_crf)) if on]   # index in setup_optimizer's tuple
+        # between compositing and the loss kernels as torch modules (per-ray work, thousands of rows); their parameters live in
+        # the flat buffers like everything else: same fused Adam (same range gate), same all-reduce bucket
+        self.crf_params, self.crf_groups = [], []       # groups: (offset, count, lr0, decay, index in setup_optimizer's tuple)
+        oc = o + 31
+        for mod, lr0, dr, slot in crf_mods:
+            first = oc
+            for p_ in mod.parameters():
+                n_ = p_.numel()
+                v = self.flat_p[oc:oc + n_].view(p_.shape)
+                v.copy_(p_.detach())
+                p_.data = v
+                self.crf_params.append(p_)
+                oc += n_
+            self.crf_groups.append((first, oc - first, lr0, dr, slot))
+        self.off_crf = o + 31
         self.global_step = 0
         # replicas start from rank 0's parameters (and its - zero - Adam state), whatever their local initialisation was
         for buf in (self.flat_p, self.flat_m, self.flat_v):
@@ -323,13 +347,12 @@ class TrainStep:
     def _trained_optimizers(self, optimizers):
         cfg = self.cfg
         return ((optimizers[0], self._lr(cfg.lrate, cfg.decay_rate)), (optimizers[1], self._lr(cfg.pose_lrate, cfg.decay_rate_pose)),
-                (optimizers[2], self._lr(cfg.transform_lrate, cfg.decay_rate_transform)))
+                (optimizers[2], self._lr(cfg.transform_lrate, cfg.decay_rate_transform))) + \
+            tuple((optimizers[slot], self._lr(lr0, dr)) for _, _, lr0, dr, slot in self.crf_groups)
 
     def export_optimizer_state(self, optimizers):
         """Fills the Adam objects of Model.setup_optimizer (nerf, pose, transform, ...) with this step's moments, step
         count and current learning rates, ready for checkpoint.save (the tone-mapper optimisers too, when they are trained)."""
-        for slot, (opt, _, _) in zip(self._crf_slots, self.crf_opts):
-            optimizers[slot].load_state_dict(opt.state_dict())
         for opt, lr in self._trained_optimizers(optimizers):
             for group in opt.param_groups:
                 group["lr"] = lr
@@ -351,11 +374,14 @@ class TrainStep:
                     off, n = self._flat_slice(p)
                     self.flat_m[off:off + n].copy_(st["exp_avg"].reshape(-1))
                     self.flat_v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
-        for slot, (opt, _, _) in zip(self._crf_slots, self.crf_opts):
-            opt.load_state_dict(optimizers[slot].state_dict())
         self.global_step = int(global_step)
         self.net_c.packed.pack()
         self.net_f.packed.pack()
+
+    def check_range(self, reset=True):
+        """Synchronises.  Raises kernels.BenerfRangeError if a step since the last reset left the f16 range of the split mode
+        (those steps were skipped on every rank: parameters and Adam moments untouched)."""
+        self.guard.check(reset)
 
     def shard(self, idx):
         """Contiguous slice of a global pixel-index vector for this rank."""
@@ -368,6 +394,10 @@ class TrainStep:
         z_fine_forced [N, S+Ni]: parity runs may supply the merged fine depths instead of K5's (sample_pdf is
         ill-conditioned in the coarse weights: isolates everything behind it)."""
         cfg, C, dev = self.cfg, self.C, self.dev
+        # range guard: a run whose steps keep being skipped on the device must not go on silently - looks at the last copy
+        # of the counters that has landed in pinned host memory (no synchronisation)
+        self.guard.poll(max_consecutive=self.MAX_SKIPPED_IN_A_ROW)
+        st = self.guard.words
         P = cfg.num_interpolated_pose
         S, Ni = cfg.N_samples, cfg.N_importance
         idx_e, idx_r = self.shard(idx_evt_global), self.shard(idx_rgb_global)
@@ -397,12 +427,12 @@ class TrainStep:
         if getattr(cfg, "use_barf_c2f", False):     # iter_step of graph.forward(i, ...) = the iteration counter (train.py:160)
             pw = K.barf_pe_weights(step_id, cfg.max_iter, cfg.barf_c2f_start, cfg.barf_c2f_end, dev)
         self.net_c.packed.pe_weights = self.net_f.packed.pe_weights = pw
-        raw0, acts0 = K.mlp_fwd(self.net_c.packed, ro, rd, vd, z, True)
+        raw0, acts0 = K.mlp_fwd(self.net_c.packed, ro, rd, vd, z, True, status=st)
         nz0 = d.noise_args(0)
         c0 = K.composite_fwd(raw0, z, rd, nz0[0], nz0[1], nz0[2], nz0[3], want=("rgb_map", "weights"))
         u, usd, uoff = d.u_args()
         z_fine = K.sample_pdf_merge(z, c0["weights"], Ni, u, usd, uoff) if z_fine_forced is None else z_fine_forced.contiguous()
-        raw1, acts1 = K.mlp_fwd(self.net_f.packed, ro, rd, vd, z_fine, True)
+        raw1, acts1 = K.mlp_fwd(self.net_f.packed, ro, rd, vd, z_fine, True, status=st)
         nz1 = d.noise_args(1)
         c1 = K.composite_fwd(raw1, z_fine, rd, nz1[0], nz1[1], nz1[2], nz1[3], want=("rgb_map",))
         rgb_map, rgb0 = c1["rgb_map"], c0["rgb_map"]
@@ -441,6 +471,8 @@ class TrainStep:
                 p_.grad = None
             torch.autograd.backward(mapped, [g_rgb, g_rgb0])
             g_rgb, g_rgb0 = leaves[0].grad.contiguous(), leaves[1].grad.contiguous()
+            n_crf = sum(p_.numel() for p_ in self.crf_params)
+            torch.cat([p_.grad.reshape(-1) for p_ in self.crf_params], out=self.flat_g[self.off_crf:self.off_crf + n_crf])
             rgb_map, rgb0 = raw_maps[0].detach(), raw_maps[1].detach()
 
         # ---- backward -------------------------------------------------------------------------------
@@ -454,7 +486,7 @@ class TrainStep:
         main, side = torch.cuda.current_stream(dev), self.dw_stream
         d_raw1, _ = K.composite_bwd(raw1, z_fine, rd, nz1[0], nz1[1], nz1[2], nz1[3], g_rgb, d_rays_d=d_d)
         d_raw0, _ = K.composite_bwd(raw0, z, rd, nz0[0], nz0[1], nz0[2], nz0[3], g_rgb0, d_rays_d=d_d, accumulate=True)
-        d_pts1, d_vp1, dacts1 = K.mlp_bwd_dx(self.net_f.packed, d_raw1.view(-1, C + 1), acts1, N, S + Ni, slot="_fine")
+        d_pts1, d_vp1, dacts1 = K.mlp_bwd_dx(self.net_f.packed, d_raw1.view(-1, C + 1), acts1, N, S + Ni, slot="_fine", status=st)
         side.wait_stream(main)
         with torch.cuda.stream(side):
             K.mlp_bwd_dw(self.net_f.packed, d_raw1.view(-1, C + 1), acts1, dacts1, N, S + Ni, self.net_f.gviews_w,
@@ -462,7 +494,7 @@ class TrainStep:
             # gradient exchange, bucket 1 of 3: the fine network's gradients are final - their all-reduce (RCCL over
             # xGMI) runs on the communicator's stream while the coarse backward computes
             pending = [dist.allreduce_sum_async_(self.flat_g[n:2 * n], self.world, self.pg)]
-        d_pts0, d_vp0, dacts0 = K.mlp_bwd_dx(self.net_c.packed, d_raw0.view(-1, C + 1), acts0, N, S, slot="_coarse")
+        d_pts0, d_vp0, dacts0 = K.mlp_bwd_dx(self.net_c.packed, d_raw0.view(-1, C + 1), acts0, N, S, slot="_coarse", status=st)
         side.wait_stream(main)
         with torch.cuda.stream(side):
             K.mlp_bwd_dw(self.net_c.packed, d_raw0.view(-1, C + 1), acts0, dacts0, N, S, self.net_c.gviews_w,
@@ -476,7 +508,10 @@ class TrainStep:
         torch.add(dk_e, dk_r, out=self.g_knots)
         self.g_transform.copy_(dt_r)
 
-        # ---- gradient exchange, bucket 3: the 30 trajectory gradients; then every bucket must have landed ------------
+        # ---- gradient exchange, bucket 3: the 30 trajectory gradients + this rank's range-guard verdict (+ the tone-mapper
+        # gradients); then every bucket must have landed ---------------------------------------------------------------
+        if self.world > 1:
+            self.guard.gate(self.flag, phase=0)
         pending.append(dist.allreduce_sum_async_(self.flat_g[2 * n:], self.world, self.pg))
         with torch.cuda.stream(side):
             for w in pending[:2]:
@@ -485,30 +520,24 @@ class TrainStep:
         pending[2].wait()
 
         # ---- Adam (K8) with the reference's per-group switches and LR schedule ---------------------------------
+        # the range guard's verdict for this step (summed over the ranks): [SKIP] makes every Adam launch below a no-op
+        self.guard.gate(self.flag if self.world > 1 else None, phase=1)
         t = self.global_step + 1
+
+        def adam(lo, cnt, lr):
+            K.adam_step(self.flat_p[lo:lo + cnt], self.flat_g[lo:lo + cnt], self.flat_m[lo:lo + cnt], self.flat_v[lo:lo + cnt], lr, t,
+                        status=st)
         if cfg.optimize_nerf:
-            K.adam_step(self.flat_p[:2 * self.n_net], self.flat_g[:2 * self.n_net], self.flat_m[:2 * self.n_net],
-                        self.flat_v[:2 * self.n_net], self._lr(cfg.lrate, cfg.decay_rate), t)
+            adam(0, 2 * self.n_net, self._lr(cfg.lrate, cfg.decay_rate))
         o = self.off_pose
         if cfg.optimize_pose:
-            K.adam_step(self.flat_p[o:o + 24], self.flat_g[o:o + 24], self.flat_m[o:o + 24], self.flat_v[o:o + 24],
-                        self._lr(cfg.pose_lrate, cfg.decay_rate_pose), t)
+            adam(o, 24, self._lr(cfg.pose_lrate, cfg.decay_rate_pose))
         if cfg.optimize_trans:
-            K.adam_step(self.flat_p[o + 24:o + 30], self.flat_g[o + 24:o + 30], self.flat_m[o + 24:o + 30],
-                        self.flat_v[o + 24:o + 30],
-                        self._lr(cfg.transform_lrate, cfg.decay_rate_transform), t)
-        if self.crf_params:
-            if self.world > 1:
-                flat = torch.cat([p_.grad.reshape(-1) for p_ in self.crf_params])
-                dist.allreduce_sum_(flat, self.world, self.pg)
-                o_ = 0
-                for p_ in self.crf_params:
-                    p_.grad.copy_(flat[o_:o_ + p_.numel()].view_as(p_))
-                    o_ += p_.numel()
-            for opt, lr0, dr in self.crf_opts:
-                for grp in opt.param_groups:
-                    grp["lr"] = self._lr(lr0, dr)
-                opt.step()
+            adam(o + 24, 6, self._lr(cfg.transform_lrate, cfg.decay_rate_transform))
+        for lo, cnt, lr0, dr, _ in self.crf_groups:
+            adam(lo, cnt, self._lr(lr0, dr))
+        if self.global_step % self.GUARD_POST_EVERY == 0:
+            self.guard.post()
         self.net_c.packed.pack()
         self.net_f.packed.pack()
         self.global_step += 1

@@ -205,27 +205,100 @@ def get_mlp_precision():
     return _default_precision
 
 
-_status = {}
+class RangeGuard:
+    """Range-guard words of the split-f16 MLP mode (include/benerf_hip.h, K3 `status`) for ONE owner: a TrainStep, or
+    the per-device guard of the stand-alone / autograd entry points.  Nothing here synchronises except check():
+    post() queues a copy of the words into pinned host memory, poll() looks at the last copy that has landed."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.words = torch.zeros(_lib.ST_WORDS, dtype=torch.int32, device=self.device)
+        self._mirror = self._event = None
+        self._posted = False        # a copy queued by post() that poll() has not looked at yet
+
+    def gate(self, reduce_flag=None, phase=1):
+        """benerf_step_gate: phase 0 writes this rank's verdict into reduce_flag[0]; phase 1 turns the (summed) verdict
+        into the skip word the Adam launches read, updates the counters and clears the per-step words."""
+        _lib.check(_lib.load().benerf_step_gate(self.words.data_ptr(), _chk(reduce_flag, name="reduce_flag"), phase, _stream()),
+                   "step_gate")
+
+    def post(self):
+        if self._mirror is None:
+            self._mirror = torch.zeros(_lib.ST_WORDS, dtype=torch.int32).pin_memory()
+            self._event = torch.cuda.Event()
+        self._mirror.copy_(self.words, non_blocking=True)
+        self._event.record()
+        self._posted = True
+
+    def _raise(self, h):
+        import struct
+        f = lambda w: struct.unpack("f", struct.pack("I", int(w) & 0xffffffff))[0]   # noqa: E731
+        if h[_lib.ST_SKIPPED]:
+            raise _lib.BenerfRangeError(
+                "mlp(split): %d of %d training steps were skipped on the device (%d in a row at the end): an activation (max %g) "
+                "or a scaled gradient (max %g) left the f16 range (65504) on this or another rank - train with mlp precision 'f32'"
+                % (h[_lib.ST_SKIPPED], h[_lib.ST_STEPS], h[_lib.ST_CONSECUTIVE], f(h[_lib.ST_LAST_ACT]), f(h[_lib.ST_LAST_GRAD])))
+        raise _lib.BenerfRangeError("mlp(split): activation max %g / scaled gradient max %g left the f16 range (65504): the gradients "
+                                    "of that backward pass are inf / NaN - use mlp precision 'f32'" % (f(h[_lib.ST_ACT]), f(h[_lib.ST_GRAD])))
+
+    def poll(self, max_consecutive=1):
+        """Non-blocking.  Raises BenerfRangeError when the last landed copy shows `max_consecutive` skipped steps in a row
+        (TrainStep) or a violation nobody has gated (autograd path)."""
+        if not self._posted or not self._event.query():
+            return
+        self._posted = False
+        h = [int(v) & 0xffffffff for v in self._mirror.tolist()]
+        lim = 0x477fe000
+        if h[_lib.ST_CONSECUTIVE] >= max_consecutive or h[_lib.ST_ACT] >= lim or h[_lib.ST_GRAD] >= lim:
+            self._raise(h)
+
+    def check(self, reset=True):
+        """Synchronises.  Raises BenerfRangeError if a launch since the last reset saw a value outside the f16 range or a
+        training step was skipped for it; BenerfHipError for a precision-mode mix-up of forward and backward buffers."""
+        rc = _lib.load().benerf_mlp_status_check(self.words.data_ptr(), _stream())
+        self._posted = False            # whatever an earlier post() copied is older than this synchronous look
+        if rc != 0 and reset:
+            self.words.zero_()
+        _lib.check(rc, "mlp_status_check")
+
+
+_guards = {}
+_auto_words = {}
+
+
+def range_guard(device):
+    """The device's guard of the stand-alone and autograd entry points (TrainStep owns its own)."""
+    key = str(torch.device(device))
+    g = _guards.get(key)
+    if g is None:
+        g = _guards[key] = RangeGuard(device)
+    return g
 
 
 def mlp_status(device):
-    """The device's status words of the split-f16 mode (uint32[4], include/benerf_hip.h K3)."""
+    """The device's default status words (uint32[BENERF_ST_WORDS] as int32, include/benerf_hip.h K3)."""
+    return range_guard(device).words
+
+
+def _auto_status(device):
+    # BENERF_MLP_AUTO launches (inference) handle an overflow themselves by re-running in exact f32: their words are kept
+    # apart, so that an overflow during e.g. render_image_test can never gate a training step
     key = str(torch.device(device))
-    t = _status.get(key)
+    t = _auto_words.get(key)
     if t is None:
-        t = torch.zeros(4, dtype=torch.int32, device=device)
-        _status[key] = t
+        t = _auto_words[key] = torch.zeros(_lib.ST_WORDS, dtype=torch.int32, device=device)
     return t
 
 
+def auto_fallback_max(device):
+    """Synchronises: largest |activation| that made a BENERF_MLP_AUTO launch fall back to exact f32 so far (0.0 if none)."""
+    return float(_auto_status(device)[_lib.ST_ACT:_lib.ST_ACT + 1].view(torch.float32).item())
+
+
 def check_mlp_status(device, reset=True):
-    """Synchronises.  Raises BenerfRangeError if a split-mode launch since the last reset saw an activation or a
-    scaled gradient outside the f16 range (the affected Adam steps were skipped on the device)."""
-    st = mlp_status(device)
-    rc = _lib.load().benerf_mlp_status_check(st.data_ptr(), _stream())
-    if rc != 0 and reset:
-        st.zero_()
-    _lib.check(rc, "mlp_status_check")
+    """Synchronises.  Raises BenerfRangeError if a split-mode launch on the device's default status words since the last
+    reset saw an activation or a scaled gradient outside the f16 range."""
+    range_guard(device).check(reset)
 
 
 _param_generation = 0
@@ -286,9 +359,10 @@ def barf_pe_weights(iter_step, max_iter, start, end, device):
     return torch.tensor(tab, dtype=torch.float32, device=device)
 
 
-def mlp_fwd(net, rays_o, rays_d, viewdirs, z, save_acts, precision=None):
+def mlp_fwd(net, rays_o, rays_d, viewdirs, z, save_acts, precision=None, status=None):
     """Returns (raw, acts).  Inference launches (save_acts False) in split mode run as BENERF_MLP_AUTO: the output is
-    valid even if an activation leaves the f16 range (include/benerf_hip.h)."""
+    valid even if an activation leaves the f16 range (include/benerf_hip.h).  status: the owner's range-guard words
+    (default: the device's)."""
     lib = _lib.load()
     n_rays, n_samples = z.shape
     C = net.channels
@@ -303,15 +377,18 @@ def mlp_fwd(net, rays_o, rays_d, viewdirs, z, save_acts, precision=None):
     code = MLP_PRECISIONS[mode]
     if code == 1 and not save_acts:
         code = _MLP_AUTO
+        status = _auto_status(z.device)
+    if status is None:
+        status = mlp_status(z.device)
     _timer("mlp_fwd", n_rays * n_samples)
     _lib.check(lib.benerf_mlp_fwd(ctypes.byref(s), net.packed.data_ptr(), C, n_rays, n_samples, _chk(rays_o),
                                   _chk(rays_d), _chk(viewdirs), _chk(z), raw.data_ptr(), _chk(acts), code,
-                                  mlp_status(z.device).data_ptr(), _stream()), "mlp_fwd")
+                                  status.data_ptr(), _stream()), "mlp_fwd")
     _timer(None, 0)
     return raw, acts
 
 
-def mlp_bwd_dx(net, d_raw, acts, n_rays, n_samples, slot=""):
+def mlp_bwd_dx(net, d_raw, acts, n_rays, n_samples, slot="", status=None):
     """Activation-gradient chain of one network: returns per-point (d_pts [M,3], d_vdir [M,3]) and the per-layer
     activation gradients (scratch buffer `slot`: give the two networks different slots when the weight-gradient launch
     of one is to overlap the chain of the other)."""
@@ -328,7 +405,8 @@ def mlp_bwd_dx(net, d_raw, acts, n_rays, n_samples, slot=""):
     _timer("mlp_bwd_dx", M)
     _lib.check(lib.benerf_mlp_bwd_dx(ctypes.byref(s), net.packed.data_ptr(), net.channels, n_rays, n_samples,
                                      _chk(d_raw, name="d_raw"), _chk(acts), dacts.data_ptr(), d_pts.data_ptr(),
-                                     d_vd.data_ptr(), code, mlp_status(dev).data_ptr(), _stream()), "mlp_bwd_dx")
+                                     d_vd.data_ptr(), code, (mlp_status(dev) if status is None else status).data_ptr(),
+                                     _stream()), "mlp_bwd_dx")
     _timer(None, 0)
     return d_pts, d_vd, dacts
 
@@ -482,10 +560,11 @@ def sample_pixels(n_total, count, seed, offset, device):
 
 # ----------------------------------------------------------------------------- K8 optimiser
 def adam_step(param, grad, exp_avg, exp_avg_sq, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0,
-              guard_range=True):
-    """guard_range: skip the update on the device when the split-mode status words show a range violation."""
+              guard_range=True, status=None):
+    """guard_range: skip the update on the device when the range-guard words (`status`, default: the device's) show a
+    violation or carry benerf_step_gate's skip verdict."""
     lib = _lib.load()
-    st = mlp_status(param.device).data_ptr() if guard_range else None
+    st = (mlp_status(param.device) if status is None else status).data_ptr() if guard_range else None
     _lib.check(lib.benerf_adam_step(_chk(param), _chk(grad), _chk(exp_avg), _chk(exp_avg_sq), param.numel(), lr, beta1,
                                     beta2, eps, step, grad_scale, st, _stream()), "adam_step")
     params_changed()

@@ -185,6 +185,23 @@ class Graph(nn.Module):
             self._event_cache = (key, cache)
         return self._event_cache[1]
 
+    def _device_lut(self, remap, H, W):
+        """TUM_VIE undistortion table [H, W, 2] as a float32 device tensor, uploaded once per source array: the training loop
+        hands the same host table to every render() (twice per iteration), inference to every chunk."""
+        dev = self._device()
+        if isinstance(remap, torch.Tensor) and remap.is_cuda and remap.dtype == torch.float32:
+            return remap.reshape(H, W, 2).contiguous()
+        cache = getattr(self, "_lut_cache", None)
+        if cache is None:
+            cache = self._lut_cache = {}
+        key = (id(remap), H, W)
+        hit = cache.get(key)
+        if hit is None or hit[0] is not remap:
+            if len(cache) >= 4:
+                cache.clear()
+            hit = cache[key] = (remap, torch.as_tensor(remap, dtype=torch.float32, device=dev).reshape(H, W, 2).contiguous())
+        return hit[1]
+
     def forward(self, iter_step, events, rgb_exp_ts, H, W, K, K_event, args, img_xy_remap, evt_xy_remap):
         """One training iteration's rendering (model/nerf.py:160-234): event-window accumulation,
         two trajectory queries, two renders.  Same return tuple as the reference."""
@@ -221,10 +238,13 @@ class Graph(nn.Module):
         ray_idx_event = torch.randperm(He * We, device=dev)[:args.sampling_event_rays]
         ret_event = self.render(iter_step, spline_evt_poses, ray_idx_event.reshape(-1, 1).squeeze(), He, We,
                                 torch.Tensor(K_event), args, enable_crf=True, sensor_type="event",
-                                remap=torch.tensor(evt_xy_remap), training=True)
+                                remap=self._device_lut(evt_xy_remap, He, We) if args.dataset == "TUM_VIE" else torch.tensor(evt_xy_remap),
+                                training=True)
         ray_idx_rgb = torch.randperm(H * W, device=dev)[:args.sampling_rgb_rays // args.num_interpolated_pose]
         ret_rgb = self.render(iter_step, spline_rgb_poses, ray_idx_rgb.reshape(-1, 1).squeeze(), H, W, torch.Tensor(K),
-                              args, enable_crf=True, sensor_type="rgb", remap=torch.tensor(img_xy_remap), training=True)
+                              args, enable_crf=True, sensor_type="rgb",
+                              remap=self._device_lut(img_xy_remap, H, W) if args.dataset == "TUM_VIE" else torch.tensor(img_xy_remap),
+                              training=True)
         return ret_event, ret_rgb, ray_idx_event, ray_idx_rgb, events_accu
 
     # ---- render -------------------------------------------------------------------------------------------
@@ -234,14 +254,14 @@ class Graph(nn.Module):
         (model/nerf.py:236-343).  `training` only selects how the reference builds its rays; both
         branches give the same rays, generated on the fly here."""
         if not args.use_viewdirs:
-            raise NotImplementedError("use_viewdirs=False is not supported")
-        if near != 0. or far != 1.:
-            raise NotImplementedError("render() supports the reference's near=0, far=1 only")
+            # the reference cannot run this combination either: model/optimize.py:9 builds both networks with use_viewdirs=True and
+            # NeRF.forward (model/nerf.py:93) then splits the 63-wide encoding into 63 + 27 columns -> RuntimeError
+            raise NotImplementedError("use_viewdirs=False: the reference's own NeRF.forward raises for it (INTEGRATION.md)")
         dev = self._device()
         poses = poses[:, :3, :4]
         lut = None
         if args.dataset == "TUM_VIE":      # rect = remap[j, i] (model/nerf.py:247-250; run_nerf_helpers.py:17-23 for inference)
-            lut = torch.as_tensor(remap, dtype=torch.float32, device=dev).reshape(H, W, 2).contiguous()
+            lut = self._device_lut(remap, H, W)
         cam = Camera.from_K(H, W, K, lut)
         ray_idx = ray_idx.reshape(-1).to(device=dev, dtype=torch.int64).contiguous()
         N = poses.shape[0] * ray_idx.shape[0]
@@ -249,13 +269,13 @@ class Graph(nn.Module):
         std = float(getattr(args, "benerf_raw_noise_std", engine.NOISE_STD_DEFAULT))
         if getattr(args, "benerf_rng", "torch") == "philox":
             self._philox_calls = getattr(self, "_philox_calls", 0) + 1
-            draws = Draws(seed=int(getattr(args, "benerf_seed", 0)), offset=self._philox_calls, noise_std=std)
+            draws = Draws(seed=int(getattr(args, "benerf_seed", 0)), offset=self._philox_calls, noise_std=std, near=near, far=far)
         else:   # reference behaviour: four draws from the global torch generator, in its order
             t_rand = _draw(torch.rand, (N, S), dev)
             noise0 = _draw(torch.randn, (N, S), dev, std) if std > 0 else None
             u = _draw(torch.rand, [N, Ni], dev) if Ni > 0 else None
             noise1 = _draw(torch.randn, (N, S + Ni), dev, std) if (std > 0 and Ni > 0) else None
-            draws = Draws(t_rand, noise0, u, noise1, noise_std=0.0 if std <= 0 else std)
+            draws = Draws(t_rand, noise0, u, noise1, noise_std=0.0 if std <= 0 else std, near=near, far=far)
         net_c = self.nerf.packed()
         net_f = self.nerf_fine.packed() if Ni > 0 else None
         net_c.pe_weights = barf_weights(iter_step, args, dev)

@@ -152,16 +152,30 @@ size_t benerf_mlp_dw_workspace_floats(int64_t n_points);
  * The saved-activation / gradient buffers have a mode-specific layout: forward and backward of one step must
  * use the same mode (the buffers are tagged; a mismatch is reported through status[2]).
  *
- * status: caller-owned DEVICE uint32[4], zeroed by the caller, may be NULL for BENERF_MLP_F32:
- *   [0] max |activation| seen by split forward launches (f32 bit pattern; written only once it passes 2^15; sticky)
- *   [1] max |gradient| of the tile-scaled split dX chain, taken before its rounding to f16 (same convention)
- *   [2] != 0: a backward launch got activation buffers of another mode
- *   [3] scratch of BENERF_MLP_AUTO (maximum of the current call)
- * Nothing here synchronises; benerf_mlp_status_check does (copy + stream sync) and returns BENERF_ERANGE when
- * [0] or [1] reached 65504, BENERF_EBADARG for [2].  benerf_adam_step takes the same pointer and leaves the
- * parameters untouched for a step whose status shows a range violation. */
+ * status: caller-owned DEVICE uint32[BENERF_ST_WORDS], zeroed by the caller, may be NULL for BENERF_MLP_F32:
+ *   [ACT]  max |activation| seen by split forward launches (f32 bit pattern; written only once it passes 2^15)
+ *   [GRAD] max |gradient| of the tile-scaled split dX chain, taken before its rounding to f16 (same convention)
+ *   [MODE] != 0: a backward launch got activation buffers of another mode
+ *   [AUTO] scratch of BENERF_MLP_AUTO (maximum of the current call)
+ *   [SKIP .. LAST_GRAD] bookkeeping of benerf_step_gate (below).
+ * [ACT], [GRAD], [MODE] stay set until benerf_step_gate or the caller clears them.  Nothing here synchronises;
+ * benerf_mlp_status_check does (copy + stream sync) and returns BENERF_ERANGE when [ACT] or [GRAD] reached 65504 or
+ * training steps were skipped since the words were last zeroed, BENERF_EBADARG for [MODE].
+ * benerf_adam_step takes the same pointer and leaves the parameters untouched when [SKIP] is set or [ACT] / [GRAD]
+ * show a violation. */
 enum { BENERF_MLP_F32 = 0, BENERF_MLP_SPLIT = 1, BENERF_MLP_AUTO = 2 };
+enum { BENERF_ST_ACT = 0, BENERF_ST_GRAD = 1, BENERF_ST_MODE = 2, BENERF_ST_AUTO = 3, BENERF_ST_SKIP = 4, BENERF_ST_SKIPPED = 5,
+       BENERF_ST_CONSECUTIVE = 6, BENERF_ST_STEPS = 7, BENERF_ST_LAST_ACT = 8, BENERF_ST_LAST_GRAD = 9, BENERF_ST_WORDS = 16 };
 int benerf_mlp_status_check(const uint32_t* status, benerf_stream_t stream);
+/* Per-step verdict of the range guard, on the device (no synchronisation), between the backward pass and the
+ * benerf_adam_step launches of a training iteration (train.py:340-352):
+ *   phase 0: reduce_flag[0] = 1.f if this rank's [ACT] / [GRAD] / [MODE] show a violation, else 0.f - data-parallel
+ *            callers SUM it over the ranks together with the gradients, so that every replica takes the same decision
+ *            (a rank that overflowed contributes inf / NaN to everybody's gradient sum);
+ *   phase 1: [SKIP] = violation (reduce_flag[0] > 0 when reduce_flag != NULL, this rank's words otherwise), counters
+ *            [SKIPPED] (total), [CONSECUTIVE], [STEPS] updated, the tripping maxima kept in [LAST_ACT] / [LAST_GRAD],
+ *            [ACT] / [GRAD] / [MODE] cleared for the next step: one violation costs one step, not the rest of the run. */
+int benerf_step_gate(uint32_t* status, float* reduce_flag, int phase, benerf_stream_t stream);
 
 /* Fused positional encoding + 8x256 MLP + view branch, forward.
  * Replaces Embedder.embed (model/embedder.py:9-34) and NeRF.forward

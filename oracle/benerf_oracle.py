@@ -119,7 +119,7 @@ def se3_to_quat_trans(wu):
     w, u = wu[..., :3], wu[..., 3:]
     wx = hat(w)
     theta = w.norm(dim=-1)[..., None, None]
-    eye = torch.eye(3, dtype=torch.float32)
+    eye = torch.eye(3, dtype=wu.dtype)
     V = eye + _taylor(theta, 1) * wx + _taylor(theta, 2) * wx @ wx
     t = (V @ u[..., None]).squeeze(-1)
     return rotvec_to_quat(w), t
@@ -202,7 +202,9 @@ def trajectory_poses(knots, transform, ts2, n_poses, traj="spline"):
     transform in se(3), model/optimize.py:86-89); ts2 = (t_start, t_end).
     """
     k = knots if transform is None else knots + transform.reshape(1, 6)
-    ts = torch.linspace(float(ts2[0]), float(ts2[1]), n_poses)
+    # sample times are float32 data in every evaluation precision (the float64 runs of oracle/f64_truth.py differentiate the
+    # same function of the same inputs)
+    ts = torch.linspace(float(ts2[0]), float(ts2[1]), n_poses, dtype=torch.float32).to(knots.dtype)
     if traj == "linear":
         return linear_poses(k[0], k[3], ts)
     return cubic_spline_poses(k, ts)
@@ -218,6 +220,7 @@ def pixel_rays(ray_idx, W, K, poses):
     Returns rays_o, rays_d [P*R,3]."""
     P = poses.shape[0]
     R = ray_idx.shape[0]
+    K = K.to(poses.dtype)      # float32 intrinsics (a no-op in the float32 evaluation)
     idx = ray_idx.repeat(P)
     c2w = poses.unsqueeze(1).repeat(1, R, 1, 1).reshape(-1, 3, 4)
     j = idx // W
@@ -247,7 +250,7 @@ def make_rays(poses, ray_idx, H, W, K, ndc=True):
     viewdirs = rays_d / torch.norm(rays_d, dim=-1, keepdim=True)
     if ndc:
         rays_o, rays_d = ndc_project(H, W, K[0][0], 1.0, rays_o, rays_d)
-    return rays_o.float(), rays_d.float(), viewdirs.float()
+    return rays_o.to(poses.dtype), rays_d.to(poses.dtype), viewdirs.to(poses.dtype)
 
 
 def stratified_z(n_rays, n_samples, t_rand, near=0.0, far=1.0):
@@ -441,22 +444,40 @@ def fine_depths(z, weights, u, exact=False):
 # --------------------------------------------------------------------------------------
 
 def render(p_coarse, p_fine, poses, ray_idx, H, W, K, channels, n_samples, n_importance,
-           draws, ndc=True, exact_pdf=False, want_extras=False, barf=None):
+           draws, ndc=True, exact_pdf=False, want_extras=False, barf=None, z_forced=None, mlp_inputs_forced=None,
+           near=0.0, far=1.0):
     """Graph.render.  draws = dict(t_rand [N,S], noise0 [N,S] | None, u [N,Ni],
     noise1 [N,S+Ni] | None) - the four RNG draws in reference order.
+    z_forced = (z_coarse [N,S], z_fine [N,S+Ni]): depths of another evaluation of the same render, used INSTEAD of the
+    stratified / importance samples (sample_pdf is ill-conditioned in the coarse weights; oracle/f64_truth.py hands the
+    float32 evaluation's depths to the float64 one so that both differentiate the same function).
+    mlp_inputs_forced = (pts_coarse [N,S,3], pts_fine [N,S+Ni,3], viewdirs [N,3]): VALUES of the network inputs of another
+    evaluation, substituted with a straight-through gradient (x + (forced - x).detach()).  The float32 rounding of
+    pts = o + d z is common to every float32 implementation and is amplified 2^9 times by the positional encoding; with the
+    float32 values forced, a float64 evaluation measures the arithmetic of everything behind the inputs.
     Returns the reference's dict (rgb_map, disp_map, acc_map, rgb0, disp0, acc0, sigma)."""
     rays_o, rays_d, viewdirs = make_rays(poses, ray_idx, H, W, K, ndc)
     N = rays_o.shape[0]
-    z = stratified_z(N, n_samples, draws["t_rand"])
+    z = stratified_z(N, n_samples, draws["t_rand"], near, far) if z_forced is None else z_forced[0]
     pts = rays_o[..., None, :] + rays_d[..., None, :] * z[..., :, None]
+    pts_coarse = pts
+    if mlp_inputs_forced is not None:
+        pts = pts + (mlp_inputs_forced[0] - pts).detach()
+        viewdirs = viewdirs + (mlp_inputs_forced[2] - viewdirs).detach()
     raw0 = mlp_forward(p_coarse, pts, viewdirs, barf=barf)
     rgb0, disp0, acc0, w0, depth0, sigma0 = composite(raw0, z, rays_d, draws.get("noise0"), channels)
     ret = {"rgb_map": rgb0, "disp_map": disp0, "acc_map": acc0}
     extras = {"rays_o": rays_o, "rays_d": rays_d, "viewdirs": viewdirs, "z_coarse": z,
-              "raw0": raw0, "weights0": w0}
+              "raw0": raw0, "weights0": w0, "pts_coarse": pts_coarse}
     if n_importance > 0:
-        z_all, z_samples = fine_depths(z, w0, draws["u"], exact=exact_pdf)
+        if z_forced is None:
+            z_all, z_samples = fine_depths(z, w0, draws["u"], exact=exact_pdf)
+        else:
+            z_all, z_samples = z_forced[1], None
         pts = rays_o[..., None, :] + rays_d[..., None, :] * z_all[..., :, None]
+        extras["pts_fine"] = pts
+        if mlp_inputs_forced is not None:
+            pts = pts + (mlp_inputs_forced[1] - pts).detach()
         raw1 = mlp_forward(p_fine, pts, viewdirs, barf=barf)
         rgb1, disp1, acc1, w1, depth1, sigma1 = composite(raw1, z_all, rays_d, draws.get("noise1"), channels)
         ret = {"rgb_map": rgb1, "disp_map": disp1, "acc_map": acc1,
@@ -599,17 +620,20 @@ def tone_map(p, x):
 
 
 def step_loss(cfg, p_coarse, p_fine, knots, transform, evt_ts, rgb_ts, idx_evt, idx_rgb,
-              target_acc, target_rgb, draws_evt, draws_rgb, exact_pdf=False, event_crf=None, rgb_crf=None, barf=None):
+              target_acc, target_rgb, draws_evt, draws_rgb, exact_pdf=False, event_crf=None, rgb_crf=None, barf=None,
+              z_forced_evt=None, z_forced_rgb=None, want_extras=False, inputs_forced_evt=None, inputs_forced_rgb=None):
     """Forward of one training iteration (model/nerf.py:208-232 + train.py:163-337) on
     explicit inputs.  event_crf / rgb_crf: tone-mapper parameters applied to the rendered colours as train.py:180-192
     does when optimize_event_crf / optimize_rgb_crf are set.  Returns (loss, dict of parts)."""
     K = cfg.K()
     poses_e = trajectory_poses(knots, None, evt_ts, 2, cfg.traj)
     poses_r = trajectory_poses(knots, transform, rgb_ts, cfg.n_poses, cfg.traj)
-    ret_e = render(p_coarse, p_fine, poses_e, idx_evt, cfg.H, cfg.W, K, cfg.channels,
-                   cfg.n_samples, cfg.n_importance, draws_evt, exact_pdf=exact_pdf, barf=barf)
-    ret_r = render(p_coarse, p_fine, poses_r, idx_rgb, cfg.H, cfg.W, K, cfg.channels,
-                   cfg.n_samples, cfg.n_importance, draws_rgb, exact_pdf=exact_pdf, barf=barf)
+    ret_e, ex_e = render(p_coarse, p_fine, poses_e, idx_evt, cfg.H, cfg.W, K, cfg.channels, cfg.n_samples, cfg.n_importance,
+                         draws_evt, exact_pdf=exact_pdf, barf=barf, z_forced=z_forced_evt, want_extras=True,
+                         mlp_inputs_forced=inputs_forced_evt)
+    ret_r, ex_r = render(p_coarse, p_fine, poses_r, idx_rgb, cfg.H, cfg.W, K, cfg.channels, cfg.n_samples, cfg.n_importance,
+                         draws_rgb, exact_pdf=exact_pdf, barf=barf, z_forced=z_forced_rgb, want_extras=True,
+                         mlp_inputs_forced=inputs_forced_rgb)
     if event_crf is not None:
         ret_e = dict(ret_e, rgb_map=tone_map(event_crf, ret_e["rgb_map"]), rgb0=tone_map(event_crf, ret_e["rgb0"]))
     if rgb_crf is not None:
@@ -618,6 +642,9 @@ def step_loss(cfg, p_coarse, p_fine, knots, transform, evt_ts, rgb_ts, idx_evt, 
                                 cfg.channels, cfg.dataset, cfg.threshold, cfg.coeff_syn, cfg.coeff_real)
     lr_, lr_f, lr_c = blur_loss(ret_r["rgb_map"], ret_r["rgb0"], target_rgb, cfg.n_poses, cfg.rgb_coeff)
     loss = le + lr_
-    return loss, {"event": le, "event_fine": le_f, "event_coarse": le_c, "rgb": lr_,
-                  "rgb_fine": lr_f, "rgb_coarse": lr_c, "ret_event": ret_e, "ret_rgb": ret_r,
-                  "poses_evt": poses_e, "poses_rgb": poses_r}
+    parts = {"event": le, "event_fine": le_f, "event_coarse": le_c, "rgb": lr_,
+             "rgb_fine": lr_f, "rgb_coarse": lr_c, "ret_event": ret_e, "ret_rgb": ret_r,
+             "poses_evt": poses_e, "poses_rgb": poses_r}
+    if want_extras:
+        parts["extras_evt"], parts["extras_rgb"] = ex_e, ex_r
+    return loss, parts

@@ -239,8 +239,22 @@ def _dp_worker(rank, world, port, out_q, mode):
     if world > 1:   # a global batch the ranks cannot split evenly is refused, not silently truncated
         with pytest.raises(ValueError):
             step.step(torch.tensor([0.2, 0.45], device=DEV), torch.tensor([0.0, 1.0], device=DEV), idx_e[:31], idx_r, accu, img)
+    result = (losses.cpu().numpy(), step.flat_g.cpu().numpy(), step.flat_p.cpu().numpy())
+    if world > 1 and mode == "split":
+        # range guard across ranks: ONE rank leaves the f16 range (its words are poisoned here; its gradients would be inf /
+        # NaN and reach everybody through the sum) -> the verdict rides the trajectory bucket and EVERY replica skips the step
+        from benerf_amd import _lib
+        p_before, m_before = step.flat_p.clone(), step.flat_m.clone()
+        if rank == world - 1:
+            step.guard.words[_lib.ST_ACT] = 0x7f800000
+        step.step(torch.tensor([0.2, 0.45], device=DEV), torch.tensor([0.0, 1.0], device=DEV), idx_e, idx_r, accu, img,
+                  shard(d_e, 2, 32), shard(d_r, P, 4))
+        torch.cuda.synchronize()
+        assert torch.equal(step.flat_p, p_before) and torch.equal(step.flat_m, m_before), "rank %d did not skip the step" % rank
+        w = step.guard.words.cpu().tolist()
+        assert w[_lib.ST_SKIPPED] == 1 and w[_lib.ST_SKIP] == 1 and w[_lib.ST_ACT] == 0
     if rank == 0:
-        out_q.put((losses.cpu().numpy(), step.flat_g.cpu().numpy(), step.flat_p.cpu().numpy()))
+        out_q.put(result)
     if world > 1:
         torch.distributed.destroy_process_group()
 
@@ -309,7 +323,8 @@ def test_render_after_fused_steps_uses_current_weights():
 def test_f16_range_guard():
     """Hidden weights x300 drive activations past f16's maximum.  Split mode: the training forward reports it through
     the status words (BenerfRangeError from check_mlp_status, never a silent inf); inference launches run as
-    BENERF_MLP_AUTO and return the exact-f32 result; the fused Adam step leaves the parameters untouched."""
+    BENERF_MLP_AUTO, return the exact-f32 result and keep their words to themselves (an overflow handled during e.g.
+    render_image_test must not gate training); the fused Adam step leaves the parameters untouched."""
     from benerf_amd import _lib, kernels as K
     if K.get_mlp_precision() != "split":
         pytest.skip("range guard concerns the split-f16 mode")
@@ -326,21 +341,28 @@ def test_f16_range_guard():
     rd = GI.f32(rng.uniform(-1, 1, (N, 3))).to(DEV)
     vd = torch.nn.functional.normalize(GI.f32(rng.standard_normal((N, 3))), dim=-1).to(DEV)
     z = GI.f32(np.sort(rng.random((N, S)), -1)).to(DEV)
-    K.check_mlp_status(torch.device(DEV))                         # clean slate
+    K.range_guard(DEV).words.zero_()                              # clean slate
     raw_f32, _ = K.mlp_fwd(net, ro, rd, vd, z, False, precision="f32")
     assert torch.isfinite(raw_f32).all() and float(raw_f32.abs().max()) > 0
-    # inference (AUTO): valid output although the split launch overflowed
+    # inference (AUTO): valid output although the split launch overflowed; the device's training words stay clean
     raw_auto, _ = K.mlp_fwd(net, ro, rd, vd, z, False, precision="split")
     assert torch.equal(raw_auto, raw_f32), "BENERF_MLP_AUTO must fall back to the exact-f32 kernels"
-    with pytest.raises(_lib.BenerfRangeError):
-        K.check_mlp_status(torch.device(DEV))                     # ... and the violation is still reported (then reset)
+    assert K.auto_fallback_max(DEV) >= 65504.0
     K.check_mlp_status(torch.device(DEV))
-    # training forward: no silent inf - the status check raises
-    raw_s, acts = K.mlp_fwd(net, ro, rd, vd, z, True, precision="split")
     prm = torch.ones(1000, device=DEV)
     before = prm.clone()
     K.adam_step(prm, torch.ones_like(prm), torch.zeros_like(prm), torch.zeros_like(prm), 1e-3, 1)
+    assert not torch.equal(prm, before), "an overflow that AUTO handled must not gate an optimiser step"
+    # training forward: no silent inf - Adam skips, the status check raises
+    raw_s, acts = K.mlp_fwd(net, ro, rd, vd, z, True, precision="split")
+    before = prm.clone()
+    K.adam_step(prm, torch.ones_like(prm), torch.zeros_like(prm), torch.zeros_like(prm), 1e-3, 1)
     assert torch.equal(prm, before), "Adam must skip a step whose status shows a range violation"
+    g = K.range_guard(DEV)
+    g.post()
+    torch.cuda.synchronize()
+    with pytest.raises(_lib.BenerfRangeError):
+        g.poll()                                                  # the non-blocking look at the mirrored words sees it too
     with pytest.raises(_lib.BenerfRangeError):
         K.check_mlp_status(torch.device(DEV))
     K.adam_step(prm, torch.ones_like(prm), torch.zeros_like(prm), torch.zeros_like(prm), 1e-3, 1)
@@ -351,6 +373,66 @@ def test_f16_range_guard():
     net2.pack()
     K.mlp_fwd(net2, ro, rd, vd, z, True, precision="split")
     K.check_mlp_status(torch.device(DEV))
+
+
+def test_train_step_range_guard_skips_counts_and_raises():
+    """TrainStep owns its guard words: a step that leaves the f16 range is skipped as a whole (networks, trajectory, Adam
+    moments untouched), counted, and the next step starts clean; after MAX_SKIPPED_IN_A_ROW skipped steps in a row step()
+    raises from the mirrored counters without a synchronisation of its own; check_range() raises at once.  Inference on the
+    same device in between (AUTO fallback) does not disturb it."""
+    from benerf_amd import _lib, engine, kernels as K, workloads as WL
+    if K.get_mlp_precision() != "split":
+        pytest.skip("range guard concerns the split-f16 mode")
+    wl = dict(WL.WORKLOADS["C1"], S=16, Ni=16, Re=16, Rr=2, n=5)
+    args = WL.make_args(wl, optimize_trans=True)
+    cam = WL.CAMERAS[wl["cam"]]
+    model, g = _graph(args, seed=9)
+    cam_o = engine.Camera(cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+    step = engine.TrainStep(g, args, cam_o, cam_o, torch.device(DEV))
+    step.GUARD_POST_EVERY = 1
+    rng = np.random.default_rng(3)
+    HW = cam["H"] * cam["W"]
+    accu = torch.from_numpy(rng.integers(-3, 4, HW).astype(np.float32)).to(DEV)
+    img = torch.from_numpy(rng.random((HW, 1)).astype(np.float32)).to(DEV)
+
+    def one():
+        return step.step(torch.tensor([0.2, 0.3], device=DEV), torch.tensor([0.0, 1.0], device=DEV),
+                         torch.from_numpy(rng.permutation(HW)[:16]).to(DEV), torch.from_numpy(rng.permutation(HW)[:2]).to(DEV), accu, img)
+
+    one()
+    step.check_range()                                            # a healthy step: nothing to report
+    good = step.flat_p.clone()
+    with torch.no_grad():      # fine network: hidden weights x3, first layer x300 -> finite activations far past 65504 (as test_f16_range_guard)
+        for li in range(8):
+            step.net_f.views_w[li].mul_(300.0 if li == 0 else 3.0)
+    step.net_f.packed.pack()
+    poisoned = step.flat_p.clone()
+    m_before, v_before = step.flat_m.clone(), step.flat_v.clone()
+    one()
+    torch.cuda.synchronize()
+    assert torch.equal(step.flat_p, poisoned) and torch.equal(step.flat_m, m_before) and torch.equal(step.flat_v, v_before), \
+        "a step outside the f16 range must leave parameters and Adam moments untouched"
+    words = step.guard.words.cpu().tolist()
+    assert words[_lib.ST_SKIPPED] == 1 and words[_lib.ST_CONSECUTIVE] == 1 and words[_lib.ST_STEPS] == 2 and words[_lib.ST_ACT] == 0
+    one()
+    torch.cuda.synchronize()
+    with pytest.raises(_lib.BenerfRangeError):
+        for _ in range(4):                                        # the third skipped step in a row trips the poll of a later step
+            one()
+            torch.cuda.synchronize()
+    with pytest.raises(_lib.BenerfRangeError):
+        step.check_range()
+    # repaired parameters: training resumes, the consecutive counter falls back to zero
+    with torch.no_grad():
+        step.flat_p.copy_(good)
+    step.net_c.packed.pack()
+    step.net_f.packed.pack()
+    K.params_changed()
+    step.guard.words.zero_()
+    one()
+    torch.cuda.synchronize()
+    step.check_range()
+    assert not torch.equal(step.flat_p, good)
 
 
 @pytest.mark.parametrize("which", ["rgb", "event", "both"])

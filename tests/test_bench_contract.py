@@ -47,3 +47,24 @@ def test_bench_bookkeeping_helpers():
     assert bench.EXECUTED_PER_PRODUCT == {"mlp_fwd": 3, "mlp_bwd_dx": 2, "mlp_bwd_dw": 1}
     b = bench.algorithmic_bytes_per_step(wl, wl["channels"])
     assert 3e7 < b < 1e8          # weights + gradients + Adam state + per-ray I/O: tens of MB, not the GBs of saved activations
+
+
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher in the environment re-runs itself as two ranks under
+    torch.distributed.run (rendezvous on 127.0.0.1) and proves the group spans them: an all-reduce of ones sees 2 ranks and
+    the step's three gradient buckets are exchanged and timed.  gloo stands in for RCCL here (no GPU): same launch path."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selfcheck-only", "--backend", "gloo",
+                          "--workload", "C4"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["rccl_ranks_seen"] == 2 and d["allreduce_ms"] > 0
+    assert d["allreduce_bytes"] == (2 * 595586 + 31) * 4            # fine net, coarse net, trajectory + range-guard verdict
+    assert d["scaling"] == "strong", "C4 / C5 are quoted as ONE 8192-ray batch over the GPUs (SURVEY 8e): strong scaling by default"
+    # asking for more ranks than a launcher provides is an error, not a silent single-rank run
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selfcheck-only", "--backend", "gloo"],
+                         env=env2, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert res.returncode != 0 and "WORLD_SIZE=1" in res.stderr

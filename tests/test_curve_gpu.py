@@ -55,7 +55,7 @@ def _run(g11, frames, blurry, stream_seed):
         losses = step.step(torch.tensor([t0, t1], dtype=torch.float32, device=DEV), rgb_ts, idx_e.to(DEV), idx_r.to(DEV),
                            accu.float().to(DEV).contiguous(), blurry, dd(d_e), dd(d_r))
         curve.append(losses[0:1])
-    K.check_mlp_status(torch.device(DEV))
+    step.check_range()
     # final PSNR of the mid-exposure render (noise-free deterministic draws, as oracle/curve_scene.eval_psnr)
     n = CS.H * CS.W
     pose = K.spline_poses_fwd(step.knots, None, torch.tensor([0.5, 0.5], device=DEV), 1, 0)

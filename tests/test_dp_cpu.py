@@ -128,3 +128,22 @@ def test_async_allreduce_and_broadcast_single_process():
     h = dist.allreduce_sum_async_(t, 1)
     assert h.wait() and torch.equal(t, torch.arange(5.0))
     assert dist.broadcast_(t, 1) is t
+
+
+def test_backend_detection_for_device_tensors(monkeypatch):
+    """dist picks the host-staged path from the group's backend description, whatever its spelling: plain names, per-device
+    maps ("cpu:gloo,cuda:nccl") and unknown backends (treated like gloo: correct, if slow)."""
+    sys.path.insert(0, ROOT)
+    from benerf_amd import dist
+
+    class FakeCuda:
+        is_cuda = True
+
+    class FakeCpu:
+        is_cuda = False
+
+    for be, want in (("gloo", True), ("nccl", False), ("cpu:gloo,cuda:nccl", False), ("cpu:gloo", True), ("NCCL", False),
+                     ("custom_thing", True)):
+        monkeypatch.setattr(torch.distributed, "get_backend", lambda group=None, be=be: be)
+        assert dist._through_host(FakeCuda(), None) is want, be
+        assert dist._through_host(FakeCpu(), None) is False

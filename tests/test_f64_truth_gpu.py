@@ -1,0 +1,254 @@
+"""GPU tests against a FLOAT64 evaluation - the arithmetic-neutral yardstick for the default ('split') MFMA mode, whose
+backward GEMMs take f16 operands and are therefore not the reference's fp32 arithmetic.
+
+1. test_step_gradients_vs_float64: one training step (train.py:160-340).  For every gradient (knots, transform, every weight
+   and bias of both networks) the error of the HIP path against the float64 evaluation of the same step is compared with
+   the error of the float32 oracle (= the reference's arithmetic, torch CPU) against the same float64 evaluation:
+       err(HIP) <= FACTOR * err(float32 oracle) + FLOOR.
+   Both HIP modes are held to the same bound - the exact-f32 mode is the control: two float32 implementations of this
+   path already differ from each other by about the contract's 1e-3 (the float32 rounding of pts = o + d z is amplified
+   2^9 times by the positional encoding and flips ReLU masks), tools/experiments/f64_truth.py prints the decomposition.
+   Sizes: the four G8 specs (~4 k points), 1/8 of C2, and the full C2 step of BASELINE.json (4081 rays, 783 552 points).
+2. test_full_size_step_vs_oracle: the full C2 step, HIP against the float32 oracle directly (loss, pose gradients, sampled
+   weight-gradient entries, gradient norms) - the comparison SURVEY 8c words its tolerances for, at benchmark size.
+3. test_mlp_backward_arithmetic_vs_float64: one network on IDENTICAL points (no trajectory / ray / sampling in front), forward
+   and backward, against torch float64 at 130 560 points: what the MFMA arithmetic itself contributes.
+"""
+import numpy as np
+import pytest
+import torch
+
+import benerf_oracle as O
+import f64_truth as T
+import golden_inputs as GI
+from conftest import REPORT
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+G8_SPECS = [
+    ("unreal_C1", "unreal", 1, "BeNeRF_Unreal", 0.1, 19, 16, 16, 24, 3),
+    ("unreal_C3", "unreal", 3, "BeNeRF_Unreal", 0.1, 19, 16, 16, 24, 3),
+    ("e2syn_C3", "e2nerf_syn", 3, "E2NeRF_Synthetic", 0.2, 7, 32, 32, 16, 5),
+    ("e2real_C3", "e2nerf_real", 3, "E2NeRF_Real", -1.0, 31, 16, 32, 16, 2),
+]
+# err(HIP) <= FACTOR * err(float32 oracle) + FLOOR, per statistic.  L2 (||x - t|| / ||t||) is the stable one; the largest
+# entry error and the norm error of one gradient are single draws of the same noise and scatter by 2-3x between ANY two
+# float32 implementations (the exact-f32 control included), hence the wider factors.  FLOOR = 3 % of the contract's 1e-3:
+# gradients behind the last ReLU are exact to 1e-6 in float32, the f16 operands of the split backward leave ~1e-5 there.
+FACTOR = {"L2": 1.5, "max": 2.5, "norm": 3.0}
+FLOOR = {"L2": 3e-5, "max": 3e-5, "norm": 1e-4}     # norm: the contract's own tolerance
+
+
+def _case(name):
+    from benerf_amd import workloads as WL
+    if name.startswith("g8_"):
+        si = int(name[3:])
+        tag, cname, C, dataset, thr, P, S, Ni, Re, Rr = G8_SPECS[si]
+        rng = np.random.default_rng(1808 + si)
+        cam = GI.CAMERAS[cname]
+        window, chunks = (0.1 if "unreal" in tag else 0.25), 1
+    else:
+        wl = WL.WORKLOADS["C2"]
+        frac = 8 if name.endswith("eighth") else 1
+        cname, C, dataset, thr, P, S, Ni = wl["cam"], wl["channels"], wl["dataset"], wl["threshold"], wl["n"], wl["S"], wl["Ni"]
+        Re, Rr = wl["Re"] // frac, max(wl["Rr"] // frac, 1)
+        rng = np.random.default_rng(2024)
+        cam = WL.CAMERAS[cname]
+        window, chunks = wl["window"], (2 if frac == 8 else 12)
+    pc, pf = O.xavier_params(rng, C), O.xavier_params(rng, C)
+    pc["alpha_linear.bias"] += 1.0
+    pf["alpha_linear.bias"] += 1.0
+    x = dict(cam=cam, C=C, dataset=dataset, thr=thr, P=P, S=S, Ni=Ni, Re=Re, Rr=Rr, chunks=chunks, pc=pc, pf=pf,
+             knots=GI.knots_init(rng) * 3, tr=GI.transform_small(rng) * 0.1, idx_e=GI.pixel_indices(rng, cam, Re),
+             idx_r=GI.pixel_indices(rng, cam, Rr))
+    HW = cam["H"] * cam["W"]
+    x["accu"] = torch.from_numpy(rng.integers(-3, 4, HW).astype(np.float32))
+    x["img"] = torch.from_numpy(rng.random((HW, C)).astype(np.float32))
+    low = float(rng.random() * (1 - window))
+    x["evt_ts"] = torch.tensor([low, low + window], dtype=torch.float32)
+    x["d_e"], x["d_r"] = GI.render_draws(rng, 2 * Re, S, Ni), GI.render_draws(rng, P * Rr, S, Ni)
+    return x
+
+
+def _oracle_args(x):
+    cam = x["cam"]
+    cfg = O.StepConfig(H=cam["H"], W=cam["W"], fx=cam["fx"], fy=cam["fy"], cx=cam["cx"], cy=cam["cy"], channels=x["C"],
+                       n_samples=x["S"], n_importance=x["Ni"], n_poses=x["P"], dataset=x["dataset"], threshold=x["thr"])
+    tacc = x["accu"].double().reshape(-1, 1)[x["idx_e"]]
+    return (cfg, x["pc"], x["pf"], x["knots"], x["tr"], x["evt_ts"], torch.tensor([0.0, 1.0]), x["idx_e"], x["idx_r"], tacc,
+            x["img"][x["idx_r"]], x["d_e"], x["d_r"])
+
+
+def _hip_step(x, mode, z_forced):
+    from benerf_amd import engine, kernels as K, workloads as WL
+    from benerf_amd.model import optimize
+    prev = K.get_mlp_precision()
+    K.set_mlp_precision(mode)
+    try:
+        cam = x["cam"]
+        wl = dict(cam="_t", channels=x["C"], dataset=x["dataset"], threshold=x["thr"], window=0.1, n=x["P"], S=x["S"], Ni=x["Ni"],
+                  Re=x["Re"], Rr=x["Rr"])
+        WL.CAMERAS["_t"] = cam
+        args = WL.make_args(wl, optimize_trans=True)
+        model = optimize.Model(args)
+        model.graph.to(DEV)
+        g = model.build_network(args)
+        with torch.no_grad():
+            for net, p in ((g.nerf, x["pc"]), (g.nerf_fine, x["pf"])):
+                for name in K.LAYER_NAMES:
+                    lin = engine.getattr_path(net, name)
+                    lin.weight.copy_(p[name + ".weight"])
+                    lin.bias.copy_(p[name + ".bias"])
+            g.evt_knot_pose_se3.params.weight.copy_(x["knots"])
+            g.transform.params.weight.copy_(x["tr"])
+        cam_o = engine.Camera(cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+        step = engine.TrainStep(g, args, cam_o, cam_o, torch.device(DEV))
+
+        def dd(d):
+            return engine.Draws(*(d[k].to(DEV) for k in ("t_rand", "noise0", "u", "noise1")))
+        zf = torch.cat([z_forced["evt"][1], z_forced["rgb"][1]]).to(DEV)
+        losses = step.step(x["evt_ts"].to(DEV), torch.tensor([0.0, 1.0], device=DEV), x["idx_e"].to(DEV), x["idx_r"].to(DEV),
+                           x["accu"].to(DEV), x["img"].to(DEV), dd(x["d_e"]), dd(x["d_r"]), z_fine_forced=zf)
+        step.check_range()
+        grads = {"knots": step.g_knots.cpu().clone(), "transform": step.g_transform.cpu().clone()}
+        for nn_, fn in (("nerf", step.net_c), ("nerf_fine", step.net_f)):
+            for i, name in enumerate(K.LAYER_NAMES):
+                grads["%s.%s.weight" % (nn_, name)] = fn.gviews_w[i].cpu().clone()
+                grads["%s.%s.bias" % (nn_, name)] = fn.gviews_b[i].cpu().clone()
+        return float(losses[0]), grads
+    finally:
+        K.set_mlp_precision(prev)
+
+
+def _assert_no_worse(tab, label, case):
+    """tab: f64_truth.error_table rows {name: {label: (max, norm, L2)}} with the float32 oracle under 'o32'."""
+    bad, worst = [], {"L2": (0.0, ""), "max": (0.0, ""), "norm": (0.0, "")}
+    for name, row in tab.items():
+        n_entries = 24 if name == "knots" else 6 if name == "transform" else 1 << 20
+        for j, stat in ((2, "L2"), (0, "max"), (1, "norm")):
+            if stat == "norm" and (n_entries < 256 or name.endswith(".bias") and "rgb_linear" in name):
+                continue      # the norm of a handful of numbers is one more draw of the L2 error, which is bounded above
+            e, ref = row[label][j], row["o32"][j]
+            bound = FACTOR[stat] * ref + FLOOR[stat]
+            ratio = e / bound
+            if ratio > worst[stat][0]:
+                worst[stat] = (ratio, "%s %.2e vs oracle %.2e" % (name, e, ref))
+            if e > bound:
+                bad.append("%s %s: %.3e > %.1f x %.3e + %.0e" % (name, stat, e, FACTOR[stat], ref, FLOOR[stat]))
+    for stat, (ratio, what) in worst.items():
+        REPORT.append("f64 truth %-10s %-5s %-4s closest to its bound: %.2f of it (%s)" % (case, label, stat, ratio, what))
+    assert not bad, "%s, mode %s - gradients further from float64 than the float32 oracle allows:\n%s" % (case, label, "\n".join(bad))
+
+
+@pytest.mark.parametrize("case", ["g8_0", "g8_1", "g8_2", "g8_3", "C2_eighth", "C2"])
+def test_step_gradients_vs_float64(case):
+    x = _case(case)
+    a = _oracle_args(x)
+    o32 = T.step_grads(*a, dtype=torch.float32, z_forced=None, n_chunks=x["chunks"])
+    o64 = T.step_grads(*a, dtype=torch.float64, z_forced=o32["z"], n_chunks=x["chunks"], force_inputs=False)
+    assert abs(o32["loss"] - o64["loss"]) <= 2e-6 * max(1.0, abs(o64["loss"]))
+    cands = {"o32": o32["grads"]}
+    for mode in ("f32", "split"):
+        loss, cands[mode] = _hip_step(x, mode, o32["z"])
+        assert abs(loss - o64["loss"]) <= 2e-5 * max(1.0, abs(o64["loss"])), (mode, loss, o64["loss"])
+    tab = T.error_table(o64["grads"], cands)
+    for mode in ("f32", "split"):
+        _assert_no_worse(tab, mode, case)
+
+
+def test_full_size_step_vs_oracle():
+    """The C2 step of BASELINE.json on explicit draws, HIP (both modes) against the float32 oracle itself: loss, pose
+    gradients, 64 sampled entries and the norm of every weight gradient.  Fine depths forced to the oracle's (sample_pdf's
+    conditioning is tested by itself, test_kernels_gpu K5).  Tolerances: loss 2e-5; gradients SURVEY 8c's 1e-3 of the largest
+    entry / 1e-4 on norms, times the factor two float32 implementations of this step are apart at this size anyway
+    (test_step_gradients_vs_float64 holds both modes to the float64 yardstick; measured: profiles/r03_f64_truth_*.log)."""
+    x = _case("C2")
+    a = _oracle_args(x)
+    o32 = T.step_grads(*a, dtype=torch.float32, z_forced=None, n_chunks=x["chunks"])
+    rng = np.random.default_rng(7)
+    for mode in ("f32", "split"):
+        loss, g = _hip_step(x, mode, o32["z"])
+        assert abs(loss - o32["loss"]) <= 2e-5 * max(1.0, abs(o32["loss"])), (mode, loss, o32["loss"])
+        bad = []
+        for name, ref in o32["grads"].items():
+            got = g[name].double().reshape(ref.shape)
+            mx = float(ref.abs().max())
+            if name in ("knots", "transform"):
+                e = float((got - ref).abs().max()) / mx
+                REPORT.append("full-size C2 vs oracle, %-5s d%-36s max err %.2e of the largest entry" % (mode, name, e))
+                if e > 2e-3:
+                    bad.append("%s: %.2e" % (name, e))
+                continue
+            idx = torch.from_numpy(rng.integers(0, ref.numel(), 64))
+            e = float((got.reshape(-1)[idx] - ref.reshape(-1)[idx]).abs().max()) / mx
+            en = abs(float(got.norm() / ref.norm()) - 1.0)
+            REPORT.append("full-size C2 vs oracle, %-5s d%-36s sampled entries %.2e  norm %.2e" % (mode, name, e, en))
+            if e > 2e-3 or en > 2e-4:
+                bad.append("%s: entries %.2e norm %.2e" % (name, e, en))
+        assert not bad, "mode %s:\n%s" % (mode, "\n".join(bad))
+
+
+def test_mlp_backward_arithmetic_vs_float64():
+    """One network, forward + backward on identical points: HIP (both modes) and torch float32 against torch float64.
+    Upstream gradient = what compositing produces for a mean-squared colour loss (structured, not noise).  The exact-f32 mode
+    has to match float64 like torch's float32 does; the split mode's f16 backward operands have to stay inside the contract
+    (1e-3 of the largest entry, 1e-4 on the norms of the weight gradients) at this size."""
+    from benerf_amd import kernels as K
+    rng = np.random.default_rng(91)
+    C, N, S = 1, 1020, 128
+    p = O.xavier_params(rng, C)
+    p["alpha_linear.bias"] += 1.0
+    ro = GI.f32(rng.uniform(-0.3, 0.3, (N, 3)))
+    rd = GI.f32(rng.uniform(-1, 1, (N, 3)))
+    vd = torch.nn.functional.normalize(GI.f32(rng.standard_normal((N, 3))), dim=-1)
+    z = GI.f32(np.sort(rng.random((N, S)), -1))
+    noise = GI.f32(rng.standard_normal((N, S)))
+    target = GI.f32(rng.random((N, C)))
+    pts32 = ro[:, None, :] + rd[:, None, :] * z[:, :, None]        # float32 values every evaluation consumes
+
+    def torch_grads(dtype):
+        with T.default_dtype(dtype):
+            q = {k: v.to(dtype).clone().requires_grad_(True) for k, v in p.items()}
+            pts = pts32.to(dtype).requires_grad_(True)
+            raw = O.mlp_forward(q, pts, vd.to(dtype))
+            raw.retain_grad()
+            rgb = O.composite(raw, z.to(dtype), rd.to(dtype), noise.to(dtype), C)[0]
+            (((rgb - target.to(dtype)) ** 2).mean()).backward()
+            out = {k: v.grad.double() for k, v in q.items()}
+            out["d_pts"] = pts.grad.double().reshape(-1, 3)
+            return out, raw.grad.float().reshape(-1, C + 1), raw.detach().double()
+
+    g64, _, raw64 = torch_grads(torch.float64)
+    g32, d_raw32, _ = torch_grads(torch.float32)
+    cands = {"o32": g32}
+    dv = lambda t: t.to(DEV).contiguous()   # noqa: E731
+    prev = K.get_mlp_precision()
+    try:
+        for mode in ("f32", "split"):
+            K.set_mlp_precision(mode)
+            net = K.PackedMlp([dv(p[n + ".weight"]) for n in K.LAYER_NAMES], [dv(p[n + ".bias"]) for n in K.LAYER_NAMES], C)
+            net.pack()
+            raw, acts = K.mlp_fwd(net, dv(ro), dv(rd), dv(vd), dv(z), True)
+            e_raw = float((raw.cpu().double() - raw64).abs().max() / raw64.abs().max())
+            REPORT.append("MLP arithmetic vs f64, %-5s raw: %.2e of the largest" % (mode, e_raw))
+            assert e_raw <= 1e-5
+            gw = [torch.zeros_like(w) for w in net.weights]
+            gb = [torch.zeros_like(b) for b in net.biases]
+            d_pts, _ = K.mlp_bwd(net, dv(d_raw32), acts, N, S, gw, gb, False)     # the SAME upstream gradient for everybody
+            g = {"d_pts": d_pts.cpu()}
+            for i, n in enumerate(K.LAYER_NAMES):
+                g[n + ".weight"], g[n + ".bias"] = gw[i].cpu(), gb[i].cpu()
+            cands[mode] = g
+    finally:
+        K.set_mlp_precision(prev)
+    tab = T.error_table(g64, cands)
+    bad = []
+    for name, row in tab.items():
+        for mode, tol_max, tol_norm in (("f32", 5e-5, 2e-5), ("split", 1e-3, 1e-4)):
+            e_max, e_norm, e_l2 = row[mode]
+            REPORT.append("MLP arithmetic vs f64, %-5s d%-24s max %.2e norm %.2e L2 %.2e   (torch f32: %.2e %.2e %.2e)"
+                          % ((mode, name, e_max, e_norm, e_l2) + row["o32"]))
+            if e_max > tol_max or (name.endswith("weight") and e_norm > tol_norm):
+                bad.append("%s %s: max %.2e norm %.2e" % (mode, name, e_max, e_norm))
+    assert not bad, "\n".join(bad)

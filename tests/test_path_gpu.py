@@ -101,6 +101,42 @@ def test_render_golden_g7(golden):
                            atol=1e-4, rtol=2e-4)
 
 
+def test_render_near_far_and_coarse_only():
+    """Graph.render honours its near / far arguments (model/nerf.py:236-240,297-299) and N_importance == 0 (model/nerf.py:322,
+    336-343: three keys, no fine pass) - against the oracle on replayed draws, forward and the gradient to the poses."""
+    from benerf_amd import workloads as WL
+    cam = GI.CAMERAS["unreal"]
+    Kmat = GI.cam_K(cam)
+    rng = np.random.default_rng(717)
+    C, P, Rn, S = 1, 3, 16, 32
+    pc, pf = O.xavier_params(rng, C), O.xavier_params(rng, C)
+    pc["alpha_linear.bias"] += 1.0
+    pf["alpha_linear.bias"] += 1.0
+    knots = GI.knots_init(rng) * 5
+    idx = GI.pixel_indices(rng, cam, Rn)
+    for Ni, near, far in ((32, 0.2, 0.8), (0, 0.0, 1.0), (0, 0.1, 0.9)):
+        draws = GI.render_draws(rng, P * Rn, S, max(Ni, 1))
+        args = WL.make_args("C2", channels=C, N_samples=S, N_importance=Ni, num_interpolated_pose=P)
+        _, g = build_graph(args, pc, pf, knots, torch.zeros(1, 6))
+        poses = O.trajectory_poses(knots, None, (0.0, 1.0), P, "spline")
+        po = poses.clone().requires_grad_(True)
+        ref = O.render(pc, pf, po, idx, cam["H"], cam["W"], Kmat, C, S, Ni, draws, exact_pdf=True, near=near, far=far)
+        ph = poses.to(DEV).requires_grad_(True)
+        queue = [draws["t_rand"], draws["noise0"]] + ([draws["u"], draws["noise1"]] if Ni > 0 else [])
+        with ReplayRNG(queue):
+            ret = g.render(0, ph, idx.to(DEV), cam["H"], cam["W"], Kmat, args, True, "rgb", torch.tensor([]), near=near, far=far,
+                           training=True)
+        tag = "Ni=%d near=%g far=%g" % (Ni, near, far)
+        assert set(ret) == ({"rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "sigma"} if Ni > 0 else {"rgb_map", "disp_map", "acc_map"})
+        for k in ("rgb_map", "acc_map") + (("rgb0",) if Ni > 0 else ()):
+            report("render(%s) %s" % (tag, k), ret[k], ref[k], atol=1e-4)
+        Gm = GI.f32(rng.standard_normal(tuple(ref["rgb_map"].shape)))
+        (ref["rgb_map"] * Gm).sum().backward()
+        (ret["rgb_map"] * Gm.to(DEV)).sum().backward()
+        sc = float(po.grad.abs().max())
+        report("render(%s) d poses" % tag, ph.grad, po.grad, atol=2e-3 * sc, rtol=2e-3)
+
+
 G8_SPECS = [
     ("unreal_C1", "unreal", 1, "BeNeRF_Unreal", 0.1, 19, 16, 16, 24, 3),
     ("unreal_C3", "unreal", 3, "BeNeRF_Unreal", 0.1, 19, 16, 16, 24, 3),
@@ -433,7 +469,7 @@ def test_full_size_step_modes_agree(wl_name):
                                     torch.rand((n, Ni), device=DEV, generator=g_t), torch.randn((n, S + Ni), device=DEV, generator=g_t))
             losses = step.step(torch.tensor([0.3, 0.3 + wl["window"]], device=DEV), torch.tensor([0.0, 1.0], device=DEV), idx_e, idx_r,
                                accu, img, draws(2 * Re), draws(P * Rr))
-            K.check_mlp_status(torch.device(DEV))
+            step.check_range()
             res[mode] = (losses.cpu().numpy(), step.g_knots.cpu().numpy().copy(), step.g_transform.cpu().numpy().copy(),
                          step.net_f.gviews_w[7].cpu().numpy().copy())
             del step, g
