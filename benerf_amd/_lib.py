@@ -42,7 +42,9 @@ _SIGNATURES = {
     "benerf_spline_op_fwd": (c_int, [c_int, P, c_int64, P, P]),
     "benerf_spline_op_bwd": (c_int, [c_int, P, c_int64, P, P, P]),
     "benerf_rays_fwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_int, P, P, P, P, P]),
-    "benerf_rays_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_int, P, P, P, P, P, P]),
+    "benerf_rays_bwd_workspace_floats": (c_size_t, [c_int, c_int]),
+    "benerf_rays_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_float, c_float, c_float, c_float, c_int, P, P, P, P, P, P, c_size_t, P]),
+    "benerf_workspace_bytes": (c_size_t, [c_int, c_int64, c_int, c_int]),
     "benerf_stratified_z": (c_int, [c_int, c_int, c_float, c_float, P, c_uint64, c_uint64, P, P]),
     "benerf_ray_grad_reduce": (c_int, [c_int, c_int, P, P, P, c_int, P, P, P, P]),
     "benerf_mlp_packed_floats": (c_size_t, []),
@@ -54,11 +56,11 @@ _SIGNATURES = {
     "benerf_mlp_fwd": (c_int, [POINTER(MlpParams), P, c_int, c_int, c_int, P, P, P, P, P, P, c_int, P, P]),
     "benerf_mlp_status_check": (c_int, [P, P]),
     "benerf_step_gate": (c_int, [P, P, c_int, P]),
-    "benerf_mlp_bwd_dx": (c_int, [POINTER(MlpParams), P, c_int, c_int, c_int, P, P, P, P, P, c_int, P, P]),
+    "benerf_mlp_bwd_dx": (c_int, [POINTER(MlpParams), P, c_int, c_int, c_int, P, P, P, P, P, c_int, P, P, P]),
     "benerf_mlp_bwd_dw": (c_int, [c_int, c_int, c_int, P, P, P, P, c_size_t, POINTER(MlpGrads), c_int, c_int, P, P]),
     "benerf_composite_fwd": (c_int, [P, P, P, P, c_float, c_uint64, c_uint64, c_int, c_int, c_int, P, P, P, P, P, P, P]),
     "benerf_composite_bwd": (c_int, [P, P, P, P, c_float, c_uint64, c_uint64, c_int, c_int, c_int, P, P, P, P, P, P,
-                                     c_int, P]),
+                                     c_int, P, P]),
     "benerf_sample_pdf_merge": (c_int, [P, P, P, c_uint64, c_uint64, c_int, c_int, c_int, P, P, P, P]),
     "benerf_sample_pdf": (c_int, [P, P, P, c_uint64, c_uint64, c_int, c_int, c_int, P, P, P]),
     "benerf_pixel_rays": (c_int, [P, c_int, P, P, c_int64, c_float, c_float, c_float, c_float, P, P, P]),

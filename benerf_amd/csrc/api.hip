@@ -46,3 +46,15 @@ extern "C" int benerf_mlp_status_check(const uint32_t* status, benerf_stream_t s
     }
     return BENERF_OK;
 }
+
+// One size query for every caller-owned scratch buffer (include/benerf_hip.h).
+extern "C" size_t benerf_workspace_bytes(int which, int64_t n_points, int n_poses, int n_pix) {
+    switch (which) {
+        case BENERF_WS_MLP_ACTS: return sizeof(float) * benerf_mlp_act_floats(n_points);
+        case BENERF_WS_MLP_DACTS: return sizeof(float) * benerf_mlp_dact_floats(n_points);
+        case BENERF_WS_MLP_DW: return sizeof(float) * benerf_mlp_dw_workspace_floats(n_points);
+        case BENERF_WS_MLP_PACKED: return sizeof(float) * benerf_mlp_packed_floats();
+        case BENERF_WS_RAYS_BWD: return sizeof(float) * benerf_rays_bwd_workspace_floats(n_poses, n_pix);
+        default: return 0;
+    }
+}

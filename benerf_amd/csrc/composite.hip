@@ -131,7 +131,8 @@ __global__ void composite_bwd_kernel(const float* __restrict__ raw, const float*
                                      float noise_std, uint64_t seed, uint64_t offset, int C, int n_rays, int S,
                                      const float* __restrict__ g_rgb, const float* __restrict__ g_acc,
                                      const float* __restrict__ g_depth, const float* __restrict__ g_disp,
-                                     float* __restrict__ d_raw, float* __restrict__ d_rays_d, int accumulate) {
+                                     float* __restrict__ d_raw, float* __restrict__ d_rays_d, int accumulate,
+                                     float* __restrict__ d_raw_absmax) {
     int64_t ray = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x / 64);
     int lane = threadIdx.x & 63;
     if (ray >= n_rays) return;
@@ -187,6 +188,7 @@ __global__ void composite_bwd_kernel(const float* __restrict__ raw, const float*
     float after = __shfl_down(incl, 1, 64);
     if (lane == 63) after = 0.f;
     float g_norm = 0.f;
+    float mx = 0.f;      // max |d_raw| this lane writes (the split-f16 dX chain scales its input by it: saves that a pass over d_raw)
     float run = after;   // sum over samples after the current one
 #pragma unroll
     for (int k = IPL - 1; k >= 0; --k) {
@@ -198,12 +200,21 @@ __global__ void composite_bwd_kernel(const float* __restrict__ raw, const float*
             float dsig = (st.pre[k] > 0.f) ? dalpha * st.dist[k] * e : 0.f;
             float ddist = dalpha * st.sig[k] * e;
             g_norm += ddist * (st.dist[k] / norm);
-            FOR_CH(c) dr[(int64_t)i * (C + 1) + c] = grgb[c] * st.w[k] * sg[k][c] * (1.0f - sg[k][c]);
+            FOR_CH(c) {
+                const float dv = grgb[c] * st.w[k] * sg[k][c] * (1.0f - sg[k][c]);
+                dr[(int64_t)i * (C + 1) + c] = dv;
+                mx = fmaxf(mx, fabsf(dv));
+            }
             dr[(int64_t)i * (C + 1) + C] = dsig;
+            mx = fmaxf(mx, fabsf(dsig));
             run += gw[k] * st.w[k];
         }
     }
     g_norm = wave_sum(g_norm);
+    if (d_raw_absmax) {   // non-negative floats order like their bit patterns; NaN (sign clear) sorts above everything: never lost
+        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        if (lane == 0 && mx > 0.f) atomicMax(reinterpret_cast<unsigned int*>(d_raw_absmax), __float_as_uint(mx));
+    }
     if (d_rays_d && lane < 3) {
         float dv = lane == 0 ? d0 : (lane == 1 ? d1 : d2);
         float v = g_norm * (dv / norm);
@@ -246,7 +257,7 @@ extern "C" int benerf_composite_bwd(const float* raw, const float* z, const floa
                                     float noise_std, uint64_t seed, uint64_t offset, int channels, int n_rays,
                                     int n_samples, const float* d_rgb_map, const float* d_acc, const float* d_depth,
                                     const float* d_disp, float* d_raw, float* d_rays_d, int accumulate,
-                                    benerf_stream_t stream) {
+                                    float* d_raw_absmax, benerf_stream_t stream) {
     BENERF_REQUIRE(raw && z && rays_d && d_rgb_map && d_raw, "composite_bwd: null pointer");
     BENERF_REQUIRE(channels >= 1 && channels <= 3, "composite_bwd: channels must be 1..3");
     BENERF_REQUIRE(n_rays > 0 && n_samples > 0 && n_samples <= 64 * MAX_IPL, "composite_bwd: n_samples must be <= 512");
@@ -255,7 +266,7 @@ extern "C" int benerf_composite_bwd(const float* raw, const float* z, const floa
 #define CALL(IPL)                                                                                                      \
     hipLaunchKernelGGL(composite_bwd_kernel<IPL>, grid, block, 0, as_stream(stream), raw, z, rays_d, noise, noise_std, \
                        seed, offset, channels, n_rays, n_samples, d_rgb_map, d_acc, d_depth, d_disp, d_raw, d_rays_d,  \
-                       accumulate)
+                       accumulate, d_raw_absmax)
     DISPATCH_IPL(n_samples, CALL);
 #undef CALL
     BENERF_LAUNCH_CHECK("composite_bwd");

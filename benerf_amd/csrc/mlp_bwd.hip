@@ -344,7 +344,8 @@ int benerf_mlp_dw_launch(int precision, int channels, int64_t M, const float* d_
 
 // f16 variant (mlp_bwd_h.hip)
 int benerf_mlp_dx_split_launch(const BenerfMlpParams* params, const float* packed, int channels, int64_t M, const float* d_raw,
-                               const float* acts, float* dacts, float* d_pts, float* d_vdir_pts, uint32_t* status, hipStream_t stream);
+                               const float* acts, float* dacts, float* d_pts, float* d_vdir_pts, uint32_t* status,
+                               const float* d_raw_absmax, hipStream_t stream);
 
 static int launch_dx(const BenerfMlpParams* params, const float* packed, int channels, int64_t M, const float* d_raw,
                      const float* acts, float* dacts, float* d_pts, float* d_vdir_pts, hipStream_t stream) {
@@ -363,8 +364,11 @@ static int launch_dx(const BenerfMlpParams* params, const float* packed, int cha
     BENERF_REQUIRE(tiles < (1ll << 31), "mlp_bwd: too many points");
     dim3 grid((unsigned)tiles), block(mlp::NTHREADS);
     const int smem = (int)mlp::TILE_SMEM;
-    const void* fn = channels == 1 ? (const void*)mlp_bwd_kernel<1> : (const void*)mlp_bwd_kernel<3>;
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
+    // once per process and variant: the attribute sticks to the function
+    static const bool lds_ok[2] = {
+        hipFuncSetAttribute((const void*)mlp_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) == hipSuccess,
+        hipFuncSetAttribute((const void*)mlp_bwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) == hipSuccess};
+    if (!lds_ok[channels == 1 ? 0 : 1]) {
         benerf_set_error("mlp_bwd(dx): cannot reserve %d bytes of LDS", smem);
         return BENERF_EHIP;
     }
@@ -376,7 +380,8 @@ static int launch_dx(const BenerfMlpParams* params, const float* packed, int cha
 
 extern "C" int benerf_mlp_bwd_dx(const BenerfMlpParams* params, const float* packed, int channels, int n_rays,
                                  int n_samples, const float* d_raw, const float* acts, float* dacts, float* d_pts,
-                                 float* d_vdir_pts, int precision, uint32_t* status, benerf_stream_t stream) {
+                                 float* d_vdir_pts, int precision, uint32_t* status, const float* d_raw_absmax,
+                                 benerf_stream_t stream) {
     BENERF_REQUIRE(params && packed && d_raw && acts && dacts && d_pts && d_vdir_pts, "mlp_bwd_dx: null pointer");
     BENERF_REQUIRE(channels == 1 || channels == 3, "mlp_bwd_dx: channels must be 1 or 3");
     BENERF_REQUIRE(n_rays > 0 && n_samples > 0, "mlp_bwd_dx: bad sizes");
@@ -384,7 +389,8 @@ extern "C" int benerf_mlp_bwd_dx(const BenerfMlpParams* params, const float* pac
     for (int l = 0; l < BENERF_NLAYERS; ++l) BENERF_REQUIRE(params->w[l], "mlp_bwd_dx: null parameter %d", l);
     const int64_t M = (int64_t)n_rays * n_samples;
     if (precision == BENERF_MLP_SPLIT)
-        return benerf_mlp_dx_split_launch(params, packed, channels, M, d_raw, acts, dacts, d_pts, d_vdir_pts, status, as_stream(stream));
+        return benerf_mlp_dx_split_launch(params, packed, channels, M, d_raw, acts, dacts, d_pts, d_vdir_pts, status, d_raw_absmax,
+                                          as_stream(stream));
     return launch_dx(params, packed, channels, M, d_raw, acts, dacts, d_pts, d_vdir_pts, as_stream(stream));
 }
 

@@ -46,6 +46,7 @@ struct BwdArgs {
     float* d_pts;           // [M][3]
     float* d_vdir;          // [M][3]
     uint32_t* status;       // [1]: max |tile-scaled gradient| bits once >= 2^15, [2]: acts buffer written by another mode (may be null)
+    const float* absmax;    // max |d_raw| of the call from the compositing backward, or null: then it is in the dacts info word
     int64_t M;
 };
 
@@ -335,7 +336,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_f16_kernel(BwdArgs a) {
     _Float16* st_dyh = reinterpret_cast<_Float16*>(dacts + sdact_h(Mp, 0));      // layer l: + l * Mp * 256 halfs
     auto st_tile = [&](int l) { return st_dyh + ((int64_t)l * Mp + m0) * 256; };   // tile's part of layer l's SH array
     float s_g, inv_s_g;
-    pow2_scale6(dacts[sdact_info(Mp) + SD_DRAW], s_g, inv_s_g);                   // scale of the dY arrays of this call
+    const float mx_call = a.absmax ? *a.absmax : dacts[sdact_info(Mp) + SD_DRAW];
+    if (a.absmax && blockIdx.x == 0 && tid == 0) dacts[sdact_info(Mp) + SD_DRAW] = mx_call;   // the dW reduce reads it there
+    pow2_scale6(mx_call, s_g, inv_s_g);                                          // scale of the dY arrays of this call
     if (a.status && blockIdx.x == 0 && tid == 0 && reinterpret_cast<const uint32_t*>(acts + sact_info(Mp))[SI_TAG] != SACT_TAG_SPLIT)
         a.status[2] = 1u;
     TR(0);
@@ -596,7 +599,8 @@ __global__ void grad_absmax_kernel(const float* __restrict__ d_raw, int64_t n, f
 }  // namespace
 
 int benerf_mlp_dx_split_launch(const BenerfMlpParams* params, const float* packed, int channels, int64_t M, const float* d_raw,
-                               const float* acts, float* dacts, float* d_pts, float* d_vdir_pts, uint32_t* status, hipStream_t stream) {
+                               const float* acts, float* dacts, float* d_pts, float* d_vdir_pts, uint32_t* status,
+                               const float* d_raw_absmax, hipStream_t stream) {
     BwdArgs a;
     a.d_raw = d_raw;
     a.acts = acts;
@@ -608,19 +612,25 @@ int benerf_mlp_dx_split_launch(const BenerfMlpParams* params, const float* packe
     a.d_pts = d_pts;
     a.d_vdir = d_vdir_pts;
     a.status = status;
+    a.absmax = d_raw_absmax;
     a.M = M;
     const int64_t tiles = mlp::m_pad(M) / TMB;
     BENERF_REQUIRE(tiles < (1ll << 31), "mlp_bwd: too many points");
-    float* info = dacts + mlp::sdact_info(mlp::m_pad(M));
-    if (hipMemsetAsync(info, 0, mlp::SD_COUNT * sizeof(float), stream) != hipSuccess) {
-        benerf_set_error("mlp_bwd: memset failed");
-        return BENERF_EHIP;
+    if (!d_raw_absmax) {    // nobody computed max |d_raw| for us: one pass over d_raw into the info word
+        float* info = dacts + mlp::sdact_info(mlp::m_pad(M));
+        if (hipMemsetAsync(info, 0, mlp::SD_COUNT * sizeof(float), stream) != hipSuccess) {
+            benerf_set_error("mlp_bwd: memset failed");
+            return BENERF_EHIP;
+        }
+        hipLaunchKernelGGL(grad_absmax_kernel, dim3(256), dim3(256), 0, stream, d_raw, M * (channels + 1), info + mlp::SD_DRAW);
     }
-    hipLaunchKernelGGL(grad_absmax_kernel, dim3(256), dim3(256), 0, stream, d_raw, M * (channels + 1), info + mlp::SD_DRAW);
     dim3 grid((unsigned)tiles), block(mlp::NTHREADS);
     const int smem = (int)BWD_SMEM;
-    const void* fn = channels == 1 ? (const void*)mlp_bwd_f16_kernel<1> : (const void*)mlp_bwd_f16_kernel<3>;
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
+    // once per process and variant: the attribute sticks to the function
+    static const bool lds_ok[2] = {
+        hipFuncSetAttribute((const void*)mlp_bwd_f16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) == hipSuccess,
+        hipFuncSetAttribute((const void*)mlp_bwd_f16_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) == hipSuccess};
+    if (!lds_ok[channels == 1 ? 0 : 1]) {
         benerf_set_error("mlp_bwd(dx, f16): cannot reserve %d bytes of LDS", smem);
         return BENERF_EHIP;
     }

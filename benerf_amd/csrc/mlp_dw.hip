@@ -395,7 +395,8 @@ int benerf_mlp_dw_launch(int precision, int channels, int64_t M, const float* d_
     a.ws = dw_ws;
     a.M = M;
     a.C = channels;
-    if (hipFuncSetAttribute((const void*)mlp_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DW_SMEM) != hipSuccess) {
+    static const bool lds_ok = hipFuncSetAttribute((const void*)mlp_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DW_SMEM) == hipSuccess;
+    if (!lds_ok) {
         benerf_set_error("mlp_bwd(dw): cannot reserve LDS");
         return BENERF_EHIP;
     }

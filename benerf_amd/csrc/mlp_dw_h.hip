@@ -376,9 +376,11 @@ int benerf_mlp_dw_split_launch(int channels, int64_t M, const float* d_raw, cons
     a.M = M;
     a.C = channels;
     static_assert(DW_L0 + 1 == DW_L5P && DW_L5P + 1 == DW_VIEWSP && DW_VIEWSP + 1 == DW_RGB, "small-kernel instance order");
-    if (hipFuncSetAttribute((const void*)mlp_dw_f16_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DWH_SMEM) != hipSuccess ||
-        hipFuncSetAttribute((const void*)mlp_dw_f16_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DWH_SMEM_SMALL) !=
-            hipSuccess) {
+    // once per process: the attribute sticks to the function
+    static const bool lds_ok =
+        hipFuncSetAttribute((const void*)mlp_dw_f16_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DWH_SMEM) == hipSuccess &&
+        hipFuncSetAttribute((const void*)mlp_dw_f16_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DWH_SMEM_SMALL) == hipSuccess;
+    if (!lds_ok) {
         benerf_set_error("mlp_bwd(dw, f16): cannot reserve LDS");
         return BENERF_EHIP;
     }

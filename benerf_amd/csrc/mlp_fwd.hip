@@ -413,8 +413,9 @@ extern "C" int benerf_mlp_fwd(const BenerfMlpParams* params, const float* packed
     const int smem = (int)mlp::TILE_SMEM;
 #define BENERF_FWD_LAUNCH(CH, SV)                                                                                  \
     do {                                                                                                           \
-        if (hipFuncSetAttribute((const void*)mlp_fwd_kernel<CH, SV>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                                smem) != hipSuccess) {                                                             \
+        static const bool lds_ok = hipFuncSetAttribute((const void*)mlp_fwd_kernel<CH, SV>,                        \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem) == hipSuccess; \
+        if (!lds_ok) {                                                                                             \
             benerf_set_error("mlp_fwd: cannot reserve %d bytes of LDS", smem);                                     \
             return BENERF_EHIP;                                                                                    \
         }                                                                                                          \

@@ -7,14 +7,13 @@
 // both modes; test_mlp_modes_agree_at_full_size compares them at BASELINE size).
 // Three f16 MFMAs (16-deep, 32 cycles each) replace eight f32 MFMAs (2-deep, 32 cycles each).
 //
-// LDS: two f16 planes Th/Tl[64][320] (hi / scaled lo) = 80 KiB, so two workgroups still share a CU.
+// LDS: two f16 planes Th/Tl[128][320] (hi / scaled lo) = 160 KiB: one workgroup of 8 waves per CU and 128-point tile.
 // 16-byte slots (8 halfs) are XOR-swizzled: element (row, col) lives in slot (col>>3) ^ ((row>>1)&7).
 // Range: |x| must stay below 65504 (f16 max) - NeRF activations are O(1..100); every launch folds max|activation|
 // into the caller's status word once it passes 2^15 (mlp_split.h, 'Range guard'), so a violation is never silent.
 // Training mode saves the f16 (hi) halves of the activations as SH arrays (mlp_split.h) + ReLU sign-bit words for the
 // f16 dX / dW kernels.
 #include "mlp_split.h"
-#include <stdlib.h>
 
 namespace {
 using namespace mlp;
@@ -125,38 +124,6 @@ __device__ __forceinline__ void epilogue_t(f32x16 (&acc1)[NR][NCT], f32x16 (&acc
     }
 }
 
-// One PAIR of the epilogue above as a unit of work that a K-loop can carry in one of its k-steps (software pipelining of
-// the two 64-point halves of a tile, see the kernel): pair p = 0..7 of row tile rt covers accumulator elements
-// e = 4 (p >> 1) + 2 (p & 1), e + 1; after the fourth pair of a slot pair (p & 3 == 3) the two 16-byte plane slots leave.
-struct EpiWords { uint32_t h[2][2], l[2][2]; };
-template <bool RELU>
-__device__ __forceinline__ void epi_slice(const f32x16& a1, const f32x16& a2, EpiWords& w, _Float16* __restrict__ th,
-                                          _Float16* __restrict__ tl, int rt, int pair, int ct, int lane, float& amax) {
-    const int q = pair >> 1, jp = pair & 1, e = q * 4 + jp * 2;
-#ifdef BENERF_ABL_NOEPI       // experiment build: the accumulators stay live, the epilogue's work is gone
-    asm volatile("" :: "v"(a1[e]), "v"(a2[e]), "v"(a1[e + 1]), "v"(a2[e + 1]));
-    return;
-#endif
-    float2v v = {a1[e] + a2[e] * LO_INV, a1[e + 1] + a2[e + 1] * LO_INV};
-    if (RELU) {
-        v[0] = fmaxf(v[0], 0.f);
-        v[1] = fmaxf(v[1], 0.f);
-        amax = fmaxf(amax, fmaxf(v[0], v[1]));
-    } else {
-        amax = fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1])));
-    }
-    const half2v hi = __builtin_convertvector(v, half2v);
-    const float2v res = (v - __builtin_convertvector(hi, float2v)) * LO_SCALE;
-    w.h[q & 1][jp] = __builtin_bit_cast(uint32_t, hi);
-    w.l[q & 1][jp] = __builtin_bit_cast(uint32_t, __builtin_convertvector(res, half2v));
-    if ((pair & 3) == 3) {
-        const int row = rt * 32 + (lane & 31), sw = hsw(row);
-        const int slot = ct * 4 + 2 * (q >> 1) + (lane >> 5);
-        *reinterpret_cast<uint4*>(th + row * LD + ((slot ^ sw) << 3)) = sh_pair_unit(uint2{w.h[0][0], w.h[0][1]}, uint2{w.h[1][0], w.h[1][1]});
-        *reinterpret_cast<uint4*>(tl + row * LD + ((slot ^ sw) << 3)) = sh_pair_unit(uint2{w.l[0][0], w.l[0][1]}, uint2{w.l[1][0], w.l[1][1]});
-    }
-}
-
 // Training mode, after the barrier behind epilogue_t: the finished hi plane -> the SH activation array of width W (tile part
 // at `st_tile`) and the ReLU sign-bit word.  ds_read_b64_tr_b16 (tools/hwprobe/tr_read.hip: within a 16-lane group lane t
 // supplies the address of row t >> 2, halfs 4 (t & 3) .. +3 of a 4 x 16 block and receives column t) hands lane l the 4
@@ -241,14 +208,7 @@ static_assert(pack_offset(PF_L1) + 3 * pack_floats(PF_L1) == pack_offset(PF_L4) 
 constexpr int FTM = 128, FNT = 512, FPF = 2;
 constexpr size_t FWD_SMEM = (size_t)2 * FTM * LD * sizeof(_Float16);      // 163 840 B
 
-// PIPE: the tile's two 64-point halves A (rows 0-63) and B (rows 64-127) run one phase apart through the hidden layers:
-//   ... | K(l,A) + E(l-1,B) | barrier | K(l,B) + E(l,A) | barrier | K(l+1,A) + E(l,B) | ...
-// K(l,X) = the K-loop of layer l over the rows of half X (two row tiles per wave, NR = 2), E(l,X) = the epilogue of layer l for
-// half X (combine, ReLU, hi/lo split, plane stores), cut into 16 slices that ride in the k-steps of the OTHER half's K-loop:
-// the VALU work of an epilogue issues in the shadow of MFMAs instead of leaving the matrix pipe idle between two K-loops.
-// In place is safe: rows are independent, a half's rows are only written in the phase after every wave has read them.
-// Price: a wave streams its column tile's weight fragments twice per layer (L2 -> register traffic doubles).
-template <int C, bool SAVE, bool PIPE>
+template <int C, bool SAVE>
 __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) _Float16 Tsm[];   // Th | Tl
     _Float16* Th = Tsm;
@@ -332,104 +292,48 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
         lds_barrier();          // the staging columns are layer 0's output columns
     }
 
-    float4 bq[1][4];
-    if constexpr (PIPE) {
-        f32x16 kA1[2][1], kA2[2][1], kB1[2][1], kB2[2][1];
-        _Float16* ThB = Th + 64 * LD;            // rows + 64: same swizzle
-        _Float16* TlB = Tl + 64 * LD;
-        EpiWords ew;
-        auto epiA = [&](int s) { epi_slice<true>(kA1[s >> 3][0], kA2[s >> 3][0], ew, Th, Tl, s >> 3, s & 7, wave, lane, amax); };
-        auto epiB = [&](int s) { epi_slice<true>(kB1[s >> 3][0], kB2[s >> 3][0], ew, ThB, TlB, s >> 3, s & 7, wave, lane, amax); };
-        // ---- L0 (K = 64: 4 k-steps; its outputs go to columns [0,256), its inputs are the PE columns: no barrier between) ----
-        load_bias<1>(a.bias[0], wave, lane, bq);
-        acc_init_bias(kA1, bq);
-        zero_acc(kA2);
-        gemm_stage<4, 1, FPF, true, 2>(Th, Tl, COL_PE, a.packed + pack_offset(PF_L0), wave, lane, kA1, kA2);
-        acc_init_bias(kB1, bq);
-        zero_acc(kB2);
-        load_bias<1>(a.bias[1], wave, lane, bq);
-        gemm_stage<4, 1, FPF, true, 2>(ThB, TlB, COL_PE, a.packed + pack_offset(PF_L0), wave, lane, kB1, kB2, NoAfterHead(), [&](int ks) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) epiA(ks * 4 + i);
-        });
-        lds_barrier();
-        // ---- L1..L7 ---------------------------------------------------------------------------------------------------
-#pragma unroll 1
-        for (int l = 1; l < 8; ++l) {
-            uint64_t pbits = 0;
-            const __amdgpu_buffer_rsrc_t prs = uniform_rsrc(SAVE ? st_h + ((int64_t)(l - 1) * Mp + m0) * 256 : nullptr);
-            // phase A: K(l, A) with E(l-1, B) in its k-steps; the finished h_{l-1}(A) leaves for HBM in k-steps 4..7
-            auto stepA = [&](int ks) {
-                if (ks < 16) epiB(ks);
-                if (SAVE && ks >= 4 && ks < 8) save_pair<256, true, 16>(Th, wave, ks - 4, lane, prs, pbits);
-            };
-            // phase B: K(l, B) with E(l, A); h_{l-1}(B) (complete since the barrier) leaves for HBM
-            auto stepB = [&](int ks) {
-                if (ks < 16) epiA(ks);
-                if (SAVE && ks >= 4 && ks < 8) save_pair<256, true, 16>(Th, wave, ks, lane, prs, pbits);
-                if (SAVE && ks == 8) store_bits(l - 1, pbits);
-            };
-            acc_init_bias(kA1, bq);
-            zero_acc(kA2);
-            if (l == 5) gemm_stage<20, 1, FPF, true, 2>(Th, Tl, 0, a.packed + pack_offset(PF_L5), wave, lane, kA1, kA2, NoAfterHead(), stepA);
-            else gemm_stage<16, 1, FPF, true, 2>(Th, Tl, 0, a.packed + fwd_layer_offset(l), wave, lane, kA1, kA2, NoAfterHead(), stepA);
-            lds_barrier();
-            acc_init_bias(kB1, bq);
-            zero_acc(kB2);
-            load_bias<1>(a.bias[l < 7 ? l + 1 : BENERF_L_FEAT], wave, lane, bq);
-            if (l == 5) gemm_stage<20, 1, FPF, true, 2>(ThB, TlB, 0, a.packed + pack_offset(PF_L5), wave, lane, kB1, kB2, NoAfterHead(), stepB);
-            else gemm_stage<16, 1, FPF, true, 2>(ThB, TlB, 0, a.packed + fwd_layer_offset(l), wave, lane, kB1, kB2, NoAfterHead(), stepB);
-            lds_barrier();
-        }
-        // drain: E(7, B)
-#pragma unroll
-        for (int sidx = 0; sidx < 16; ++sidx) epiB(sidx);
-        lds_barrier();
-    } else {
     f32x16 acc1[4][1], acc2[4][1];
 
-        // ---- L0 ---------------------------------------------------------------------------------
-        load_bias<1>(a.bias[0], wave, lane, bq);
+    // ---- L0 ---------------------------------------------------------------------------------
+    float4 bq[1][4];
+    load_bias<1>(a.bias[0], wave, lane, bq);
+    acc_init_bias(acc1, bq);
+    zero_acc(acc2);
+    gemm_stage<4, 1, FPF, true, 4>(Th, Tl, COL_PE, a.packed + pack_offset(PF_L0), wave, lane, acc1, acc2);
+    load_bias<1>(a.bias[1], wave, lane, bq);
+    epilogue_t<1, true, 4>(acc1, acc2, Th, Tl, wave, lane, amax);
+    lds_barrier();
+
+    // ---- L1..L7 -------------------------------------------------------------------------------
+    // the previous layer's activations leave for HBM (save_tile: transpose reads of the finished hi plane, 16-byte stores)
+    // right behind this layer's first weight-fragment requests
+#pragma unroll 1
+    for (int l = 1; l < 8; ++l) {
+        // The previous layer's activations leave for HBM during this layer's LAST two k-steps (four block pairs each: two
+        // transpose reads of the finished hi plane, the sign bits, one 16-byte store per pair): behind the K-loop's last
+        // weight-fragment request, so that no fragment is queued behind a store (in-order retirement), and in the gaps
+        // between the MFMAs.  The next requests (the following layer's) come an epilogue later.
+        uint64_t pbits = 0;
+        const __amdgpu_buffer_rsrc_t prs = uniform_rsrc(SAVE ? st_h + ((int64_t)(l - 1) * Mp + m0) * 256 : nullptr);
+        auto save_at = [&](int ks, int first) {
+            if (SAVE && ks >= first) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) save_pair<256, true, 16>(Th, wave, (ks - first) * 4 + i, lane, prs, pbits);
+                if (ks == first + 1) store_bits(l - 1, pbits);
+            }
+        };
         acc_init_bias(acc1, bq);
         zero_acc(acc2);
-        gemm_stage<4, 1, FPF, true, 4>(Th, Tl, COL_PE, a.packed + pack_offset(PF_L0), wave, lane, acc1, acc2);
-        load_bias<1>(a.bias[1], wave, lane, bq);
+        if (l == 5) gemm_stage<20, 1, FPF, true, 4>(Th, Tl, 0, a.packed + pack_offset(PF_L5), wave, lane, acc1, acc2, NoAfterHead(),
+                                                    [&](int ks) { save_at(ks, 18); });
+        else gemm_stage<16, 1, FPF, true, 4>(Th, Tl, 0, a.packed + fwd_layer_offset(l), wave, lane, acc1, acc2, NoAfterHead(),
+                                             [&](int ks) { save_at(ks, 14); });
+        lds_barrier();
+        load_bias<1>(a.bias[l < 7 ? l + 1 : BENERF_L_FEAT], wave, lane, bq);
         epilogue_t<1, true, 4>(acc1, acc2, Th, Tl, wave, lane, amax);
         lds_barrier();
-
-        // ---- L1..L7 -------------------------------------------------------------------------------
-        // the previous layer's activations leave for HBM (save_tile: transpose reads of the finished hi plane, 16-byte stores)
-        // right behind this layer's first weight-fragment requests
-#pragma unroll 1
-        for (int l = 1; l < 8; ++l) {
-            // The previous layer's activations leave for HBM during this layer's LAST two k-steps (four block pairs each: two
-            // transpose reads of the finished hi plane, the sign bits, one 16-byte store per pair): behind the K-loop's last
-            // weight-fragment request, so that no fragment is queued behind a store (in-order retirement), and in the gaps
-            // between the MFMAs.  The next requests (the following layer's) come an epilogue later.
-            uint64_t pbits = 0;
-            const __amdgpu_buffer_rsrc_t prs = uniform_rsrc(SAVE ? st_h + ((int64_t)(l - 1) * Mp + m0) * 256 : nullptr);
-            auto save_at = [&](int ks, int first) {
-                if (SAVE && ks >= first) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) save_pair<256, true, 16>(Th, wave, (ks - first) * 4 + i, lane, prs, pbits);
-                    if (ks == first + 1) store_bits(l - 1, pbits);
-                }
-            };
-            acc_init_bias(acc1, bq);
-            zero_acc(acc2);
-            if (l == 5) gemm_stage<20, 1, FPF, true, 4>(Th, Tl, 0, a.packed + pack_offset(PF_L5), wave, lane, acc1, acc2, NoAfterHead(),
-                                                        [&](int ks) { save_at(ks, 18); });
-            else gemm_stage<16, 1, FPF, true, 4>(Th, Tl, 0, a.packed + fwd_layer_offset(l), wave, lane, acc1, acc2, NoAfterHead(),
-                                                 [&](int ks) { save_at(ks, 14); });
-            lds_barrier();
-            load_bias<1>(a.bias[l < 7 ? l + 1 : BENERF_L_FEAT], wave, lane, bq);
-            epilogue_t<1, true, 4>(acc1, acc2, Th, Tl, wave, lane, amax);
-            lds_barrier();
-        }
     }
     if (SAVE) store_bits(7, save_tile<1, 256, true, 16>(Th, wave, lane, st_h + ((int64_t)7 * Mp + m0) * 256));
-
-    f32x16 acc1[4][1], acc2[4][1];
 
     // ---- alpha partials (reads h7) + PE(viewdir) into columns [256,288) ---------------------------
     {
@@ -580,31 +484,23 @@ int benerf_mlp_fwd_split_launch(const BenerfMlpParams* params, const float* pack
     BENERF_REQUIRE(tiles < (1ll << 31) && a.M < (1ll << 31), "mlp_fwd(split): too many points");
     dim3 grid((unsigned)tiles), block(FNT);
     const int smem = (int)FWD_SMEM;
-    // BENERF_FWD_PIPE=0: the unpipelined tile loop (A/B timing of the two schedules on one box)
-    static const bool pipe = [] { const char* e = getenv("BENERF_FWD_PIPE"); return !(e && e[0] == '0'); }();
-#define BENERF_FWD_LAUNCH(CH, SV, PP)                                                                                    \
+#define BENERF_FWD_LAUNCH(CH, SV)                                                                                        \
     do {                                                                                                                 \
-        static const hipError_t attr = hipFuncSetAttribute((const void*)mlp_fwd_split_kernel<CH, SV, PP>,                 \
+        static const hipError_t attr = hipFuncSetAttribute((const void*)mlp_fwd_split_kernel<CH, SV>,                     \
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem); /* once */ \
         if (attr != hipSuccess) {                                                                                        \
             benerf_set_error("mlp_fwd(split): cannot reserve %d bytes of LDS", smem);                                    \
             return BENERF_EHIP;                                                                                          \
         }                                                                                                                \
-        hipLaunchKernelGGL((mlp_fwd_split_kernel<CH, SV, PP>), grid, block, smem, stream, a);                            \
-    } while (0)
-#define BENERF_FWD_LAUNCH2(CH, SV)                                                                                       \
-    do {                                                                                                                 \
-        if (pipe) BENERF_FWD_LAUNCH(CH, SV, true);                                                                       \
-        else BENERF_FWD_LAUNCH(CH, SV, false);                                                                           \
+        hipLaunchKernelGGL((mlp_fwd_split_kernel<CH, SV>), grid, block, smem, stream, a);                                \
     } while (0)
     if (channels == 1) {
-        if (acts) BENERF_FWD_LAUNCH2(1, true);
-        else BENERF_FWD_LAUNCH2(1, false);
+        if (acts) BENERF_FWD_LAUNCH(1, true);
+        else BENERF_FWD_LAUNCH(1, false);
     } else {
-        if (acts) BENERF_FWD_LAUNCH2(3, true);
-        else BENERF_FWD_LAUNCH2(3, false);
+        if (acts) BENERF_FWD_LAUNCH(3, true);
+        else BENERF_FWD_LAUNCH(3, false);
     }
-#undef BENERF_FWD_LAUNCH2
 #undef BENERF_FWD_LAUNCH
     BENERF_LAUNCH_CHECK("mlp_fwd(split)");
     return BENERF_OK;

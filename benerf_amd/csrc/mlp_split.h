@@ -1,6 +1,6 @@
 // Shared pieces of the split-f16 MLP kernels (mlp_fwd_h.hip, mlp_bwd_h.hip, mlp_dw_h.hip).  Forward: an f32 value x
 // is carried as two f16 numbers x = hi + lo * 2^-11 and a product block is three f16 MFMAs (hi*hi, hi*lo, lo*hi)
-// with f32 accumulation; LDS holds two f16 planes Th/Tl[64][LD].  Backward (dX chain, dW): f16 operands, one MFMA
+// with f32 accumulation; LDS holds two f16 planes Th/Tl[128][LD] (forward: one workgroup of 8 waves per CU).  Backward (dX chain, dW): f16 operands, one MFMA
 // per product block, f32 accumulation.  16-byte LDS slots (8 halfs) are XOR-swizzled: element (row, col) lives in
 // slot (col>>3) ^ ((row>>1)&7) of its row.
 #pragma once
@@ -54,17 +54,8 @@ __device__ __forceinline__ void gemm_stage(const _Float16* __restrict__ Th, cons
     const int ct0u = __builtin_amdgcn_readfirstlane(ct0);
     const int tbase = (ct0u >> 1) * KS * 4096 + (ct0u & 1) * 2048;
     auto load_b = [&](int c, int ks, int plane) -> u32x4 {
-#ifdef BENERF_ABL_NOLOAD      // experiment build (tools/experiments/ablate_fwd.sh): fragments without the L2 round trip
-        return __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + c * 2048 + plane * 1024, tbase, 0);   // k-step 0 again: L1-resident
-#else
         return __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + c * 2048 + plane * 1024, tbase + ks * 4096, 0);
-#endif
     };
-#ifdef BENERF_ABL_NOLDS
-#define BENERF_A_READ(P, OFF) __builtin_bit_cast(half8, u32x4{(uint32_t)(OFF) | 0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u})
-#else
-#define BENERF_A_READ(P, OFF) (*reinterpret_cast<const half8*>((P) + (OFF)))
-#endif
     u32x4 bq[PF + 1][NCT][2];
 #pragma unroll
     for (int p = 0; p < PF; ++p)
@@ -90,8 +81,8 @@ __device__ __forceinline__ void gemm_stage(const _Float16* __restrict__ Th, cons
     auto a_off = [&](int ks) { return abase[ks & 3] + ((slot0 + ((2 * ks) & ~7)) << 3); };
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
-        ah[r] = BENERF_A_READ(Th, a_off(0) + r * 32 * LD);
-        al[r] = BENERF_A_READ(Tl, a_off(0) + r * 32 * LD);
+        ah[r] = *reinterpret_cast<const half8*>(Th + a_off(0) + r * 32 * LD);
+        al[r] = *reinterpret_cast<const half8*>(Tl + a_off(0) + r * 32 * LD);
     }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -115,13 +106,13 @@ __device__ __forceinline__ void gemm_stage(const _Float16* __restrict__ Th, cons
             for (int c = 0; c < NCT; ++c) acc1[r][c] = SWAP ? mfma16(bh[c], ah[r], acc1[r][c]) : mfma16(ah[r], bh[c], acc1[r][c]);
 #pragma unroll
             for (int c = 0; c < NCT; ++c) acc2[r][c] = SWAP ? mfma16(bl[c], ah[r], acc2[r][c]) : mfma16(ah[r], bl[c], acc2[r][c]);
-            if (ks + 1 < KS) ah[r] = BENERF_A_READ(Th, a_off(ks + 1) + r * 32 * LD);
+            if (ks + 1 < KS) ah[r] = *reinterpret_cast<const half8*>(Th + a_off(ks + 1) + r * 32 * LD);
         }
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
 #pragma unroll
             for (int c = 0; c < NCT; ++c) acc2[r][c] = SWAP ? mfma16(bh[c], al[r], acc2[r][c]) : mfma16(al[r], bh[c], acc2[r][c]);
-            if (ks + 1 < KS) al[r] = BENERF_A_READ(Tl, a_off(ks + 1) + r * 32 * LD);
+            if (ks + 1 < KS) al[r] = *reinterpret_cast<const half8*>(Tl + a_off(ks + 1) + r * 32 * LD);
         }
         __builtin_amdgcn_sched_barrier(0);          // one k-step per scheduling region: keeps the prefetch distances as written
     }

@@ -3,8 +3,10 @@
 // Forward follows run_nerf_helpers.py:35-44 (pinhole dirs, rays_d = R dirs, rays_o = t),
 // model/nerf.py:272-275 (viewdirs from PRE-NDC rays_d), run_nerf_helpers.py:46-71 (NDC,
 // near = 1, focal = K[0][0]) and model/nerf.py:297-307 (stratified z).
-// Backward: the same templated code on forward-mode duals, one tangent per pose entry
-// (12 per ray), then a fixed-order block reduction per pose -> deterministic d_poses.
+// Backward: a pose enters a ray only through rd = R dirs and ro = t (6 numbers), so the same templated code runs on
+// forward-mode duals with one tangent per component of (rd, ro) - 6 passes per ray - and the pose gradient is the outer
+// product d_pose[r][0..2] = g_rd[r] * dirs, d_pose[r][3] = g_ro[r]; grid over (pixel chunk, pose), wave shuffles + one
+// LDS hop per block, chunks summed in fixed order -> deterministic d_poses.
 //
 // Built with -ffp-contract=off so mul/add stay separately rounded like the torch ops.
 #include "common.h"
@@ -54,17 +56,9 @@ __device__ __forceinline__ void pixel_coords(int64_t idx, const Cam& c, const fl
     }
 }
 
+// everything behind the camera-to-world product: rd = R dirs (un-normalised), ro = t  ->  o, d (NDC'd when c.ndc), viewdirs
 template <class T>
-__device__ __forceinline__ void ray_from_pose(const T pose[12], float fi, float fj, const Cam& c, T o[3], T d[3], T vd[3]) {
-    float dx = (fi - c.cx) / c.fx;          // run_nerf_helpers.py:36-38
-    float dy = -(fj - c.cy) / c.fy;
-    float dz = -1.0f;
-    T rd[3], ro[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        rd[r] = (dx * pose[r * 4 + 0] + dy * pose[r * 4 + 1]) + dz * pose[r * 4 + 2];
-        ro[r] = pose[r * 4 + 3];
-    }
+__device__ __forceinline__ void ray_from_rd(const T rd[3], const T ro[3], const Cam& c, T o[3], T d[3], T vd[3]) {
     T nrm = t_sqrt((rd[0] * rd[0] + rd[1] * rd[1]) + rd[2] * rd[2]);   // model/nerf.py:272-275
     vd[0] = rd[0] / nrm;
     vd[1] = rd[1] / nrm;
@@ -90,6 +84,25 @@ __device__ __forceinline__ void ray_from_pose(const T pose[12], float fi, float 
     }
 }
 
+__device__ __forceinline__ void pixel_dirs(float fi, float fj, const Cam& c, float dirs[3]) {
+    dirs[0] = (fi - c.cx) / c.fx;          // run_nerf_helpers.py:36-38
+    dirs[1] = -(fj - c.cy) / c.fy;
+    dirs[2] = -1.0f;
+}
+
+template <class T>
+__device__ __forceinline__ void ray_from_pose(const T pose[12], float fi, float fj, const Cam& c, T o[3], T d[3], T vd[3]) {
+    float dirs[3];
+    pixel_dirs(fi, fj, c, dirs);
+    T rd[3], ro[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        rd[r] = (dirs[0] * pose[r * 4 + 0] + dirs[1] * pose[r * 4 + 1]) + dirs[2] * pose[r * 4 + 2];
+        ro[r] = pose[r * 4 + 3];
+    }
+    ray_from_rd(rd, ro, c, o, d, vd);
+}
+
 __global__ void rays_fwd_kernel(const float* __restrict__ poses, const int64_t* __restrict__ ray_idx, int n_poses,
                                 int n_pix, Cam cam, const float* __restrict__ remap, float* __restrict__ rays_o,
                                 float* __restrict__ rays_d, float* __restrict__ viewdirs) {
@@ -112,23 +125,29 @@ __global__ void rays_fwd_kernel(const float* __restrict__ poses, const int64_t* 
     }
 }
 
-// one block (256 threads) per pose; thread handles pixels tid, tid+256, ...; each pixel
-// evaluates 12 dual passes; LDS tree reduction in fixed order.
-__global__ void rays_bwd_kernel(const float* __restrict__ poses, const int64_t* __restrict__ ray_idx, int n_poses,
-                                int n_pix, Cam cam, const float* __restrict__ remap, const float* __restrict__ g_o,
-                                const float* __restrict__ g_d, const float* __restrict__ g_v, float* __restrict__ d_poses) {
-    __shared__ float red[256 * 12];
-    int p = blockIdx.x;
-    float pose[12];
-#pragma unroll
-    for (int e = 0; e < 12; ++e) pose[e] = poses[p * 12 + e];
+// grid (pixel chunks of 256, poses), one pixel per thread.  out: d_poses itself when there is one chunk, else the chunk
+// partials [n_poses][n_chunks][12] that rays_bwd_reduce_kernel sums in chunk order.
+constexpr int RB_T = 256;
+__global__ __launch_bounds__(RB_T) void rays_bwd_kernel(const float* __restrict__ poses, const int64_t* __restrict__ ray_idx, int n_pix,
+                                                         Cam cam, const float* __restrict__ remap, const float* __restrict__ g_o,
+                                                         const float* __restrict__ g_d, const float* __restrict__ g_v,
+                                                         float* __restrict__ out) {
+    __shared__ float red[RB_T / 64][12];
+    const int p = blockIdx.y, r = blockIdx.x * RB_T + threadIdx.x;
     float acc[12];
 #pragma unroll
     for (int e = 0; e < 12; ++e) acc[e] = 0.f;
-    for (int r = threadIdx.x; r < n_pix; r += blockDim.x) {
-        int64_t n = (int64_t)p * n_pix + r;
-        float i, j;
-        pixel_coords(ray_idx[r], cam, remap, i, j);
+    if (r < n_pix) {
+        const int64_t n = (int64_t)p * n_pix + r;
+        float fi, fj, dirs[3], rdv[3], rov[3];
+        pixel_coords(ray_idx[r], cam, remap, fi, fj);
+        pixel_dirs(fi, fj, cam, dirs);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float* row = poses + p * 12 + c * 4;
+            rdv[c] = (dirs[0] * row[0] + dirs[1] * row[1]) + dirs[2] * row[2];
+            rov[c] = row[3];
+        }
         float go[3], gd[3], gv[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -137,29 +156,51 @@ __global__ void rays_bwd_kernel(const float* __restrict__ poses, const int64_t* 
             gv[c] = g_v ? g_v[n * 3 + c] : 0.f;
         }
 #pragma unroll
-        for (int e = 0; e < 12; ++e) {
-            Dual dp[12];
+        for (int e = 0; e < 6; ++e) {            // tangent e: rd[e] (e < 3) or ro[e - 3]
+            Dual rd[3], ro[3], o[3], d[3], vd[3];
 #pragma unroll
-            for (int q = 0; q < 12; ++q) dp[q] = Dual{pose[q], q == e ? 1.f : 0.f};
-            Dual o[3], d[3], vd[3];
-            ray_from_pose(dp, i, j, cam, o, d, vd);
-            float s = 0.f;
+            for (int c = 0; c < 3; ++c) {
+                rd[c] = Dual{rdv[c], e == c ? 1.f : 0.f};
+                ro[c] = Dual{rov[c], e == c + 3 ? 1.f : 0.f};
+            }
+            ray_from_rd(rd, ro, cam, o, d, vd);
+            float g = 0.f;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) s += go[c] * o[c].d + gd[c] * d[c].d + gv[c] * vd[c].d;
-            acc[e] += s;
+            for (int c = 0; c < 3; ++c) g += go[c] * o[c].d + gd[c] * d[c].d + gv[c] * vd[c].d;
+            if (e < 3) {
+                acc[e * 4 + 0] = dirs[0] * g;
+                acc[e * 4 + 1] = dirs[1] * g;
+                acc[e * 4 + 2] = dirs[2] * g;
+            } else {
+                acc[(e - 3) * 4 + 3] = g;
+            }
         }
     }
 #pragma unroll
-    for (int e = 0; e < 12; ++e) red[threadIdx.x * 12 + e] = acc[e];
+    for (int e = 0; e < 12; ++e) {
+        float v = acc[e];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        acc[e] = v;
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int e = 0; e < 12; ++e) red[threadIdx.x >> 6][e] = acc[e];
+    }
     __syncthreads();
-    for (int stride = 128; stride > 0; stride >>= 1) {
-        if (threadIdx.x < stride) {
-#pragma unroll
-            for (int e = 0; e < 12; ++e) red[threadIdx.x * 12 + e] += red[(threadIdx.x + stride) * 12 + e];
-        }
-        __syncthreads();
+    if (threadIdx.x < 12) {
+        float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        out[((int64_t)p * gridDim.x + blockIdx.x) * 12 + threadIdx.x] = v;
     }
-    if (threadIdx.x < 12) d_poses[p * 12 + threadIdx.x] = red[threadIdx.x];
+}
+
+__global__ void rays_bwd_reduce_kernel(const float* __restrict__ part, int n_chunks, int n_out, float* __restrict__ d_poses) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // (pose, entry)
+    if (i >= n_out) return;
+    const int p = i / 12, e = i - p * 12;
+    float v = 0.f;
+    for (int c = 0; c < n_chunks; ++c) v += part[((int64_t)p * n_chunks + c) * 12 + e];
+    d_poses[i] = v;
 }
 
 // torch.linspace(0,1,S)[i]
@@ -249,16 +290,32 @@ extern "C" int benerf_rays_fwd(const float* poses, const int64_t* ray_idx, int n
     return BENERF_OK;
 }
 
+extern "C" size_t benerf_rays_bwd_workspace_floats(int n_poses, int n_pix) {
+    const int chunks = (n_pix + RB_T - 1) / RB_T;
+    return chunks > 1 ? (size_t)n_poses * chunks * 12 : 0;
+}
+
 extern "C" int benerf_rays_bwd(const float* poses, const int64_t* ray_idx, int n_poses, int n_pix, int H, int W,
                                float fx, float fy, float cx, float cy, int ndc, const float* remap,
                                const float* d_rays_o, const float* d_rays_d, const float* d_viewdirs, float* d_poses,
-                               benerf_stream_t stream) {
+                               float* workspace, size_t workspace_floats, benerf_stream_t stream) {
     BENERF_REQUIRE(poses && ray_idx && d_poses, "rays_bwd: null pointer");
     BENERF_REQUIRE(n_poses > 0 && n_pix > 0, "rays_bwd: bad sizes");
     Cam cam{H, W, fx, fy, cx, cy, ndc};
-    hipLaunchKernelGGL(rays_bwd_kernel, dim3(n_poses), dim3(256), 0, as_stream(stream), poses, ray_idx, n_poses, n_pix,
-                       cam, remap, d_rays_o, d_rays_d, d_viewdirs, d_poses);
+    const int chunks = (n_pix + RB_T - 1) / RB_T;
+    const size_t need = benerf_rays_bwd_workspace_floats(n_poses, n_pix);
+    if (need > 0 && (!workspace || workspace_floats < need)) {
+        benerf_set_error("rays_bwd: workspace of %zu floats needed, %zu given", need, workspace ? workspace_floats : (size_t)0);
+        return BENERF_EWORKSPACE;
+    }
+    hipLaunchKernelGGL(rays_bwd_kernel, dim3(chunks, n_poses), dim3(RB_T), 0, as_stream(stream), poses, ray_idx, n_pix, cam, remap,
+                       d_rays_o, d_rays_d, d_viewdirs, chunks > 1 ? workspace : d_poses);
     BENERF_LAUNCH_CHECK("rays_bwd");
+    if (chunks > 1) {
+        hipLaunchKernelGGL(rays_bwd_reduce_kernel, dim3((n_poses * 12 + 63) / 64), dim3(64), 0, as_stream(stream), workspace, chunks,
+                           n_poses * 12, d_poses);
+        BENERF_LAUNCH_CHECK("rays_bwd(reduce)");
+    }
     return BENERF_OK;
 }
 

@@ -484,9 +484,13 @@ class TrainStep:
         # (MFMA-bound, little HBM traffic); the two networks keep separate activation-gradient buffers for that.
         n = self.n_net
         main, side = torch.cuda.current_stream(dev), self.dw_stream
-        d_raw1, _ = K.composite_bwd(raw1, z_fine, rd, nz1[0], nz1[1], nz1[2], nz1[3], g_rgb, d_rays_d=d_d)
-        d_raw0, _ = K.composite_bwd(raw0, z, rd, nz0[0], nz0[1], nz0[2], nz0[3], g_rgb0, d_rays_d=d_d, accumulate=True)
-        d_pts1, d_vp1, dacts1 = K.mlp_bwd_dx(self.net_f.packed, d_raw1.view(-1, C + 1), acts1, N, S + Ni, slot="_fine", status=st)
+        # max |d_raw| of both networks comes out of the compositing backward (the split-f16 dX chain scales by it)
+        amax = torch.zeros(2, dtype=torch.float32, device=dev)
+        d_raw1, _ = K.composite_bwd(raw1, z_fine, rd, nz1[0], nz1[1], nz1[2], nz1[3], g_rgb, d_rays_d=d_d, absmax_out=amax[0:1])
+        d_raw0, _ = K.composite_bwd(raw0, z, rd, nz0[0], nz0[1], nz0[2], nz0[3], g_rgb0, d_rays_d=d_d, accumulate=True,
+                                    absmax_out=amax[1:2])
+        d_pts1, d_vp1, dacts1 = K.mlp_bwd_dx(self.net_f.packed, d_raw1.view(-1, C + 1), acts1, N, S + Ni, slot="_fine", status=st,
+                                             d_raw_absmax=amax[0:1])
         side.wait_stream(main)
         with torch.cuda.stream(side):
             K.mlp_bwd_dw(self.net_f.packed, d_raw1.view(-1, C + 1), acts1, dacts1, N, S + Ni, self.net_f.gviews_w,
@@ -494,7 +498,8 @@ class TrainStep:
             # gradient exchange, bucket 1 of 3: the fine network's gradients are final - their all-reduce (RCCL over
             # xGMI) runs on the communicator's stream while the coarse backward computes
             pending = [dist.allreduce_sum_async_(self.flat_g[n:2 * n], self.world, self.pg)]
-        d_pts0, d_vp0, dacts0 = K.mlp_bwd_dx(self.net_c.packed, d_raw0.view(-1, C + 1), acts0, N, S, slot="_coarse", status=st)
+        d_pts0, d_vp0, dacts0 = K.mlp_bwd_dx(self.net_c.packed, d_raw0.view(-1, C + 1), acts0, N, S, slot="_coarse", status=st,
+                                             d_raw_absmax=amax[1:2])
         side.wait_stream(main)
         with torch.cuda.stream(side):
             K.mlp_bwd_dw(self.net_c.packed, d_raw0.view(-1, C + 1), acts0, dacts0, N, S, self.net_c.gviews_w,

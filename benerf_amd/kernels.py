@@ -120,9 +120,12 @@ def rays_fwd(poses, ray_idx, H, W, fx, fy, cx, cy, ndc=True, out=None, remap=Non
 def rays_bwd(poses, ray_idx, H, W, fx, fy, cx, cy, ndc, d_rays_o, d_rays_d, d_viewdirs, remap=None):
     lib = _lib.load()
     d_poses = _new((poses.shape[0], 3, 4), poses)
+    n_ws = lib.benerf_rays_bwd_workspace_floats(poses.shape[0], ray_idx.shape[0])
+    ws = scratch("rays_bwd", n_ws, poses.device) if n_ws else None
     _lib.check(lib.benerf_rays_bwd(_chk(poses), _chk(ray_idx, torch.int64), poses.shape[0], ray_idx.shape[0], H, W, fx,
                                    fy, cx, cy, int(bool(ndc)), _chk(remap, name="remap"), _chk(d_rays_o), _chk(d_rays_d),
-                                   _chk(d_viewdirs), d_poses.data_ptr(), _stream()), "rays_bwd")
+                                   _chk(d_viewdirs), d_poses.data_ptr(), None if ws is None else ws.data_ptr(), n_ws, _stream()),
+               "rays_bwd")
     return d_poses
 
 
@@ -388,7 +391,7 @@ def mlp_fwd(net, rays_o, rays_d, viewdirs, z, save_acts, precision=None, status=
     return raw, acts
 
 
-def mlp_bwd_dx(net, d_raw, acts, n_rays, n_samples, slot="", status=None):
+def mlp_bwd_dx(net, d_raw, acts, n_rays, n_samples, slot="", status=None, d_raw_absmax=None):
     """Activation-gradient chain of one network: returns per-point (d_pts [M,3], d_vdir [M,3]) and the per-layer
     activation gradients (scratch buffer `slot`: give the two networks different slots when the weight-gradient launch
     of one is to overlap the chain of the other)."""
@@ -406,7 +409,7 @@ def mlp_bwd_dx(net, d_raw, acts, n_rays, n_samples, slot="", status=None):
     _lib.check(lib.benerf_mlp_bwd_dx(ctypes.byref(s), net.packed.data_ptr(), net.channels, n_rays, n_samples,
                                      _chk(d_raw, name="d_raw"), _chk(acts), dacts.data_ptr(), d_pts.data_ptr(),
                                      d_vd.data_ptr(), code, (mlp_status(dev) if status is None else status).data_ptr(),
-                                     _stream()), "mlp_bwd_dx")
+                                     _chk(d_raw_absmax, name="d_raw_absmax"), _stream()), "mlp_bwd_dx")
     _timer(None, 0)
     return d_pts, d_vd, dacts
 
@@ -453,7 +456,8 @@ def composite_fwd(raw, z, rays_d, noise=None, noise_std=0.0, seed=0, offset=0, w
 
 
 def composite_bwd(raw, z, rays_d, noise, noise_std, seed, offset, d_rgb_map, d_acc=None, d_depth=None, d_disp=None,
-                  d_rays_d=None, accumulate=False):
+                  d_rays_d=None, accumulate=False, absmax_out=None):
+    """absmax_out: None, or a zeroed 1-element device float that receives max |d_raw| (hand it to mlp_bwd_dx)."""
     lib = _lib.load()
     n_rays, n_samples, c1 = raw.shape
     d_raw = torch.empty_like(raw)
@@ -462,7 +466,8 @@ def composite_bwd(raw, z, rays_d, noise, noise_std, seed, offset, d_rgb_map, d_a
         accumulate = False
     _lib.check(lib.benerf_composite_bwd(_chk(raw), _chk(z), _chk(rays_d), _chk(noise), noise_std, seed, offset, c1 - 1,
                                         n_rays, n_samples, _chk(d_rgb_map), _chk(d_acc), _chk(d_depth), _chk(d_disp),
-                                        d_raw.data_ptr(), d_rays_d.data_ptr(), int(bool(accumulate)), _stream()),
+                                        d_raw.data_ptr(), d_rays_d.data_ptr(), int(bool(accumulate)), _chk(absmax_out, name="absmax_out"),
+                                        _stream()),
                "composite_bwd")
     return d_raw, d_rays_d
 

@@ -88,11 +88,14 @@ int benerf_spline_op_bwd(int op, const float* in, int64_t n, const float* d_out,
 int benerf_rays_fwd(const float* poses, const int64_t* ray_idx, int n_poses, int n_pix,
                     int H, int W, float fx, float fy, float cx, float cy, int ndc, const float* remap,
                     float* rays_o, float* rays_d, float* viewdirs, benerf_stream_t stream);
-/* (d_rays_o, d_rays_d, d_viewdirs) [N,3] -> d_poses [n_poses,3,4] (overwritten). */
+/* (d_rays_o, d_rays_d, d_viewdirs) [N,3] -> d_poses [n_poses,3,4] (overwritten).  workspace: caller-owned scratch of
+ * benerf_rays_bwd_workspace_floats(n_poses, n_pix) floats (0 - NULL allowed - up to 256 pixels per pose): per-chunk partial
+ * sums, added in chunk order (deterministic). */
+size_t benerf_rays_bwd_workspace_floats(int n_poses, int n_pix);
 int benerf_rays_bwd(const float* poses, const int64_t* ray_idx, int n_poses, int n_pix,
                     int H, int W, float fx, float fy, float cx, float cy, int ndc, const float* remap,
                     const float* d_rays_o, const float* d_rays_d, const float* d_viewdirs,
-                    float* d_poses, benerf_stream_t stream);
+                    float* d_poses, float* workspace, size_t workspace_floats, benerf_stream_t stream);
 /* Stratified coarse depths: z = lower + (upper-lower)*t_rand (model/nerf.py:297-307).
  * t_rand [n_rays,n_samples] uniform draws, or NULL for in-kernel Philox(seed, offset). */
 int benerf_stratified_z(int n_rays, int n_samples, float near, float far, const float* t_rand,
@@ -136,6 +139,16 @@ size_t benerf_mlp_dact_floats_per_point(void);
 size_t benerf_mlp_dact_floats(int64_t n_points);
 /* floats of the weight-gradient partial-sum workspace for n_points */
 size_t benerf_mlp_dw_workspace_floats(int64_t n_points);
+/* One size query for every caller-owned buffer of a render + backward over n_points = n_rays * n_samples sample points
+ * of n_poses x n_pix rays, in BYTES (SURVEY 8b2's benerf_workspace_bytes): `which` =
+ *   BENERF_WS_MLP_ACTS    saved activations of one benerf_mlp_fwd call          (= 4 * benerf_mlp_act_floats)
+ *   BENERF_WS_MLP_DACTS   activation gradients of one benerf_mlp_bwd_dx call    (= 4 * benerf_mlp_dact_floats)
+ *   BENERF_WS_MLP_DW      partial sums of one benerf_mlp_bwd_dw call            (= 4 * benerf_mlp_dw_workspace_floats)
+ *   BENERF_WS_MLP_PACKED  the MFMA-shaped weight copy of one network            (= 4 * benerf_mlp_packed_floats)
+ *   BENERF_WS_RAYS_BWD    chunk partials of benerf_rays_bwd                     (= 4 * benerf_rays_bwd_workspace_floats)
+ * Returns 0 for an unknown `which`.  Sizes cover either MLP precision mode. */
+enum { BENERF_WS_MLP_ACTS = 0, BENERF_WS_MLP_DACTS = 1, BENERF_WS_MLP_DW = 2, BENERF_WS_MLP_PACKED = 3, BENERF_WS_RAYS_BWD = 4 };
+size_t benerf_workspace_bytes(int which, int64_t n_points, int n_poses, int n_pix);
 
 /* MFMA arithmetic of the fused MLP kernels - a PER-CALL argument (the library keeps no mode state):
  *   BENERF_MLP_F32    exact f32 MFMA (v_mfma_f32_32x32x2_f32) in forward and backward, bit-for-bit f32 products;
@@ -194,10 +207,11 @@ int benerf_mlp_fwd(const BenerfMlpParams* params, const float* packed, int chann
  *   _dw: weight gradients from acts + dacts; dw_ws scratch [benerf_mlp_dw_workspace_floats(n_points)];
  *        grads: overwritten when accumulate == 0, added to otherwise; pe_weights: the forward call's
  *        BenerfMlpParams.pe_weights (the saved encodings are unweighted; the columns are scaled in the reduce).
- * precision: BENERF_MLP_F32 or BENERF_MLP_SPLIT, the mode of the forward launch that wrote acts. */
+ * precision: BENERF_MLP_F32 or BENERF_MLP_SPLIT, the mode of the forward launch that wrote acts.
+ * d_raw_absmax (_dx): NULL, or the device float benerf_composite_bwd filled with max |d_raw| for exactly this d_raw. */
 int benerf_mlp_bwd_dx(const BenerfMlpParams* params, const float* packed, int channels,
                       int n_rays, int n_samples, const float* d_raw, const float* acts,
-                      float* dacts, float* d_pts, float* d_vdir_pts, int precision, uint32_t* status,
+                      float* dacts, float* d_pts, float* d_vdir_pts, int precision, uint32_t* status, const float* d_raw_absmax,
                       benerf_stream_t stream);
 int benerf_mlp_bwd_dw(int channels, int n_rays, int n_samples, const float* d_raw,
                       const float* acts, const float* dacts, float* dw_ws, size_t dw_ws_floats,
@@ -216,12 +230,14 @@ int benerf_composite_fwd(const float* raw, const float* z, const float* rays_d,
                          benerf_stream_t stream);
 /* d_rgb_map [n_rays,C] (required); d_acc, d_depth, d_disp [n_rays] optional (NULL = 0).
  * Out: d_raw [n_rays,n_samples,C+1]; d_rays_d [n_rays,3] through ||rays_d|| in dists
- * (overwritten, or added to when accumulate != 0; may be NULL). */
+ * (overwritten, or added to when accumulate != 0; may be NULL).
+ * d_raw_absmax: NULL, or one device float the caller zeroed: receives max |d_raw| (atomic maximum over the launch) - the
+ * split-f16 benerf_mlp_bwd_dx takes it instead of running its own pass over d_raw. */
 int benerf_composite_bwd(const float* raw, const float* z, const float* rays_d,
                          const float* noise, float noise_std, uint64_t seed, uint64_t offset,
                          int channels, int n_rays, int n_samples, const float* d_rgb_map,
                          const float* d_acc, const float* d_depth, const float* d_disp,
-                         float* d_raw, float* d_rays_d, int accumulate, benerf_stream_t stream);
+                         float* d_raw, float* d_rays_d, int accumulate, float* d_raw_absmax, benerf_stream_t stream);
 
 /* ---------------------------------------------------------------- K5: sample_pdf --- */
 /* Inverse-CDF importance sampling + sorted merge with the coarse depths.

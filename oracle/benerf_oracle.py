@@ -307,13 +307,20 @@ def barf_c2f(embedded, n_freqs, progress, start, end):
     return (embedded.reshape(-1, L) * weight).reshape(embedded.shape)
 
 
-def mlp_forward(p, pts, viewdirs, multires=10, multires_views=4, want_acts=False, barf=None):
+def mlp_forward(p, pts, viewdirs, multires=10, multires_views=4, want_acts=False, barf=None, relu_masks=None):
     """NeRF.forward (model/nerf.py:67-116).  pts [N,S,3], viewdirs [N,3] -> raw [N,S,C+1].
 
     Layer 5 consumes cat[input_pts, h] (input first).  alpha_linear has no
     activation; rgb and alpha are concatenated as [rgb..., sigma].
     barf = (iter_step, max_iter, c2f_start, c2f_end): use_barf_c2f (model/nerf.py:78-89) - the encodings are built
-    without the raw input, coarse-to-fine weighted, and the raw input is concatenated in front."""
+    without the raw input, coarse-to-fine weighted, and the raw input is concatenated in front.
+    relu_masks = {"h0".."h7", "hv": 0/1 tensors [N*S, width]}: the ReLUs are replaced by multiplication with these fixed
+    masks (tests/test_f64_truth_gpu.py: a float64 evaluation of exactly the piecewise-linear branch another evaluation took -
+    a pre-activation within round-off of zero otherwise flips between any two evaluations and moves gradients by far more
+    than their arithmetic differs)."""
+    def act(name, x):
+        return torch.relu(x) if relu_masks is None else x * relu_masks[name].to(x.dtype)
+
     N, S = pts.shape[0], pts.shape[1]
     x = posenc(pts.reshape(-1, 3), multires)
     dirs = viewdirs[:, None].expand(pts.shape).reshape(-1, 3)
@@ -325,15 +332,14 @@ def mlp_forward(p, pts, viewdirs, multires=10, multires_views=4, want_acts=False
     acts = {"pe": x, "ped": xd}
     h = x
     for i in range(8):
-        h = torch.relu(torch.nn.functional.linear(h, p["pts_linears.%d.weight" % i], p["pts_linears.%d.bias" % i]))
+        h = act("h%d" % i, torch.nn.functional.linear(h, p["pts_linears.%d.weight" % i], p["pts_linears.%d.bias" % i]))
         acts["h%d" % i] = h
         if i == 4:
             h = torch.cat([x, h], -1)
     alpha = torch.nn.functional.linear(h, p["alpha_linear.weight"], p["alpha_linear.bias"])
     feat = torch.nn.functional.linear(h, p["feature_linear.weight"], p["feature_linear.bias"])
     acts["feat"] = feat
-    hv = torch.relu(torch.nn.functional.linear(torch.cat([feat, xd], -1),
-                                               p["views_linears.0.weight"], p["views_linears.0.bias"]))
+    hv = act("hv", torch.nn.functional.linear(torch.cat([feat, xd], -1), p["views_linears.0.weight"], p["views_linears.0.bias"]))
     acts["hv"] = hv
     rgb = torch.nn.functional.linear(hv, p["rgb_linear.weight"], p["rgb_linear.bias"])
     raw = torch.cat([rgb, alpha], -1).reshape(N, S, -1)

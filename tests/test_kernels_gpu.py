@@ -251,7 +251,8 @@ def _g4_case(C, variant, S):
 
 @pytest.fixture(params=["f32", "split"])
 def mlp_mode(K, request):
-    """Every K3 test runs under both MFMA arithmetic modes with the SAME tolerances."""
+    """Every K3 test runs under both MFMA arithmetic modes; forward tolerances are the same, the backward ones differ where the
+    test says so (split mode: f16 operands in the backward GEMMs)."""
     K.set_mlp_precision(request.param)
     yield request.param
     K.set_mlp_precision("split")
@@ -401,11 +402,12 @@ def test_mlp_bwd_golden(K, mlp_mode, golden, C, variant, S):
             flat = got.reshape(-1).cpu().numpy()
             nrm = float(np.linalg.norm(flat.astype(np.float64)))
             ref_n = float(g[key + "__norm"])
-            # split mode: the backward chain rounds the gradient to f16 once per layer (random, unbiased); on these
-            # 1k-4k-point batches the heavily cancelling early-layer bias sums keep up to 1.2e-4 of that in their norm.
-            # (test_mlp_modes_agree_at_full_size compares the norms of the two modes at benchmark size)
+            # 1e-4 on the norms - both modes for the weight gradients.  Bias gradients in split mode: the chain
+            # rounds the gradient to f16 once per layer (random, unbiased); a bias gradient is a plain sum of those rows over
+            # 1k-4k points, the heavily cancelling early-layer ones keep up to 1.3e-4 of it in their 256-entry norm.
+            # (against float64 on identical inputs AND masks: tests/test_f64_truth_gpu.py, <= 6.9e-5 for every norm)
             report("K3 |d%s.%s| %s" % (name, kind, tag), np.array(nrm), np.array(ref_n), atol=1e-9,
-                   rtol=1e-4 if mlp_mode == "f32" else 2e-4)
+                   rtol=1e-4 if (mlp_mode == "f32" or kind == "weight") else 2e-4)
             idx = g[key + "__idx"]
             ref_v = g[key + "__val"]
             report("K3 d%s.%s[64] %s" % (name, kind, tag), flat[idx], ref_v, atol=1e-3 * float(np.abs(ref_v).max()) + 1e-9,
@@ -733,3 +735,38 @@ def test_adam_golden(K, golden):
         K.adam_step(p, dev(g["g_%d" % step]), m, v, lr, step + 1)
         lr = O.decayed_lr(5e-4, 0.1, step)
         report("K8 adam step %d" % step, p, g["p_after_%d" % step], atol=2e-7, rtol=2e-6)
+
+
+def test_composite_bwd_reports_max_d_raw(K):
+    """benerf_composite_bwd's optional max |d_raw| output (consumed by the split-f16 dX chain instead of a pass over d_raw of
+    its own) equals the maximum of what it wrote; the dX launch gives identical results with and without it."""
+    rng = np.random.default_rng(55)
+    C, N, S = 3, 37, 48
+    raw = dev(GI.f32(rng.standard_normal((N, S, C + 1))))
+    z = dev(GI.f32(np.sort(rng.random((N, S)), -1)))
+    rd = dev(GI.f32(rng.uniform(-1, 1, (N, 3))))
+    noise = dev(GI.f32(rng.standard_normal((N, S))))
+    g_rgb = dev(GI.f32(rng.standard_normal((N, C)) * 1e-3))
+    amax = torch.zeros(1, device=DEV)
+    d_raw, _ = K.composite_bwd(raw, z, rd, noise, 0.0, 0, 0, g_rgb, absmax_out=amax)
+    assert float(amax) == float(d_raw.abs().max()) > 0.0
+    p = _params_for(rng, C, "trained")
+    net = _packed(K, p, C)
+    ro = dev(GI.f32(rng.uniform(-0.5, 0.5, (N, 3))))
+    vd = torch.nn.functional.normalize(dev(GI.f32(rng.standard_normal((N, 3)))), dim=-1)
+    prev = K.get_mlp_precision()
+    K.set_mlp_precision("split")
+    try:
+        _, acts = K.mlp_fwd(net, ro, rd, vd, z, True)
+        a = K.mlp_bwd_dx(net, d_raw.view(-1, C + 1), acts, N, S, slot="_t1")
+        b = K.mlp_bwd_dx(net, d_raw.view(-1, C + 1), acts, N, S, slot="_t2", d_raw_absmax=amax)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        grads = []
+        for dacts in (a[2], b[2]):      # same scale word -> the weight gradients (which divide it out) agree bit for bit
+            gw = [torch.zeros_like(w) for w in net.weights]
+            gb = [torch.zeros_like(x) for x in net.biases]
+            K.mlp_bwd_dw(net, d_raw.view(-1, C + 1), acts, dacts, N, S, gw, gb, False)
+            grads.append(gw + gb)
+        assert all(torch.equal(x, y) for x, y in zip(*grads))
+    finally:
+        K.set_mlp_precision(prev)

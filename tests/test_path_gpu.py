@@ -46,7 +46,9 @@ def build_graph(args, pc, pf, knots, transform):
     model.graph.to(DEV)
     g = model.build_network(args)
     with torch.no_grad():
-        for net, p in ((g.nerf, pc), (g.nerf_fine, pf)):
+        for net, p in ((g.nerf, pc), (getattr(g, "nerf_fine", None), pf)):
+            if net is None:      # N_importance == 0: no fine network (model/nerf.py:156-157)
+                continue
             for name in K.LAYER_NAMES:
                 lin = engine.getattr_path(net, name)
                 lin.weight.copy_(p[name + ".weight"])
@@ -167,13 +169,13 @@ def _g8_inputs(si, spec):
                 img=img, d_e=d_e, d_r=d_r)
 
 
-def _check_grads(g8, tag, named, knots_g, tr_g, who, fine_entry_tol=2e-2, fine_norm_tol=1e-3, coarse_entry_tol=5e-3):
+def _check_grads(g8, tag, named, knots_g, tr_g, who, fine_entry_tol=2e-2, fine_norm_tol=1e-3, coarse_entry_tol=5e-3, pose_tol=2e-3):
     # Pose gradients (and bias gradients of the early layers) are sums over every sample point with
     # heavy cancellation (|sum| << sum|.|): f32 round-off of ANY summation order is ~1e-3 of the
     # largest entry, so tolerances are relative to that entry (1e-3 on entries).
     sc = float(np.abs(g8[tag + "_dknots"]).max())
-    report("%s dknots %s" % (who, tag), knots_g, g8[tag + "_dknots"], atol=2e-3 * sc, rtol=2e-3)
-    report("%s dtransform %s" % (who, tag), tr_g, g8[tag + "_dtransform"], atol=2e-3 * sc, rtol=2e-3)
+    report("%s dknots %s" % (who, tag), knots_g, g8[tag + "_dknots"], atol=pose_tol * sc, rtol=pose_tol)
+    report("%s dtransform %s" % (who, tag), tr_g, g8[tag + "_dtransform"], atol=pose_tol * sc, rtol=pose_tol)
     for key, got in named.items():
         base = "%s_g_%s" % (tag, key)
         flat = got.reshape(-1).detach().cpu().numpy()
@@ -526,12 +528,15 @@ def test_training_iteration_golden_g8_forced_fine_depths(golden, si):
         for i, name in enumerate(K.LAYER_NAMES):
             named["%s.%s.weight" % (nn_, name)] = fn.gviews_w[i]
             named["%s.%s.bias" % (nn_, name)] = fn.gviews_b[i]
-    # 1e-3 on sampled entries, 1e-4 on norms - met by the exact-f32 mode.  The split mode's backward GEMMs
-    # take the gradient as f16 (random, unbiased rounding per layer): on these 24-pixel batches up to 1.2e-3 / 1.4e-4
-    # remain (at benchmark size the sums average it away, test_kernels_gpu.test_mlp_modes_agree_at_full_size)
-    f32 = K.get_mlp_precision() == "f32"
-    _check_grads(g8, tag, named, step.g_knots, step.g_transform, "step(forced z)", fine_entry_tol=1e-3 if f32 else 1.5e-3,
-                 fine_norm_tol=1e-4 if f32 else 2e-4, coarse_entry_tol=1e-3 if f32 else 1.5e-3)
+    # THE contract test of the gradients: 1e-3 of the largest entry on the pose gradients and on 64 sampled entries
+    # per layer, 1e-4 on the norms - both arithmetic modes.  One exception, split mode on the e2real spec only: its L2-normalised
+    # event loss makes the gradient orthogonal to the rendered difference BY CONSTRUCTION (sum_i g_i d_i = 0), every weight and
+    # bias gradient is what is left of sums that cancel; on 16 + 2 pixels the f16 operands of the split backward leave
+    # 1.2e-3 / 1.4e-4 there.  What that arithmetic contributes on identical inputs and masks is measured against float64 in
+    # tests/test_f64_truth_gpu.py (<= 8.2e-4 / 6.9e-5 at 1 k points, <= 4.6e-4 / 3.2e-5 at 130 k), the whole step at C2 size too.
+    strict = K.get_mlp_precision() == "f32" or thr > 0
+    _check_grads(g8, tag, named, step.g_knots, step.g_transform, "step(forced z)", fine_entry_tol=1e-3 if strict else 1.5e-3,
+                 fine_norm_tol=1e-4 if strict else 2e-4, coarse_entry_tol=1e-3 if strict else 1.5e-3, pose_tol=1e-3)
 
 
 def test_fine_pass_gradients_with_forced_samples():
