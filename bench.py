@@ -69,6 +69,9 @@ def parse():
                     help="process-group backend: nccl = RCCL over xGMI (the product path); gloo only with --selfcheck-only (CPU test)")
     ap.add_argument("--selfcheck-only", action="store_true",
                     help="rendezvous + collective self-check only (ranks seen, all-reduce time), no training step")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="development: every rank uses device 0 and the gloo transport (the whole multi-rank flow of this script on a "
+                         "one-GPU box; the number it prints is not a measurement)")
     ap.add_argument("--batch-fraction", type=int, default=1,
                     help="render 1/F of the workload's pixels per rank (F = 8 on one GPU: the per-rank step of a strong-scaled 8-GPU run)")
     ap.add_argument("--n-events", type=int, default=2_000_000)
@@ -88,7 +91,7 @@ def spawn_ranks(a):
     (one process per GPU, rendezvous on 127.0.0.1) and pass its exit code on.  Refuses when the node has fewer devices."""
     import socket
     import subprocess
-    if a.backend == "nccl" and torch.cuda.device_count() < a.gpus:
+    if a.backend == "nccl" and not a.oversubscribe and torch.cuda.device_count() < a.gpus:
         print("bench.py: --gpus %d but only %d device(s) visible" % (a.gpus, torch.cuda.device_count()), file=sys.stderr)
         return 2
     with socket.socket() as sock:
@@ -284,7 +287,10 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if world != a.gpus:
         sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node == --gpus)" % (a.gpus, world))
-    if a.backend == "gloo":
+    if a.oversubscribe:
+        a.backend = "gloo"
+        local_rank = 0
+    if a.backend == "gloo" and not a.oversubscribe:
         if not a.selfcheck_only:
             sys.exit("bench.py: --backend gloo is the CPU self-check of the launch path (--selfcheck-only); the product path is nccl")
         device = torch.device("cpu")
@@ -301,7 +307,8 @@ def main():
         else:
             torch.distributed.init_process_group("gloo")
         pg = torch.distributed.group.WORLD
-        comm = collective_selfcheck(world, device, 595586)
+        comm_dev = device if a.backend == "nccl" else torch.device("cpu")     # gloo: host buffers
+        comm = collective_selfcheck(world, comm_dev, 595586)
     if a.selfcheck_only:
         if rank == 0:
             print(json.dumps({"metric": "collective self-check", "n_gpus": world, "backend": a.backend, "scaling": a.scaling,
@@ -382,7 +389,7 @@ def main():
     step_ms = sorted(step_series)
     median_ms = step_ms[len(step_ms) // 2]
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device=device if a.backend == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -513,7 +520,8 @@ def main():
     mlp_ms = sum(v[1] for v in summ.values()) / a.steps if summ else None
 
     out = {
-        "metric": "training rays/s", "value": round(value, 1), "unit": "rays/s", "n_gpus": world, "steps": a.steps,
+        "metric": "training rays/s" if not a.oversubscribe else "training rays/s (ranks oversubscribed on one device: not a measurement)",
+        "value": round(value, 1), "unit": "rays/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": a.scaling,
         "vs_baseline": None,
         "dtype": ("f32 storage; MLP GEMMs on f16 MFMA with f32 accumulate: forward 3 MFMAs on hi/lo-split operands (22-bit), "
