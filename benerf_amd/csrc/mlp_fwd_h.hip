@@ -456,18 +456,9 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
 
 }  // namespace
 
-// experimental register-chain schedule (mlp_fwd_r.hip; inference launches, BENERF_FWD_R=1): 1 = not selected
-int benerf_mlp_fwd_r_launch(const BenerfMlpParams* params, const float* packed, int channels, int n_rays, int n_samples,
-                            const float* rays_o, const float* rays_d, const float* viewdirs, const float* z, float* raw, uint32_t* status,
-                            hipStream_t stream);
-
 int benerf_mlp_fwd_split_launch(const BenerfMlpParams* params, const float* packed, int channels, int n_rays, int n_samples,
                                 const float* rays_o, const float* rays_d, const float* viewdirs, const float* z, float* raw,
                                 float* acts, uint32_t* status, hipStream_t stream) {
-    if (!acts) {
-        const int rc = benerf_mlp_fwd_r_launch(params, packed, channels, n_rays, n_samples, rays_o, rays_d, viewdirs, z, raw, status, stream);
-        if (rc != 1) return rc;
-    }
     FwdArgs a;
     a.rays_o = rays_o;
     a.rays_d = rays_d;

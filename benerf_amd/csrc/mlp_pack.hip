@@ -1,7 +1,7 @@
 // K3 helper: re-pack one network's nn.Linear weights ([out,in] row-major, model/nerf.py:53-64)
 // into the MFMA-operand-shaped blocks described in mlp_common.h.  One launch per network
 // per optimiser step (2.4 M floats read, 4.9 M written) - once as f32 blocks, once as split-f16 blocks.
-#include "mlp_r.h"
+#include "mlp_split.h"
 
 namespace {
 using namespace mlp;
@@ -53,36 +53,8 @@ __device__ __forceinline__ float pack_source(const PackArgs& a, int id, int col,
     return W[(int64_t)n * in + k];
 }
 
-// weight stream of the register-chain forward kernel (mlp_r.h): one 16-byte unit (hi or lo fragment piece) per thread
-__device__ void pack_r_layer(const PackArgs& a, int rl) {
-    typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-    half8* dst = reinterpret_cast<half8*>(a.packed + 2 * PACKED_FLOATS) + (int64_t)r_chunk_base(rl) * (R_CHUNK_BYTES / 16);
-    const int id = r_pack_id(rl);
-    const int n = r_groups(rl) * r_kchunks(rl) * 4 * 4 * 64;          // (group, k-chunk, tile, k-step, lane): hi and lo each
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
-        const int lane = e & 63, ks4 = (e >> 6) & 3, t = (e >> 8) & 3, gc = e >> 10;
-        const int c = gc % r_kchunks(rl), g = gc / r_kchunks(rl);
-        const int col = 32 * (4 * g + t) + (lane & 31);
-        const int k0 = 16 * (4 * c + ks4) + 8 * (lane >> 5);
-        half8 hi, lo;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float w = pack_source(a, id, col, k0 + j);
-            hi[j] = (_Float16)w;
-            lo[j] = (_Float16)((w - (float)hi[j]) * 2048.f);
-        }
-        const int64_t frag = ((int64_t)gc * 16 + t * 4 + ks4) * 2;        // 1 KiB fragments: hi, lo
-        dst[frag * 64 + lane] = hi;
-        dst[(frag + 1) * 64 + lane] = lo;
-    }
-}
-
 __global__ void pack_kernel(PackArgs a) {
     const int id = blockIdx.y;
-    if (id >= PACK_COUNT) {
-        pack_r_layer(a, id - PACK_COUNT);
-        return;
-    }
     const PackShape sh = pack_shape(id);
     const int64_t n4 = (int64_t)sh.tiles * sh.kblocks * 64;   // float4 slots
     float4* dst = reinterpret_cast<float4*>(a.packed + pack_offset(id));
@@ -142,8 +114,7 @@ __global__ void pack_kernel(PackArgs a) {
 
 }  // namespace
 
-// f32 blocks | split-f16 blocks | weight stream of the register-chain forward
-extern "C" size_t benerf_mlp_packed_floats(void) { return (size_t)(2 * mlp::PACKED_FLOATS + mlp::R_FLOATS); }
+extern "C" size_t benerf_mlp_packed_floats(void) { return (size_t)(2 * mlp::PACKED_FLOATS); }   // f32 blocks | split-f16 blocks
 // buffers are sized for either arithmetic mode (the split mode pads the point count to whole 128-point tiles)
 extern "C" size_t benerf_mlp_act_floats(int64_t n_points) {
     const int64_t a = mlp::act_total_floats(n_points), b = mlp::sact_total_floats(n_points);
@@ -169,7 +140,7 @@ extern "C" int benerf_mlp_pack_weights(const BenerfMlpParams* params, int channe
         a.w[l] = params->w[l];
     }
     a.packed = packed;
-    hipLaunchKernelGGL(pack_kernel, dim3(40, mlp::PACK_COUNT + mlp::RL_COUNT), dim3(256), 0, as_stream(stream), a);
+    hipLaunchKernelGGL(pack_kernel, dim3(40, mlp::PACK_COUNT), dim3(256), 0, as_stream(stream), a);
     BENERF_LAUNCH_CHECK("mlp_pack_weights");
     return BENERF_OK;
 }
