@@ -417,10 +417,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_f16_kernel(BwdArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) ap[0][e] = 0.f;
         gemm_row<8, 1>(T, packed_h + pack_offset(PB_VIEWS), 8, wave, lane, ap);
-        if ((lane & 31) < 27) {
+        const int ln = stage_local(lane);       // addresses of this block only (not shared with the dPE blocks further down)
+        if ((ln & 31) < 27) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) *fscr1(T, wave * 32 + acc_row(e, lane), lane & 31) = ap[0][e];
+            for (int e = 0; e < 16; ++e) *fscr1(T, wave * 32 + acc_row(e, ln), ln & 31) = ap[0][e];
         }
+        __builtin_amdgcn_sched_barrier(0);      // the block's accumulators are stored before the next GEMM's prologue starts
     }
     zero4(acc);
     gemm16<8, 2>(T, packed_h + pack_offset(PB_VIEWS), ct0, lane, acc);
@@ -500,13 +502,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_f16_kernel(BwdArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) dpe[c][e] = 0.f;
         gemm_row<16, 2>(T, packed_h + pack_offset(PB_L5), 8, wave, lane, dpe);
+        const int ln = stage_local(lane);
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 amax = __builtin_fmaxf(amax, __builtin_fabsf(dpe[c][e]));
-                T[hidx(wave * 32 + acc_row(e, lane), 256 + c * 32 + (lane & 31))] = (_Float16)dpe[c][e];
+                T[hidx(wave * 32 + acc_row(e, ln), 256 + c * 32 + (ln & 31))] = (_Float16)dpe[c][e];
             }
+        __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll 1
     for (int l = 5; l >= 1; --l) layer(l);
@@ -526,10 +530,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_f16_kernel(BwdArgs a) {
         for (int k = 0; k < 8; ++k) per[k] = pe_tile[tid + k * NTHREADS];
     }
     f32x16 dpe[2];
+    {
+        const int ln = stage_local(lane);
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+        for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) dpe[c][e] = (float)T[hidx(wave * 32 + acc_row(e, lane), 256 + c * 32 + (lane & 31))];
+            for (int e = 0; e < 16; ++e) dpe[c][e] = (float)T[hidx(wave * 32 + acc_row(e, ln), 256 + c * 32 + (ln & 31))];
+    }
     gemm_row<16, 2>(T, packed_h + pack_offset(PB_L0), 0, wave, lane, dpe);
     lds_barrier(); TR(40);      // every wave is done reading dY0: the plane becomes f32 scratch, 133 floats per point:
     // [0,64) dPE, [64,68) the odd-frequency partial sums, [68,132) PE.  The odd row stride keeps P6's per-point walks
@@ -537,10 +544,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_f16_kernel(BwdArgs a) {
     float* F = reinterpret_cast<float*>(T);
     constexpr int FLD = 133;
     static_assert((size_t)TMB * FLD * sizeof(float) <= BWD_SMEM, "P6 scratch fits the plane");
+    {
+        const int ln = stage_local(lane);
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+        for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) F[(wave * 32 + acc_row(e, lane)) * FLD + c * 32 + (lane & 31)] = dpe[c][e];
+            for (int e = 0; e < 16; ++e) F[(wave * 32 + acc_row(e, ln)) * FLD + c * 32 + (ln & 31)] = dpe[c][e];
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int u = tid + k * NTHREADS;                         // float4 u of the tile: point u / 16, floats 4 (u % 16) ..

@@ -11,6 +11,15 @@ the two loss passes.
 """
 import torch
 
+# Self-test switch: issue every collective even on a world of ONE rank (needs an initialised process group).  A one-rank RCCL
+# communicator is the only way to run the device branch below - in-place all-reduce of slices of the flat gradient buffer on
+# the communicator's stream, the handle's wait() on a side stream - on a box with a single GPU (tests/test_api_gpu.py).
+ALWAYS_COMMUNICATE = False
+
+
+def _active(world):
+    return world > 1 or (ALWAYS_COMMUNICATE and torch.distributed.is_initialized())
+
 
 def shard_indices(idx, rank, world):
     """Contiguous slice [rank*n/world, (rank+1)*n/world) of a global index vector."""
@@ -32,7 +41,7 @@ def allreduce_sum_(t, world, group=None):
     """In-place sum over ranks (no-op on one rank).  With the gloo backend (CPU tests, or the
     2-ranks-on-one-GPU equivalence test) device tensors are staged through host memory; the
     production backend is nccl (= RCCL over xGMI), which reduces the device buffer directly."""
-    if world > 1:
+    if _active(world):
         if _through_host(t, group):
             h = t.cpu()
             torch.distributed.all_reduce(h, op=torch.distributed.ReduceOp.SUM, group=group)
@@ -53,7 +62,7 @@ def allreduce_sum_async_(t, world, group=None):
     current stream, so kernels launched after this call overlap with it: TrainStep issues the fine network's bucket
     as soon as its weight gradients are complete and computes the coarse backward meanwhile.  gloo (CPU
     tests / several ranks on one GPU) has no device path: reduced synchronously through host memory."""
-    if world <= 1:
+    if not _active(world):
         return _Done()
     if _through_host(t, group):      # blocking round trip through host memory: no overlap with the kernels that follow
         allreduce_sum_(t, world, group)
@@ -63,7 +72,7 @@ def allreduce_sum_async_(t, world, group=None):
 
 def broadcast_(t, world, src=0, group=None):
     """Rank `src`'s values everywhere (parameters + optimiser state at start-up: replicas must not rely on seeds)."""
-    if world > 1:
+    if _active(world):
         if _through_host(t, group):
             h = t.cpu()
             torch.distributed.broadcast(h, src=src, group=group)

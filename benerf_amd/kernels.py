@@ -14,7 +14,15 @@ LAYER_NAMES = tuple(["pts_linears.%d" % i for i in range(8)] + ["views_linears.0
                                                                "rgb_linear"])
 
 
+try:        # the raw handle of the current stream without building a torch.cuda.Stream object (~50 launches per training step)
+    _raw_stream, _cur_device = torch._C._cuda_getCurrentRawStream, torch._C._cuda_getDevice
+except AttributeError:      # pragma: no cover - older / newer torch without these private entry points
+    _raw_stream = None
+
+
 def _stream():
+    if _raw_stream is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -179,11 +187,24 @@ def _timer(name, n_points):
     TIMERS.mark(name, n_points)
 
 
+_struct_cache = {}
+
+
 def _param_struct(cls, tensors_w, tensors_b):
+    """Pointer table of one network's 12 weights + 12 biases (or their gradients).  The tables of a training run never
+    change (parameters and gradients are views of flat buffers): validated once per distinct set of pointers."""
+    key = (cls,) + tuple(t.data_ptr() for t in tensors_w) + tuple(t.data_ptr() for t in tensors_b)
+    hit = _struct_cache.get(key)
+    if hit is None:
+        if len(_struct_cache) > 64:
+            _struct_cache.clear()
+        hit = [_chk(tensors_w[i], name="weight %d" % i) for i in range(_lib.NLAYERS)], \
+              [_chk(tensors_b[i], name="bias %d" % i) for i in range(_lib.NLAYERS)]
+        _struct_cache[key] = hit
     s = cls()
     for i in range(_lib.NLAYERS):
-        s.w[i] = _chk(tensors_w[i], name="weight %d" % i)
-        s.b[i] = _chk(tensors_b[i], name="bias %d" % i)
+        s.w[i] = hit[0][i]
+        s.b[i] = hit[1][i]
     return s
 
 

@@ -286,6 +286,68 @@ def test_sharded_step_equals_single_rank():
         report("DP parameters after Adam (%d ranks vs 1)" % world, p2, p1, atol=2e-5, rtol=1e-5)
 
 
+def _rccl_worker(port, out_q, mode):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import test_api_gpu as me
+    from benerf_amd import dist, engine, kernels, workloads as WL
+    kernels.set_mlp_precision(mode)
+    torch.cuda.set_device(0)
+    dev = torch.device(DEV)
+    torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=dev)      # RCCL, a communicator of one
+    pg = torch.distributed.group.WORLD
+    assert not dist._through_host(torch.zeros(1, device=dev), pg), "nccl must reduce device buffers in place"
+    wl = dict(WL.WORKLOADS["C5"], S=32, Ni=32, Re=64, Rr=8, n=5)       # the normalised loss: the 16-double exchange too
+    args = WL.make_args(wl, optimize_trans=True)
+    cam = WL.CAMERAS[wl["cam"]]
+    cam_o = engine.Camera(cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+    rng = np.random.default_rng(5)
+    HW = cam["H"] * cam["W"]
+    idx_e = torch.from_numpy(rng.permutation(HW)[:64]).to(DEV)
+    idx_r = torch.from_numpy(rng.permutation(HW)[:8]).to(DEV)
+    accu = torch.from_numpy(rng.integers(-3, 4, HW).astype(np.float32)).to(DEV)
+    img = torch.from_numpy(rng.random((HW, 3)).astype(np.float32)).to(DEV)
+    res = {}
+    for communicate in (False, True):
+        dist.ALWAYS_COMMUNICATE = communicate
+        _, g = me._graph(args, seed=21)
+        step = engine.TrainStep(g, args, cam_o, cam_o, dev, world_size=1, rank=0, process_group=pg, seed=3)
+        for k in range(3):
+            losses = step.step(torch.tensor([0.2, 0.45], device=DEV), torch.tensor([0.0, 1.0], device=DEV), idx_e, idx_r, accu, img)
+        step.check_range()
+        res[communicate] = (losses.cpu().numpy(), step.flat_g.cpu().numpy(), step.flat_p.cpu().numpy())
+    # the bench's collective self-check on the same communicator
+    sys.path.insert(0, ROOT)
+    import bench
+    dist.ALWAYS_COMMUNICATE = False
+    comm = bench.collective_selfcheck(1, dev, 595586)
+    out_q.put((res, comm))
+    torch.distributed.destroy_process_group()
+
+
+def test_step_over_rccl_communicator_of_one():
+    """The device branch of the gradient exchange on real RCCL: a one-rank communicator (all a single-GPU box offers), every
+    collective of the step issued (dist.ALWAYS_COMMUNICATE) - three asynchronous in-place all-reduces of slices of the flat
+    gradient buffer on the communicator's stream, waited for on the side / main streams, the 16-double statistics exchange and
+    the start-up broadcast.  A sum over one rank is the identity, so three steps must reproduce the plain run BIT FOR BIT: any
+    missing stream dependency between the kernels and the communicator would show as a changed gradient or parameter."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(29720 + (os.getpid() % 100), q, me_mode()))
+    p.start()
+    res, comm = q.get(timeout=300)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    for a, b, what in zip(res[False], res[True], ("losses", "flat gradient", "parameters after 3 steps")):
+        assert np.array_equal(a, b), "%s changed when the collectives ran over RCCL" % what
+    assert comm["rccl_ranks_seen"] == 1 and comm["allreduce_ms"] > 0
+    report("RCCL one-rank bucketed all-reduce [ms]", np.array([comm["allreduce_ms"]]), np.array([comm["allreduce_ms"]]), atol=1, rtol=0)
+
+
 def test_render_after_fused_steps_uses_current_weights():
     """Graph.render / render_video between TrainStep.step calls must see the UPDATED weights: the fused Adam kernel
     rewrites parameter storage without bumping torch's version counters, so the module-level packed copies are

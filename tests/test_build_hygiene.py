@@ -10,9 +10,9 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = "/opt/rocm/bin/hipcc"
-# kernel-name fragment -> most VGPRs the compiler may spill (dX: 33 known, in its prologue / tail phases)
+# kernel-name fragment -> most VGPRs the compiler may spill (none: the dX kernel's last 33 went in round 3)
 LIMITS = {"mlp_fwd_h.hip": {"mlp_fwd_split_kernel": 0}, "mlp_dw_h.hip": {"mlp_dw_f16_big_kernel": 0, "mlp_dw_f16_small_kernel": 0},
-          "mlp_bwd_h.hip": {"mlp_bwd_f16_kernel": 33}}
+          "mlp_bwd_h.hip": {"mlp_bwd_f16_kernel": 0}}
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
