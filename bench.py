@@ -344,20 +344,45 @@ def main():
     accu = torch.zeros((cam["H"], cam["W"]), dtype=torch.float32, device=device)
     Re_g, Rr_g = wl["Re"] * world, wl["Rr"] * world
 
-    draw = [0]
+    # Inputs of a step - event-window accumulation (K7), window times, pixel draws - are a data loader's job: step k + 1's are
+    # prepared on a second stream while step k computes (two image buffers), like any input pipeline; everything stays inside
+    # the timed region.  The pixel draws are a keyed bijection (np.random.choice(..., replace=False) in train.py), identical
+    # on every rank; TrainStep shards them.
+    main_stream = torch.cuda.current_stream(device)
+    loader = torch.cuda.Stream(device)
+    accus = [accu, torch.zeros_like(accu)]
+    freed = [None, None]          # main-stream event behind the last step that read accus[i]
+    queue = []
 
-    def one_step():
+    def prepare(k):
         low_t = float(rng.random() * (1 - wl["window"]))
         up_t = low_t + wl["window"]
-        accu.zero_()
-        K.event_window_accumulate(ev_x, ev_y, ev_p, ev_t, low_t, up_t, cam["H"], cam["W"], out=accu)
-        evt_ts = torch.tensor([low_t, up_t], dtype=torch.float32).to(device, non_blocking=True)
-        # pixel draws without replacement (np.random.choice(..., replace=False) in train.py): a keyed bijection,
-        # identical on every rank; TrainStep shards them
-        draw[0] += 2
-        idx_e = K.sample_pixels(HW, Re_g, a.seed + 1234, draw[0], device)
-        idx_r = K.sample_pixels(HW, Rr_g, a.seed + 1234, draw[0] + 1, device)
-        return step.step(evt_ts, rgb_ts, idx_e, idx_r, accu.view(-1), image)
+        buf = accus[k % 2]
+        with torch.cuda.stream(loader):
+            if freed[k % 2] is not None:
+                loader.wait_event(freed[k % 2])
+            buf.zero_()
+            K.event_window_accumulate(ev_x, ev_y, ev_p, ev_t, low_t, up_t, cam["H"], cam["W"], out=buf)
+            evt_ts = torch.tensor([low_t, up_t], dtype=torch.float32).to(device, non_blocking=True)
+            idx_e = K.sample_pixels(HW, Re_g, a.seed + 1234, 2 * k + 2, device)
+            idx_r = K.sample_pixels(HW, Rr_g, a.seed + 1234, 2 * k + 3, device)
+            for t in (evt_ts, idx_e, idx_r):
+                t.record_stream(main_stream)      # allocated on the loader's stream, consumed on the main one
+            ready = loader.record_event()
+        queue.append((k, ready, evt_ts, idx_e, idx_r, buf))
+
+    counter = [0]
+
+    def one_step():
+        if not queue:
+            prepare(counter[0])
+        k, ready, evt_ts, idx_e, idx_r, buf = queue.pop(0)
+        main_stream.wait_event(ready)
+        out = step.step(evt_ts, rgb_ts, idx_e, idx_r, buf.view(-1), image)
+        freed[k % 2] = main_stream.record_event()
+        counter[0] = k + 1
+        prepare(k + 1)
+        return out
 
     def sync():
         if world > 1:

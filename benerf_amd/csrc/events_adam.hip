@@ -92,6 +92,8 @@ __global__ void step_gate_kernel(uint32_t* __restrict__ st, float* __restrict__ 
     st[BENERF_ST_ACT] = 0u;    // the next step starts clean: one violation does not disable training for good
     st[BENERF_ST_GRAD] = 0u;
     st[BENERF_ST_MODE] = 0u;
+    st[BENERF_ST_STEP_SCRATCH] = 0u;
+    st[BENERF_ST_STEP_SCRATCH + 1] = 0u;
 }
 
 }  // namespace

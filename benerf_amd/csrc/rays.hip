@@ -261,15 +261,12 @@ __global__ void ray_grad_reduce_kernel(int n_rays, int S, const float* __restric
     if (lane < 3) {
         int c = lane;
         float vo = a[c], vdd = a[3 + c], vv = a[6 + c];
-        if (accumulate) {
-            if (d_o) d_o[ray * 3 + c] += vo;
-            if (d_d) d_d[ray * 3 + c] += vdd;
-            if (d_v) d_v[ray * 3 + c] += vv;
-        } else {
-            if (d_o) d_o[ray * 3 + c] = vo;
-            if (d_d) d_d[ray * 3 + c] = vdd;
-            if (d_v) d_v[ray * 3 + c] = vv;
-        }
+        // accumulate: 0 overwrite, 1 add into all three, 2 add into d_rays_d only (it already holds the compositing
+        // backward's part: the first of a step's two calls needs no zeroed d_rays_o / d_viewdirs then)
+        const bool add_od = accumulate == 1, add_d = accumulate != 0;
+        if (d_o) d_o[ray * 3 + c] = add_od ? d_o[ray * 3 + c] + vo : vo;
+        if (d_d) d_d[ray * 3 + c] = add_d ? d_d[ray * 3 + c] + vdd : vdd;
+        if (d_v) d_v[ray * 3 + c] = add_od ? d_v[ray * 3 + c] + vv : vv;
     }
 }
 

@@ -17,6 +17,7 @@ import math
 
 import torch
 
+from . import _lib
 from . import dist
 from . import kernels as K
 
@@ -307,6 +308,9 @@ class TrainStep:
         # as a float behind the trajectory gradients - it rides their all-reduce, so every replica skips the same steps.
         self.guard = K.RangeGuard(device)
         self.flag = self.flat_g[o + 30:o + 31]
+        # max |d_raw| of the two networks (compositing backward -> dX chain): the guard's two per-step scratch words, which the
+        # step gate zeroes on the device at the end of every step - no memset launch of their own
+        self.amax = self.guard.words[_lib.ST_STEP_SCRATCH:_lib.ST_STEP_SCRATCH + 2].view(torch.float32)
         # CRF tone-mappers (train.py:180-192; off in every shipped config): 385 parameters each, applied to the rendered colours
         # between compositing and the loss kernels as torch modules (per-ray work, thousands of rows); their parameters live in
         # the flat buffers like everything else: same fused Adam (same range gate), same all-reduce bucket
@@ -476,16 +480,16 @@ class TrainStep:
             rgb_map, rgb0 = raw_maps[0].detach(), raw_maps[1].detach()
 
         # ---- backward -------------------------------------------------------------------------------
-        d_o = torch.zeros_like(ro)
+        d_o = torch.empty_like(ro)
         d_d = torch.empty_like(ro)
-        d_v = torch.zeros_like(ro)
+        d_v = torch.empty_like(ro)
         # The weight-gradient launches (HBM-bound: they stream the saved activations and activation gradients once) go to
         # a second stream and run beside the other network's activation-gradient chain and the trajectory tail
         # (MFMA-bound, little HBM traffic); the two networks keep separate activation-gradient buffers for that.
         n = self.n_net
         main, side = torch.cuda.current_stream(dev), self.dw_stream
         # max |d_raw| of both networks comes out of the compositing backward (the split-f16 dX chain scales by it)
-        amax = torch.zeros(2, dtype=torch.float32, device=dev)
+        amax = self.amax
         d_raw1, _ = K.composite_bwd(raw1, z_fine, rd, nz1[0], nz1[1], nz1[2], nz1[3], g_rgb, d_rays_d=d_d, absmax_out=amax[0:1])
         d_raw0, _ = K.composite_bwd(raw0, z, rd, nz0[0], nz0[1], nz0[2], nz0[3], g_rgb0, d_rays_d=d_d, accumulate=True,
                                     absmax_out=amax[1:2])
@@ -505,8 +509,8 @@ class TrainStep:
             K.mlp_bwd_dw(self.net_c.packed, d_raw0.view(-1, C + 1), acts0, dacts0, N, S, self.net_c.gviews_w,
                          self.net_c.gviews_b, False)
             pending.append(dist.allreduce_sum_async_(self.flat_g[:n], self.world, self.pg))      # bucket 2: coarse network
-        K.ray_grad_reduce(z_fine, d_pts1, d_vp1, d_o, d_d, d_v, True)
-        K.ray_grad_reduce(z, d_pts0, d_vp0, d_o, d_d, d_v, True)
+        K.ray_grad_reduce(z_fine, d_pts1, d_vp1, d_o, d_d, d_v, 2)       # d_d holds the compositing part; d_o, d_v start here
+        K.ray_grad_reduce(z, d_pts0, d_vp0, d_o, d_d, d_v, 1)
         dp_e = K.rays_bwd(poses_e, idx_e, ce.H, ce.W, ce.fx, ce.fy, ce.cx, ce.cy, cfg.ndc, d_o[:Ne], d_d[:Ne], d_v[:Ne], remap=ce.remap)
         dp_r = K.rays_bwd(poses_r, idx_r, cr.H, cr.W, cr.fx, cr.fy, cr.cx, cr.cy, cfg.ndc, d_o[Ne:], d_d[Ne:], d_v[Ne:], remap=cr.remap)
         dk_e, dk_r, dt_r = K.spline_poses_bwd_pair(self.knots, self.transform.view(6), evt_ts2, 2, rgb_ts2, P, traj, dp_e, dp_r)

@@ -146,9 +146,10 @@ def stratified_z(n_rays, n_samples, device, t_rand=None, seed=0, offset=0, near=
 
 
 def ray_grad_reduce(z, d_pts, d_vdir_pts, d_rays_o, d_rays_d, d_viewdirs, accumulate):
+    """accumulate: False / 0 overwrite, True / 1 add into all three outputs, 2 add into d_rays_d only."""
     lib = _lib.load()
     _lib.check(lib.benerf_ray_grad_reduce(z.shape[0], z.shape[1], _chk(z), _chk(d_pts), _chk(d_vdir_pts),
-                                          int(bool(accumulate)), _chk(d_rays_o), _chk(d_rays_d), _chk(d_viewdirs),
+                                          int(accumulate), _chk(d_rays_o), _chk(d_rays_d), _chk(d_viewdirs),
                                           _stream()), "ray_grad_reduce")
 
 

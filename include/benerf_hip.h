@@ -102,7 +102,8 @@ int benerf_stratified_z(int n_rays, int n_samples, float near, float far, const 
                         uint64_t seed, uint64_t offset, float* z, benerf_stream_t stream);
 /* Sums per-sample point gradients into ray gradients: pts = o + d*z (model/nerf.py:308,327)
  *   d_o = sum_s d_pts, d_d = sum_s z*d_pts, d_viewdirs = sum_s d_vdir_pts.
- * accumulate != 0 adds into the outputs instead of overwriting. */
+ * accumulate: 0 overwrites the outputs, 1 adds into all three, 2 adds into d_rays_d only (which then already holds
+ * benerf_composite_bwd's part) and overwrites d_rays_o / d_viewdirs. */
 int benerf_ray_grad_reduce(int n_rays, int n_samples, const float* z, const float* d_pts,
                            const float* d_vdir_pts, int accumulate, float* d_rays_o,
                            float* d_rays_d, float* d_viewdirs, benerf_stream_t stream);
@@ -178,7 +179,10 @@ size_t benerf_workspace_bytes(int which, int64_t n_points, int n_poses, int n_pi
  * show a violation. */
 enum { BENERF_MLP_F32 = 0, BENERF_MLP_SPLIT = 1, BENERF_MLP_AUTO = 2 };
 enum { BENERF_ST_ACT = 0, BENERF_ST_GRAD = 1, BENERF_ST_MODE = 2, BENERF_ST_AUTO = 3, BENERF_ST_SKIP = 4, BENERF_ST_SKIPPED = 5,
-       BENERF_ST_CONSECUTIVE = 6, BENERF_ST_STEPS = 7, BENERF_ST_LAST_ACT = 8, BENERF_ST_LAST_GRAD = 9, BENERF_ST_WORDS = 16 };
+       BENERF_ST_CONSECUTIVE = 6, BENERF_ST_STEPS = 7, BENERF_ST_LAST_ACT = 8, BENERF_ST_LAST_GRAD = 9,
+       BENERF_ST_STEP_SCRATCH = 10,     /* [10], [11]: two per-step words of the caller, zeroed by benerf_step_gate phase 1 (a training
+                                         * step keeps the two networks' max |d_raw| there: benerf_composite_bwd's d_raw_absmax) */
+       BENERF_ST_WORDS = 16 };
 int benerf_mlp_status_check(const uint32_t* status, benerf_stream_t stream);
 /* Per-step verdict of the range guard, on the device (no synchronisation), between the backward pass and the
  * benerf_adam_step launches of a training iteration (train.py:340-352):
@@ -187,7 +191,8 @@ int benerf_mlp_status_check(const uint32_t* status, benerf_stream_t stream);
  *            (a rank that overflowed contributes inf / NaN to everybody's gradient sum);
  *   phase 1: [SKIP] = violation (reduce_flag[0] > 0 when reduce_flag != NULL, this rank's words otherwise), counters
  *            [SKIPPED] (total), [CONSECUTIVE], [STEPS] updated, the tripping maxima kept in [LAST_ACT] / [LAST_GRAD],
- *            [ACT] / [GRAD] / [MODE] cleared for the next step: one violation costs one step, not the rest of the run. */
+ *            [ACT] / [GRAD] / [MODE] and the two [STEP_SCRATCH] words cleared for the next step: one violation costs one step,
+ *            not the rest of the run. */
 int benerf_step_gate(uint32_t* status, float* reduce_flag, int phase, benerf_stream_t stream);
 
 /* Fused positional encoding + 8x256 MLP + view branch, forward.
