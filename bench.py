@@ -138,6 +138,48 @@ def collective_selfcheck(world, device, n_net):
             "allreduce_bus_gbs": round(2 * (world - 1) / world * nbytes / (ms * 1e-3) / 1e9, 2)}
 
 
+def power_leg(one_step, device_index, seconds):
+    """Average / peak socket power, power cap and shader clock over `seconds` of back-to-back steps (None without amdsmi)."""
+    try:
+        import threading
+        import amdsmi
+        amdsmi.amdsmi_init()
+        h = amdsmi.amdsmi_get_processor_handles()[device_index]
+        cap = amdsmi.amdsmi_get_power_cap_info(h).get("power_cap")
+    except Exception:      # noqa: BLE001 - diagnostics only
+        return None
+    rows, stop = [], [False]
+
+    def sample():
+        while not stop[0]:
+            try:
+                p = amdsmi.amdsmi_get_power_info(h)
+                c = amdsmi.amdsmi_get_clock_info(h, amdsmi.AmdSmiClkType.GFX)
+                rows.append((p.get("current_socket_power", p.get("socket_power")), c.get("clk")))
+            except Exception:      # noqa: BLE001
+                pass
+            time.sleep(0.01)
+    for _ in range(5):
+        one_step()
+    torch.cuda.synchronize()
+    th = threading.Thread(target=sample, daemon=True)
+    th.start()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(10):
+            one_step()
+        torch.cuda.synchronize()
+    stop[0] = True
+    th.join()
+    pw = [float(r[0]) for r in rows if isinstance(r[0], (int, float))]
+    ck = [float(r[1]) for r in rows if isinstance(r[1], (int, float))]
+    if not pw:
+        return None
+    return {"cap_w": round(cap / 1e6, 1) if isinstance(cap, (int, float)) else None, "avg_w": round(sum(pw) / len(pw), 1), "max_w": max(pw),
+            "gfx_mhz_avg": round(sum(ck) / len(ck), 1) if ck else None, "samples": len(pw),
+            "note": "socket power / shader clock sampled every 10 ms over back-to-back training steps (small-kernel phases included)"}
+
+
 def split_mode(a):
     return a.mlp_precision == "split"
 
@@ -438,6 +480,11 @@ def main():
     # ---- secondary: the same training step with exact-f32 MFMA products (the strict arithmetic mode), >= 20 timed steps,
     # its own per-kernel HIP-event durations -> `exact_f32` + `roofline_f32` in the JSON line --------------------------------
     summ_main = K.TIMERS.summary()
+    # ---- secondary: board power and shader clock while the step runs (amdsmi, sampled from a thread for ~1.5 s of extra steps):
+    # the K3 kernels sit at the board's power cap, the clock the roofline's 2.4 GHz peak assumes is not available to them ------
+    power = None
+    if world == 1 and not a.primary_only:
+        power = power_leg(one_step, device.index or 0, 1.5)
     exact = roof_f32 = None
     if world == 1 and split_mode(a) and not a.primary_only:
         K.set_mlp_precision("f32")
@@ -514,9 +561,9 @@ def main():
                 "frac": kern[dom]["frac_of_mfma_peak"], "frac_executed": kern[dom]["frac_executed"],
                 "traffic": traffic_of(dom), "avg_launch_ms": kern[dom]["avg_ms"],
                 "flops_per_point": fpp, "points_per_launch": kern[dom]["points_per_launch"],
-                "peak_note": "dense %s MFMA peak at 2.4 GHz (the isolated K-loop runs at the pipe's pace and 1.5-1.7 GHz, "
-                             "tools/hwprobe/kloop_bound.hip; the fused kernels are bound by the serial phases of a tile, "
-                             "DESIGN.md 4)" % ("f16" if split else "f32"),
+                "peak_note": "dense %s MFMA peak at 2.4 GHz; the K3 kernels run at the board's power cap (`power` below, "
+                             "profiles/r03_power_trace.log) and are clocked at 1.7-2.1 GHz, the isolated MFMA K-loop at 1.5-1.7 GHz "
+                             "(tools/hwprobe/kloop_bound.hip): DESIGN.md 4" % ("f16" if split else "f32"),
                 "per_kernel_note": "mlp_bwd_dw launches run on a second stream beside mlp_bwd_dx of the other network "
                                    "(engine.TrainStep): the HIP-event durations of these two include that time slicing; "
                                    "mlp_fwd, the dominant kernel, runs alone",
@@ -563,6 +610,8 @@ def main():
     }
     if exact is not None:
         out["exact_f32"], out["roofline_f32"] = exact, roof_f32
+    if power and out.get("roofline"):
+        out["roofline"]["power"] = power
     if comm is not None:
         out.update(comm)
     if rank == 0:

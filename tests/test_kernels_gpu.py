@@ -737,6 +737,32 @@ def test_adam_golden(K, golden):
         report("K8 adam step %d" % step, p, g["p_after_%d" % step], atol=2e-7, rtol=2e-6)
 
 
+def test_ray_grad_reduce_accumulate_modes(K):
+    """benerf_ray_grad_reduce: 0 overwrites, 1 adds into all three outputs, 2 adds into d_rays_d only (the first of a training
+    step's two calls: d_rays_d already holds the compositing backward's part, d_rays_o / d_viewdirs are uninitialised)."""
+    rng = np.random.default_rng(77)
+    N, S = 45, 70
+    z = dev(GI.f32(rng.random((N, S))))
+    d_pts = dev(GI.f32(rng.standard_normal((N * S, 3))))
+    d_vd = dev(GI.f32(rng.standard_normal((N * S, 3))))
+    ref_o = d_pts.view(N, S, 3).double().sum(1)
+    ref_d = (d_pts.view(N, S, 3).double() * z.double()[..., None]).sum(1)
+    ref_v = d_vd.view(N, S, 3).double().sum(1)
+    base = dev(GI.f32(rng.standard_normal((N, 3))))
+    for mode in (0, 1, 2):
+        d_o = torch.full((N, 3), float("nan") if mode != 1 else 0.0, device=DEV)
+        d_v = d_o.clone()
+        d_d = base.clone()
+        if mode == 1:
+            d_o, d_v = base.clone(), base.clone()
+        K.ray_grad_reduce(z, d_pts, d_vd, d_o, d_d, d_v, mode)
+        add_od = base.double() if mode == 1 else 0.0
+        add_d = base.double() if mode != 0 else 0.0
+        report("ray_grad_reduce mode %d d_o" % mode, d_o, (ref_o + add_od).float(), atol=2e-5, rtol=1e-5)
+        report("ray_grad_reduce mode %d d_d" % mode, d_d, (ref_d + add_d).float(), atol=2e-5, rtol=1e-5)
+        report("ray_grad_reduce mode %d d_v" % mode, d_v, (ref_v + add_od).float(), atol=2e-5, rtol=1e-5)
+
+
 def test_composite_bwd_reports_max_d_raw(K):
     """benerf_composite_bwd's optional max |d_raw| output (consumed by the split-f16 dX chain instead of a pass over d_raw of
     its own) equals the maximum of what it wrote; the dX launch gives identical results with and without it."""
@@ -750,6 +776,19 @@ def test_composite_bwd_reports_max_d_raw(K):
     amax = torch.zeros(1, device=DEV)
     d_raw, _ = K.composite_bwd(raw, z, rd, noise, 0.0, 0, 0, g_rgb, absmax_out=amax)
     assert float(amax) == float(d_raw.abs().max()) > 0.0
+    # the maximum is reduced per workgroup (16 rays; 8 beyond 256 samples) before it reaches the word: ragged ray counts, every
+    # samples-per-lane variant, the ray holding the maximum anywhere in its workgroup
+    for n2, s2 in ((1, 7), (16, 64), (17, 65), (531, 192), (100, 256), (41, 300), (9, 512)):
+        raw2 = dev(GI.f32(rng.standard_normal((n2, s2, C + 1))))
+        z2 = dev(GI.f32(np.sort(rng.random((n2, s2)), -1)))
+        rd2 = dev(GI.f32(rng.uniform(-1, 1, (n2, 3))))
+        g2 = GI.f32(rng.standard_normal((n2, C)) * 1e-3)
+        g2[int(rng.integers(n2))] *= 50.0
+        a2 = torch.zeros(1, device=DEV)
+        plain, dd_plain = K.composite_bwd(raw2, z2, rd2, None, 1.0, 5, 9, dev(g2))
+        d2, dd2 = K.composite_bwd(raw2, z2, rd2, None, 1.0, 5, 9, dev(g2), absmax_out=a2)
+        assert torch.equal(plain, d2) and torch.equal(dd_plain, dd2)
+        assert float(a2) == float(d2.abs().max()) > 0.0, (n2, s2)
     p = _params_for(rng, C, "trained")
     net = _packed(K, p, C)
     ro = dev(GI.f32(rng.uniform(-0.5, 0.5, (N, 3))))
