@@ -30,8 +30,9 @@ extern "C" int benerf_mlp_status_check(const uint32_t* status, benerf_stream_t s
     if (h[BENERF_ST_SKIPPED] && act < 65504.f && grad < 65504.f) {   // steps gated since the host last cleared the words
         memcpy(&act, &h[BENERF_ST_LAST_ACT], 4);
         memcpy(&grad, &h[BENERF_ST_LAST_GRAD], 4);
-        benerf_set_error("mlp(split): %u of %u training steps were skipped (%u in a row at the end) - an activation (max %g) or a scaled "
-                         "gradient (max %g) left the f16 range (65504) on this or another rank; train with BENERF_MLP_F32",
+        benerf_set_error("mlp: %u of %u training steps were skipped (%u in a row at the end) - an activation (max %g) or a scaled "
+                         "gradient (max %g; inf: the loss gradient itself was not finite) left the f16 range (65504) of the split mode on "
+                         "this or another rank; train with BENERF_MLP_F32 unless the loss is NaN",
                          h[BENERF_ST_SKIPPED], h[BENERF_ST_STEPS], h[BENERF_ST_CONSECUTIVE], (double)act, (double)grad);
         return BENERF_ERANGE;
     }

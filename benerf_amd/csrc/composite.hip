@@ -201,10 +201,10 @@ __device__ __forceinline__ float composite_bwd_ray(const float* __restrict__ raw
             FOR_CH(c) {
                 const float dv = grgb[c] * st.w[k] * sg[k][c] * (1.0f - sg[k][c]);
                 dr[(int64_t)i * (C + 1) + c] = dv;
-                mx = fmaxf(mx, fabsf(dv));
+                mx = fmaxf(mx, dv == dv ? fabsf(dv) : __builtin_inff());      // fmaxf drops NaN: record it as +inf
             }
             dr[(int64_t)i * (C + 1) + C] = dsig;
-            mx = fmaxf(mx, fabsf(dsig));
+            mx = fmaxf(mx, dsig == dsig ? fabsf(dsig) : __builtin_inff());
             run += gw[k] * st.w[k];
         }
     }

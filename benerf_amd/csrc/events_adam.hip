@@ -75,7 +75,10 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 
 // Range-guard bookkeeping of one training step (include/benerf_hip.h, benerf_step_gate).  One thread.
 __global__ void step_gate_kernel(uint32_t* __restrict__ st, float* __restrict__ flag, int phase) {
-    const bool local = st[BENERF_ST_ACT] >= 0x477fe000u || st[BENERF_ST_GRAD] >= 0x477fe000u || st[BENERF_ST_MODE] != 0u;
+    // the two per-step words hold max |d_raw| of the step's networks (benerf_composite_bwd; NaN arrives as +inf): a loss gradient that
+    // is not finite - NaN / inf weights or inputs, in either arithmetic mode - must not reach the parameters either
+    const bool nonfinite = st[BENERF_ST_STEP_SCRATCH] >= 0x7f800000u || st[BENERF_ST_STEP_SCRATCH + 1] >= 0x7f800000u;
+    const bool local = st[BENERF_ST_ACT] >= 0x477fe000u || st[BENERF_ST_GRAD] >= 0x477fe000u || st[BENERF_ST_MODE] != 0u || nonfinite;
     if (phase == 0) {          // this rank's verdict as a float, to be SUMMED over the ranks with the gradients
         flag[0] = local ? 1.f : 0.f;
         return;
@@ -83,7 +86,7 @@ __global__ void step_gate_kernel(uint32_t* __restrict__ st, float* __restrict__ 
     const bool skip = flag ? (flag[0] > 0.f || local) : local;
     if (local) {               // keep what tripped the guard for the host's message
         st[BENERF_ST_LAST_ACT] = st[BENERF_ST_ACT];
-        st[BENERF_ST_LAST_GRAD] = st[BENERF_ST_GRAD];
+        st[BENERF_ST_LAST_GRAD] = nonfinite ? 0x7f800000u : st[BENERF_ST_GRAD];
     }
     st[BENERF_ST_SKIP] = skip ? 1u : 0u;
     st[BENERF_ST_SKIPPED] += skip ? 1u : 0u;

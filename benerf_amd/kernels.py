@@ -260,8 +260,9 @@ class RangeGuard:
         f = lambda w: struct.unpack("f", struct.pack("I", int(w) & 0xffffffff))[0]   # noqa: E731
         if h[_lib.ST_SKIPPED]:
             raise _lib.BenerfRangeError(
-                "mlp(split): %d of %d training steps were skipped on the device (%d in a row at the end): an activation (max %g) "
-                "or a scaled gradient (max %g) left the f16 range (65504) on this or another rank - train with mlp precision 'f32'"
+                "mlp: %d of %d training steps were skipped on the device (%d in a row at the end): an activation (max %g) or a scaled "
+                "gradient (max %g; inf = the loss gradient itself was not finite) left the f16 range (65504) of the split mode on this "
+                "or another rank - train with mlp precision 'f32' unless the loss is NaN"
                 % (h[_lib.ST_SKIPPED], h[_lib.ST_STEPS], h[_lib.ST_CONSECUTIVE], f(h[_lib.ST_LAST_ACT]), f(h[_lib.ST_LAST_GRAD])))
         raise _lib.BenerfRangeError("mlp(split): activation max %g / scaled gradient max %g left the f16 range (65504): the gradients "
                                     "of that backward pass are inf / NaN - use mlp precision 'f32'" % (f(h[_lib.ST_ACT]), f(h[_lib.ST_GRAD])))

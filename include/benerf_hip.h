@@ -180,13 +180,14 @@ size_t benerf_workspace_bytes(int which, int64_t n_points, int n_poses, int n_pi
 enum { BENERF_MLP_F32 = 0, BENERF_MLP_SPLIT = 1, BENERF_MLP_AUTO = 2 };
 enum { BENERF_ST_ACT = 0, BENERF_ST_GRAD = 1, BENERF_ST_MODE = 2, BENERF_ST_AUTO = 3, BENERF_ST_SKIP = 4, BENERF_ST_SKIPPED = 5,
        BENERF_ST_CONSECUTIVE = 6, BENERF_ST_STEPS = 7, BENERF_ST_LAST_ACT = 8, BENERF_ST_LAST_GRAD = 9,
-       BENERF_ST_STEP_SCRATCH = 10,     /* [10], [11]: two per-step words of the caller, zeroed by benerf_step_gate phase 1 (a training
-                                         * step keeps the two networks' max |d_raw| there: benerf_composite_bwd's d_raw_absmax) */
+       BENERF_ST_STEP_SCRATCH = 10,     /* [10], [11]: max |d_raw| of the step's (up to) two networks - benerf_composite_bwd's
+                                         * d_raw_absmax, NaN recorded as +inf; zeroed by benerf_step_gate phase 1, which treats a
+                                         * non-finite value as a violation (the loss gradient of the step is not finite) */
        BENERF_ST_WORDS = 16 };
 int benerf_mlp_status_check(const uint32_t* status, benerf_stream_t stream);
 /* Per-step verdict of the range guard, on the device (no synchronisation), between the backward pass and the
  * benerf_adam_step launches of a training iteration (train.py:340-352):
- *   phase 0: reduce_flag[0] = 1.f if this rank's [ACT] / [GRAD] / [MODE] show a violation, else 0.f - data-parallel
+ *   phase 0: reduce_flag[0] = 1.f if this rank's [ACT] / [GRAD] / [MODE] / [STEP_SCRATCH] show a violation, else 0.f - data-parallel
  *            callers SUM it over the ranks together with the gradients, so that every replica takes the same decision
  *            (a rank that overflowed contributes inf / NaN to everybody's gradient sum);
  *   phase 1: [SKIP] = violation (reduce_flag[0] > 0 when reduce_flag != NULL, this rank's words otherwise), counters
@@ -236,8 +237,8 @@ int benerf_composite_fwd(const float* raw, const float* z, const float* rays_d,
 /* d_rgb_map [n_rays,C] (required); d_acc, d_depth, d_disp [n_rays] optional (NULL = 0).
  * Out: d_raw [n_rays,n_samples,C+1]; d_rays_d [n_rays,3] through ||rays_d|| in dists
  * (overwritten, or added to when accumulate != 0; may be NULL).
- * d_raw_absmax: NULL, or one device float the caller zeroed: receives max |d_raw| (atomic maximum over the launch) - the
- * split-f16 benerf_mlp_bwd_dx takes it instead of running its own pass over d_raw. */
+ * d_raw_absmax: NULL, or one device float the caller zeroed: receives max |d_raw| (atomic maximum over the launch; +inf if any
+ * entry is NaN) - the split-f16 benerf_mlp_bwd_dx takes it instead of running its own pass over d_raw. */
 int benerf_composite_bwd(const float* raw, const float* z, const float* rays_d,
                          const float* noise, float noise_std, uint64_t seed, uint64_t offset,
                          int channels, int n_rays, int n_samples, const float* d_rgb_map,

@@ -497,6 +497,56 @@ def test_train_step_range_guard_skips_counts_and_raises():
     assert not torch.equal(step.flat_p, good)
 
 
+def test_train_step_skips_a_nonfinite_loss_gradient():
+    """Both arithmetic modes: a NaN parameter (here the fine network's colour bias; a NaN density is clamped away by the
+    compositing kernel's relu, fmaxf(NaN, 0) = 0) makes raw, the loss and d_raw NaN - the
+    compositing backward records NaN as +inf in the step's max |d_raw| word, the step gate turns that into the skip verdict:
+    every other parameter and the Adam moments stay as they were, the step is counted, and training resumes once the
+    parameter is repaired."""
+    from benerf_amd import _lib, engine, kernels as K, workloads as WL
+    wl = dict(WL.WORKLOADS["C1"], S=16, Ni=16, Re=16, Rr=2, n=5)
+    args = WL.make_args(wl, optimize_trans=True)
+    cam = WL.CAMERAS[wl["cam"]]
+    model, g = _graph(args, seed=19)
+    cam_o = engine.Camera(cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+    step = engine.TrainStep(g, args, cam_o, cam_o, torch.device(DEV))
+    rng = np.random.default_rng(13)
+    HW = cam["H"] * cam["W"]
+    accu = torch.from_numpy(rng.integers(-3, 4, HW).astype(np.float32)).to(DEV)
+    img = torch.from_numpy(rng.random((HW, 1)).astype(np.float32)).to(DEV)
+
+    def one():
+        return step.step(torch.tensor([0.2, 0.3], device=DEV), torch.tensor([0.0, 1.0], device=DEV),
+                         torch.from_numpy(rng.permutation(HW)[:16]).to(DEV), torch.from_numpy(rng.permutation(HW)[:2]).to(DEV), accu, img)
+
+    one()
+    step.check_range()
+    bias = step.net_f.views_b[_lib.L_RGB]
+    keep = bias.clone()
+    with torch.no_grad():
+        bias.fill_(float("nan"))
+    step.net_f.packed.pack()
+    before, m_before = step.flat_p.clone(), step.flat_m.clone()
+    losses = one()
+    torch.cuda.synchronize()
+    assert not bool(torch.isfinite(losses[0]))
+    same = torch.isnan(before) | (step.flat_p == before)
+    assert bool(same.all()) and torch.equal(step.flat_m, m_before), "a step with a NaN loss gradient must not touch parameters or moments"
+    words = step.guard.words.cpu().tolist()
+    assert words[_lib.ST_SKIPPED] == 1 and words[_lib.ST_SKIP] == 1 and (words[_lib.ST_LAST_GRAD] & 0xffffffff) == 0x7f800000
+    assert words[_lib.ST_STEP_SCRATCH] == 0 and words[_lib.ST_STEP_SCRATCH + 1] == 0      # cleared for the next step
+    with pytest.raises(_lib.BenerfRangeError):
+        step.check_range()
+    with torch.no_grad():
+        bias.copy_(keep)
+    step.net_f.packed.pack()
+    K.params_changed()
+    one()
+    torch.cuda.synchronize()
+    step.check_range()
+    assert bool(torch.isfinite(step.flat_p).all()) and not torch.equal(step.flat_p, before)
+
+
 @pytest.mark.parametrize("which", ["rgb", "event", "both"])
 def test_fused_step_with_crf(which):
     """optimize_rgb_crf / optimize_event_crf (train.py:180-192) in the fused TrainStep: losses, tone-mapper gradients and the
