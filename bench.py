@@ -24,8 +24,10 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before the HIP runtime initialises: one hardware queue per stream (benerf_amd/__init__.py)
+
+import numpy as np      # noqa: E402
+import torch            # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -72,6 +74,10 @@ def parse():
     ap.add_argument("--oversubscribe", action="store_true",
                     help="development: every rank uses device 0 and the gloo transport (the whole multi-rank flow of this script on a "
                          "one-GPU box; the number it prints is not a measurement)")
+    ap.add_argument("--rccl-loopback", action="store_true",
+                    help="one GPU, but every collective of the step is issued on a one-rank RCCL communicator (a sum over one rank is "
+                         "the identity): the fixed per-step cost of the data-parallel plumbing - RCCL launches, stream hand-overs - "
+                         "without wire time")
     ap.add_argument("--batch-fraction", type=int, default=1,
                     help="render 1/F of the workload's pixels per rank (F = 8 on one GPU: the per-rank step of a strong-scaled 8-GPU run)")
     ap.add_argument("--n-events", type=int, default=2_000_000)
@@ -321,6 +327,12 @@ def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(a))
+    # The contract is ONE JSON line on stdout.  Communication libraries write to fd 1 themselves (RCCL: "Librccl path : ...",
+    # gloo: "[Gloo] Rank 0 is connected to ..."): keep a private handle on the real stdout for the line and point fd 1 at
+    # stderr for everybody else in this process.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -343,6 +355,17 @@ def main():
         device = torch.device("cuda", local_rank)
     pg = None
     comm = None
+    if a.rccl_loopback:
+        if world != 1:
+            sys.exit("bench.py: --rccl-loopback is a one-GPU mode")
+        from benerf_amd import dist as _dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+        pg = torch.distributed.group.WORLD
+        _dist.ALWAYS_COMMUNICATE = True
+        comm = collective_selfcheck(1, device, 595586)
     if world > 1:
         if a.backend == "nccl":
             torch.distributed.init_process_group("nccl", device_id=device)   # RCCL over xGMI
@@ -354,7 +377,7 @@ def main():
     if a.selfcheck_only:
         if rank == 0:
             print(json.dumps({"metric": "collective self-check", "n_gpus": world, "backend": a.backend, "scaling": a.scaling,
-                              "config": {"workload": a.workload}, **(comm or {"rccl_ranks_seen": 1})}), flush=True)
+                              "config": {"workload": a.workload}, **(comm or {"rccl_ranks_seen": 1})}), file=json_out, flush=True)
         if world > 1:
             torch.distributed.destroy_process_group()
         return
@@ -629,8 +652,10 @@ def main():
                 out["torch_gpu_baseline"] = {"error": repr(e)[:200]}
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        if a.rccl_loopback:
+            out["config"]["rccl_loopback"] = True
+        print(json.dumps(out), file=json_out, flush=True)
+    if world > 1 or a.rccl_loopback:
         torch.distributed.destroy_process_group()
 
 
