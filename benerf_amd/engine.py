@@ -464,11 +464,18 @@ class TrainStep:
         largs = ((rgb_map[:Ne], rgb0[:Ne], target_acc) if use_e else (None, None, None)) + \
                 ((rgb_map[Ne:], rgb0[Ne:], target_rgb) if use_r else (None, None, None))
         stats = K.loss_stats(lcfg, *largs)
-        dist.allreduce_sum_(stats, self.world, self.pg)
+        # Data-parallel: the L2-normalised event loss (train.py:238-292) needs the GLOBAL sums of squares before its gradient - a
+        # blocking 16-double exchange in the middle of the step.  The mean-squared losses do not: their gradients use the global
+        # COUNTS only and the reported values are linear in the sums, so every rank computes its part and the 8 loss values are
+        # summed asynchronously behind the gradient buckets, off the critical path.
+        stats_first = use_e and not syn
+        if stats_first:
+            dist.allreduce_sum_(stats, self.world, self.pg)
         g_rgb = torch.empty_like(rgb_map) if (use_e and use_r) else torch.zeros_like(rgb_map)
         g_rgb0 = torch.empty_like(rgb0) if (use_e and use_r) else torch.zeros_like(rgb0)
         losses, _ = K.loss_grads(lcfg, stats, *largs, out=((g_rgb[:Ne], g_rgb0[:Ne]) if use_e else (None, None)) +
                                  ((g_rgb[Ne:], g_rgb0[Ne:]) if use_r else (None, None)))
+        loss_sum = None if stats_first else dist.allreduce_sum_async_(losses, self.world, self.pg)
 
         if crf:   # gradients w.r.t. the tone-mapped colours -> the rendered colours and the tone-mapper parameters
             for p_ in self.crf_params:
@@ -527,6 +534,8 @@ class TrainStep:
                 w.wait()
         main.wait_stream(side)
         pending[2].wait()
+        if loss_sum is not None:
+            loss_sum.wait()
 
         # ---- Adam (K8) with the reference's per-group switches and LR schedule ---------------------------------
         # the range guard's verdict for this step (summed over the ranks): [SKIP] makes every Adam launch below a no-op

@@ -198,7 +198,7 @@ def me_mode():
     return K.get_mlp_precision()
 
 
-def _dp_worker(rank, world, port, out_q, mode):
+def _dp_worker(rank, world, port, out_q, mode, base="C5"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -212,7 +212,9 @@ def _dp_worker(rank, world, port, out_q, mode):
     if world > 1:
         torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
         pg = torch.distributed.group.WORLD
-    wl = dict(WL.WORKLOADS["C5"], S=16, Ni=16, Re=32, Rr=4, n=5)     # E2NeRF_Real: the globally normalised loss
+    # C5 = E2NeRF_Real: the globally normalised loss (blocking exchange of the sums of squares before the gradient); C4 =
+    # E2NeRF_Synthetic: mean-squared losses (no exchange before the gradient, the loss VALUES are summed asynchronously)
+    wl = dict(WL.WORKLOADS[base], S=16, Ni=16, Re=32, Rr=4, n=5)
     args = WL.make_args(wl, optimize_trans=True)
     cam = WL.CAMERAS[wl["cam"]]
     _, g = me._graph(args, seed=11 + 100 * rank)      # replicas initialise DIFFERENTLY: TrainStep broadcasts rank 0's parameters
@@ -240,7 +242,7 @@ def _dp_worker(rank, world, port, out_q, mode):
         with pytest.raises(ValueError):
             step.step(torch.tensor([0.2, 0.45], device=DEV), torch.tensor([0.0, 1.0], device=DEV), idx_e[:31], idx_r, accu, img)
     result = (losses.cpu().numpy(), step.flat_g.cpu().numpy(), step.flat_p.cpu().numpy())
-    if world > 1 and mode == "split":
+    if world > 1 and mode == "split" and base == "C5":
         # range guard across ranks: ONE rank leaves the f16 range (its words are poisoned here; its gradients would be inf /
         # NaN and reach everybody through the sum) -> the verdict rides the trajectory bucket and EVERY replica skips the step
         from benerf_amd import _lib
@@ -264,26 +266,27 @@ def test_sharded_step_equals_single_rank():
     parameters of the sharded step equal the single-rank step on the same global batch; replicas start from rank 0's
     parameters whatever their own initialisation; uneven global batches are rejected."""
     ctx = mp.get_context("spawn")
-    res = {}
-    for world in (1, 2, 4):
-        q = ctx.Queue()
-        port = 29650 + world + (os.getpid() % 100)
-        procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q, me_mode())) for r in range(world)]
-        for p in procs:
-            p.start()
-        res[world] = q.get(timeout=300)
-        for p in procs:
-            p.join(timeout=120)
-            assert p.exitcode == 0
-    l1, g1, p1 = res[1]
-    for world in (2, 4):
-        l2, g2, p2 = res[world]
-        report("DP loss (%d ranks vs 1)" % world, l2, l1, atol=1e-6, rtol=1e-5)
-        # both modes: only the summation order differs (the split mode's per-rank gradient scales are powers of two)
-        report("DP flat gradient (%d ranks vs 1)" % world, g2, g1, atol=2e-6 * float(np.abs(g1).max()), rtol=1e-4)
-        # the first Adam step is lr * g / (|g| + eps): entries with |g| ~ eps amplify the 1e-7 gradient wobble,
-        # bounded by a few percent of lr = 5e-4
-        report("DP parameters after Adam (%d ranks vs 1)" % world, p2, p1, atol=2e-5, rtol=1e-5)
+    for base, worlds in (("C5", (1, 2, 4)), ("C4", (1, 2))):
+        res = {}
+        for world in worlds:
+            q = ctx.Queue()
+            port = 29650 + world + (os.getpid() % 100) + (10 if base == "C4" else 0)
+            procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q, me_mode(), base)) for r in range(world)]
+            for p in procs:
+                p.start()
+            res[world] = q.get(timeout=300)
+            for p in procs:
+                p.join(timeout=120)
+                assert p.exitcode == 0
+        l1, g1, p1 = res[1]
+        for world in worlds[1:]:
+            l2, g2, p2 = res[world]
+            report("DP %s loss (%d ranks vs 1)" % (base, world), l2, l1, atol=1e-6, rtol=1e-5)
+            # both modes: only the summation order differs (the split mode's per-rank gradient scales are powers of two)
+            report("DP %s flat gradient (%d ranks vs 1)" % (base, world), g2, g1, atol=2e-6 * float(np.abs(g1).max()), rtol=1e-4)
+            # the first Adam step is lr * g / (|g| + eps): entries with |g| ~ eps amplify the 1e-7 gradient wobble,
+            # bounded by a few percent of lr = 5e-4
+            report("DP %s parameters after Adam (%d ranks vs 1)" % (base, world), p2, p1, atol=2e-5, rtol=1e-5)
 
 
 def _rccl_worker(port, out_q, mode):
@@ -301,25 +304,27 @@ def _rccl_worker(port, out_q, mode):
     torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=dev)      # RCCL, a communicator of one
     pg = torch.distributed.group.WORLD
     assert not dist._through_host(torch.zeros(1, device=dev), pg), "nccl must reduce device buffers in place"
-    wl = dict(WL.WORKLOADS["C5"], S=32, Ni=32, Re=64, Rr=8, n=5)       # the normalised loss: the 16-double exchange too
-    args = WL.make_args(wl, optimize_trans=True)
-    cam = WL.CAMERAS[wl["cam"]]
-    cam_o = engine.Camera(cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"])
-    rng = np.random.default_rng(5)
-    HW = cam["H"] * cam["W"]
-    idx_e = torch.from_numpy(rng.permutation(HW)[:64]).to(DEV)
-    idx_r = torch.from_numpy(rng.permutation(HW)[:8]).to(DEV)
-    accu = torch.from_numpy(rng.integers(-3, 4, HW).astype(np.float32)).to(DEV)
-    img = torch.from_numpy(rng.random((HW, 3)).astype(np.float32)).to(DEV)
     res = {}
-    for communicate in (False, True):
-        dist.ALWAYS_COMMUNICATE = communicate
-        _, g = me._graph(args, seed=21)
-        step = engine.TrainStep(g, args, cam_o, cam_o, dev, world_size=1, rank=0, process_group=pg, seed=3)
-        for k in range(3):
-            losses = step.step(torch.tensor([0.2, 0.45], device=DEV), torch.tensor([0.0, 1.0], device=DEV), idx_e, idx_r, accu, img)
-        step.check_range()
-        res[communicate] = (losses.cpu().numpy(), step.flat_g.cpu().numpy(), step.flat_p.cpu().numpy())
+    # C5: the normalised loss (the blocking 16-double exchange too); C4: mean-squared losses (asynchronous sum of the loss values)
+    for base in ("C5", "C4"):
+        wl = dict(WL.WORKLOADS[base], S=32, Ni=32, Re=64, Rr=8, n=5)
+        args = WL.make_args(wl, optimize_trans=True)
+        cam = WL.CAMERAS[wl["cam"]]
+        cam_o = engine.Camera(cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+        rng = np.random.default_rng(5)
+        HW = cam["H"] * cam["W"]
+        idx_e = torch.from_numpy(rng.permutation(HW)[:64]).to(DEV)
+        idx_r = torch.from_numpy(rng.permutation(HW)[:8]).to(DEV)
+        accu = torch.from_numpy(rng.integers(-3, 4, HW).astype(np.float32)).to(DEV)
+        img = torch.from_numpy(rng.random((HW, 3)).astype(np.float32)).to(DEV)
+        for communicate in (False, True):
+            dist.ALWAYS_COMMUNICATE = communicate
+            _, g = me._graph(args, seed=21)
+            step = engine.TrainStep(g, args, cam_o, cam_o, dev, world_size=1, rank=0, process_group=pg, seed=3)
+            for k in range(3):
+                losses = step.step(torch.tensor([0.2, 0.45], device=DEV), torch.tensor([0.0, 1.0], device=DEV), idx_e, idx_r, accu, img)
+            step.check_range()
+            res[(base, communicate)] = (losses.cpu().numpy(), step.flat_g.cpu().numpy(), step.flat_p.cpu().numpy())
     # the bench's collective self-check on the same communicator
     sys.path.insert(0, ROOT)
     import bench
@@ -342,8 +347,9 @@ def test_step_over_rccl_communicator_of_one():
     res, comm = q.get(timeout=300)
     p.join(timeout=120)
     assert p.exitcode == 0
-    for a, b, what in zip(res[False], res[True], ("losses", "flat gradient", "parameters after 3 steps")):
-        assert np.array_equal(a, b), "%s changed when the collectives ran over RCCL" % what
+    for base in ("C5", "C4"):
+        for a, b, what in zip(res[(base, False)], res[(base, True)], ("losses", "flat gradient", "parameters after 3 steps")):
+            assert np.array_equal(a, b), "%s: %s changed when the collectives ran over RCCL" % (base, what)
     assert comm["rccl_ranks_seen"] == 1 and comm["allreduce_ms"] > 0
     report("RCCL one-rank bucketed all-reduce [ms]", np.array([comm["allreduce_ms"]]), np.array([comm["allreduce_ms"]]), atol=1, rtol=0)
 
