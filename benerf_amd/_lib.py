@@ -39,6 +39,7 @@ _SIGNATURES = {
     "benerf_last_error": (c_char_p, []),
     "benerf_spline_poses_fwd": (c_int, [P, P, P, c_int, c_int, c_int, P, P]),
     "benerf_spline_poses_bwd": (c_int, [P, P, P, c_int, c_int, c_int, P, P, P, P]),
+    "benerf_spline_poses_fwd_pair": (c_int, [P, P, P, c_int, P, c_int, c_int, P, P, P]),
     "benerf_spline_poses_bwd_pair": (c_int, [P, P, P, c_int, P, c_int, c_int, P, P, P, P, P, P]),
     "benerf_spline_op_fwd": (c_int, [c_int, P, c_int64, P, P]),
     "benerf_spline_op_bwd": (c_int, [c_int, P, c_int64, P, P, P]),
@@ -50,6 +51,7 @@ _SIGNATURES = {
     "benerf_ray_grad_reduce": (c_int, [c_int, c_int, P, P, P, c_int, P, P, P, P]),
     "benerf_mlp_packed_floats": (c_size_t, []),
     "benerf_mlp_pack_weights": (c_int, [POINTER(MlpParams), c_int, P, P]),
+    "benerf_mlp_pack_weights_pair": (c_int, [POINTER(MlpParams), P, POINTER(MlpParams), P, c_int, P]),
     "benerf_mlp_act_floats": (c_size_t, [c_int64]),
     "benerf_mlp_dact_floats_per_point": (c_size_t, []),
     "benerf_mlp_dact_floats": (c_size_t, [c_int64]),

@@ -53,7 +53,15 @@ __device__ __forceinline__ float pack_source(const PackArgs& a, int id, int col,
     return W[(int64_t)n * in + k];
 }
 
-__global__ void pack_kernel(PackArgs a) {
+struct PackArgs2 { PackArgs net[2]; };
+
+__device__ __forceinline__ void pack_body(const PackArgs& a);
+
+__global__ void pack_kernel(PackArgs a) { pack_body(a); }
+// both networks of a training step in one launch (blockIdx.z)
+__global__ void pack_pair_kernel(PackArgs2 a) { pack_body(a.net[blockIdx.z]); }
+
+__device__ __forceinline__ void pack_body(const PackArgs& a) {
     const int id = blockIdx.y;
     const PackShape sh = pack_shape(id);
     const int64_t n4 = (int64_t)sh.tiles * sh.kblocks * 64;   // float4 slots
@@ -142,5 +150,22 @@ extern "C" int benerf_mlp_pack_weights(const BenerfMlpParams* params, int channe
     a.packed = packed;
     hipLaunchKernelGGL(pack_kernel, dim3(40, mlp::PACK_COUNT), dim3(256), 0, as_stream(stream), a);
     BENERF_LAUNCH_CHECK("mlp_pack_weights");
+    return BENERF_OK;
+}
+
+extern "C" int benerf_mlp_pack_weights_pair(const BenerfMlpParams* params_a, float* packed_a, const BenerfMlpParams* params_b,
+                                            float* packed_b, int channels, benerf_stream_t stream) {
+    BENERF_REQUIRE(params_a && packed_a && params_b && packed_b, "mlp_pack_weights_pair: null pointer");
+    BENERF_REQUIRE(channels >= 1 && channels <= 3, "mlp_pack_weights_pair: channels must be 1..3");
+    PackArgs2 a;
+    for (int l = 0; l < BENERF_NLAYERS; ++l) {
+        BENERF_REQUIRE(params_a->w[l] && params_b->w[l], "mlp_pack_weights_pair: null weight %d", l);
+        a.net[0].w[l] = params_a->w[l];
+        a.net[1].w[l] = params_b->w[l];
+    }
+    a.net[0].packed = packed_a;
+    a.net[1].packed = packed_b;
+    hipLaunchKernelGGL(pack_pair_kernel, dim3(40, mlp::PACK_COUNT, 2), dim3(256), 0, as_stream(stream), a);
+    BENERF_LAUNCH_CHECK("mlp_pack_weights_pair");
     return BENERF_OK;
 }

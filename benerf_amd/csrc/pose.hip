@@ -285,10 +285,9 @@ __device__ void linear_from_qt(const T qs[4], const T ts[3], const T qe[4], cons
     quat_to_pose(qt, tr, out);
 }
 
-__global__ void spline_fwd_kernel(const float* __restrict__ knots, const float* __restrict__ transform,
-                                  const float* __restrict__ ts2, int n_poses, int traj, int explicit_ts,
-                                  float* __restrict__ poses) {
-    int p = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void spline_fwd_body(const float* __restrict__ knots, const float* __restrict__ transform,
+                                                const float* __restrict__ ts2, int n_poses, int traj, int explicit_ts,
+                                                float* __restrict__ poses, int p) {
     if (p >= n_poses) return;
     float k[4][6];
 #pragma unroll
@@ -305,6 +304,22 @@ __global__ void spline_fwd_kernel(const float* __restrict__ knots, const float* 
         cubic_pose<false>(k, u, out);
 #pragma unroll
     for (int i = 0; i < 12; ++i) poses[p * 12 + i] = out[i];
+}
+
+__global__ void spline_fwd_kernel(const float* __restrict__ knots, const float* __restrict__ transform,
+                                  const float* __restrict__ ts2, int n_poses, int traj, int explicit_ts,
+                                  float* __restrict__ poses) {
+    spline_fwd_body(knots, transform, ts2, n_poses, traj, explicit_ts, poses, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// the two trajectories of a training step in one launch (blockIdx.y: 0 = event poses on the knots themselves, 1 = exposure
+// poses on knots + transform): a pose is one thread's long serial chain, two launches were two of them back to back
+__global__ void spline_fwd_pair_kernel(const float* __restrict__ knots, const float* __restrict__ transform_b,
+                                       const float* __restrict__ ts_a, int n_a, const float* __restrict__ ts_b, int n_b, int traj,
+                                       float* __restrict__ poses_a, float* __restrict__ poses_b) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.y == 0) spline_fwd_body(knots, nullptr, ts_a, n_a, traj, 0, poses_a, p);
+    else spline_fwd_body(knots, transform_b, ts_b, n_b, traj, 0, poses_b, p);
 }
 
 // one block; thread (p, j): tangent of pose p w.r.t. effective-knot coefficient j (0..23);
@@ -475,6 +490,18 @@ extern "C" int benerf_spline_poses_fwd(const float* knots, const float* transfor
     hipLaunchKernelGGL(spline_fwd_kernel, dim3(blocks), dim3(threads), 0, as_stream(stream), knots, transform, ts2,
                        n_poses, traj, explicit_ts, poses);
     BENERF_LAUNCH_CHECK("spline_poses_fwd");
+    return BENERF_OK;
+}
+
+extern "C" int benerf_spline_poses_fwd_pair(const float* knots, const float* transform_b, const float* ts_a, int n_a,
+                                            const float* ts_b, int n_b, int traj, float* poses_a, float* poses_b,
+                                            benerf_stream_t stream) {
+    BENERF_REQUIRE(knots && transform_b && ts_a && ts_b && poses_a && poses_b, "spline_poses_fwd_pair: null pointer");
+    BENERF_REQUIRE(n_a > 0 && n_b > 0 && (traj >= 0 && traj <= 2), "spline_poses_fwd_pair: bad sizes");
+    const int n_max = n_a > n_b ? n_a : n_b, threads = 64;
+    hipLaunchKernelGGL(spline_fwd_pair_kernel, dim3((n_max + threads - 1) / threads, 2), dim3(threads), 0, as_stream(stream), knots,
+                       transform_b, ts_a, n_a, ts_b, n_b, traj, poses_a, poses_b);
+    BENERF_LAUNCH_CHECK("spline_poses_fwd_pair");
     return BENERF_OK;
 }
 

@@ -412,8 +412,7 @@ class TrainStep:
         step_id = self.global_step
 
         # ---- forward ---------------------------------------------------------------------------
-        poses_e = K.spline_poses_fwd(self.knots, None, evt_ts2, 2, traj)
-        poses_r = K.spline_poses_fwd(self.knots, self.transform.view(6), rgb_ts2, P, traj)
+        poses_e, poses_r = K.spline_poses_fwd_pair(self.knots, self.transform.view(6), evt_ts2, 2, rgb_ts2, P, traj)
         ro = torch.empty((N, 3), dtype=torch.float32, device=dev)
         rd = torch.empty_like(ro)
         vd = torch.empty_like(ro)
@@ -556,8 +555,7 @@ class TrainStep:
             adam(lo, cnt, self._lr(lr0, dr))
         if self.global_step % self.GUARD_POST_EVERY == 0:
             self.guard.post()
-        self.net_c.packed.pack()
-        self.net_f.packed.pack()
+        K.PackedMlp.pack_pair(self.net_c.packed, self.net_f.packed)
         self.global_step += 1
         self.last_losses = losses
         return losses

@@ -77,6 +77,18 @@ def spline_poses_bwd(knots, transform, ts, n_poses, traj, d_poses, explicit_ts=F
     return d_knots, d_tr
 
 
+def spline_poses_fwd_pair(knots, transform_b, ts_a, n_a, ts_b, n_b, traj=0):
+    """Both trajectory evaluations of a step in one launch -> (poses_a [n_a,3,4] on the knots, poses_b [n_b,3,4] on knots +
+    transform_b); ts_* are [2] ranges."""
+    lib = _lib.load()
+    pa, pb = _new((n_a, 3, 4), knots), _new((n_b, 3, 4), knots)
+    assert ts_a.numel() == 2 and ts_b.numel() == 2
+    _lib.check(lib.benerf_spline_poses_fwd_pair(_chk(knots, name="knots"), _chk(transform_b, name="transform"), _chk(ts_a, name="ts"), n_a,
+                                                _chk(ts_b, name="ts"), n_b, traj, pa.data_ptr(), pb.data_ptr(), _stream()),
+               "spline_poses_fwd_pair")
+    return pa, pb
+
+
 def spline_poses_bwd_pair(knots, transform_b, ts_a, n_a, ts_b, n_b, traj, d_poses_a, d_poses_b):
     """Both trajectory backward passes of a step in one launch -> (d_knots_a, d_knots_b, d_transform_b)."""
     lib = _lib.load()
@@ -362,6 +374,16 @@ class PackedMlp:
         _lib.check(lib.benerf_mlp_pack_weights(ctypes.byref(s), self.channels, self.packed.data_ptr(), _stream()),
                    "mlp_pack_weights")
         self.version = self._key()
+
+    @staticmethod
+    def pack_pair(a, b):
+        """Re-packs two networks of the same channel count (a training step's coarse and fine one) in one launch."""
+        lib = _lib.load()
+        assert a.channels == b.channels
+        sa, sb = a.struct(), b.struct()
+        _lib.check(lib.benerf_mlp_pack_weights_pair(ctypes.byref(sa), a.packed.data_ptr(), ctypes.byref(sb), b.packed.data_ptr(),
+                                                    a.channels, _stream()), "mlp_pack_weights_pair")
+        a.version, b.version = a._key(), b._key()
 
     def pack_if_stale(self):
         # torch updates bump ._version; updates through the raw Adam kernel / in-place loads bump the generation

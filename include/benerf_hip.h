@@ -60,6 +60,12 @@ int benerf_spline_poses_fwd(const float* knots, const float* transform, const fl
 int benerf_spline_poses_bwd(const float* knots, const float* transform, const float* ts,
                             int n_poses, int traj, int explicit_ts, const float* d_poses,
                             float* d_knots, float* d_transform, benerf_stream_t stream);
+/* The two trajectory evaluations of one training step (a: event camera, on the knots themselves; b: RGB camera, knots +
+ * transform_b; both linspace timestamps ts_* [2]) as one launch.  Same results as two benerf_spline_poses_fwd calls
+ * (model/optimize.py:58-111). */
+int benerf_spline_poses_fwd_pair(const float* knots, const float* transform_b, const float* ts_a, int n_a,
+                                 const float* ts_b, int n_b, int traj, float* poses_a, float* poses_b,
+                                 benerf_stream_t stream);
 /* The two trajectory backward passes of one training step (a: event camera, no transform; b: RGB camera with
  * transform; both linspace timestamps) as one launch.  Same results as two benerf_spline_poses_bwd calls. */
 int benerf_spline_poses_bwd_pair(const float* knots, const float* transform_b, const float* ts_a, int n_a,
@@ -131,6 +137,10 @@ size_t benerf_mlp_packed_floats(void);
 /* Re-pack one network (call after every optimiser step). packed [benerf_mlp_packed_floats()] */
 int benerf_mlp_pack_weights(const BenerfMlpParams* params, int channels, float* packed,
                             benerf_stream_t stream);
+/* Both networks of a training step (coarse, fine: same channel count) in one launch; same results as two
+ * benerf_mlp_pack_weights calls. */
+int benerf_mlp_pack_weights_pair(const BenerfMlpParams* params_a, float* packed_a, const BenerfMlpParams* params_b,
+                                 float* packed_b, int channels, benerf_stream_t stream);
 /* floats of the saved-activation buffer for n_points sample points (layer outputs, PE tiles and
  * the per-tile ReLU sign-bit words), and floats per point of the activation-gradient scratch */
 size_t benerf_mlp_act_floats(int64_t n_points);

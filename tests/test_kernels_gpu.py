@@ -66,6 +66,31 @@ def test_spline_bwd_pair_equals_two_calls(K):
         assert torch.equal(ka, pa) and torch.equal(kb, pb) and torch.equal(tb, ptb)
 
 
+def test_pair_launches_equal_two_calls(K):
+    """One-launch forms of a training step's paired work: both trajectory evaluations (every trajectory type, pose counts on
+    both sides of the 64-thread block) and the re-pack of two networks give bit for bit what the two separate calls give."""
+    rng = np.random.default_rng(6)
+    knots = dev(GI.knots_init(rng) * 3)
+    tr = dev(GI.f32(rng.uniform(-0.02, 0.02, (6,))))
+    ts_a, ts_b = dev(GI.f32([0.2, 0.35])), dev(GI.f32([0.0, 1.0]))
+    for traj in (0, 1, 2):
+        for n_a, n_b in ((2, 19), (2, 31), (70, 3)):
+            pa, pb = K.spline_poses_fwd_pair(knots, tr, ts_a, n_a, ts_b, n_b, traj)
+            assert torch.equal(pa, K.spline_poses_fwd(knots, None, ts_a, n_a, traj))
+            assert torch.equal(pb, K.spline_poses_fwd(knots, tr, ts_b, n_b, traj))
+    for C in (1, 3):
+        nets = [_packed(K, _params_for(rng, C, "xavier"), C) for _ in range(4)]
+        for i, n in enumerate(nets):
+            n.packed.zero_()            # padding the pack kernel may leave untouched compares equal
+            if i >= 2:
+                for w, w0 in zip(n.weights, nets[i - 2].weights):
+                    w.copy_(w0)
+        nets[0].pack()
+        nets[1].pack()
+        K.PackedMlp.pack_pair(nets[2], nets[3])
+        assert torch.equal(nets[0].packed, nets[2].packed) and torch.equal(nets[1].packed, nets[3].packed)
+
+
 def test_spline_no_transform(K):
     rng = np.random.default_rng(5)
     knots = GI.knots_init(rng)
