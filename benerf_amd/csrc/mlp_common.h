@@ -149,21 +149,45 @@ __host__ __device__ constexpr int64_t dw_inst_offset(int inst) {
 constexpr int64_t DW_WS_FLOATS = dw_inst_offset(DW_COUNT);
 
 // Split-f16 dW (mlp_dw_h.hip): HBM-bound, so workgroup counts follow the bytes an instance streams per point.
-//   big kernel, one workgroup per CU: a whole 256x256 instance block per workgroup (one accumulator set), 30 point-
-//     splits for each of the eight instances + 16 for the 128x256 views block: 8*30 + 16 = 256.
+//   big kernel, one workgroup per CU: a whole 256x256 instance block per workgroup (one accumulator set), 29 point-
+//     splits for each of the eight instances (1024 B per point) + 24 for the 128x256 views block (768 B): 8*29 + 24 = 256.
 //   small kernel: the thin instances (PE / PE(dir) operands, rgb head) move few bytes per chunk and are latency-
 //     bound per workgroup; 128 point-splits each = 512 light workgroups, two per CU (128 registers).
-constexpr int DWH_THIN_SPLITS = 128;
+// Split counts of the big kernel, balanced by the BYTES a workgroup streams (round 3: with 30 / 16 the views workgroups carried
+// 41 % more bytes than the others and the launch waited for them: 29 / 24 took 7 % off the dW launch).  The thin instances keep
+// 128 splits each: they are latency-bound per workgroup, byte-proportional counts (176 / 176 / 96 / 64) measured 3 % slower
+// (profiles/r03_dw_balance.log).  Overridable at compile time for experiments.
+#ifndef DWH_LS
+#define DWH_LS 29
+#endif
+#ifndef DWH_VS
+#define DWH_VS 24
+#endif
+#ifndef DWH_T0
+#define DWH_T0 128
+#endif
+#ifndef DWH_T1
+#define DWH_T1 128
+#endif
+#ifndef DWH_T2
+#define DWH_T2 128
+#endif
+constexpr int DWH_FULL_SPLITS = DWH_LS, DWH_VIEWS_SPLITS = DWH_VS;
 __host__ __device__ constexpr int dwh_splits(int inst) {
     switch (inst) {
-        case DW_VIEWSF: return 16;
-        case DW_L0: case DW_L5P: case DW_VIEWSP: case DW_RGB: return DWH_THIN_SPLITS;
-        default: return 30;
+        case DW_VIEWSF: return DWH_VIEWS_SPLITS;
+        case DW_L0: case DW_L5P: return DWH_T0;
+        case DW_VIEWSP: return DWH_T1;
+        case DW_RGB: return DWH_T2;
+        default: return DWH_FULL_SPLITS;
     }
 }
-constexpr int DWH_FULL_BLOCKS = 8 * 30;
-constexpr int DWH_BIG_BLOCKS = DWH_FULL_BLOCKS + 16;
-constexpr int DWH_SMALL_BLOCKS = 4 * DWH_THIN_SPLITS;
+constexpr int DWH_FULL_BLOCKS = 8 * DWH_FULL_SPLITS;
+constexpr int DWH_BIG_BLOCKS = DWH_FULL_BLOCKS + DWH_VIEWS_SPLITS;
+constexpr int DWH_SMALL_BLOCKS = 2 * DWH_T0 + DWH_T1 + DWH_T2;
+// thin instance and split of workgroup b of the small kernel (instances in DwInst order: L0, L5P, VIEWSP, RGB)
+__host__ __device__ constexpr int dwh_thin_inst(int b) { return b < DWH_T0 ? DW_L0 : b < 2 * DWH_T0 ? DW_L5P : b < 2 * DWH_T0 + DWH_T1 ? DW_VIEWSP : DW_RGB; }
+__host__ __device__ constexpr int dwh_thin_split(int b) { return b < DWH_T0 ? b : b < 2 * DWH_T0 ? b - DWH_T0 : b < 2 * DWH_T0 + DWH_T1 ? b - 2 * DWH_T0 : b - 2 * DWH_T0 - DWH_T1; }
 __host__ __device__ constexpr int64_t dwh_inst_offset(int inst) {
     int64_t o = 0;
     for (int i = 0; i < inst; ++i) o += dw_inst_floats(i) * dwh_splits(i);
@@ -171,6 +195,7 @@ __host__ __device__ constexpr int64_t dwh_inst_offset(int inst) {
 }
 static_assert(dwh_inst_offset(DW_COUNT) <= DW_WS_FLOATS, "split-mode partials fit the f32-mode workspace");
 static_assert(DWH_BIG_BLOCKS == 256, "one workgroup per CU");
+static_assert(DWH_SMALL_BLOCKS == 512, "two light workgroups per CU");
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global load and
 // STORE (s_waitcnt vmcnt(0)) - with ~10 KB of activations stored per point that is one HBM write latency per stage.

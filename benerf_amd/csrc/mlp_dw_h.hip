@@ -348,7 +348,7 @@ __global__ __launch_bounds__(DWT, 2) void mlp_dw_f16_big_kernel(DwArgs a) {
 // the thin instances: L0 and L5P (256 x 64, X = PE), VIEWSP (128 x 32, X = PE(dir)), rgb head (VALU)
 __global__ __launch_bounds__(DWT, 4) void mlp_dw_f16_small_kernel(DwArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32x4 smem_u[];
-    const int inst = DW_L0 + blockIdx.x / DWH_THIN_SPLITS, split = blockIdx.x % DWH_THIN_SPLITS;
+    const int inst = dwh_thin_inst(blockIdx.x), split = dwh_thin_split(blockIdx.x);
     int64_t cb, ce;
     chunk_range(a, inst, split, cb, ce);
     float* part = a.ws + dwh_inst_offset(inst) + (int64_t)split * dw_inst_floats(inst);
