@@ -149,19 +149,25 @@ __host__ __device__ constexpr int64_t dw_inst_offset(int inst) {
 constexpr int64_t DW_WS_FLOATS = dw_inst_offset(DW_COUNT);
 
 // Split-f16 dW (mlp_dw_h.hip): HBM-bound, so workgroup counts follow the bytes an instance streams per point.
-//   big kernel, one workgroup per CU: a whole 256x256 instance block per workgroup (one accumulator set), 29 point-
-//     splits for each of the eight instances (1024 B per point) + 24 for the 128x256 views block (768 B): 8*29 + 24 = 256.
+//   big kernel, one workgroup per CU: a whole 256x256 instance block per workgroup (one accumulator set); point-splits per
+//     instance as tabulated below (7 x 28 + 38 + 22 = 256).
 //   small kernel: the thin instances (PE / PE(dir) operands, rgb head) move few bytes per chunk and are latency-
 //     bound per workgroup; 128 point-splits each = 512 light workgroups, two per CU (128 registers).
-// Split counts of the big kernel, balanced by the BYTES a workgroup streams (round 3: with 30 / 16 the views workgroups carried
-// 41 % more bytes than the others and the launch waited for them: 29 / 24 took 7 % off the dW launch).  The thin instances keep
-// 128 splits each: they are latency-bound per workgroup, byte-proportional counts (176 / 176 / 96 / 64) measured 3 % slower
-// (profiles/r03_dw_balance.log).  Overridable at compile time for experiments.
+// Split counts of the big kernel, balanced by MEASURED time per point and instance (tools/experiments/trace_dw.py stamps every
+// workgroup's start and finish).  Round 3 found the launch waiting for its slowest instance: with 30 splits per 256x256 instance
+// and 16 for the views block, the views workgroups streamed 41 % more bytes than the others; after 29 / 24 the trace showed the
+// FEAT instance (which also carries the alpha head and its d_sigma stream on the VALU) 37 % behind the seven plain instances.
+// 28 / 38 / 22 lets all three kinds finish together.  The thin instances keep 128 splits each: they are latency-bound per
+// workgroup, byte-proportional counts (176 / 176 / 96 / 64) measured 3 % slower (profiles/r03_dw_balance.log).
+// Overridable at compile time for experiments.
 #ifndef DWH_LS
-#define DWH_LS 29
+#define DWH_LS 28
+#endif
+#ifndef DWH_FS
+#define DWH_FS 38
 #endif
 #ifndef DWH_VS
-#define DWH_VS 24
+#define DWH_VS 22
 #endif
 #ifndef DWH_T0
 #define DWH_T0 128
@@ -172,18 +178,21 @@ constexpr int64_t DW_WS_FLOATS = dw_inst_offset(DW_COUNT);
 #ifndef DWH_T2
 #define DWH_T2 128
 #endif
-constexpr int DWH_FULL_SPLITS = DWH_LS, DWH_VIEWS_SPLITS = DWH_VS;
 __host__ __device__ constexpr int dwh_splits(int inst) {
     switch (inst) {
-        case DW_VIEWSF: return DWH_VIEWS_SPLITS;
+        case DW_FEAT: return DWH_FS;
+        case DW_VIEWSF: return DWH_VS;
         case DW_L0: case DW_L5P: return DWH_T0;
         case DW_VIEWSP: return DWH_T1;
         case DW_RGB: return DWH_T2;
-        default: return DWH_FULL_SPLITS;
+        default: return DWH_LS;
     }
 }
-constexpr int DWH_FULL_BLOCKS = 8 * DWH_FULL_SPLITS;
-constexpr int DWH_BIG_BLOCKS = DWH_FULL_BLOCKS + DWH_VIEWS_SPLITS;
+constexpr int DWH_BIG_BLOCKS = 7 * DWH_LS + DWH_FS + DWH_VS;
+// instance and split of workgroup b of the big kernel (instances DW_L1 .. DW_VIEWSF in DwInst order)
+__host__ __device__ constexpr int dwh_big_inst(int b) { return b < 7 * DWH_LS ? b / DWH_LS : b < 7 * DWH_LS + DWH_FS ? DW_FEAT : DW_VIEWSF; }
+__host__ __device__ constexpr int dwh_big_split(int b) { return b < 7 * DWH_LS ? b % DWH_LS : b < 7 * DWH_LS + DWH_FS ? b - 7 * DWH_LS : b - 7 * DWH_LS - DWH_FS; }
+static_assert(DW_L7 == 6 && DW_FEAT == 7 && DW_VIEWSF == 8, "big-kernel instance order");
 constexpr int DWH_SMALL_BLOCKS = 2 * DWH_T0 + DWH_T1 + DWH_T2;
 // thin instance and split of workgroup b of the small kernel (instances in DwInst order: L0, L5P, VIEWSP, RGB)
 __host__ __device__ constexpr int dwh_thin_inst(int b) { return b < DWH_T0 ? DW_L0 : b < 2 * DWH_T0 ? DW_L5P : b < 2 * DWH_T0 + DWH_T1 ? DW_VIEWSP : DW_RGB; }

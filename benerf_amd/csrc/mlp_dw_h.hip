@@ -175,11 +175,14 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int64_t 
             }
             bsum += s;
         }
-        if (ALPHA && tid < K) {
+        // the alpha head rides on waves 4..7 (column tid - 256): waves 0..3 already carry the bias sums, and with both on the
+        // same four waves the FEAT workgroups were VALU-bound and finished 30 % behind every other instance (trace_dw.py)
+        if (ALPHA && tid >= DWT - K) {
+            const int ka = tid - (DWT - K);
             float s = 0.f, sb = 0.f;
 #pragma unroll
             for (int mb = 0; mb < CHB; ++mb) {
-                const half8 h = __builtin_bit_cast(half8, Xl[mb * K + tid]);
+                const half8 h = __builtin_bit_cast(half8, Xl[mb * K + ka]);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float d = da[mb * 8 + j];
@@ -229,9 +232,9 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int64_t 
                 }
     }
     if (tid < N) part[(int64_t)N * K + tid] = src.bias ? bsum : 0.f;
-    if (ALPHA && tid < K) {
-        part[(int64_t)N * K + N + tid] = asum;
-        if (tid == 0) part[(int64_t)N * K + N + 256] = absum;
+    if (ALPHA && tid >= DWT - K) {
+        part[(int64_t)N * K + N + tid - (DWT - K)] = asum;
+        if (tid == DWT - K) part[(int64_t)N * K + N + 256] = absum;
     }
 }
 
@@ -324,18 +327,19 @@ __device__ __forceinline__ void chunk_range(const DwArgs& a, int inst, int split
     if (ce > nchunks) ce = nchunks;
 }
 
+// -DBENERF_TRACE_DW: thread 0 of every workgroup stamps the 100 MHz wall clock at its start and end behind the partial sums in
+// the workspace (u64 [kernel: 0 small, 1 big][512 workgroups][2]) - tools/experiments/trace_dw.py prints per-instance finish times.
+#ifdef BENERF_TRACE_DW
+#define DW_TRACE(kern, which) do { if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(a.ws + ((dwh_inst_offset(DW_COUNT) + 63) & ~63LL))[((kern) * 512 + blockIdx.x) * 2 + (which)] = wall_clock64(); } while (0)
+#else
+#define DW_TRACE(kern, which) do { } while (0)
+#endif
+
 // the eight 256x256 instances + the 128x256 views block: one workgroup per CU, every operand byte read once
 __global__ __launch_bounds__(DWT, 2) void mlp_dw_f16_big_kernel(DwArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32x4 smem_u[];
-    const int id = blockIdx.x;
-    int inst, split;
-    if (id < DWH_FULL_BLOCKS) {
-        inst = id / dwh_splits(DW_L1);    // DW_L1 .. DW_FEAT
-        split = id % dwh_splits(DW_L1);
-    } else {
-        inst = DW_VIEWSF;
-        split = id - DWH_FULL_BLOCKS;
-    }
+    DW_TRACE(1, 0);
+    const int inst = dwh_big_inst(blockIdx.x), split = dwh_big_split(blockIdx.x);
     int64_t cb, ce;
     chunk_range(a, inst, split, cb, ce);
     float* part = a.ws + dwh_inst_offset(inst) + (int64_t)split * dw_inst_floats(inst);
@@ -343,22 +347,26 @@ __global__ __launch_bounds__(DWT, 2) void mlp_dw_f16_big_kernel(DwArgs a) {
     if (inst == DW_FEAT) dw_gemm<256, 256, 4, 2, 4, true>(a, src, cb, ce, part, smem_u);
     else if (inst <= DW_L7) dw_gemm<256, 256, 4, 2, 4, false>(a, src, cb, ce, part, smem_u);
     else dw_gemm<128, 256, 2, 2, 2, false>(a, src, cb, ce, part, smem_u);
+    DW_TRACE(1, 1);
 }
 
 // the thin instances: L0 and L5P (256 x 64, X = PE), VIEWSP (128 x 32, X = PE(dir)), rgb head (VALU)
 __global__ __launch_bounds__(DWT, 4) void mlp_dw_f16_small_kernel(DwArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32x4 smem_u[];
+    DW_TRACE(0, 0);
     const int inst = dwh_thin_inst(blockIdx.x), split = dwh_thin_split(blockIdx.x);
     int64_t cb, ce;
     chunk_range(a, inst, split, cb, ce);
     float* part = a.ws + dwh_inst_offset(inst) + (int64_t)split * dw_inst_floats(inst);
     if (inst == DW_RGB) {
         dw_rgb(a, cb * CHB, ce * CHB, part, reinterpret_cast<float*>(smem_u));
+        DW_TRACE(0, 1);
         return;
     }
     const Src src = inst_src(a, inst);
     if (inst == DW_VIEWSP) dw_gemm<128, 32, 4, 1, 1, false, true>(a, src, cb, ce, part, smem_u);
     else dw_gemm<256, 64, 4, 2, 1, false, true>(a, src, cb, ce, part, smem_u);   // DW_L0, DW_L5P
+    DW_TRACE(0, 1);
 }
 
 }  // namespace
