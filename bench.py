@@ -410,44 +410,28 @@ def main():
     Re_g, Rr_g = wl["Re"] * world, wl["Rr"] * world
 
     # Inputs of a step - event-window accumulation (K7), window times, pixel draws - are a data loader's job: step k + 1's are
-    # prepared on a second stream while step k computes (two image buffers), like any input pipeline; everything stays inside
-    # the timed region.  The pixel draws are a keyed bijection (np.random.choice(..., replace=False) in train.py), identical
-    # on every rank; TrainStep shards them.
-    main_stream = torch.cuda.current_stream(device)
-    loader = torch.cuda.Stream(device)
-    accus = [accu, torch.zeros_like(accu)]
-    freed = [None, None]          # main-stream event behind the last step that read accus[i]
+    # prepared inside step k, in TrainStep.step's `overlap` slot (main stream, behind the last backward launch, while the
+    # weight-gradient launches of the side stream finish) - like any input pipeline; everything stays inside the timed
+    # region.  Same stream as the step's own reads of the event image, so one buffer is enough.  The pixel draws are a keyed
+    # bijection (np.random.choice(..., replace=False) in train.py), identical on every rank; TrainStep shards them.
     queue = []
 
     def prepare(k):
         low_t = float(rng.random() * (1 - wl["window"]))
         up_t = low_t + wl["window"]
-        buf = accus[k % 2]
-        with torch.cuda.stream(loader):
-            if freed[k % 2] is not None:
-                loader.wait_event(freed[k % 2])
-            buf.zero_()
-            K.event_window_accumulate(ev_x, ev_y, ev_p, ev_t, low_t, up_t, cam["H"], cam["W"], out=buf)
-            evt_ts = torch.tensor([low_t, up_t], dtype=torch.float32).to(device, non_blocking=True)
-            idx_e = K.sample_pixels(HW, Re_g, a.seed + 1234, 2 * k + 2, device)
-            idx_r = K.sample_pixels(HW, Rr_g, a.seed + 1234, 2 * k + 3, device)
-            for t in (evt_ts, idx_e, idx_r):
-                t.record_stream(main_stream)      # allocated on the loader's stream, consumed on the main one
-            ready = loader.record_event()
-        queue.append((k, ready, evt_ts, idx_e, idx_r, buf))
-
-    counter = [0]
+        accu.zero_()
+        K.event_window_accumulate(ev_x, ev_y, ev_p, ev_t, low_t, up_t, cam["H"], cam["W"], out=accu)
+        evt_ts = torch.full((2,), low_t, dtype=torch.float32, device=device)      # scalars by value: no host buffer to keep alive
+        evt_ts[1:].fill_(up_t)
+        idx_e = K.sample_pixels(HW, Re_g, a.seed + 1234, 2 * k + 2, device)
+        idx_r = K.sample_pixels(HW, Rr_g, a.seed + 1234, 2 * k + 3, device)
+        queue.append((k, evt_ts, idx_e, idx_r))
 
     def one_step():
         if not queue:
-            prepare(counter[0])
-        k, ready, evt_ts, idx_e, idx_r, buf = queue.pop(0)
-        main_stream.wait_event(ready)
-        out = step.step(evt_ts, rgb_ts, idx_e, idx_r, buf.view(-1), image)
-        freed[k % 2] = main_stream.record_event()
-        counter[0] = k + 1
-        prepare(k + 1)
-        return out
+            prepare(0)
+        k, evt_ts, idx_e, idx_r = queue.pop(0)
+        return step.step(evt_ts, rgb_ts, idx_e, idx_r, accu.view(-1), image, overlap=lambda: prepare(k + 1))
 
     def sync():
         if world > 1:

@@ -392,11 +392,15 @@ class TrainStep:
         return dist.shard_indices(idx, self.rank, self.world)
 
     def step(self, evt_ts2, rgb_ts2, idx_evt_global, idx_rgb_global, events_accu, image, draws_evt=None,
-             draws_rgb=None, z_fine_forced=None):
+             draws_rgb=None, z_fine_forced=None, overlap=None):
         """evt_ts2/rgb_ts2: [2] device floats; idx_*_global: int64 device pixel indices (global batch,
         identical on every rank); events_accu [H_e*W_e] float32 device; image [H*W, C] float32 device.
         z_fine_forced [N, S+Ni]: parity runs may supply the merged fine depths instead of K5's (sample_pdf is
-        ill-conditioned in the coarse weights: isolates everything behind it)."""
+        ill-conditioned in the coarse weights: isolates everything behind it).
+        overlap: optional callable, run on the main stream behind the step's last backward launch and before the step waits
+        for its weight-gradient stream - where the main stream has ~0.6 ms of slack at C2.  For work that touches neither this
+        step's parameters nor its gradients, e.g. preparing the NEXT batch's inputs (this step's reads of events_accu / image /
+        the index vectors are already queued ahead of it on the same stream)."""
         cfg, C, dev = self.cfg, self.C, self.dev
         # range guard: a run whose steps keep being skipped on the device must not go on silently - looks at the last copy
         # of the counters that has landed in pinned host memory (no synchronisation)
@@ -528,6 +532,8 @@ class TrainStep:
         if self.world > 1:
             self.guard.gate(self.flag, phase=0)
         pending.append(dist.allreduce_sum_async_(self.flat_g[2 * n:], self.world, self.pg))
+        if overlap is not None:
+            overlap()
         with torch.cuda.stream(side):
             for w in pending[:2]:
                 w.wait()
