@@ -45,3 +45,25 @@ for b in range(512):
     g[int(key[b])].append(b)
 print("distinct CU keys among first 512 blocks:", len(g), "sizes", collections.Counter(len(v) for v in g.values()))
 print("examples", list(g.values())[:6])
+
+# gaps between consecutive workgroups in one CU slot: a CU holds two dX workgroups at a time; when one finishes, how long until
+# the next one of the launch starts there?  (finish = last stamp, TR(42); start = TR(0))
+slots = collections.defaultdict(list)
+for b in range(2048):
+    slots[int(key[b])].append((int(t[b, 0]), int(t[b, 42]), b))
+gaps, durs = [], []
+for k_, lst in slots.items():
+    lst.sort()
+    ends = []
+    for s_, e_, b_ in lst:
+        durs.append(e_ - s_)
+        free = [x for x in ends if x <= s_]
+        if free:            # the slot this workgroup took over: the latest finish before its start
+            prev = max(free)
+            gaps.append(s_ - prev)
+            ends.remove(prev)
+        ends.append(e_)
+gaps, durs = np.array(gaps), np.array(durs)
+print("workgroup duration (10 ns): median %d, p10 %d, p90 %d" % (np.median(durs), np.percentile(durs, 10), np.percentile(durs, 90)))
+print("gap between a workgroup's finish and its successor's start on the same CU (10 ns): median %d, p10 %d, p90 %d, n = %d"
+      % (np.median(gaps), np.percentile(gaps, 10), np.percentile(gaps, 90), len(gaps)))
