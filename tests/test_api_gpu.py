@@ -503,6 +503,48 @@ def test_train_step_range_guard_skips_counts_and_raises():
     assert not torch.equal(step.flat_p, good)
 
 
+def test_train_step_overlap_slot():
+    """TrainStep.step(overlap=f): f runs exactly once per step, on the step's main stream, and work queued in it (here: the
+    NEXT step's event image and pixel draws, written into the buffers the current step has already read) changes neither this
+    step's result nor the next one's - two steps with the slot equal two steps with everything prepared up front, bit for bit."""
+    from benerf_amd import engine, kernels as K, workloads as WL
+    wl = dict(WL.WORKLOADS["C1"], S=16, Ni=16, Re=32, Rr=4, n=5)
+    args = WL.make_args(wl, optimize_trans=True)
+    cam = WL.CAMERAS[wl["cam"]]
+    cam_o = engine.Camera(cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+    HW = cam["H"] * cam["W"]
+    rng = np.random.default_rng(31)
+    accus = [torch.from_numpy(rng.integers(-3, 4, HW).astype(np.float32)).to(DEV) for _ in range(2)]
+    idxs = [(torch.from_numpy(rng.permutation(HW)[:32]).to(DEV), torch.from_numpy(rng.permutation(HW)[:4]).to(DEV)) for _ in range(2)]
+    img = torch.from_numpy(rng.random((HW, 1)).astype(np.float32)).to(DEV)
+    ets, rts = torch.tensor([0.2, 0.3], device=DEV), torch.tensor([0.0, 1.0], device=DEV)
+    res = []
+    for use_slot in (False, True):
+        _, g = _graph(args, seed=23)
+        step = engine.TrainStep(g, args, cam_o, cam_o, torch.device(DEV), seed=5)
+        calls = []
+        if not use_slot:
+            l0 = step.step(ets, rts, idxs[0][0], idxs[0][1], accus[0], img)
+            l1 = step.step(ets, rts, idxs[1][0], idxs[1][1], accus[1], img)
+        else:
+            accu = accus[0].clone()
+            ie, ir = idxs[0][0].clone(), idxs[0][1].clone()
+
+            def prepare_next():
+                calls.append(torch.cuda.current_stream().cuda_stream)
+                accu.copy_(accus[1])          # same buffers the running step was given: its reads are queued ahead
+                ie.copy_(idxs[1][0])
+                ir.copy_(idxs[1][1])
+            main = torch.cuda.current_stream().cuda_stream
+            l0 = step.step(ets, rts, ie, ir, accu, img, overlap=prepare_next)
+            assert calls == [main]
+            l1 = step.step(ets, rts, ie, ir, accu, img)
+        step.check_range()
+        res.append((l0.cpu().numpy(), l1.cpu().numpy(), step.flat_p.cpu().numpy()))
+    for a, b, what in zip(res[0], res[1], ("first step's losses", "second step's losses", "parameters after two steps")):
+        assert np.array_equal(a, b), what
+
+
 def test_train_step_skips_a_nonfinite_loss_gradient():
     """Both arithmetic modes: a NaN parameter (here the fine network's colour bias; a NaN density is clamped away by the
     compositing kernel's relu, fmaxf(NaN, 0) = 0) makes raw, the loss and d_raw NaN - the
