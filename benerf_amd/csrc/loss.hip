@@ -112,7 +112,7 @@ __global__ void loss_grads_kernel(BenerfLossCfg cfg, const double* __restrict__ 
     const bool syn = cfg.event_threshold > 0.f;
     const double thr = syn ? (double)cfg.event_threshold : 1.0;
     const double coeff = (double)cfg.event_coeff;
-    const double s_tt = stats[6];
+    const double s_tt = stats ? stats[6] : 0.0;      // stats == NULL: gradient-only call for mean-squared losses (launcher checks)
     const double n_t = sqrt(s_tt), sc_t = n_t + 1e-9;
     int tid = blockIdx.x * blockDim.x + threadIdx.x;
     int nth = gridDim.x * blockDim.x;
@@ -221,7 +221,8 @@ extern "C" int benerf_loss_grads(const BenerfLossCfg* cfg, const double* stats, 
                                  float* d_rgb0_evt, float* d_rgb_rgb, float* d_rgb0_rgb, benerf_stream_t stream) {
     int rc = check_cfg(cfg, "loss_grads");
     if (rc) return rc;
-    BENERF_REQUIRE(stats, "loss_grads: null stats");
+    BENERF_REQUIRE(stats || (!losses && (!rgb_evt || cfg->event_threshold > 0.f)),
+                   "loss_grads: stats may only be NULL for a gradient-only call (losses == NULL) without the L2-normalised event loss");
     BENERF_REQUIRE(!rgb_evt || (rgb0_evt && target_acc), "loss_grads: event inputs incomplete");
     BENERF_REQUIRE(!rgb_rgb || (rgb0_rgb && target_rgb), "loss_grads: rgb inputs incomplete");
     int work = 2 * cfg->n_evt_pix + 2 * cfg->n_rgb_pix * cfg->channels;

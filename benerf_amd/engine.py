@@ -466,19 +466,20 @@ class TrainStep:
             rgb_map, rgb0 = mapped[0].detach(), mapped[1].detach()
         largs = ((rgb_map[:Ne], rgb0[:Ne], target_acc) if use_e else (None, None, None)) + \
                 ((rgb_map[Ne:], rgb0[Ne:], target_rgb) if use_r else (None, None, None))
-        stats = K.loss_stats(lcfg, *largs)
-        # Data-parallel: the L2-normalised event loss (train.py:238-292) needs the GLOBAL sums of squares before its gradient - a
-        # blocking 16-double exchange in the middle of the step.  The mean-squared losses do not: their gradients use the global
-        # COUNTS only and the reported values are linear in the sums, so every rank computes its part and the 8 loss values are
-        # summed asynchronously behind the gradient buckets, off the critical path.
+        # The L2-normalised event loss (train.py:238-292) needs the sums of squares - GLOBAL ones when data-parallel: a blocking
+        # 16-double exchange - before its gradient.  The mean-squared losses do not: their gradients use the global COUNTS only,
+        # so the gradient launch goes first and the sums + loss values follow behind the backward launches, off the critical
+        # path (values are linear in the sums: every rank computes its part, the 8 numbers are summed asynchronously).
         stats_first = use_e and not syn
         if stats_first:
+            stats = K.loss_stats(lcfg, *largs)
             dist.allreduce_sum_(stats, self.world, self.pg)
         g_rgb = torch.empty_like(rgb_map) if (use_e and use_r) else torch.zeros_like(rgb_map)
         g_rgb0 = torch.empty_like(rgb0) if (use_e and use_r) else torch.zeros_like(rgb0)
-        losses, _ = K.loss_grads(lcfg, stats, *largs, out=((g_rgb[:Ne], g_rgb0[:Ne]) if use_e else (None, None)) +
-                                 ((g_rgb[Ne:], g_rgb0[Ne:]) if use_r else (None, None)))
-        loss_sum = None if stats_first else dist.allreduce_sum_async_(losses, self.world, self.pg)
+        losses, _ = K.loss_grads(lcfg, stats if stats_first else None, *largs,
+                                 out=((g_rgb[:Ne], g_rgb0[:Ne]) if use_e else (None, None)) + ((g_rgb[Ne:], g_rgb0[Ne:]) if use_r else (None, None)),
+                                 want_losses=stats_first)
+        loss_sum = None
 
         if crf:   # gradients w.r.t. the tone-mapped colours -> the rendered colours and the tone-mapper parameters
             for p_ in self.crf_params:
@@ -532,6 +533,10 @@ class TrainStep:
         if self.world > 1:
             self.guard.gate(self.flag, phase=0)
         pending.append(dist.allreduce_sum_async_(self.flat_g[2 * n:], self.world, self.pg))
+        if not stats_first:      # loss values of the mean-squared losses: in the main stream's slack, like the caller's overlap work
+            stats = K.loss_stats(lcfg, *largs)
+            losses, _ = K.loss_grads(lcfg, stats, *largs, want_grads=False)
+            loss_sum = dist.allreduce_sum_async_(losses, self.world, self.pg)
         if overlap is not None:
             overlap()
         with torch.cuda.stream(side):

@@ -555,17 +555,22 @@ def loss_stats(cfg, rgb_evt, rgb0_evt, target_acc, rgb_rgb, rgb0_rgb, target_rgb
     return stats
 
 
-def loss_grads(cfg, stats, rgb_evt, rgb0_evt, target_acc, rgb_rgb, rgb0_rgb, target_rgb, out=None):
+def loss_grads(cfg, stats, rgb_evt, rgb0_evt, target_acc, rgb_rgb, rgb0_rgb, target_rgb, out=None, want_losses=True,
+               want_grads=True):
+    """Returns (losses [8] or None, [four gradient tensors or None]).  want_losses=False with stats=None: gradient-only call
+    (mean-squared losses need no sums); want_grads=False: loss values only."""
     lib = _lib.load()
     ref = rgb_evt if rgb_evt is not None else rgb_rgb
-    losses = torch.empty(8, dtype=torch.float32, device=ref.device)
-    if out is not None:
+    losses = torch.empty(8, dtype=torch.float32, device=ref.device) if want_losses else None
+    if not want_grads:
+        g = [None] * 4
+    elif out is not None:
         g = list(out)
     else:
         g = [None if t is None else torch.empty_like(t) for t in (rgb_evt, rgb0_evt, rgb_rgb, rgb0_rgb)]
     _lib.check(lib.benerf_loss_grads(ctypes.byref(cfg), _chk(stats, torch.float64), _chk(rgb_evt), _chk(rgb0_evt),
                                      _chk(target_acc), _chk(rgb_rgb), _chk(rgb0_rgb), _chk(target_rgb),
-                                     losses.data_ptr(), _chk(g[0]), _chk(g[1]), _chk(g[2]), _chk(g[3]), _stream()),
+                                     _chk(losses), _chk(g[0]), _chk(g[1]), _chk(g[2]), _chk(g[3]), _stream()),
                "loss_grads")
     return losses, g
 

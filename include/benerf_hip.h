@@ -317,7 +317,10 @@ int benerf_loss_stats(const BenerfLossCfg* cfg, const float* rgb_evt, const floa
                       const float* target_rgb, double* stats, benerf_stream_t stream);
 /* Pass 2: loss values (losses[8] floats: total, event, event_fine, event_coarse, rgb,
  * rgb_fine, rgb_coarse, 0) and gradients w.r.t. the four rendered colour arrays.
- * Replaces train.py:163-337 + loss/imgloss.py:3-5 + utils/img_utils.py:7-16. */
+ * Replaces train.py:163-337 + loss/imgloss.py:3-5 + utils/img_utils.py:7-16.
+ * losses and any gradient pointer may be NULL.  The gradients of the mean-squared losses (event_threshold > 0, and the
+ * blur loss) use the global COUNTS only: a gradient-only call (losses == NULL) may pass stats == NULL then - pass 1 and a
+ * values-only call (all gradient pointers NULL) can follow off the critical path. */
 int benerf_loss_grads(const BenerfLossCfg* cfg, const double* stats, const float* rgb_evt,
                       const float* rgb0_evt, const float* target_acc, const float* rgb_rgb,
                       const float* rgb0_rgb, const float* target_rgb, float* losses,
