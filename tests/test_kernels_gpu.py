@@ -562,6 +562,49 @@ def test_mlp_modes_agree_at_full_size(K, C, N, S):
             report("K3 full size, split vs f32: |d%s.%s|" % (name, kind), x.norm().reshape(1), y.norm().reshape(1), rtol=3e-4)
 
 
+@pytest.mark.parametrize("N,S", [(1, 1), (1, 31), (3, 11), (2, 64), (5, 77), (37, 100), (300, 29), (700, 143)])
+def test_mlp_modes_agree_at_ragged_sizes(K, N, S):
+    """Point counts on every side of the kernels' granules - one point, less than a 32-point dW chunk, less than a 128-point
+    tile, fewer chunks than an instance has point-splits (38 for FEAT, 28 / 22 for the others: most workgroups of the dW
+    launch get an empty range), ragged last chunk / tile: the split-f16 mode against the exact-f32 mode, forward and backward."""
+    rng = np.random.default_rng(9000 + 7 * N + S)
+    C = 3
+    p = _params_for(rng, C, "trained")
+    net = _packed(K, p, C)
+    ro = dev(GI.f32(rng.uniform(-0.5, 0.5, (N, 3))))
+    rd = dev(GI.f32(rng.uniform(-1, 1, (N, 3))))
+    vd = torch.nn.functional.normalize(dev(GI.f32(rng.standard_normal((N, 3)))), dim=-1)
+    z = dev(GI.f32(np.sort(rng.random((N, S)), -1)))
+    G = dev(GI.f32(rng.standard_normal((N * S, C + 1)) / (N * S)))
+    out = {}
+    for mode in ("f32", "split"):
+        K.set_mlp_precision(mode)
+        raw, acts = K.mlp_fwd(net, ro, rd, vd, z, True)
+        gw = [torch.full_like(w, float("nan")) for w in net.weights]       # every entry must be written
+        gb = [torch.full_like(b, float("nan")) for b in net.biases]
+        d_pts, d_vd = K.mlp_bwd(net, G, acts, N, S, gw, gb, False)
+        out[mode] = (raw.clone(), d_pts.clone(), d_vd.clone(), gw, gb)
+    K.set_mlp_precision("split")
+    a, b = out["f32"], out["split"]
+    report("K3 ragged %dx%d, split vs f32: raw" % (N, S), b[0], a[0], atol=2e-6 * float(a[0].abs().max()), rtol=1e-5)
+    # per-point gradients: within 1e-3 of the largest entry except the few points whose ReLU mask differs between the two
+    # forward arithmetics (test_mlp_modes_agree_at_full_size), small L2 distance
+    for nm, x, y in (("d_pts", b[1], a[1]), ("d_viewdirs", b[2], a[2])):
+        tol = 1e-3 * float(y.abs().max()) + 1e-3 * y.abs()
+        bad = int(((x - y).abs() > tol).any(dim=-1).sum())
+        rel_l2 = float((x - y).norm() / y.norm())
+        print("K3 ragged %dx%d, split vs f32: %s  points beyond 1e-3 of the largest entry: %d of %d, relative L2 distance %.2e" % (N, S, nm, bad, y.shape[0], rel_l2))
+        assert bad <= max(1, y.shape[0] // 500) and rel_l2 < 2e-2, nm
+    for i, name in enumerate(K.LAYER_NAMES):
+        for kind, x, y in (("weight", b[3][i], a[3][i]), ("bias", b[4][i], a[4][i])):
+            assert bool(torch.isfinite(x).all()) and bool(torch.isfinite(y).all()), "d%s.%s has unwritten entries" % (name, kind)
+            # a ReLU mask that differs between the two forward arithmetics moves an entry by one point's whole term (with a few
+            # thousand points that is percents of an entry): 5e-2 of the largest entry, 2e-2 in L2 - a wrong chunk range or an
+            # unwritten partial sum would be an O(1) error
+            report("K3 ragged %dx%d, split vs f32: d%s.%s" % (N, S, name, kind), x, y, atol=5e-2 * float(y.abs().max()) + 1e-12, rtol=1e-3)
+            assert float((x - y).norm()) <= 2e-2 * float(y.norm()) + 1e-12, "d%s.%s: relative L2 distance" % (name, kind)
+
+
 @pytest.mark.parametrize("wscale,gscale", [(3.0, 1.0), (0.35, 1e-12), (1.0, 1e6)])
 def test_mlp_split_operand_rescale_ranges(K, wscale, gscale):
     """The split dW kernels rescale activations and gradients by per-launch powers of two (from published maxima) so
