@@ -105,19 +105,19 @@ __host__ __device__ constexpr int layer_out(int l, int C) {
 // GEMM instances of the dW kernel (dW = dY^T X over all points), each split DW_SPLITS ways
 // along the point dimension; partials are summed in fixed order by the reduce kernel.
 enum DwInst { DW_L1 = 0, DW_L2, DW_L3, DW_L4, DW_L5H, DW_L6, DW_L7, DW_FEAT, DW_VIEWSF, DW_L0, DW_L5P, DW_VIEWSP, DW_RGB, DW_COUNT };
-// Split counts follow the instance's cost per point so that every workgroup carries about the
-// same time and the grid is exactly 2 x 256 workgroups (one per CU, two rounds).  The MFMA
-// instances scale 256x256 : 128x256 : 256x64 = 4 : 2 : 1; the two tiny ones (128x32 block, VALU
-// rgb head) are latency-bound per chunk, not MFMA-bound, and get more splits than their FLOPs
-// suggest:  8*52 + 28 + 14 + 14 + 16 + 24 = 512.
+// Split counts (exact-f32 kernel, mlp_dw.hip): 512 workgroups that run as two rounds of one per CU, so every workgroup
+// should take the same time.  Counts are proportional to MEASURED workgroup-time per instance (tools/experiments/trace_dw.py
+// on a tracing build, 522 k points; round 3 - the FLOP-proportional table 8*52 + 28 + 14 + 14 + 16 + 24 left the second round
+// waiting for the L0 workgroups while the VIEWSP / RGB ones idled for 2 of its 3 ms):  7*54 + 58 + 29 + 17 + 16 + 7 + 7 = 512.
 __host__ __device__ constexpr int dw_splits(int inst) {
     switch (inst) {
-        case DW_VIEWSF: return 28;
-        case DW_L0: return 14;
-        case DW_L5P: return 14;
-        case DW_VIEWSP: return 16;
-        case DW_RGB: return 24;
-        default: return 52;
+        case DW_FEAT: return 58;        // + alpha head
+        case DW_VIEWSF: return 29;
+        case DW_L0: return 17;
+        case DW_L5P: return 16;
+        case DW_VIEWSP: return 7;
+        case DW_RGB: return 7;
+        default: return 54;
     }
 }
 __host__ __device__ constexpr int dw_block_base(int inst) {   // first workgroup id of an instance

@@ -173,7 +173,9 @@ __device__ __forceinline__ void dw_rgb(const DwArgs& a, int64_t row_begin, int64
     const int tid = threadIdx.x, j = tid & 127, half = tid >> 7;   // half = row phase 0..3 (512 threads)
     const float* hv = a.acts + act_hv(a.M);
     const int C = a.C;
-    float s[3] = {0.f, 0.f, 0.f}, sb[3] = {0.f, 0.f, 0.f};
+    // a workgroup's share is tens of thousands of rows per thread (7 point-splits): the running sums are kept in double and fed
+    // with f32 partial sums of 8 rows, so the rounding of this head does not grow with the length of the share
+    double s[3] = {0.0, 0.0, 0.0}, sb[3] = {0.0, 0.0, 0.0};
     // 8 rows in flight per thread (independent loads), fixed summation order
     constexpr int U = 8;
     int64_t mrow = row_begin + half;
@@ -185,13 +187,19 @@ __device__ __forceinline__ void dw_rgb(const DwArgs& a, int64_t row_begin, int64
 #pragma unroll
             for (int c = 0; c < 3; ++c) g[q][c] = c < C ? a.d_raw[(mrow + 4 * q) * (C + 1) + c] : 0.f;
         }
+        float ts[3] = {0.f, 0.f, 0.f}, tb[3] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < U; ++q)
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                s[c] += g[q][c] * h[q];
-                sb[c] += g[q][c];
+                ts[c] += g[q][c] * h[q];
+                tb[c] += g[q][c];
             }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            s[c] += (double)ts[c];
+            sb[c] += (double)tb[c];
+        }
     }
     for (; mrow < row_end; mrow += 4) {
         const float h = hv[mrow * ACT_HV_W + j];
@@ -206,8 +214,8 @@ __device__ __forceinline__ void dw_rgb(const DwArgs& a, int64_t row_begin, int64
     if (half > 0) {   // phases 1..3 -> LDS [phase-1][{w,b}][3][128]
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            smem[((half - 1) * 6 + c) * 128 + j] = s[c];
-            smem[((half - 1) * 6 + 3 + c) * 128 + j] = sb[c];
+            smem[((half - 1) * 6 + c) * 128 + j] = (float)s[c];
+            smem[((half - 1) * 6 + 3 + c) * 128 + j] = (float)sb[c];
         }
     }
     __syncthreads();
@@ -215,13 +223,13 @@ __device__ __forceinline__ void dw_rgb(const DwArgs& a, int64_t row_begin, int64
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             float v = 0.f;
-            if (c < 3 && c < C) v = ((s[c] + smem[(0 * 6 + c) * 128 + j]) + smem[(1 * 6 + c) * 128 + j]) + smem[(2 * 6 + c) * 128 + j];
+            if (c < 3 && c < C) v = (((float)s[c] + smem[(0 * 6 + c) * 128 + j]) + smem[(1 * 6 + c) * 128 + j]) + smem[(2 * 6 + c) * 128 + j];
             part[c * 128 + j] = v;
         }
         if (j < 4) {
             float v = 0.f;
             if (j < 3 && j < C) {
-                const float own = j == 0 ? sb[0] : j == 1 ? sb[1] : sb[2];
+                const float own = (float)(j == 0 ? sb[0] : j == 1 ? sb[1] : sb[2]);
                 v = ((own + smem[(0 * 6 + 3 + j) * 128 + j]) + smem[(1 * 6 + 3 + j) * 128 + j]) + smem[(2 * 6 + 3 + j) * 128 + j];
             }
             part[4 * 128 + j] = v;
@@ -229,8 +237,18 @@ __device__ __forceinline__ void dw_rgb(const DwArgs& a, int64_t row_begin, int64
     }
 }
 
+// -DBENERF_TRACE_DW: thread 0 of every workgroup stamps the 100 MHz wall clock at its start and end behind the partial sums
+// (u64 [512 workgroups][2] at ws + DW_WS_FLOATS; benerf_mlp_dw_workspace_floats grows by 4096 in such a build) -
+// tools/experiments/trace_dw.py f32
+#ifdef BENERF_TRACE_DW
+#define DW32_TRACE(which) do { if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(a.ws + DW_WS_FLOATS)[blockIdx.x * 2 + (which)] = wall_clock64(); } while (0)
+#else
+#define DW32_TRACE(which) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(DWT, 2) void mlp_dw_kernel(DwArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    DW32_TRACE(0);
     // workgroup -> (instance, split); instances in cost order, split counts proportional to cost
     int split = blockIdx.x, inst = 0;
     while (split >= dw_splits(inst)) {
@@ -248,6 +266,7 @@ __global__ __launch_bounds__(DWT, 2) void mlp_dw_kernel(DwArgs a) {
         if (re > a.M) re = a.M;
         if (rb > a.M) rb = a.M;
         dw_rgb(a, rb, re, part, smem);
+        DW32_TRACE(1);
         return;
     }
     const InstSrc src = inst_src(a, inst);
@@ -256,6 +275,7 @@ __global__ __launch_bounds__(DWT, 2) void mlp_dw_kernel(DwArgs a) {
     else if (inst == DW_VIEWSF) dw_gemm<128, 256, 4, false>(a, src, cb, ce, part, smem);
     else if (inst == DW_VIEWSP) dw_gemm<128, 32, 4, false>(a, src, cb, ce, part, smem);
     else dw_gemm<256, 64, 8, false>(a, src, cb, ce, part, smem);   // DW_L0, DW_L5P
+    DW32_TRACE(1);
 }
 
 constexpr size_t DW_SMEM = (size_t)(CH * 256 + CH * 256 + CH) * sizeof(float);

@@ -135,7 +135,11 @@ extern "C" size_t benerf_mlp_dact_floats(int64_t n_points) {
 }
 extern "C" size_t benerf_mlp_dw_workspace_floats(int64_t n_points) {
     (void)n_points;
+#ifdef BENERF_TRACE_DW
+    return (size_t)mlp::DW_WS_FLOATS + 4096;      // room for the tracing builds' time stamps (mlp_dw.hip)
+#else
     return (size_t)mlp::DW_WS_FLOATS;
+#endif
 }
 
 extern "C" int benerf_mlp_pack_weights(const BenerfMlpParams* params, int channels, float* packed,

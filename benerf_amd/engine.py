@@ -362,7 +362,7 @@ class TrainStep:
                 group["lr"] = lr
                 for p in group["params"]:
                     off, n = self._flat_slice(p)
-                    opt.state[p] = {"step": torch.tensor(float(self.global_step)),
+                    opt.state[p] = {"step": torch.tensor(float(self.global_step), device="cpu"),
                                     "exp_avg": self.flat_m[off:off + n].view_as(p).clone(),
                                     "exp_avg_sq": self.flat_v[off:off + n].view_as(p).clone()}
 

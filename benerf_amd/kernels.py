@@ -261,7 +261,7 @@ class RangeGuard:
 
     def post(self):
         if self._mirror is None:
-            self._mirror = torch.zeros(_lib.ST_WORDS, dtype=torch.int32).pin_memory()
+            self._mirror = torch.zeros(_lib.ST_WORDS, dtype=torch.int32, device="cpu").pin_memory()   # explicit: the reference's drivers make CUDA the default tensor type
             self._event = torch.cuda.Event()
         self._mirror.copy_(self.words, non_blocking=True)
         self._event.record()

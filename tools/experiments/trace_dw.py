@@ -43,6 +43,29 @@ torch.cuda.synchronize()
 full, feat, views, thin0, thin1, rgb = 256 * 256 + 256, 256 * 256 + 256 + 257, 128 * 256 + 128, 256 * 64 + 256, 128 * 32 + 128, 4 * 128 + 4
 used = 7 * LS * full + FS * feat + VS * views + 2 * THIN * thin0 + THIN * thin1 + THIN * rgb
 off = (used + 63) & ~63
+if os.environ.get("BENERF_MLP_PRECISION", "split") == "f32":
+    # exact-f32 kernel (mlp_dw.hip): one launch of 512 workgroups; split counts of mlp_common.h dw_splits(), overridable here
+    # as "name=count,..." in TRACE_DW_SPLITS for variant builds
+    splits = dict(L=52, VIEWSF=28, L0=14, L5P=14, VIEWSP=16, RGB=24)
+    for kv in filter(None, os.environ.get("TRACE_DW_SPLITS", "").split(",")):
+        k_, v_ = kv.split("=")
+        splits[k_] = int(v_)
+    order = [("L%d" % (i + 1) if i != 4 else "L5H", splits["L"]) for i in range(7)] + [("FEAT", splits.get("FEAT", splits["L"])), ("VIEWSF", splits["VIEWSF"]),
+                                                                                     ("L0", splits["L0"]), ("L5P", splits["L5P"]), ("VIEWSP", splits["VIEWSP"]), ("RGB", splits["RGB"])]
+    n_wg = sum(c for _, c in order)
+    ws = K.scratch("dw_ws", 0, dev)
+    lib = __import__("benerf_amd._lib", fromlist=["load"]).load()
+    base = lib.benerf_mlp_dw_workspace_floats(n_rays * n_samples) - 4096
+    t = ws[base:base + n_wg * 4].view(torch.int64).cpu().numpy().reshape(n_wg, 2)
+    t0 = t[:, 0].min()
+    print("f32 dW kernel: %d workgroups, span %.1f us; starts within %.1f us" % (n_wg, (t[:, 1].max() - t0) / 100.0, (t[:, 0].max() - t0) / 100.0))
+    b0 = 0
+    for name, cnt in order:
+        e = (t[b0:b0 + cnt, 1] - t0) / 100.0
+        s_ = (t[b0:b0 + cnt, 0] - t0) / 100.0
+        print("   %-7s x%-3d start median %.1f  finish min %.1f  median %.1f  max %.1f us" % (name, cnt, float(np.median(s_)), e.min(), float(np.median(e)), e.max()))
+        b0 += cnt
+    sys.exit(0)
 ws = K.scratch("dw_ws", 0, dev)
 t = ws[off:off + 2 * 512 * 2 * 2].view(torch.int64).cpu().numpy().reshape(2, 512, 2)
 names_big = ["L1", "L2", "L3", "L4", "L5H", "L6", "L7", "FEAT"]
