@@ -426,6 +426,7 @@ def main():
         idx_e = K.sample_pixels(HW, Re_g, a.seed + 1234, 2 * k + 2, device)
         idx_r = K.sample_pixels(HW, Rr_g, a.seed + 1234, 2 * k + 3, device)
         queue.append((k, evt_ts, idx_e, idx_r))
+        return evt_ts, rgb_ts, idx_e, idx_r       # TrainStep sets up the poses / rays / depths of these in the same slack
 
     def one_step():
         if not queue:

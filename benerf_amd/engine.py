@@ -328,6 +328,7 @@ class TrainStep:
             self.crf_groups.append((first, oc - first, lr0, dr, slot))
         self.off_crf = o + 31
         self.global_step = 0
+        self._prefetched = None     # next step's ray set-up, computed in this step's slack (step(overlap=...))
         # replicas start from rank 0's parameters (and its - zero - Adam state), whatever their local initialisation was
         for buf in (self.flat_p, self.flat_m, self.flat_v):
             dist.broadcast_(buf, self.world, 0, self.pg)
@@ -379,6 +380,7 @@ class TrainStep:
                     self.flat_m[off:off + n].copy_(st["exp_avg"].reshape(-1))
                     self.flat_v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
         self.global_step = int(global_step)
+        self._prefetched = None
         self.net_c.packed.pack()
         self.net_f.packed.pack()
 
@@ -391,6 +393,25 @@ class TrainStep:
         """Contiguous slice of a global pixel-index vector for this rank."""
         return dist.shard_indices(idx, self.rank, self.world)
 
+    def _ray_setup(self, evt_ts2, rgb_ts2, idx_e, idx_r, d):
+        """Poses of both trajectories (K1), rays of both batches (K2), stratified coarse depths: everything in front of the
+        first MLP launch.  idx_*: this rank's shard; d: the step's Draws."""
+        cfg, dev = self.cfg, self.dev
+        P, S = cfg.num_interpolated_pose, cfg.N_samples
+        Ne, Nr = 2 * idx_e.shape[0], P * idx_r.shape[0]
+        N = Ne + Nr
+        traj = 1 if cfg.traj == "linear" else 0
+        poses_e, poses_r = K.spline_poses_fwd_pair(self.knots, self.transform.view(6), evt_ts2, 2, rgb_ts2, P, traj)
+        ro = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        rd = torch.empty_like(ro)
+        vd = torch.empty_like(ro)
+        ce, cr = self.cam_evt, self.cam_rgb
+        K.rays_fwd(poses_e, idx_e, ce.H, ce.W, ce.fx, ce.fy, ce.cx, ce.cy, cfg.ndc, out=(ro[:Ne], rd[:Ne], vd[:Ne]), remap=ce.remap)
+        K.rays_fwd(poses_r, idx_r, cr.H, cr.W, cr.fx, cr.fy, cr.cx, cr.cy, cfg.ndc, out=(ro[Ne:], rd[Ne:], vd[Ne:]), remap=cr.remap)
+        t_rand, sd, off = d.jitter_args()
+        z = K.stratified_z(N, S, dev, t_rand, sd, off)
+        return poses_e, poses_r, ro, rd, vd, z
+
     def step(self, evt_ts2, rgb_ts2, idx_evt_global, idx_rgb_global, events_accu, image, draws_evt=None,
              draws_rgb=None, z_fine_forced=None, overlap=None):
         """evt_ts2/rgb_ts2: [2] device floats; idx_*_global: int64 device pixel indices (global batch,
@@ -400,7 +421,10 @@ class TrainStep:
         overlap: optional callable, run on the main stream behind the step's last backward launch and before the step waits
         for its weight-gradient stream - where the main stream has ~0.6 ms of slack at C2.  For work that touches neither this
         step's parameters nor its gradients, e.g. preparing the NEXT batch's inputs (this step's reads of events_accu / image /
-        the index vectors are already queued ahead of it on the same stream)."""
+        the index vectors are already queued ahead of it on the same stream).  If it RETURNS the next step's
+        (evt_ts2, rgb_ts2, idx_evt_global, idx_rgb_global), the step also sets up that step's poses, rays and coarse depths in
+        the same slack (behind its own trajectory update); the next step() call uses them when it is handed those very
+        tensor objects, and computes them itself otherwise."""
         cfg, C, dev = self.cfg, self.C, self.dev
         # range guard: a run whose steps keep being skipped on the device must not go on silently - looks at the last copy
         # of the counters that has landed in pinned host memory (no synchronisation)
@@ -416,20 +440,18 @@ class TrainStep:
         step_id = self.global_step
 
         # ---- forward ---------------------------------------------------------------------------
-        poses_e, poses_r = K.spline_poses_fwd_pair(self.knots, self.transform.view(6), evt_ts2, 2, rgb_ts2, P, traj)
-        ro = torch.empty((N, 3), dtype=torch.float32, device=dev)
-        rd = torch.empty_like(ro)
-        vd = torch.empty_like(ro)
         ce, cr = self.cam_evt, self.cam_rgb
-        K.rays_fwd(poses_e, idx_e, ce.H, ce.W, ce.fx, ce.fy, ce.cx, ce.cy, cfg.ndc, out=(ro[:Ne], rd[:Ne], vd[:Ne]), remap=ce.remap)
-        K.rays_fwd(poses_r, idx_r, cr.H, cr.W, cr.fx, cr.fy, cr.cx, cr.cy, cfg.ndc, out=(ro[Ne:], rd[Ne:], vd[Ne:]), remap=cr.remap)
         if draws_evt is not None:   # parity mode: explicit draws for both renders, concatenated
             d = Draws(torch.cat([draws_evt.t_rand, draws_rgb.t_rand]), torch.cat([draws_evt.noise0, draws_rgb.noise0]),
                       torch.cat([draws_evt.u, draws_rgb.u]), torch.cat([draws_evt.noise1, draws_rgb.noise1]))
         else:
             d = Draws(seed=self.seed + self.rank * 7919, offset=step_id)
-        t_rand, sd, off = d.jitter_args()
-        z = K.stratified_z(N, S, dev, t_rand, sd, off)
+        pre, self._prefetched = self._prefetched, None
+        if (pre is not None and draws_evt is None and pre["step_id"] == step_id and
+                all(x is y for x, y in zip(pre["inputs"], (evt_ts2, rgb_ts2, idx_evt_global, idx_rgb_global)))):
+            poses_e, poses_r, ro, rd, vd, z = pre["rays"]      # set up in the previous step's slack (see the end of this method)
+        else:
+            poses_e, poses_r, ro, rd, vd, z = self._ray_setup(evt_ts2, rgb_ts2, idx_e, idx_r, d)
         pw = None
         if getattr(cfg, "use_barf_c2f", False):     # iter_step of graph.forward(i, ...) = the iteration counter (train.py:160)
             pw = K.barf_pe_weights(step_id, cfg.max_iter, cfg.barf_c2f_start, cfg.barf_c2f_end, dev)
@@ -537,31 +559,40 @@ class TrainStep:
             stats = K.loss_stats(lcfg, *largs)
             losses, _ = K.loss_grads(lcfg, stats, *largs, want_grads=False)
             loss_sum = dist.allreduce_sum_async_(losses, self.world, self.pg)
-        if overlap is not None:
-            overlap()
-        with torch.cuda.stream(side):
-            for w in pending[:2]:
-                w.wait()
-        main.wait_stream(side)
-        pending[2].wait()
-        if loss_sum is not None:
-            loss_sum.wait()
+        nxt = overlap() if overlap is not None else None
 
         # ---- Adam (K8) with the reference's per-group switches and LR schedule ---------------------------------
-        # the range guard's verdict for this step (summed over the ranks): [SKIP] makes every Adam launch below a no-op
+        # The trajectory's part comes first, still in the main stream's slack: its gradients (bucket 3) and the range guard's
+        # verdict for this step (summed over the ranks) are final long before the weight-gradient stream is.  [SKIP] makes
+        # every Adam launch of the step a no-op.
+        pending[2].wait()
         self.guard.gate(self.flag if self.world > 1 else None, phase=1)
         t = self.global_step + 1
 
         def adam(lo, cnt, lr):
             K.adam_step(self.flat_p[lo:lo + cnt], self.flat_g[lo:lo + cnt], self.flat_m[lo:lo + cnt], self.flat_v[lo:lo + cnt], lr, t,
                         status=st)
-        if cfg.optimize_nerf:
-            adam(0, 2 * self.n_net, self._lr(cfg.lrate, cfg.decay_rate))
         o = self.off_pose
         if cfg.optimize_pose:
             adam(o, 24, self._lr(cfg.pose_lrate, cfg.decay_rate_pose))
         if cfg.optimize_trans:
             adam(o + 24, 6, self._lr(cfg.transform_lrate, cfg.decay_rate_transform))
+        if nxt is not None:
+            # overlap() returned the NEXT step's (evt_ts2, rgb_ts2, idx_evt_global, idx_rgb_global): its poses (on the trajectory
+            # just updated), rays and coarse depths need nothing else - set up here, behind the running weight-gradient
+            # launches, instead of in front of the next forward launch (~45 us of dependent small kernels)
+            nxt = tuple(nxt)
+            dn = Draws(seed=self.seed + self.rank * 7919, offset=step_id + 1)
+            self._prefetched = {"inputs": nxt, "step_id": step_id + 1,
+                                "rays": self._ray_setup(nxt[0], nxt[1], self.shard(nxt[2]), self.shard(nxt[3]), dn)}
+        with torch.cuda.stream(side):
+            for w in pending[:2]:
+                w.wait()
+        main.wait_stream(side)
+        if loss_sum is not None:
+            loss_sum.wait()
+        if cfg.optimize_nerf:
+            adam(0, 2 * self.n_net, self._lr(cfg.lrate, cfg.decay_rate))
         for lo, cnt, lr0, dr, _ in self.crf_groups:
             adam(lo, cnt, self._lr(lr0, dr))
         if self.global_step % self.GUARD_POST_EVERY == 0:

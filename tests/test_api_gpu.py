@@ -519,11 +519,19 @@ def test_train_step_overlap_slot():
     img = torch.from_numpy(rng.random((HW, 1)).astype(np.float32)).to(DEV)
     ets, rts = torch.tensor([0.2, 0.3], device=DEV), torch.tensor([0.0, 1.0], device=DEV)
     res = []
-    for use_slot in (False, True):
+    for use_slot in (False, True, "prefetch"):
         _, g = _graph(args, seed=23)
         step = engine.TrainStep(g, args, cam_o, cam_o, torch.device(DEV), seed=5)
         calls = []
-        if not use_slot:
+        if use_slot == "prefetch":
+            # the slot returns the next step's inputs: TrainStep sets up their poses / rays / depths behind its own trajectory
+            # update; used by the next call because it is handed the same tensor objects, ignored by the one after
+            nxt = (ets.clone(), rts, idxs[1][0], idxs[1][1])
+            l0 = step.step(ets, rts, idxs[0][0], idxs[0][1], accus[0], img, overlap=lambda: nxt)
+            assert step._prefetched is not None
+            l1 = step.step(nxt[0], nxt[1], nxt[2], nxt[3], accus[1], img)
+            assert step._prefetched is None
+        elif not use_slot:
             l0 = step.step(ets, rts, idxs[0][0], idxs[0][1], accus[0], img)
             l1 = step.step(ets, rts, idxs[1][0], idxs[1][1], accus[1], img)
         else:
@@ -541,8 +549,9 @@ def test_train_step_overlap_slot():
             l1 = step.step(ets, rts, ie, ir, accu, img)
         step.check_range()
         res.append((l0.cpu().numpy(), l1.cpu().numpy(), step.flat_p.cpu().numpy()))
-    for a, b, what in zip(res[0], res[1], ("first step's losses", "second step's losses", "parameters after two steps")):
-        assert np.array_equal(a, b), what
+    for other in (1, 2):
+        for a, b, what in zip(res[0], res[other], ("first step's losses", "second step's losses", "parameters after two steps")):
+            assert np.array_equal(a, b), what
 
 
 def test_train_step_skips_a_nonfinite_loss_gradient():
