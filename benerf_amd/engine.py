@@ -448,6 +448,7 @@ class TrainStep:
             d = Draws(seed=self.seed + self.rank * 7919, offset=step_id)
         pre, self._prefetched = self._prefetched, None
         if (pre is not None and draws_evt is None and pre["step_id"] == step_id and
+                pre["versions"] == (self.flat_p._version, evt_ts2._version, rgb_ts2._version, idx_evt_global._version, idx_rgb_global._version) and
                 all(x is y for x, y in zip(pre["inputs"], (evt_ts2, rgb_ts2, idx_evt_global, idx_rgb_global)))):
             poses_e, poses_r, ro, rd, vd, z = pre["rays"]      # set up in the previous step's slack (see the end of this method)
         else:
@@ -583,7 +584,10 @@ class TrainStep:
             # launches, instead of in front of the next forward launch (~45 us of dependent small kernels)
             nxt = tuple(nxt)
             dn = Draws(seed=self.seed + self.rank * 7919, offset=step_id + 1)
+            # torch-side writes to the parameters (a checkpoint load, a test poking a weight) or to the inputs before the next
+            # call bump these version counters - the set-up is then recomputed (the fused Adam writes through raw pointers)
             self._prefetched = {"inputs": nxt, "step_id": step_id + 1,
+                                "versions": (self.flat_p._version,) + tuple(t_._version for t_ in nxt),
                                 "rays": self._ray_setup(nxt[0], nxt[1], self.shard(nxt[2]), self.shard(nxt[3]), dn)}
         with torch.cuda.stream(side):
             for w in pending[:2]:

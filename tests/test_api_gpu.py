@@ -531,6 +531,22 @@ def test_train_step_overlap_slot():
             assert step._prefetched is not None
             l1 = step.step(nxt[0], nxt[1], nxt[2], nxt[3], accus[1], img)
             assert step._prefetched is None
+            p_two = step.flat_p.clone()
+            # a set-up made stale by a torch-side write to the trajectory parameters is not used: same result as a plain step
+            stale = (ets.clone(), rts, idxs[0][0], idxs[0][1])
+            step.step(ets, rts, idxs[1][0], idxs[1][1], accus[1], img, overlap=lambda: stale)
+            ref_step = engine.TrainStep(_graph(args, seed=23)[1], args, cam_o, cam_o, torch.device(DEV), seed=5)
+            with torch.no_grad():
+                for buf in ("flat_p", "flat_m", "flat_v"):
+                    getattr(ref_step, buf).copy_(getattr(step, buf))
+                ref_step.global_step = step.global_step
+                step.knots.mul_(1.5)
+                ref_step.knots.mul_(1.5)
+            ref_step.net_c.packed.pack()
+            ref_step.net_f.packed.pack()
+            a_ = step.step(stale[0], stale[1], stale[2], stale[3], accus[0], img)
+            b_ = ref_step.step(ets, rts, idxs[0][0], idxs[0][1], accus[0], img)
+            assert torch.equal(a_, b_) and torch.equal(step.flat_p, ref_step.flat_p)
         elif not use_slot:
             l0 = step.step(ets, rts, idxs[0][0], idxs[0][1], accus[0], img)
             l1 = step.step(ets, rts, idxs[1][0], idxs[1][1], accus[1], img)
@@ -548,7 +564,7 @@ def test_train_step_overlap_slot():
             assert calls == [main]
             l1 = step.step(ets, rts, ie, ir, accu, img)
         step.check_range()
-        res.append((l0.cpu().numpy(), l1.cpu().numpy(), step.flat_p.cpu().numpy()))
+        res.append((l0.cpu().numpy(), l1.cpu().numpy(), (p_two if use_slot == "prefetch" else step.flat_p).cpu().numpy()))
     for other in (1, 2):
         for a, b, what in zip(res[0], res[other], ("first step's losses", "second step's losses", "parameters after two steps")):
             assert np.array_equal(a, b), what
