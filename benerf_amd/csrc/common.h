@@ -27,6 +27,18 @@ void benerf_set_error(const char* fmt, ...);
 
 static inline hipStream_t as_stream(benerf_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the function ON THE CURRENT DEVICE: set once per (call site,
+// device), not once per process - a process that launches on cuda:1 after cuda:0 needs it there too.
+struct BenerfLdsAttr { unsigned long long done; };
+static inline bool benerf_lds_attr(BenerfLdsAttr& st, const void* fn, int bytes) {
+    int dev = 0;
+    const bool known = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
+    if (known && ((st.done >> dev) & 1ull)) return true;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+    if (known) st.done |= 1ull << dev;      // benign race: the call is idempotent
+    return true;
+}
+
 // ---------------------------------------------------------------------------------------
 // Philox4x32-10 counter RNG (speed mode; parity mode passes explicit draw tensors).
 // ---------------------------------------------------------------------------------------

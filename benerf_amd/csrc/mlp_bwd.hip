@@ -347,6 +347,11 @@ int benerf_mlp_dx_split_launch(const BenerfMlpParams* params, const float* packe
                                const float* acts, float* dacts, float* d_pts, float* d_vdir_pts, uint32_t* status,
                                const float* d_raw_absmax, hipStream_t stream);
 
+// 22-bit variant (mlp_bwd_s.hip)
+int benerf_mlp_dx_split22_launch(const BenerfMlpParams* params, const float* packed, int channels, int64_t M, const float* d_raw,
+                                 const float* acts, float* dacts, float* d_pts, float* d_vdir_pts, uint32_t* status,
+                                 const float* d_raw_absmax, hipStream_t stream);
+
 static int launch_dx(const BenerfMlpParams* params, const float* packed, int channels, int64_t M, const float* d_raw,
                      const float* acts, float* dacts, float* d_pts, float* d_vdir_pts, hipStream_t stream) {
     BwdArgs a;
@@ -364,11 +369,8 @@ static int launch_dx(const BenerfMlpParams* params, const float* packed, int cha
     BENERF_REQUIRE(tiles < (1ll << 31), "mlp_bwd: too many points");
     dim3 grid((unsigned)tiles), block(mlp::NTHREADS);
     const int smem = (int)mlp::TILE_SMEM;
-    // once per process and variant: the attribute sticks to the function
-    static const bool lds_ok[2] = {
-        hipFuncSetAttribute((const void*)mlp_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) == hipSuccess,
-        hipFuncSetAttribute((const void*)mlp_bwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) == hipSuccess};
-    if (!lds_ok[channels == 1 ? 0 : 1]) {
+    static BenerfLdsAttr attr[2];       // once per device and variant
+    if (!benerf_lds_attr(attr[channels == 1 ? 0 : 1], channels == 1 ? (const void*)mlp_bwd_kernel<1> : (const void*)mlp_bwd_kernel<3>, smem)) {
         benerf_set_error("mlp_bwd(dx): cannot reserve %d bytes of LDS", smem);
         return BENERF_EHIP;
     }
@@ -385,10 +387,14 @@ extern "C" int benerf_mlp_bwd_dx(const BenerfMlpParams* params, const float* pac
     BENERF_REQUIRE(params && packed && d_raw && acts && dacts && d_pts && d_vdir_pts, "mlp_bwd_dx: null pointer");
     BENERF_REQUIRE(channels == 1 || channels == 3, "mlp_bwd_dx: channels must be 1 or 3");
     BENERF_REQUIRE(n_rays > 0 && n_samples > 0, "mlp_bwd_dx: bad sizes");
-    BENERF_REQUIRE(precision == BENERF_MLP_F32 || precision == BENERF_MLP_SPLIT, "mlp_bwd_dx: precision must be BENERF_MLP_F32 or BENERF_MLP_SPLIT");
+    BENERF_REQUIRE(precision == BENERF_MLP_F32 || precision == BENERF_MLP_SPLIT || precision == BENERF_MLP_SPLIT_F16BWD,
+                   "mlp_bwd_dx: precision must be BENERF_MLP_F32, BENERF_MLP_SPLIT or BENERF_MLP_SPLIT_F16BWD");
     for (int l = 0; l < BENERF_NLAYERS; ++l) BENERF_REQUIRE(params->w[l], "mlp_bwd_dx: null parameter %d", l);
     const int64_t M = (int64_t)n_rays * n_samples;
     if (precision == BENERF_MLP_SPLIT)
+        return benerf_mlp_dx_split22_launch(params, packed, channels, M, d_raw, acts, dacts, d_pts, d_vdir_pts, status, d_raw_absmax,
+                                            as_stream(stream));
+    if (precision == BENERF_MLP_SPLIT_F16BWD)
         return benerf_mlp_dx_split_launch(params, packed, channels, M, d_raw, acts, dacts, d_pts, d_vdir_pts, status, d_raw_absmax,
                                           as_stream(stream));
     return launch_dx(params, packed, channels, M, d_raw, acts, dacts, d_pts, d_vdir_pts, as_stream(stream));
@@ -400,7 +406,8 @@ extern "C" int benerf_mlp_bwd_dw(int channels, int n_rays, int n_samples, const 
     BENERF_REQUIRE(d_raw && acts && dacts && dw_ws && grads, "mlp_bwd_dw: null pointer");
     BENERF_REQUIRE(channels == 1 || channels == 3, "mlp_bwd_dw: channels must be 1 or 3");
     BENERF_REQUIRE(n_rays > 0 && n_samples > 0, "mlp_bwd_dw: bad sizes");
-    BENERF_REQUIRE(precision == BENERF_MLP_F32 || precision == BENERF_MLP_SPLIT, "mlp_bwd_dw: precision must be BENERF_MLP_F32 or BENERF_MLP_SPLIT");
+    BENERF_REQUIRE(precision == BENERF_MLP_F32 || precision == BENERF_MLP_SPLIT || precision == BENERF_MLP_SPLIT_F16BWD,
+                   "mlp_bwd_dw: precision must be BENERF_MLP_F32, BENERF_MLP_SPLIT or BENERF_MLP_SPLIT_F16BWD");
     if (dw_ws_floats < (size_t)mlp::DW_WS_FLOATS) {
         benerf_set_error("mlp_bwd_dw: dw workspace too small (%zu < %lld floats)", dw_ws_floats, (long long)mlp::DW_WS_FLOATS);
         return BENERF_EWORKSPACE;

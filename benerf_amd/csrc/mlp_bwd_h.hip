@@ -636,11 +636,8 @@ int benerf_mlp_dx_split_launch(const BenerfMlpParams* params, const float* packe
     }
     dim3 grid((unsigned)tiles), block(mlp::NTHREADS);
     const int smem = (int)BWD_SMEM;
-    // once per process and variant: the attribute sticks to the function
-    static const bool lds_ok[2] = {
-        hipFuncSetAttribute((const void*)mlp_bwd_f16_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) == hipSuccess,
-        hipFuncSetAttribute((const void*)mlp_bwd_f16_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) == hipSuccess};
-    if (!lds_ok[channels == 1 ? 0 : 1]) {
+    static BenerfLdsAttr attr[2];       // once per device and variant
+    if (!benerf_lds_attr(attr[channels == 1 ? 0 : 1], channels == 1 ? (const void*)mlp_bwd_f16_kernel<1> : (const void*)mlp_bwd_f16_kernel<3>, smem)) {
         benerf_set_error("mlp_bwd(dx, f16): cannot reserve %d bytes of LDS", smem);
         return BENERF_EHIP;
     }

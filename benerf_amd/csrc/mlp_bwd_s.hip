@@ -1,0 +1,651 @@
+// K3 backward part 1, BENERF_MLP_SPLIT (the 22-bit backward): the activation-gradient chain of mlp_bwd.hip (phases P0..P6, same
+// d_pts / d_viewdirs outputs) with every GEMM as THREE f16 MFMAs per product block on hi/lo-split operands - the gradient as
+// hi + lo (two f16, unscaled lo), the transposed weight as hi + lo (mlp_pack.hip, backward blocks) -
+//     dY W  =  dY_hi W_hi + dY_hi W_lo + dY_lo W_hi        (lo x lo <= 2^-22 |dY W| dropped)
+// all three into ONE f32 accumulator.  Both operands keep 22 significant bits: measured against float64 with identical ReLU
+// masks the gradients carry the exact-f32 kernel's error (tools/experiments/backward_format_study.py is the CPU study that
+// fixed the formats: an f16 gradient OR an f16 activation in either backward GEMM costs 2-8e-4 of the largest entry, 15-bit
+// operands 2-4e-5, hi + lo 1e-6 = float32's own).  This is what makes the split mode fp32-equivalent in the backward pass
+// too (the reference: fp32 nn.Linear, model/nerf.py:93-112, loss.backward() through them, train.py:340).
+//
+// Range: gradients are far outside f16's range (d_raw ~ 1/n_rays), but the chain is LINEAR in d_raw: each 128-point tile
+// multiplies its d_raw by a power of two s (pow2_scale6: tile maximum -> [2^6, 2^7)), runs the chain on the scaled values and
+// multiplies every output by 1/s - both exact.  The dY arrays for the dW kernel (hi and lo twins, SH layout, mlp_split.h)
+// carry ONE power-of-two scale per call (s_s from max|d_raw| of the launch), divided out by the dW reduce kernel.
+//
+// Tiling (the split forward kernel's): one workgroup of 8 waves per 128 points, two f16 planes Th / Tl [128][320] = the CU's
+// whole 160 KiB; wave w owns the 32 input features of column tile w x all four point tiles (one accumulator set of 64
+// registers): a weight-fragment pair (hi, lo: 2 KiB from L2) feeds 12 MFMAs.  Un-transposed product (activations as the MFMA A
+// operand): an accumulator lane holds 4 consecutive points of one feature, so the lane pair (l, l + 32) forms whole 16-byte SH
+// units in registers (v_permlane32_swap) and the ReLU sign-bit words the forward pass saved line up with the accumulators.
+// The planes' PE columns [256,320) are never a GEMM operand here: f32 scratch (hi plane: dPE(dir) at floats [0,27), the tile's
+// maximum at [26] of rows 0 / 1 during P0, scaled d_raw at [28,32)), later the layer-5 skip's dPE block as hi + lo.
+#include "mlp_split.h"
+
+namespace {
+using namespace mlp;
+
+constexpr int TMB = 128;                                              // points per workgroup
+constexpr int BNT = 512;                                              // 8 waves
+constexpr size_t BWD_SMEM = (size_t)2 * TMB * LD * sizeof(_Float16);  // 163 840 B
+static_assert(TMB == SM_PAD, "the padded point count is a whole number of dX tiles");
+
+struct BwdArgs {
+    const float* d_raw;
+    const float* acts;
+    float* dacts;
+    const float* packed;    // split-f16 section at + PACKED_FLOATS (backward blocks: hi + unscaled lo)
+    const float* w_alpha;   // [256]
+    const float* w_rgb;     // [C][128]
+    const float* pe_w;      // BARF c2f column weights (include/benerf_hip.h) or null
+    float* d_pts;           // [M][3]
+    float* d_vdir;          // [M][3]
+    uint32_t* status;       // [1]: max |tile-scaled gradient| bits once >= 2^15, [2]: acts buffer written by another mode (may be null)
+    const float* absmax;    // max |d_raw| of the call from the compositing backward, or null: then it is in the dacts info word
+    int64_t M;
+};
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+// f32 scratch float i (0..31) of `row` in the hi plane's PE columns: slot 32 + i/4, swizzled like everything else
+__device__ __forceinline__ float* fscr1(_Float16* T, int row, int i) {
+    return reinterpret_cast<float*>(T + row * LD + (((32 + (i >> 2)) ^ hsw(row)) << 3)) + (i & 3);
+}
+
+// buffer descriptor on a wave-uniform base address (per-lane addresses become ONE 32-bit VGPR offset: mlp_bwd_h.hip)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* p) {
+    const uint64_t wa = reinterpret_cast<uint64_t>(p);
+    const uint64_t wau = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(wa >> 32)) << 32) |
+                         (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)wa);
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(wau), 0, 0x7fffffff, 0x00020000);
+}
+
+// weight fragments of a packed block through a buffer descriptor; layout: mlp_pack.hip / mlp_split.h
+struct WFrag {
+    __amdgpu_buffer_rsrc_t rsrc;
+    int voff;
+    __device__ __forceinline__ WFrag(const float* wp, int lane) : rsrc(uniform_rsrc(wp)), voff(lane * 16) {}
+    // fragment of column tile t (wave-uniform), k-step ks of a block with KS k-steps; plane 0 = hi, 1 = lo (unscaled)
+    __device__ __forceinline__ u32x4 load(int t_uniform, int ks, int KS, int plane) const {
+        const int soff = (((t_uniform >> 1) * KS + ks) * 2 + (t_uniform & 1)) * 2048 + plane * 1024;
+        return __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+    }
+};
+
+// offset of the backward block of hidden layer l (7..1) in closed form (a run-time pack_offset() becomes a scalar loop of branches)
+__device__ __forceinline__ int bwd_layer_offset(int l) {
+    return (int)pack_offset(PB_L7) + (7 - l) * (int)pack_floats(PB_L7) + (l < 5 ? (int)(pack_floats(PB_L5) - pack_floats(PB_L7)) : 0);
+}
+static_assert(pack_offset(PB_L7) + 1 * pack_floats(PB_L7) == pack_offset(PB_L6) && pack_offset(PB_L7) + 2 * pack_floats(PB_L7) == pack_offset(PB_L5) &&
+              pack_offset(PB_L7) + 3 * pack_floats(PB_L7) + (pack_floats(PB_L5) - pack_floats(PB_L7)) == pack_offset(PB_L4) &&
+              pack_offset(PB_L7) + 6 * pack_floats(PB_L7) + (pack_floats(PB_L5) - pack_floats(PB_L7)) == pack_offset(PB_L1), "bwd_layer_offset");
+
+// lane-derived addresses stay local to a stage (hoisted out of the layer loop they overflow the register file: mlp_bwd_h.hip)
+__device__ __forceinline__ int stage_local(int lane) {
+    asm volatile("" : "+v"(lane));
+    return lane;
+}
+
+#ifndef BWS_PF
+#define BWS_PF 3
+#endif
+template <int PF>
+struct WRing { u32x4 q[PF + 1][2]; };
+
+// the first PF k-steps of weight fragments of column tile ct.  Called BEFORE the previous stage's epilogue: vector-memory
+// operations retire in order, fragments requested behind the epilogue's 16 stores would wait for every one of them.
+template <int KS, int PF>
+__device__ __forceinline__ void gemm3_head(const float* __restrict__ wp, int ct, int lane, WRing<PF>& r) {
+    const WFrag wf(wp, lane);
+    const int ctu = __builtin_amdgcn_readfirstlane(ct);
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+        if (p < KS) {
+            r.q[p][0] = wf.load(ctu, p, KS, 0);
+            r.q[p][1] = wf.load(ctu, p, KS, 1);
+        }
+}
+
+// acc[rt] += (Th + Tl)[rt*32.., 0 .. KS*16) x (W_hi + W_lo)(tile ct) without the lo x lo term, rt = 0..3.  Per k-step: the four
+// hi x hi MFMAs, the four hi x lo, the four lo x hi - the three MFMAs on one accumulator are four issue slots apart.  Weight
+// fragments PF k-steps ahead, ONE set of activation fragments, each reloaded right behind its last MFMA of the k-step.
+template <int KS, int PF>
+__device__ __forceinline__ void gemm3_body(const _Float16* __restrict__ Th, const _Float16* __restrict__ Tl, const float* __restrict__ wp,
+                                           int ct, int lane, WRing<PF>& r, f32x16 (&acc)[4]) {
+    lane = stage_local(lane);
+    const int row = lane & 31, lh = lane >> 5;
+    const int sw = hsw(row);                        // rows row + 32 * rt share the swizzle
+    const int rbase = row * LD;
+    const WFrag wf(wp, lane);
+    const int ctu = __builtin_amdgcn_readfirstlane(ct);
+    int abase[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) abase[j] = rbase + (((2 * j + lh) ^ sw) << 3);
+    auto a_off = [&](int ks) { return abase[ks & 3] + ((((2 * ks) & ~7)) << 3); };
+    half8 ah[4], al[4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+        ah[rt] = *reinterpret_cast<const half8*>(Th + a_off(0) + rt * 32 * LD);
+        al[rt] = *reinterpret_cast<const half8*>(Tl + a_off(0) + rt * 32 * LD);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        if (ks + PF < KS) {
+            r.q[(ks + PF) % (PF + 1)][0] = wf.load(ctu, ks + PF, KS, 0);
+            r.q[(ks + PF) % (PF + 1)][1] = wf.load(ctu, ks + PF, KS, 1);
+        }
+        const half8 bh = __builtin_bit_cast(half8, r.q[ks % (PF + 1)][0]);
+        const half8 bl = __builtin_bit_cast(half8, r.q[ks % (PF + 1)][1]);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) acc[rt] = mfma16(ah[rt], bh, acc[rt]);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            acc[rt] = mfma16(ah[rt], bl, acc[rt]);
+            if (ks + 1 < KS) ah[rt] = *reinterpret_cast<const half8*>(Th + a_off(ks + 1) + rt * 32 * LD);
+        }
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+            acc[rt] = mfma16(al[rt], bh, acc[rt]);
+            if (ks + 1 < KS) al[rt] = *reinterpret_cast<const half8*>(Tl + a_off(ks + 1) + rt * 32 * LD);
+        }
+        __builtin_amdgcn_sched_barrier(0);          // one k-step per scheduling region: keeps the prefetch distances as written
+    }
+}
+
+template <int KS, int PF = BWS_PF>
+__device__ __forceinline__ void gemm3(const _Float16* __restrict__ Th, const _Float16* __restrict__ Tl, const float* __restrict__ wp, int ct,
+                                      int lane, f32x16 (&acc)[4]) {
+    WRing<PF> r;
+    gemm3_head<KS, PF>(wp, ct, lane, r);
+    gemm3_body<KS, PF>(Th, Tl, wp, ct, lane, r, acc);
+}
+
+// One row tile x one column tile: out += (Th + Tl)[rt*32.., 0 .. KS*16) x W(tile).  Three MFMAs per k-step on ONE accumulator
+// (dependent: the pipe idles between them), so only for the small dPE blocks; fragments PF k-steps ahead.
+template <int KS, int PF = 4>
+__device__ __forceinline__ void gemm_row3(const _Float16* __restrict__ Th, const _Float16* __restrict__ Tl, const float* __restrict__ wp,
+                                          int tile, int rt, int lane, f32x16& out) {
+    lane = stage_local(lane);
+    const int row = rt * 32 + (lane & 31), lh = lane >> 5;
+    const int sw = hsw(row);
+    const int rbase = row * LD;
+    const WFrag wf(wp, lane);
+    const int tu = __builtin_amdgcn_readfirstlane(tile);
+    u32x4 bq[PF + 1][2];
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+        if (p < KS) {
+            bq[p][0] = wf.load(tu, p, KS, 0);
+            bq[p][1] = wf.load(tu, p, KS, 1);
+        }
+    half8 ahn = *reinterpret_cast<const half8*>(Th + rbase + ((lh ^ sw) << 3));
+    half8 aln = *reinterpret_cast<const half8*>(Tl + rbase + ((lh ^ sw) << 3));
+    // two partial accumulators (even / odd k-steps) halve the dependent chain
+    f32x16 o2;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o2[e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const half8 ah = ahn, al = aln;
+        if (ks + PF < KS) {
+            bq[(ks + PF) % (PF + 1)][0] = wf.load(tu, ks + PF, KS, 0);
+            bq[(ks + PF) % (PF + 1)][1] = wf.load(tu, ks + PF, KS, 1);
+        }
+        if (ks + 1 < KS) {
+            ahn = *reinterpret_cast<const half8*>(Th + rbase + ((((ks + 1) * 2 + lh) ^ sw) << 3));
+            aln = *reinterpret_cast<const half8*>(Tl + rbase + ((((ks + 1) * 2 + lh) ^ sw) << 3));
+        }
+        const half8 bh = __builtin_bit_cast(half8, bq[ks % (PF + 1)][0]);
+        const half8 bl = __builtin_bit_cast(half8, bq[ks % (PF + 1)][1]);
+        if (ks & 1) {
+            o2 = mfma16(ah, bh, o2);
+            o2 = mfma16(ah, bl, o2);
+            o2 = mfma16(al, bh, o2);
+        } else {
+            out = mfma16(ah, bh, out);
+            out = mfma16(ah, bl, out);
+            out = mfma16(al, bh, out);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) out[e] += o2[e];
+}
+
+__device__ __forceinline__ void zero4(f32x16 (&acc)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
+}
+
+// bit k (compile-time) of a 32-bit mask word as an all-ones / all-zeros mask (one v_bfe_i32)
+__device__ __forceinline__ uint32_t bit_mask32(uint32_t w, int k) {
+    uint32_t m;     // asm: the compiler would turn "x & sbfe(...)" back into v_and + v_cmp + v_cndmask
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(w), "n"(k));
+    return m;
+}
+
+// v -> (hi, lo) as packed f16 pairs: hi = rn16(v), lo = rn16(v - hi)
+__device__ __forceinline__ void split2(float v0, float v1, half2v& hi, half2v& lo) {
+    hi = __builtin_convertvector(float2v{v0, v1}, half2v);                          // v_cvt_pk_f16_f32 (RNE)
+    const float2v back = __builtin_convertvector(hi, float2v);
+    lo = __builtin_convertvector(float2v{v0 - back[0], v1 - back[1]}, half2v);
+}
+
+// dY = acc masked by the forward pass' ReLU sign bits (bits[h]: this wave's 32 bits of the 64-point forward tile of row tiles
+// 2h, 2h + 1: bit r * 16 + e <-> accumulator element e of row tile 2h + r) -> both planes (hi, lo; tile scale) and, rescaled
+// by gf = s_call / s_tile (a power of two <= 1; exact), the SH gradient arrays `st_hi` / `st_lo` of width 256 (tile part).
+template <bool MASK>
+__device__ __forceinline__ void epilogue3(f32x16 (&acc)[4], const uint32_t (&bits)[2], _Float16* __restrict__ Th, _Float16* __restrict__ Tl,
+                                          int ct, int lane, const _Float16* __restrict__ st_hi, const _Float16* __restrict__ st_lo, float gf,
+                                          float& amax) {
+    lane = stage_local(lane);
+    const int lr = lane & 31, r4 = 4 * (lane >> 5);
+    const __amdgpu_buffer_rsrc_t rs_hi = uniform_rsrc(st_hi);         // this tile's 16 blocks of the SH arrays (64 KiB each)
+    const __amdgpu_buffer_rsrc_t rs_lo = uniform_rsrc(st_lo);
+    const _Float16 gh = (_Float16)gf;             // a power of two (or 0 below 2^-24: such a tile's gradients are below f16 anyway)
+    const half2v g2 = {gh, gh};
+    const int n = ct * 32 + lr;
+    const int ns = (n >> 3) ^ ((lane >> 5) << 1);
+    // plane element offsets: 4 swizzle variants x {rows 0-63, rows 64-127}; the rest are immediate offsets (mlp_bwd_h.hip)
+    int tb[4][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        tb[q][0] = r4 * LD + ((((ns ^ ((q & 1) | ((q >> 1) << 2)))) << 3) | (n & 7));
+        tb[q][1] = tb[q][0] + 64 * LD;
+    }
+    const int st_lane = (((lane >> 5) * 256 + n) * 8) * 2;   // byte offset of unit (block, n); lanes 32-63: the odd block of a pair
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int ep = 0; ep < 2; ++ep) {
+            uint2 qh[2], ql[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                uint32_t wh[2], wl[2];
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) {
+                    float v[2];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int e = (ep * 2 + h) * 4 + jp * 2 + t;
+                        v[t] = acc[rt][e];
+                        if (MASK) v[t] = __uint_as_float(__float_as_uint(v[t]) & bit_mask32(bits[rt >> 1], (rt & 1) * 16 + e));
+                    }
+                    amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])));   // v_max3_f32
+                    half2v hv, lv;
+                    split2(v[0], v[1], hv, lv);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int e = (ep * 2 + h) * 4 + jp * 2 + t;
+                        const int o = tb[((e >> 1) & 1) | (((e >> 2) & 1) << 1)][rt >> 1] + ((rt & 1) * 32 + (e & 3) + 8 * (e >> 2)) * LD;
+                        Th[o] = hv[t];
+                        Tl[o] = lv[t];
+                    }
+                    wh[jp] = __builtin_bit_cast(uint32_t, hv);
+                    wl[jp] = __builtin_bit_cast(uint32_t, lv);
+                }
+                qh[h] = uint2{wh[0], wh[1]};
+                ql[h] = uint2{wl[0], wl[1]};
+            }
+            // lanes exchange halves, then the exact rescale (v_pk_mul_f16 by a power of two)
+            const uint4 uh = sh_pair_unit(qh[0], qh[1]);
+            const uint4 ul = sh_pair_unit(ql[0], ql[1]);
+            const uint32_t uhw[4] = {uh.x, uh.y, uh.z, uh.w}, ulw[4] = {ul.x, ul.y, ul.z, ul.w};
+            u32x4 oh, ol;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                oh[i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2v, uhw[i]) * g2);
+                ol[i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2v, ulw[i]) * g2);
+            }
+            // vector offset + zero scalar offset (mlp_bwd_h.hip: the scalar-offset form of a 16-byte store reads its data late)
+            __builtin_amdgcn_raw_buffer_store_b128(oh, rs_hi, st_lane + (rt * 4 + ep * 2) * 256 * 8 * 2, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(ol, rs_lo, st_lane + (rt * 4 + ep * 2) * 256 * 8 * 2, 0, 0);
+        }
+}
+
+template <int C>
+__global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 Tsm[];   // Th | Tl
+    _Float16* Th = Tsm;
+    _Float16* Tl = Tsm + TMB * LD;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7, wave-uniform: weight pointers stay scalar
+    const int64_t m0 = (int64_t)blockIdx.x * TMB;
+    const int64_t M = a.M;
+    const float* acts = a.acts;
+    float* dacts = a.dacts;
+    const float* packed_h = a.packed + PACKED_FLOATS;
+    const int ct = wave;                                         // this wave's column tile in the 256-wide stages
+    const int64_t Mp = m_pad(M);
+    const int64_t dlo = 2 * sdact_lo_delta(Mp);                  // half offset from a gradient SH array to its lo twin
+    // ReLU sign-bit words of the two 64-point forward tiles this workgroup covers: uint64 [layer][tile][4 x 64 threads]; this
+    // wave's column tile ct is the forward thread (ct >> 1) * 64 + lane, 32-bit half ct & 1 (mlp_common.h / mlp_fwd_h.hip)
+    const __amdgpu_buffer_rsrc_t mask_rsrc =
+        uniform_rsrc(reinterpret_cast<const uint64_t*>(acts + sact_mask(Mp)) + (int64_t)blockIdx.x * 2 * NTHREADS);
+    const int mask_stride_b = (int)((Mp / TM) * NTHREADS * 8);           // bytes between layers (< 2^31 up to 8M points)
+    auto load_bits = [&](int layer, uint32_t (&b)[2]) {
+        const int so = __builtin_amdgcn_readfirstlane(layer * mask_stride_b);
+        const int vo = ((wave >> 1) * 64 + lane) * 8 + (wave & 1) * 4;
+        b[0] = __builtin_amdgcn_raw_buffer_load_b32(mask_rsrc, vo, so, 0);
+        b[1] = __builtin_amdgcn_raw_buffer_load_b32(mask_rsrc, vo + NTHREADS * 8, so, 0);
+    };
+    _Float16* st_dyh = reinterpret_cast<_Float16*>(dacts + sdact_h(Mp, 0));      // layer l: + l * Mp * 256 halfs
+    auto st_tile = [&](int l) { return st_dyh + ((int64_t)l * Mp + m0) * 256; };   // tile's part of layer l's SH array (hi)
+    float s_g, inv_s_g;
+    const float mx_call = a.absmax ? *a.absmax : dacts[sdact_info(Mp) + SD_DRAW];
+    if (a.absmax && blockIdx.x == 0 && tid == 0) dacts[sdact_info(Mp) + SD_DRAW] = mx_call;   // the dW reduce reads it there
+    pow2_scale6(mx_call, s_g, inv_s_g);                                          // scale of the dY arrays of this call
+    if (a.status && blockIdx.x == 0 && tid == 0 && reinterpret_cast<const uint32_t*>(acts + sact_info(Mp))[SI_TAG] != SACT_TAG_SPLIT22)
+        a.status[2] = 1u;
+    float amax = 0.f;          // max |tile-scaled gradient| of this thread before its f16 split (range guard)
+
+    // ---- P0: d_raw tile, its power-of-two scale, scaled values -> scratch floats [28, 28+C] of each row ------
+    float dr0[C + 1];
+    if (tid < TMB) {
+        const int64_t m = m0 + tid;
+        float mx = 0.f;
+#pragma unroll
+        for (int c = 0; c <= C; ++c) {
+            dr0[c] = m < M ? a.d_raw[m * (C + 1) + c] : 0.f;
+            mx = fmaxf(mx, fabsf(dr0[c]));
+        }
+        mx = wave_max_nonneg(mx);                                           // lane 63 of waves 0 and 1
+        if (lane == 63) *fscr1(Th, wave, 26) = mx;
+    }
+    lds_barrier();
+    float s, inv_s;
+    pow2_scale6(fmaxf(*fscr1(Th, 0, 26), *fscr1(Th, 1, 26)), s, inv_s);     // 2^(6 - exponent(max)), exact inverse
+    if (tid < TMB) {
+#pragma unroll
+        for (int c = 0; c <= C; ++c) *fscr1(Th, tid, 28 + c) = dr0[c] * s;
+    }
+    lds_barrier();
+    const float gf = s_g * inv_s;   // tile scale -> scale of the stored dY (power of two <= 1)
+
+    // ---- P1: rgb layer backward + ReLU mask of the views layer -> dYv in planes[:, 0:128) ----
+    // wave w: column tile w & 3, point half w >> 2 (row tiles 2 (w >> 2), + 1) - the split forward's VIEWS mapping, so the hv sign
+    // bits it saved (bit b*4 + j = point 8b + 4 (lane >> 5) + j of the half = accumulator element (rt & 1) * 16 + e) line up
+    {
+        const int vct = wave & 3, vrh = wave >> 2;
+        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 hvw = __builtin_amdgcn_raw_buffer_load_b64(mask_rsrc, (vct * 64 + lane) * 8 + vrh * NTHREADS * 8,
+                                                               __builtin_amdgcn_readfirstlane(8 * mask_stride_b), 0);
+        const uint32_t hvbits = hvw[0];
+        const int col = vct * 32 + (lane & 31), r4 = 4 * (lane >> 5);
+        float wr[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) wr[c] = a.w_rgb[c * 128 + col];
+        _Float16* st_lane = reinterpret_cast<_Float16*>(dacts + sdact_hv(Mp)) + (((m0 >> 3) + (lane >> 5)) * ACT_HV_W + col) * 8;
+#pragma unroll
+        for (int rtl = 0; rtl < 2; ++rtl)
+#pragma unroll
+            for (int ep = 0; ep < 2; ++ep) {
+                const int rt = vrh * 2 + rtl;
+                Quad16 qh[2], ql[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int e = (ep * 2 + h) * 4 + j;
+                        const int p = rt * 32 + (e & 3) + 8 * (e >> 2) + r4;
+                        const float4 dr = *reinterpret_cast<const float4*>(fscr1(Th, p, 28));
+                        const float drv[4] = {dr.x, dr.y, dr.z, dr.w};
+                        float g = 0.f;
+#pragma unroll
+                        for (int c = 0; c < C; ++c) g += drv[c] * wr[c];
+                        const float v = ((hvbits >> (rtl * 16 + e)) & 1u) ? g : 0.f;
+                        const _Float16 vh = (_Float16)v;
+                        Th[hidx(p, col)] = vh;
+                        Tl[hidx(p, col)] = (_Float16)(v - (float)vh);
+                        const float sv = v * gf;
+                        amax = fmaxf(amax, fabsf(v));
+                        qh[h].v[j] = (_Float16)sv;
+                        ql[h].v[j] = (_Float16)(sv - (float)qh[h].v[j]);
+                    }
+                *reinterpret_cast<uint4*>(st_lane + (int64_t)(rt * 4 + ep * 2) * ACT_HV_W * 8) = sh_pair_unit(qh[0], qh[1]);
+                *reinterpret_cast<uint4*>(st_lane + dlo + (int64_t)(rt * 4 + ep * 2) * ACT_HV_W * 8) = sh_pair_unit(ql[0], ql[1]);
+            }
+    }
+    lds_barrier();
+
+    f32x16 acc[4];
+    uint32_t bits[2] = {0u, 0u};
+
+    // ---- P2: VIEWS^T: dFeat = dYv x Wv[:, :256]; dPE(dir) = dYv x Wv[:, 256:283] --------------------------------
+    if (wave < 4) {   // dPE(dir): tile 8 of the block, row tile = wave -> scratch floats [0,27)
+        f32x16 ap;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ap[e] = 0.f;
+        gemm_row3<8>(Th, Tl, packed_h + pack_offset(PB_VIEWS), 8, wave, lane, ap);
+        const int ln = stage_local(lane);
+        if ((ln & 31) < 27) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) *fscr1(Th, wave * 32 + acc_row(e, ln), ln & 31) = ap[e];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    zero4(acc);
+    gemm3<8>(Th, Tl, packed_h + pack_offset(PB_VIEWS), ct, lane, acc);
+    lds_barrier();   // dYv fully consumed; dPE(dir) visible
+    {
+        _Float16* stf = reinterpret_cast<_Float16*>(dacts + sdact_feat(Mp)) + m0 * 256;
+        epilogue3<false>(acc, bits, Th, Tl, ct, lane, stf, stf + dlo, gf, amax);
+    }
+    if (tid < TMB && m0 + tid < M) {   // d viewdirs (per point) through PE(dir)
+        const int64_t m = m0 + tid;
+        const float* ped = acts + sact_ped32(Mp) + m * ACT_PED_W;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            float sv = *fscr1(Th, tid, d);
+            if (a.pe_w) sv *= a.pe_w[64 + d];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const int es = 3 + f * 6 + d, ec = es + 3;
+                const float sn = ped[es], cs = ped[ec];
+                const float ws = a.pe_w ? a.pe_w[64 + es] : 1.f, wc = a.pe_w ? a.pe_w[64 + ec] : 1.f;
+                sv += (float)(1 << f) * (cs * (ws * *fscr1(Th, tid, es)) - sn * (wc * *fscr1(Th, tid, ec)));
+            }
+            a.d_vdir[m * 3 + d] = sv * inv_s;
+        }
+    }
+    load_bits(7, bits);
+    lds_barrier();
+
+    // ---- P3: FEAT^T (+ alpha head), mask h7 -> dY7 ----------------------------------------------------
+    zero4(acc);
+    gemm3<16>(Th, Tl, packed_h + pack_offset(PB_FEAT), ct, lane, acc);
+    {
+        const float wa = a.w_alpha[ct * 32 + (lane & 31)];
+        const int r4 = 4 * (lane >> 5);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[rt][e] += *fscr1(Th, rt * 32 + (e & 3) + 8 * (e >> 2) + r4, 28 + C) * wa;
+    }
+    lds_barrier();
+    // Loads the next stage needs are requested BEFORE this stage's epilogue stores (in-order retirement): the sign bits of the
+    // stage after (from HBM: a whole epilogue + K-loop of cover) and the first weight fragments.
+    uint32_t bits_n[2];
+    WRing<BWS_PF> ring;
+    load_bits(6, bits_n);
+    gemm3_head<16, BWS_PF>(packed_h + pack_offset(PB_L7), ct, lane, ring);
+    epilogue3<true>(acc, bits, Th, Tl, ct, lane, st_tile(7), st_tile(7) + dlo, gf, amax);
+    lds_barrier();
+
+    // ---- P4: L7 .. L1: dY_l x W_l, mask h_{l-1} -> dY_{l-1} ----------------------------------------------
+    auto layer = [&](int l) __attribute__((always_inline)) {
+        zero4(acc);
+        gemm3_body<16, BWS_PF>(Th, Tl, packed_h + bwd_layer_offset(l), ct, lane, ring, acc);
+        lds_barrier();
+        bits[0] = bits_n[0];
+        bits[1] = bits_n[1];
+        if (l >= 2) {
+            load_bits(l - 2, bits_n);
+            gemm3_head<16, BWS_PF>(packed_h + bwd_layer_offset(l - 1), ct, lane, ring);
+        }
+        epilogue3<true>(acc, bits, Th, Tl, ct, lane, st_tile(l - 1), st_tile(l - 1) + dlo, gf, amax);
+        lds_barrier();
+    };
+#pragma unroll 1
+    for (int l = 7; l >= 6; --l) layer(l);
+    // The layer-5 skip's dPE block [row tile = wave & 3][column tile 8 + (wave >> 2)] = dY5 x W5[:, PE part] waits for layer 0's
+    // part in the planes' PE columns [256,320) as hi + lo (tile scale; free from P3 on).
+    const int prt = wave & 3, pct = wave >> 2;
+    {
+        f32x16 dpe;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dpe[e] = 0.f;
+        gemm_row3<16>(Th, Tl, packed_h + pack_offset(PB_L5), 8 + pct, prt, lane, dpe);
+        const int ln = stage_local(lane);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            amax = __builtin_fmaxf(amax, __builtin_fabsf(dpe[e]));
+            const _Float16 vh = (_Float16)dpe[e];
+            const int o = hidx(prt * 32 + acc_row(e, ln), 256 + pct * 32 + (ln & 31));
+            Th[o] = vh;
+            Tl[o] = (_Float16)(dpe[e] - (float)vh);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll 1
+    for (int l = 5; l >= 1; --l) layer(l);
+
+    if (a.status) {   // range guard of the f16 gradient halves: one atomic per wave, only near f16's maximum
+        const float wmax = wave_max_nonneg(amax);
+        if (lane == 63 && !(wmax < 32768.f)) atomicMax(a.status + 1, __float_as_uint(wmax == wmax ? wmax : __builtin_inff()));
+    }
+
+    // ---- P5: L0^T: dPE += dY0 x W0 -----------------------------------------------------------------------
+    // The tile's saved PE rows (f32 [128][64] = 32 KiB, contiguous) are requested here as coalesced 16-byte loads, so that their
+    // HBM round trip hides under the L0 GEMM; P6 reads them from LDS.
+    float4 per[4];
+    {
+        const float4* pe_tile = reinterpret_cast<const float4*>(acts + sact_pe32(Mp) + m0 * ACT_PE_W);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) per[k] = pe_tile[tid + k * BNT];
+    }
+    f32x16 dpe;
+    {
+        const int ln = stage_local(lane);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int o = hidx(prt * 32 + acc_row(e, ln), 256 + pct * 32 + (ln & 31));
+            dpe[e] = (float)Th[o] + (float)Tl[o];
+        }
+    }
+    gemm_row3<16>(Th, Tl, packed_h + pack_offset(PB_L0), pct, prt, lane, dpe);
+    lds_barrier();      // every wave is done reading dY0: the planes become f32 scratch, 133 floats per point:
+    // [0,64) dPE, [64,68) the odd-frequency partial sums, [68,132) PE.  The odd row stride keeps P6's per-point walks
+    // (lane = point, same column) free of bank conflicts.
+    float* F = reinterpret_cast<float*>(Tsm);
+    constexpr int FLD = 133;
+    static_assert((size_t)TMB * FLD * sizeof(float) <= BWD_SMEM, "P6 scratch fits the planes");
+    {
+        const int ln = stage_local(lane);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) F[(prt * 32 + acc_row(e, ln)) * FLD + pct * 32 + (ln & 31)] = dpe[e];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int u = tid + k * BNT;                              // float4 u of the tile: point u / 16, floats 4 (u % 16) ..
+        float* dst = F + (u >> 4) * FLD + 68 + (u & 15) * 4;
+        dst[0] = per[k].x;
+        dst[1] = per[k].y;
+        dst[2] = per[k].z;
+        dst[3] = per[k].w;
+    }
+    lds_barrier();
+
+    // ---- P6: dPE -> d_pts through the saved PE values; two threads per point (even / odd frequencies) ------------
+    {
+        const int pt = tid & (TMB - 1), g = tid >> 7;            // g = 0, 1 compute; 2, 3 idle
+        const int64_t m = m0 + pt;
+        const float* dp = F + pt * FLD;
+        const float* pe = dp + 68;
+        float sp[3] = {0.f, 0.f, 0.f};
+        if (g == 0) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) sp[d] = a.pe_w ? a.pe_w[d] * dp[d] : dp[d];
+        }
+        if (g < 2) {
+            for (int f = g; f < 10; f += 2) {
+                const float sc = (float)(1 << f);
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const int es = 3 + f * 6 + d, ec = es + 3;
+                    const float sn = pe[es], cs = pe[ec];
+                    const float ws = a.pe_w ? a.pe_w[es] : 1.f, wc = a.pe_w ? a.pe_w[ec] : 1.f;
+                    sp[d] += sc * (cs * (ws * dp[es]) - sn * (wc * dp[ec]));
+                }
+            }
+        }
+        float* part = F + pt * FLD + 64;                          // floats [64,68) of the row: past the dPE block
+        if (g == 1) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) part[d] = sp[d];
+        }
+        lds_barrier();
+        if (g == 0 && m < M) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) a.d_pts[m * 3 + d] = (sp[d] + part[d]) * inv_s;
+        }
+    }
+}
+
+// max |d_raw| -> dacts info word (zeroed by the launcher; non-negative floats order like their bit patterns)
+__global__ void grad_absmax22_kernel(const float* __restrict__ d_raw, int64_t n, float* __restrict__ out) {
+    float mx = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        mx = fmaxf(mx, fabsf(d_raw[i]));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(mx));
+}
+
+}  // namespace
+
+int benerf_mlp_dx_split22_launch(const BenerfMlpParams* params, const float* packed, int channels, int64_t M, const float* d_raw,
+                                 const float* acts, float* dacts, float* d_pts, float* d_vdir_pts, uint32_t* status,
+                                 const float* d_raw_absmax, hipStream_t stream) {
+    BwdArgs a;
+    a.d_raw = d_raw;
+    a.acts = acts;
+    a.dacts = dacts;
+    a.packed = packed;
+    a.w_alpha = params->w[BENERF_L_ALPHA];
+    a.w_rgb = params->w[BENERF_L_RGB];
+    a.pe_w = params->pe_weights;
+    a.d_pts = d_pts;
+    a.d_vdir = d_vdir_pts;
+    a.status = status;
+    a.absmax = d_raw_absmax;
+    a.M = M;
+    const int64_t tiles = mlp::m_pad(M) / TMB;
+    BENERF_REQUIRE(tiles < (1ll << 31), "mlp_bwd: too many points");
+    if (!d_raw_absmax) {    // nobody computed max |d_raw| for us: one pass over d_raw into the info word
+        float* info = dacts + mlp::sdact_info(mlp::m_pad(M));
+        if (hipMemsetAsync(info, 0, mlp::SD_COUNT * sizeof(float), stream) != hipSuccess) {
+            benerf_set_error("mlp_bwd: memset failed");
+            return BENERF_EHIP;
+        }
+        hipLaunchKernelGGL(grad_absmax22_kernel, dim3(256), dim3(256), 0, stream, d_raw, M * (channels + 1), info + mlp::SD_DRAW);
+    }
+    dim3 grid((unsigned)tiles), block(BNT);
+    const int smem = (int)BWD_SMEM;
+    static BenerfLdsAttr attr[2];       // once per device and variant
+    if (!benerf_lds_attr(attr[channels == 1 ? 0 : 1],
+                         channels == 1 ? (const void*)mlp_bwd_split_kernel<1> : (const void*)mlp_bwd_split_kernel<3>, smem)) {
+        benerf_set_error("mlp_bwd(dx, split): cannot reserve %d bytes of LDS", smem);
+        return BENERF_EHIP;
+    }
+    if (channels == 1) hipLaunchKernelGGL((mlp_bwd_split_kernel<1>), grid, block, smem, stream, a);
+    else hipLaunchKernelGGL((mlp_bwd_split_kernel<3>), grid, block, smem, stream, a);
+    BENERF_LAUNCH_CHECK("mlp_bwd(dx, split)");
+    return BENERF_OK;
+}

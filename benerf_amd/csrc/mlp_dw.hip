@@ -403,10 +403,16 @@ int benerf_mlp_dw_reduce_launch(const float* ws, const BenerfMlpGrads* grads, in
 int benerf_mlp_dw_split_launch(int channels, int64_t M, const float* d_raw, const float* acts, const float* dacts, float* dw_ws,
                                const BenerfMlpGrads* grads, int accumulate, const float* pe_weights, hipStream_t stream);
 
+// 22-bit variant (mlp_dw_s.hip)
+int benerf_mlp_dw_split22_launch(int channels, int64_t M, const float* d_raw, const float* acts, const float* dacts, float* dw_ws,
+                                 const BenerfMlpGrads* grads, int accumulate, const float* pe_weights, hipStream_t stream);
+
 int benerf_mlp_dw_launch(int precision, int channels, int64_t M, const float* d_raw, const float* acts,
                          const float* dacts, float* dw_ws, const BenerfMlpGrads* grads, int accumulate,
                          const float* pe_weights, hipStream_t stream) {
     if (precision == BENERF_MLP_SPLIT)
+        return benerf_mlp_dw_split22_launch(channels, M, d_raw, acts, dacts, dw_ws, grads, accumulate, pe_weights, stream);
+    if (precision == BENERF_MLP_SPLIT_F16BWD)
         return benerf_mlp_dw_split_launch(channels, M, d_raw, acts, dacts, dw_ws, grads, accumulate, pe_weights, stream);
     DwArgs a;
     a.d_raw = d_raw;
@@ -415,8 +421,8 @@ int benerf_mlp_dw_launch(int precision, int channels, int64_t M, const float* d_
     a.ws = dw_ws;
     a.M = M;
     a.C = channels;
-    static const bool lds_ok = hipFuncSetAttribute((const void*)mlp_dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DW_SMEM) == hipSuccess;
-    if (!lds_ok) {
+    static BenerfLdsAttr attr;
+    if (!benerf_lds_attr(attr, (const void*)mlp_dw_kernel, (int)DW_SMEM)) {
         benerf_set_error("mlp_bwd(dw): cannot reserve LDS");
         return BENERF_EHIP;
     }

@@ -1,24 +1,24 @@
-// K3 backward part 2, f16 variant of mlp_dw.hip: dW_l = dY_l^T X_l over all sample points with f16 operands (the SH
-// arrays the split forward / f16 dX kernels save, mlp_split.h), one v_mfma_f32_32x32x16_f16 per product block, f32
-// accumulation, + bias sums and the alpha / rgb heads on the VALU.
+// K3 backward part 2, BENERF_MLP_SPLIT (the 22-bit backward): dW_l = dY_l^T X_l over all sample points with BOTH operands as
+// hi + lo f16 pairs (the SH arrays and their lo twins the split forward / mlp_bwd_s.hip save, mlp_split.h):
+//     dY^T X  =  dY_hi^T X_hi + dY_hi^T X_lo + dY_lo^T X_hi      (three v_mfma_f32_32x32x16_f16 per block, ONE f32 accumulator)
+// + bias sums and the alpha / rgb heads on the VALU from hi + lo.  Why both lo halves: tools/experiments/
+// backward_format_study.py - with an f16 X or an f16 dY the weight gradients sit 2-3e-4 of the largest entry from float64
+// (same ReLU masks) where the exact-f32 kernel sits at 1e-6; with hi + lo on both they carry float32's own error.
 //
-// An SH array is blocks of 8 points, feature-major, one 16-byte unit per (block, feature) = exactly the MFMA fragment
-// of a contraction over points, so a workgroup (8 waves, one per CU) copies 32-point chunks (two MFMA k-steps)
-// verbatim into a triple-buffered LDS image [block][feature][8 points] with three chunks in flight in registers and
-// one LDS-only barrier per chunk.  A workgroup holds a whole 256 x 256 output block (128 accumulator registers x 8
-// waves), so every operand byte is read exactly once: HBM traffic = the algorithmic bytes, 2 bytes per element.
-// The kernel is HBM-bound (9.9 KB per point against 16 MFMAs per wave and chunk).
-// Gradient operands carry the per-call power-of-two scale s_s of the dX kernel (exact; divided out by the reduce
-// kernel); activations are stored unscaled (f16 subnormals keep an absolute floor of 3e-8).
+// Structure = mlp_dw_h.hip's: an SH array is blocks of 8 points, feature-major, one 16-byte unit per (block, feature) = the
+// MFMA fragment of a contraction over points, copied verbatim into a triple-buffered LDS image with three chunks in flight in
+// registers and one LDS-only barrier per chunk; a workgroup (8 waves, one per CU) holds a whole 256 x 256 output block (128
+// accumulator registers per wave), so every operand byte is read exactly once.  A chunk is 16 points (ONE MFMA k-step) of the
+// four arrays = 32 KiB, the same bytes per barrier and per register set as the f16 kernel's 32-point chunk of two arrays.
+// HBM-bound: 19.5 KB per point against 24 MFMAs per wave and chunk.
 #include "mlp_split.h"
 
 namespace {
 using namespace mlp;
 
 constexpr int DWT = 512;
-constexpr int CHP = 32;             // points per chunk = 4 blocks of 8 = two MFMA k-steps
+constexpr int CHP = 16;             // points per chunk = 2 blocks of 8 = one MFMA k-step
 constexpr int CHB = CHP / 8;
-// 16-byte unit as a first-class vector (arrays of HIP's uint4 struct were left in scratch memory by the compiler)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct DwArgs {
@@ -31,8 +31,9 @@ struct DwArgs {
 };
 
 struct Src {
-    const u32x4* y;    // SH array of width N (16-byte units)
+    const u32x4* y;    // SH array of width N (16-byte units), hi halves; lo twin at + ylo units
     const u32x4* x;    // SH array of width K ... or, for the thin instances (XROWS), f32 rows [Mp][K]
+    int64_t ylo, xlo;  // unit offsets of the lo twins
     bool bias;
 };
 
@@ -41,33 +42,30 @@ __device__ __forceinline__ Src inst_src(const DwArgs& a, int inst) {
     auto U = [](const float* p) { return reinterpret_cast<const u32x4*>(p); };
     const float* A = a.acts;
     const float* D = a.dacts;
+    const int64_t yl = sdact_lo_delta(Mp) / 4, xl = sact_lo_delta(Mp) / 4;        // floats -> 16-byte units
     switch (inst) {
         case DW_L1: case DW_L2: case DW_L3: case DW_L4: case DW_L5H: case DW_L6: case DW_L7:
-            return {U(D + sdact_h(Mp, 1 + (inst - DW_L1))), U(A + sact_h(Mp, inst - DW_L1)), true};
-        case DW_FEAT: return {U(D + sdact_feat(Mp)), U(A + sact_h(Mp, 7)), true};
-        case DW_VIEWSF: return {U(D + sdact_hv(Mp)), U(A + sact_feat(Mp)), true};
-        case DW_L0: return {U(D + sdact_h(Mp, 0)), U(A + sact_pe32(Mp)), true};       // X = PE as f32 rows
-        case DW_L5P: return {U(D + sdact_h(Mp, 5)), U(A + sact_pe32(Mp)), false};
-        default: return {U(D + sdact_hv(Mp)), U(A + sact_ped32(Mp)), false};          // DW_VIEWSP: PE(dir) rows
+            return {U(D + sdact_h(Mp, 1 + (inst - DW_L1))), U(A + sact_h(Mp, inst - DW_L1)), yl, xl, true};
+        case DW_FEAT: return {U(D + sdact_feat(Mp)), U(A + sact_h(Mp, 7)), yl, xl, true};
+        case DW_VIEWSF: return {U(D + sdact_hv(Mp)), U(A + sact_feat(Mp)), yl, xl, true};
+        case DW_L0: return {U(D + sdact_h(Mp, 0)), U(A + sact_pe32(Mp)), yl, 0, true};       // X = PE as f32 rows
+        case DW_L5P: return {U(D + sdact_h(Mp, 5)), U(A + sact_pe32(Mp)), yl, 0, false};
+        default: return {U(D + sdact_hv(Mp)), U(A + sact_ped32(Mp)), yl, 0, false};          // DW_VIEWSP: PE(dir) rows
     }
 }
 
-// Output block N x K (the whole instance: K = width of X).  Waves form a WN x (8/WN) grid; each owns TR x TC MFMA
-// tiles: per 32-point chunk (= two MFMA k-steps) acc += Y^T X.  Three chunks are in flight in registers (sets A, B,
-// C) and the LDS image is triple-buffered, so there is one LDS-only barrier per chunk.
+// Output block N x K (the whole instance: K = width of X).  Waves form a WN x (8/WN) grid; each owns TR x TC MFMA tiles: per
+// 16-point chunk acc += Yh^T Xh + Yh^T Xl + Yl^T Xh.  Three chunks are in flight in registers (sets A, B, C) and the LDS image
+// is triple-buffered, so there is one LDS-only barrier per chunk.
 template <int N, int K, int WN, int TR, int TC, bool ALPHA, bool XROWS = false>
 __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int64_t chunk_begin, int64_t chunk_end,
                                         float* __restrict__ part, u32x4* __restrict__ smem) {
     static_assert(WN * TR * 32 == N, "row tiling");
-    constexpr int YU = CHB * N, XU = CHB * K;                  // 16-byte units per chunk
+    constexpr int YU = CHB * N, XU = CHB * K;                  // 16-byte units per chunk and plane
     static_assert(!XROWS || (CHP * K / 4 <= DWT), "one float4 of the f32 rows per thread");
-    constexpr int NY = (YU + DWT - 1) / DWT, NX = (XU + DWT - 1) / DWT;
+    constexpr int NY = (YU + DWT - 1) / DWT, NX = XROWS ? 1 : (XU + DWT - 1) / DWT;
     constexpr bool YFULL = YU % DWT == 0, XFULL = XU % DWT == 0;
-    // thin instances: X = PE / PE(dir) rows, whose values repeat along a ray (PE(dir)) or across the whole batch (the
-    // raw direction components): their f16 rounding error would be COHERENT over the sum, so they are staged as hi + lo
-    // (two MFMAs per block, 22-bit operand; the rows are f32 anyway)
-    constexpr int XPL = XROWS ? 2 : 1;
-    constexpr int BUF = YU + XPL * XU + CHP / 4;               // + CHP floats of d_sigma
+    constexpr int BUF = 2 * YU + 2 * XU + CHP / 4;             // Yh | Yl | Xh | Xl | CHP floats of d_sigma
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 31, lh = lane >> 5;
     const int wn = wave % WN, wk = wave / WN;
@@ -83,24 +81,29 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int64_t 
             for (int e = 0; e < 16; ++e) acc[r][c][e] = 0.f;
     float bsum = 0.f, asum = 0.f, absum = 0.f;
 
-    u32x4 ryA[NY], rxA[NX], ryB[NY], rxB[NX], ryC[NY], rxC[NX];
+    u32x4 ryA[2][NY], rxA[2][NX], ryB[2][NY], rxB[2][NX], ryC[2][NY], rxC[2][NX];
     float rdaA = 0.f, rdaB = 0.f, rdaC = 0.f;
-    // Loads are UNCONDITIONAL (a chunk index past the range is clamped to the last chunk and its staged dY zeroed):
-    // with the loads under branches the compiler's waitcnt bookkeeping fell back to vmcnt(0) at every stage, i.e. one
-    // chunk in flight instead of three.
+    // Loads are UNCONDITIONAL (a chunk index past the range is clamped to the last chunk and its staged dY zeroed): with the
+    // loads under branches the compiler's waitcnt bookkeeping falls back to vmcnt(0) at every stage (mlp_dw_h.hip)
 #define DW_PREFETCH(RY, RX, RDA, CHUNK)                                                                   \
     {                                                                                                     \
         const int64_t cc = (CHUNK) < chunk_end ? (CHUNK) : chunk_end - 1;                                 \
         const u32x4* py = src.y + cc * YU + tid;                                                          \
         const u32x4* px = src.x + cc * XU + tid;                                                          \
         _Pragma("unroll") for (int j = 0; j < NY; ++j)                                                    \
-            if (YFULL || tid + j * DWT < YU) RY[j] = py[j * DWT];                                         \
+            if (YFULL || tid + j * DWT < YU) {                                                            \
+                RY[0][j] = py[j * DWT];                                                                   \
+                RY[1][j] = py[src.ylo + j * DWT];                                                         \
+            }                                                                                             \
         if (XROWS) {   /* f32 rows [point][K]: one float4 (4 features of a point) per thread */                \
             if (tid < CHP * K / 4)                                                                        \
-                RX[0] = reinterpret_cast<const u32x4*>(reinterpret_cast<const float*>(src.x) + cc * (CHP * K))[tid]; \
+                RX[0][0] = reinterpret_cast<const u32x4*>(reinterpret_cast<const float*>(src.x) + cc * (CHP * K))[tid]; \
         } else {                                                                                          \
             _Pragma("unroll") for (int j = 0; j < NX; ++j)                                                \
-                if (XFULL || tid + j * DWT < XU) RX[j] = px[j * DWT];                                     \
+                if (XFULL || tid + j * DWT < XU) {                                                        \
+                    RX[0][j] = px[j * DWT];                                                               \
+                    RX[1][j] = px[src.xlo + j * DWT];                                                     \
+                }                                                                                         \
         }                                                                                                 \
         if (ALPHA) {                                                                                      \
             const int64_t row = cc * CHP + (tid & (CHP - 1));                                             \
@@ -112,17 +115,20 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int64_t 
 #define DW_STAGE(RY, RX, RDA, B, VALID)                                                                   \
     {                                                                                                     \
         u32x4* Ys_ = smem + (B) * BUF;                                                                    \
-        u32x4* Xs_ = Ys_ + YU;                                                                            \
+        u32x4* Xs_ = Ys_ + 2 * YU;                                                                        \
         _Pragma("unroll") for (int j = 0; j < NY; ++j) {                                                  \
             const int u = tid + j * DWT;                                                                  \
-            if (YFULL || u < YU) Ys_[u] = (VALID) ? RY[j] : u32x4{0u, 0u, 0u, 0u};   /* past the range: contributes nothing */ \
+            if (YFULL || u < YU) {   /* past the range: contributes nothing */                            \
+                Ys_[u] = (VALID) ? RY[0][j] : u32x4{0u, 0u, 0u, 0u};                                      \
+                Ys_[YU + u] = (VALID) ? RY[1][j] : u32x4{0u, 0u, 0u, 0u};                                 \
+            }                                                                                             \
         }                                                                                                 \
-        if (XROWS) {   /* round to f16 and scatter the 4 features of this thread's point into their fragments */ \
+        if (XROWS) {   /* split into hi + lo and scatter the 4 features of this thread's point into their fragments */ \
             if (tid < CHP * K / 4) {                                                                      \
                 const int p = tid / (K / 4), w0 = (tid % (K / 4)) * 4;                                    \
                 _Float16* img = reinterpret_cast<_Float16*>(Xs_);                                         \
                 _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
-                    const float v = __uint_as_float(RX[0][i]);                                            \
+                    const float v = __uint_as_float(RX[0][0][i]);                                         \
                     const _Float16 hi = (_Float16)v;                                                      \
                     img[((p >> 3) * K + w0 + i) * 8 + (p & 7)] = hi;                                      \
                     img[XU * 8 + ((p >> 3) * K + w0 + i) * 8 + (p & 7)] = (_Float16)(v - (float)hi);      \
@@ -131,9 +137,12 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int64_t 
         } else                                                                                            \
         _Pragma("unroll") for (int j = 0; j < NX; ++j) {                                                  \
             const int u = tid + j * DWT;                                                                  \
-            if (XFULL || u < XU) Xs_[u] = RX[j];                                                          \
+            if (XFULL || u < XU) {                                                                        \
+                Xs_[u] = RX[0][j];                                                                        \
+                Xs_[XU + u] = RX[1][j];                                                                   \
+            }                                                                                             \
         }                                                                                                 \
-        if (ALPHA && tid < CHP) reinterpret_cast<float*>(Xs_ + XPL * XU)[tid] = (VALID) ? RDA : 0.f;      \
+        if (ALPHA && tid < CHP) reinterpret_cast<float*>(Xs_ + 2 * XU)[tid] = (VALID) ? RDA : 0.f;        \
         /* buffer B was last read three chunks ago, and every wave has passed two barriers in between */ \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");                                   \
         __builtin_amdgcn_s_barrier();                                                                     \
@@ -141,28 +150,38 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int64_t 
     }
     auto compute = [&](int b) {
         const u32x4* Yl = smem + b * BUF;
-        const u32x4* Xl = Yl + YU;
-        const float* da = reinterpret_cast<const float*>(Xl + XPL * XU);
+        const u32x4* Xl = Yl + 2 * YU;
+        const float* da = reinterpret_cast<const float*>(Xl + 2 * XU);
         if (mma_wave) {
+            half8 ayh[TR], ayl[TR];
 #pragma unroll
-            for (int ks = 0; ks < CHP / 16; ++ks) {
-                half8 ay[TR], bx[TC];
+            for (int r = 0; r < TR; ++r) {
+                ayh[r] = __builtin_bit_cast(half8, Yl[lh * N + (wn * TR + r) * 32 + lr]);
+                ayl[r] = __builtin_bit_cast(half8, Yl[YU + lh * N + (wn * TR + r) * 32 + lr]);
+            }
+            // column tiles in groups of CG: the three MFMAs of one accumulator are TR * CG issue slots apart, and only CG
+            // fragment pairs of X are live at a time (all TC at once spilled)
+            constexpr int CG = TC >= 2 ? 2 : 1;
 #pragma unroll
-                for (int r = 0; r < TR; ++r) ay[r] = __builtin_bit_cast(half8, Yl[(ks * 2 + lh) * N + (wn * TR + r) * 32 + lr]);
+            for (int c0 = 0; c0 < TC; c0 += CG) {
+                half8 bxh[CG], bxl[CG];
 #pragma unroll
-                for (int c = 0; c < TC; ++c) bx[c] = __builtin_bit_cast(half8, Xl[(ks * 2 + lh) * K + (wk * TC + c) * 32 + lr]);
+                for (int c = 0; c < CG; ++c) {
+                    bxh[c] = __builtin_bit_cast(half8, Xl[lh * K + (wk * TC + c0 + c) * 32 + lr]);
+                    bxl[c] = __builtin_bit_cast(half8, Xl[XU + lh * K + (wk * TC + c0 + c) * 32 + lr]);
+                }
 #pragma unroll
                 for (int r = 0; r < TR; ++r)
 #pragma unroll
-                    for (int c = 0; c < TC; ++c) acc[r][c] = mfma16(ay[r], bx[c], acc[r][c]);
-                if (XROWS) {
+                    for (int c = 0; c < CG; ++c) acc[r][c0 + c] = mfma16(ayh[r], bxh[c], acc[r][c0 + c]);
 #pragma unroll
-                    for (int c = 0; c < TC; ++c) bx[c] = __builtin_bit_cast(half8, Xl[XU + (ks * 2 + lh) * K + (wk * TC + c) * 32 + lr]);
+                for (int r = 0; r < TR; ++r)
 #pragma unroll
-                    for (int r = 0; r < TR; ++r)
+                    for (int c = 0; c < CG; ++c) acc[r][c0 + c] = mfma16(ayh[r], bxl[c], acc[r][c0 + c]);
 #pragma unroll
-                        for (int c = 0; c < TC; ++c) acc[r][c] = mfma16(ay[r], bx[c], acc[r][c]);
-                }
+                for (int r = 0; r < TR; ++r)
+#pragma unroll
+                    for (int c = 0; c < CG; ++c) acc[r][c0 + c] = mfma16(ayl[r], bxh[c], acc[r][c0 + c]);
             }
         }
         if (src.bias && tid < N) {
@@ -170,23 +189,24 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int64_t 
 #pragma unroll
             for (int mb = 0; mb < CHB; ++mb) {
                 const half8 h = __builtin_bit_cast(half8, Yl[mb * N + tid]);
+                const half8 l = __builtin_bit_cast(half8, Yl[YU + mb * N + tid]);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) s += (float)h[j];
+                for (int j = 0; j < 8; ++j) s += (float)h[j] + (float)l[j];
             }
             bsum += s;
         }
-        // the alpha head rides on waves 4..7 (column tid - 256): waves 0..3 already carry the bias sums, and with both on the
-        // same four waves the FEAT workgroups were VALU-bound and finished 30 % behind every other instance (trace_dw.py)
+        // the alpha head rides on waves 4..7 (column tid - 256): waves 0..3 already carry the bias sums (mlp_dw_h.hip)
         if (ALPHA && tid >= DWT - K) {
             const int ka = tid - (DWT - K);
             float s = 0.f, sb = 0.f;
 #pragma unroll
             for (int mb = 0; mb < CHB; ++mb) {
                 const half8 h = __builtin_bit_cast(half8, Xl[mb * K + ka]);
+                const half8 l = __builtin_bit_cast(half8, Xl[XU + mb * K + ka]);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float d = da[mb * 8 + j];
-                    s += d * (float)h[j];
+                    s += d * ((float)h[j] + (float)l[j]);
                     sb += d;
                 }
             }
@@ -218,8 +238,8 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int64_t 
 #undef DW_PREFETCH
 #undef DW_STAGE
 
-    // partial block -> workspace: [N][K] then bias [N] (then alpha row [256] + alpha bias).  Block and bias stay at
-    // the gradient scale s_s (the reduce kernel divides it out); the alpha row is unscaled (d_raw is)
+    // partial block -> workspace: [N][K] then bias [N] (then alpha row [256] + alpha bias).  Block and bias stay at the
+    // gradient scale s_s (the reduce kernel divides it out); the alpha row is unscaled (d_raw is)
     if (mma_wave) {
 #pragma unroll
         for (int r = 0; r < TR; ++r)
@@ -238,45 +258,50 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int64_t 
     }
 }
 
-// rgb head: dW_rgb[c][j] = sum_pt d_rgb[pt][c] * hv[pt][j], db_rgb[c] = sum_pt d_rgb[pt][c]   (unscaled d_raw, f32).
-// Batches of 512 points: d_raw staged in LDS, then every thread (column j, phase ph) streams 16 blocks of hv with
+// rgb head: dW_rgb[c][j] = sum_pt d_rgb[pt][c] * hv[pt][j], db_rgb[c] = sum_pt d_rgb[pt][c]   (unscaled d_raw, f32; hv = hi + lo).
+// Batches of 256 points: d_raw staged in LDS, then every thread (column j, phase ph) streams 8 blocks of hv (hi and lo) with
 // all its loads independent.
 __device__ __forceinline__ void dw_rgb(const DwArgs& a, int64_t blk_begin, int64_t blk_end, float* __restrict__ part,
                                        float* __restrict__ smem) {
-    constexpr int BB = 64;                                           // blocks of 8 points per batch
+    constexpr int BB = 32;                                           // blocks of 8 points per batch
     const int tid = threadIdx.x, j = tid & 127, ph = tid >> 7;     // ph: block phase 0..3
-    const u32x4* hv = reinterpret_cast<const u32x4*>(a.acts + sact_hv(m_pad(a.M)));
+    const int64_t Mp = m_pad(a.M);
+    const u32x4* hv = reinterpret_cast<const u32x4*>(a.acts + sact_hv(Mp));
+    const int64_t lo = sact_lo_delta(Mp) / 4;
     const int C = a.C;
     const int64_t M = a.M;
     float* dr = smem;                                                // [BB*8][4]
     float s[3] = {0.f, 0.f, 0.f}, sb[3] = {0.f, 0.f, 0.f};
     for (int64_t b0 = blk_begin; b0 < blk_end; b0 += BB) {
         __syncthreads();
-        {   // 512 points x 4 slots, one point per thread
+        if (tid < BB * 8) {   // 256 points x 4 slots, one point per thread
             const int64_t m = b0 * 8 + tid;
             float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
             if (m < M && m < blk_end * 8) {
-                const float* src = a.d_raw + m * (C + 1);
-                g.x = src[0];
-                if (C > 1) g.y = src[1];
-                if (C > 2) g.z = src[2];
+                const float* srcp = a.d_raw + m * (C + 1);
+                g.x = srcp[0];
+                if (C > 1) g.y = srcp[1];
+                if (C > 2) g.z = srcp[2];
             }
             reinterpret_cast<float4*>(dr)[tid] = g;
         }
         __syncthreads();
-        u32x4 hh[BB / 4];
+        u32x4 hh[BB / 4], hl[BB / 4];
 #pragma unroll
         for (int i = 0; i < BB / 4; ++i) {
             const int64_t mb = b0 + ph + 4 * i;
-            hh[i] = u32x4{0u, 0u, 0u, 0u};
-            if (mb < blk_end) hh[i] = hv[mb * ACT_HV_W + j];     // 8 points of column j
+            hh[i] = hl[i] = u32x4{0u, 0u, 0u, 0u};
+            if (mb < blk_end) {
+                hh[i] = hv[mb * ACT_HV_W + j];     // 8 points of column j
+                hl[i] = hv[lo + mb * ACT_HV_W + j];
+            }
         }
 #pragma unroll
         for (int i = 0; i < BB / 4; ++i) {
-            const half8 pq = __builtin_bit_cast(half8, hh[i]);
+            const half8 pq = __builtin_bit_cast(half8, hh[i]), pl = __builtin_bit_cast(half8, hl[i]);
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const float x = (float)pq[q];
+                const float x = (float)pq[q] + (float)pl[q];
                 const float4 g = reinterpret_cast<const float4*>(dr)[(ph + 4 * i) * 8 + q];   // zero beyond the range
                 s[0] += g.x * x;
                 s[1] += g.y * x;
@@ -315,8 +340,9 @@ __device__ __forceinline__ void dw_rgb(const DwArgs& a, int64_t blk_begin, int64
     }
 }
 
-constexpr size_t DWH_SMEM = 3 * (size_t)(CHB * 256 + CHB * 256 + CHP / 4) * 16;       // three chunk images of the 256 x 256 block: 98 688 B
-constexpr size_t DWH_SMEM_SMALL = 3 * (size_t)(CHB * 256 + 2 * CHB * 64 + CHP / 4) * 16;  // 256 x 64 block, X as hi + lo: 74 112 B
+constexpr size_t DWS_SMEM = 3 * (size_t)(2 * CHB * 256 + 2 * CHB * 256 + CHP / 4) * 16;       // three chunk images of the 256 x 256 block: 98 496 B
+constexpr size_t DWS_SMEM_SMALL = 3 * (size_t)(2 * CHB * 256 + 2 * CHB * 64 + CHP / 4) * 16;  // 256 x 64 block: 61 632 B
+static_assert(DWS_SMEM_SMALL >= (32 * 8 * 4 + 18 * 128) * sizeof(float), "rgb head scratch fits the thin image");
 
 __device__ __forceinline__ void chunk_range(const DwArgs& a, int inst, int split, int64_t& cb, int64_t& ce) {
     const int64_t nchunks = m_pad(a.M) / CHP;
@@ -336,7 +362,7 @@ __device__ __forceinline__ void chunk_range(const DwArgs& a, int inst, int split
 #endif
 
 // the eight 256x256 instances + the 128x256 views block: one workgroup per CU, every operand byte read once
-__global__ __launch_bounds__(DWT, 2) void mlp_dw_f16_big_kernel(DwArgs a) {
+__global__ __launch_bounds__(DWT, 2) void mlp_dw_split_big_kernel(DwArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32x4 smem_u[];
     DW_TRACE(1, 0);
     const int inst = dwh_big_inst(blockIdx.x), split = dwh_big_split(blockIdx.x);
@@ -351,7 +377,7 @@ __global__ __launch_bounds__(DWT, 2) void mlp_dw_f16_big_kernel(DwArgs a) {
 }
 
 // the thin instances: L0 and L5P (256 x 64, X = PE), VIEWSP (128 x 32, X = PE(dir)), rgb head (VALU)
-__global__ __launch_bounds__(DWT, 4) void mlp_dw_f16_small_kernel(DwArgs a) {
+__global__ __launch_bounds__(DWT, 4) void mlp_dw_split_small_kernel(DwArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32x4 smem_u[];
     DW_TRACE(0, 0);
     const int inst = dwh_thin_inst(blockIdx.x), split = dwh_thin_split(blockIdx.x);
@@ -374,8 +400,8 @@ __global__ __launch_bounds__(DWT, 4) void mlp_dw_f16_small_kernel(DwArgs a) {
 int benerf_mlp_dw_reduce_launch(const float* ws, const BenerfMlpGrads* grads, int channels, int accumulate, int split_mode,
                                 const float* grad_info, const float* pe_weights, hipStream_t stream);
 
-int benerf_mlp_dw_split_launch(int channels, int64_t M, const float* d_raw, const float* acts, const float* dacts, float* dw_ws,
-                               const BenerfMlpGrads* grads, int accumulate, const float* pe_weights, hipStream_t stream) {
+int benerf_mlp_dw_split22_launch(int channels, int64_t M, const float* d_raw, const float* acts, const float* dacts, float* dw_ws,
+                                 const BenerfMlpGrads* grads, int accumulate, const float* pe_weights, hipStream_t stream) {
     DwArgs a;
     a.d_raw = d_raw;
     a.acts = acts;
@@ -385,14 +411,14 @@ int benerf_mlp_dw_split_launch(int channels, int64_t M, const float* d_raw, cons
     a.C = channels;
     static_assert(DW_L0 + 1 == DW_L5P && DW_L5P + 1 == DW_VIEWSP && DW_VIEWSP + 1 == DW_RGB, "small-kernel instance order");
     static BenerfLdsAttr attr_big, attr_small;      // once per device
-    if (!benerf_lds_attr(attr_big, (const void*)mlp_dw_f16_big_kernel, (int)DWH_SMEM) ||
-        !benerf_lds_attr(attr_small, (const void*)mlp_dw_f16_small_kernel, (int)DWH_SMEM_SMALL)) {
-        benerf_set_error("mlp_bwd(dw, f16): cannot reserve LDS");
+    if (!benerf_lds_attr(attr_big, (const void*)mlp_dw_split_big_kernel, (int)DWS_SMEM) ||
+        !benerf_lds_attr(attr_small, (const void*)mlp_dw_split_small_kernel, (int)DWS_SMEM_SMALL)) {
+        benerf_set_error("mlp_bwd(dw, split): cannot reserve LDS");
         return BENERF_EHIP;
     }
-    hipLaunchKernelGGL(mlp_dw_f16_small_kernel, dim3(mlp::DWH_SMALL_BLOCKS), dim3(DWT), DWH_SMEM_SMALL, stream, a);
-    BENERF_LAUNCH_CHECK("mlp_bwd(dw small, f16)");
-    hipLaunchKernelGGL(mlp_dw_f16_big_kernel, dim3(mlp::DWH_BIG_BLOCKS), dim3(DWT), DWH_SMEM, stream, a);
-    BENERF_LAUNCH_CHECK("mlp_bwd(dw, f16)");
+    hipLaunchKernelGGL(mlp_dw_split_small_kernel, dim3(mlp::DWH_SMALL_BLOCKS), dim3(DWT), DWS_SMEM_SMALL, stream, a);
+    BENERF_LAUNCH_CHECK("mlp_bwd(dw small, split)");
+    hipLaunchKernelGGL(mlp_dw_split_big_kernel, dim3(mlp::DWH_BIG_BLOCKS), dim3(DWT), DWS_SMEM, stream, a);
+    BENERF_LAUNCH_CHECK("mlp_bwd(dw, split)");
     return benerf_mlp_dw_reduce_launch(dw_ws, grads, channels, accumulate, 1, dacts + mlp::sdact_info(mlp::m_pad(M)), pe_weights, stream);
 }

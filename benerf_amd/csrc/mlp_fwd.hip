@@ -361,7 +361,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_kernel(FwdArgs a) {
 // split-f16 variant (mlp_fwd_h.hip)
 int benerf_mlp_fwd_split_launch(const BenerfMlpParams* params, const float* packed, int channels, int n_rays, int n_samples,
                                 const float* rays_o, const float* rays_d, const float* viewdirs, const float* z, float* raw,
-                                float* acts, uint32_t* status, hipStream_t stream);
+                                float* acts, int save_lo, uint32_t* status, hipStream_t stream);
 
 extern "C" int benerf_mlp_fwd(const BenerfMlpParams* params, const float* packed, int channels, int n_rays,
                               int n_samples, const float* rays_o, const float* rays_d, const float* viewdirs,
@@ -370,8 +370,8 @@ extern "C" int benerf_mlp_fwd(const BenerfMlpParams* params, const float* packed
     BENERF_REQUIRE(params && packed && rays_o && rays_d && viewdirs && z && raw, "mlp_fwd: null pointer");
     BENERF_REQUIRE(channels == 1 || channels == 3, "mlp_fwd: channels must be 1 or 3");
     BENERF_REQUIRE(n_rays > 0 && n_samples > 0, "mlp_fwd: bad sizes");
-    BENERF_REQUIRE(precision == BENERF_MLP_F32 || precision == BENERF_MLP_SPLIT || precision == BENERF_MLP_AUTO,
-                   "mlp_fwd: unknown precision %d", precision);
+    BENERF_REQUIRE(precision == BENERF_MLP_F32 || precision == BENERF_MLP_SPLIT || precision == BENERF_MLP_AUTO ||
+                       precision == BENERF_MLP_SPLIT_F16BWD, "mlp_fwd: unknown precision %d", precision);
     BENERF_REQUIRE(precision != BENERF_MLP_AUTO || (status && !acts),
                    "mlp_fwd: BENERF_MLP_AUTO is the inference mode (acts == NULL) and needs a status word");
     for (int l = 0; l < BENERF_NLAYERS; ++l) BENERF_REQUIRE(params->b[l] && params->w[l], "mlp_fwd: null parameter %d", l);
@@ -385,8 +385,8 @@ extern "C" int benerf_mlp_fwd(const BenerfMlpParams* params, const float* packed
             gate = status + 3;
         }
         const int rc = benerf_mlp_fwd_split_launch(params, packed, channels, n_rays, n_samples, rays_o, rays_d, viewdirs, z, raw, acts,
-                                                   status, as_stream(stream));
-        if (rc != BENERF_OK || precision == BENERF_MLP_SPLIT) return rc;
+                                                   precision == BENERF_MLP_SPLIT, status, as_stream(stream));
+        if (rc != BENERF_OK || precision != BENERF_MLP_AUTO) return rc;
     }
     FwdArgs a;
     a.rays_o = rays_o;
@@ -413,9 +413,8 @@ extern "C" int benerf_mlp_fwd(const BenerfMlpParams* params, const float* packed
     const int smem = (int)mlp::TILE_SMEM;
 #define BENERF_FWD_LAUNCH(CH, SV)                                                                                  \
     do {                                                                                                           \
-        static const bool lds_ok = hipFuncSetAttribute((const void*)mlp_fwd_kernel<CH, SV>,                        \
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem) == hipSuccess; \
-        if (!lds_ok) {                                                                                             \
+        static BenerfLdsAttr attr_;                                                                                \
+        if (!benerf_lds_attr(attr_, (const void*)mlp_fwd_kernel<CH, SV>, smem)) {                                  \
             benerf_set_error("mlp_fwd: cannot reserve %d bytes of LDS", smem);                                     \
             return BENERF_EHIP;                                                                                    \
         }                                                                                                          \

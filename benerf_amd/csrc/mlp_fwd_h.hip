@@ -193,6 +193,39 @@ __device__ __forceinline__ uint64_t save_tile(const _Float16* __restrict__ Th, i
     return bits;
 }
 
+// BENERF_MLP_SPLIT (SAVE == 2, the 22-bit backward): the LOW halves leave too, as a second SH array of the same shape.  The lo
+// plane holds (x - hi) * 2^11; the backward GEMMs add hi x lo into the hi x hi accumulator, so the saved copy is unscaled
+// again by an exact v_pk_mul_f16 with 2^-11 (results below 2^-14 round into f16's subnormals: absolute floor 2^-25).
+__device__ __forceinline__ uint2 unscale_lo4(uint2 q) {
+    const half2v k = {(_Float16)LO_INV, (_Float16)LO_INV};
+    return uint2{__builtin_bit_cast(uint32_t, __builtin_bit_cast(half2v, q.x) * k), __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2v, q.y) * k)};
+}
+template <int W>
+__device__ __forceinline__ void save_pair_lo(const _Float16* __restrict__ Tl, int ct, int bp, int lane, __amdgpu_buffer_rsrc_t rs) {
+    asm volatile("" : "+v"(lane));
+    const int t = lane & 15, g = lane >> 4, hf = lane >> 5, pl = lane & 31;
+    const int n = ct * 32 + pl;
+    const int col = ct * 32 + 16 * (g & 1) + 4 * (t & 3);
+    const int rsub = 4 * (g >> 1) + (t >> 2);
+    uint2 q[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int b = 2 * bp + k, row = b * 8 + rsub;
+        const _Float16* src = Tl + row * LD + ((((col >> 3) ^ hsw(row)) << 3) | (col & 7));
+        const short4v v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (short4v __attribute__((address_space(3)))*)(reinterpret_cast<const short4v*>(src)));
+        q[k] = unscale_lo4(__builtin_bit_cast(uint2, v));
+    }
+    const uint4 u = sh_pair_unit(q[0], q[1]);
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{u.x, u.y, u.z, u.w}, rs, (((2 * bp + hf) * W + n) * 8) * 2, 0, 0);
+}
+template <int W, int NBLK>
+__device__ __forceinline__ void save_tile_lo(const _Float16* __restrict__ Tl, int ct, int lane, const _Float16* __restrict__ st_tile) {
+    const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(st_tile);
+#pragma unroll
+    for (int bp = 0; bp < NBLK / 2; ++bp) save_pair_lo<W>(Tl, ct, bp, lane, rs);
+}
+
 // offset of the forward block of hidden layer l (1..7, l != 5 at the call site) without the generic pack_offset() summation,
 // which becomes a scalar loop of branches for a run-time l
 __device__ __forceinline__ int fwd_layer_offset(int l) {
@@ -208,7 +241,8 @@ static_assert(pack_offset(PF_L1) + 3 * pack_floats(PF_L1) == pack_offset(PF_L4) 
 constexpr int FTM = 128, FNT = 512, FPF = 2;
 constexpr size_t FWD_SMEM = (size_t)2 * FTM * LD * sizeof(_Float16);      // 163 840 B
 
-template <int C, bool SAVE>
+// SAVE: 0 inference, 1 training with the f16 backward (hi halves saved), 2 training with the 22-bit backward (hi + lo)
+template <int C, int SAVE>
 __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) _Float16 Tsm[];   // Th | Tl
     _Float16* Th = Tsm;
@@ -238,7 +272,8 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
         mask_out[layer * mask_stride + 2 * NTHREADS] = (uint32_t)(b >> 32);        // points 64..127: the next 64-point tile
     };
     const bool live = m < M;
-    if (SAVE && blockIdx.x == 0 && tid == 0) reinterpret_cast<uint32_t*>(acts + sact_info(Mp))[SI_TAG] = SACT_TAG_SPLIT;
+    if (SAVE && blockIdx.x == 0 && tid == 0) reinterpret_cast<uint32_t*>(acts + sact_info(Mp))[SI_TAG] = SAVE == 2 ? SACT_TAG_SPLIT22 : SACT_TAG_SPLIT;
+    const int64_t lo_halfs = 2 * sact_lo_delta(Mp);                 // SAVE == 2: half offset from an SH array to its lo twin
     float amax = 0.f;        // running max |activation| of this thread (range guard)
     // f32 scratch in the dead PE columns [288,320) of the lo plane: logical slot 36 + j of this thread's row
     const int psw = hsw(pt);
@@ -315,25 +350,34 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
         // between the MFMAs.  The next requests (the following layer's) come an epilogue later.
         uint64_t pbits = 0;
         const __amdgpu_buffer_rsrc_t prs = uniform_rsrc(SAVE ? st_h + ((int64_t)(l - 1) * Mp + m0) * 256 : nullptr);
-        auto save_at = [&](int ks, int first) {
-            if (SAVE && ks >= first) {
+        const __amdgpu_buffer_rsrc_t prs_lo = uniform_rsrc(SAVE == 2 ? st_h + ((int64_t)(l - 1) * Mp + m0) * 256 + lo_halfs : nullptr);
+        // `last` = the loop's final k-step.  SAVE == 1: the hi halves in its last two k-steps; SAVE == 2: the lo halves in the
+        // two k-steps before those (behind the loop's last fragment request with FPF = 2 only for the final pair of k-steps -
+        // the lo stores of k-steps last - 3 / last - 2 sit in front of one / no later fragment request)
+        auto save_at = [&](int ks, int last) {
+            if (SAVE && ks >= last - 1) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) save_pair<256, true, 16>(Th, wave, (ks - first) * 4 + i, lane, prs, pbits);
-                if (ks == first + 1) store_bits(l - 1, pbits);
+                for (int i = 0; i < 4; ++i) save_pair<256, true, 16>(Th, wave, (ks - (last - 1)) * 4 + i, lane, prs, pbits);
+                if (ks == last) store_bits(l - 1, pbits);
+            }
+            if (SAVE == 2 && ks >= last - 3 && ks < last - 1) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) save_pair_lo<256>(Tl, wave, (ks - (last - 3)) * 4 + i, lane, prs_lo);
             }
         };
         acc_init_bias(acc1, bq);
         zero_acc(acc2);
         if (l == 5) gemm_stage<20, 1, FPF, true, 4>(Th, Tl, 0, a.packed + pack_offset(PF_L5), wave, lane, acc1, acc2, NoAfterHead(),
-                                                    [&](int ks) { save_at(ks, 18); });
+                                                    [&](int ks) { save_at(ks, 19); });
         else gemm_stage<16, 1, FPF, true, 4>(Th, Tl, 0, a.packed + fwd_layer_offset(l), wave, lane, acc1, acc2, NoAfterHead(),
-                                             [&](int ks) { save_at(ks, 14); });
+                                             [&](int ks) { save_at(ks, 15); });
         lds_barrier();
         load_bias<1>(a.bias[l < 7 ? l + 1 : BENERF_L_FEAT], wave, lane, bq);
         epilogue_t<1, true, 4>(acc1, acc2, Th, Tl, wave, lane, amax);
         lds_barrier();
     }
     if (SAVE) store_bits(7, save_tile<1, 256, true, 16>(Th, wave, lane, st_h + ((int64_t)7 * Mp + m0) * 256));
+    if (SAVE == 2) save_tile_lo<256, 16>(Tl, wave, lane, st_h + ((int64_t)7 * Mp + m0) * 256 + lo_halfs);
 
     // ---- alpha partials (reads h7) + PE(viewdir) into columns [256,288) ---------------------------
     {
@@ -395,6 +439,7 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
     }
     lds_barrier();
     if (SAVE) save_tile<1, 256, false, 16>(Th, wave, lane, reinterpret_cast<_Float16*>(acts + sact_feat(Mp)) + m0 * 256);
+    if (SAVE == 2) save_tile_lo<256, 16>(Tl, wave, lane, reinterpret_cast<_Float16*>(acts + sact_feat(Mp)) + m0 * 256 + lo_halfs);
 
     // ---- VIEWS: [feature | PE(dir)] (288) -> 128: wave w computes column tile w & 3 for the point half w >> 2 -------------
     {
@@ -413,6 +458,7 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
                                                                                       (m0 + vrh * 64) * ACT_HV_W);
             reinterpret_cast<uint64_t*>(acts + sact_mask(Mp))[8 * (Mp / TM) * NTHREADS + ((int64_t)blockIdx.x * 2 + vrh) * NTHREADS + vct * 64 + lane] = bits;
         }
+        if (SAVE == 2) save_tile_lo<ACT_HV_W, 8>(Tlh, vct, lane, reinterpret_cast<_Float16*>(acts + sact_hv(Mp)) + (m0 + vrh * 64) * ACT_HV_W + lo_halfs);
     }
 
     // ---- rgb: 128 -> C on the VALU; partials of channel c in scratch slot 1 + c ------------------------
@@ -456,9 +502,10 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
 
 }  // namespace
 
+// save_lo: training launches (acts != NULL) also save the low halves (BENERF_MLP_SPLIT: the 22-bit backward reads them)
 int benerf_mlp_fwd_split_launch(const BenerfMlpParams* params, const float* packed, int channels, int n_rays, int n_samples,
                                 const float* rays_o, const float* rays_d, const float* viewdirs, const float* z, float* raw,
-                                float* acts, uint32_t* status, hipStream_t stream) {
+                                float* acts, int save_lo, uint32_t* status, hipStream_t stream) {
     FwdArgs a;
     a.rays_o = rays_o;
     a.rays_d = rays_d;
@@ -486,20 +533,21 @@ int benerf_mlp_fwd_split_launch(const BenerfMlpParams* params, const float* pack
     const int smem = (int)FWD_SMEM;
 #define BENERF_FWD_LAUNCH(CH, SV)                                                                                        \
     do {                                                                                                                 \
-        static const hipError_t attr = hipFuncSetAttribute((const void*)mlp_fwd_split_kernel<CH, SV>,                     \
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem); /* once */ \
-        if (attr != hipSuccess) {                                                                                        \
+        static BenerfLdsAttr attr_;                                                                                      \
+        if (!benerf_lds_attr(attr_, (const void*)mlp_fwd_split_kernel<CH, SV>, smem)) {                                  \
             benerf_set_error("mlp_fwd(split): cannot reserve %d bytes of LDS", smem);                                    \
             return BENERF_EHIP;                                                                                          \
         }                                                                                                                \
         hipLaunchKernelGGL((mlp_fwd_split_kernel<CH, SV>), grid, block, smem, stream, a);                                \
     } while (0)
     if (channels == 1) {
-        if (acts) BENERF_FWD_LAUNCH(1, true);
-        else BENERF_FWD_LAUNCH(1, false);
+        if (acts && save_lo) BENERF_FWD_LAUNCH(1, 2);
+        else if (acts) BENERF_FWD_LAUNCH(1, 1);
+        else BENERF_FWD_LAUNCH(1, 0);
     } else {
-        if (acts) BENERF_FWD_LAUNCH(3, true);
-        else BENERF_FWD_LAUNCH(3, false);
+        if (acts && save_lo) BENERF_FWD_LAUNCH(3, 2);
+        else if (acts) BENERF_FWD_LAUNCH(3, 1);
+        else BENERF_FWD_LAUNCH(3, 0);
     }
 #undef BENERF_FWD_LAUNCH
     BENERF_LAUNCH_CHECK("mlp_fwd(split)");

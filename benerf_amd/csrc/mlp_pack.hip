@@ -125,12 +125,12 @@ __device__ __forceinline__ void pack_body(const PackArgs& a) {
 extern "C" size_t benerf_mlp_packed_floats(void) { return (size_t)(2 * mlp::PACKED_FLOATS); }   // f32 blocks | split-f16 blocks
 // buffers are sized for either arithmetic mode (the split mode pads the point count to whole 128-point tiles)
 extern "C" size_t benerf_mlp_act_floats(int64_t n_points) {
-    const int64_t a = mlp::act_total_floats(n_points), b = mlp::sact_total_floats(n_points);
+    const int64_t a = mlp::act_total_floats(n_points), b = mlp::sact22_total_floats(n_points);   // sact22 >= sact
     return (size_t)(a > b ? a : b);
 }
 extern "C" size_t benerf_mlp_dact_floats_per_point(void) { return (size_t)mlp::DACT_PER_POINT; }
 extern "C" size_t benerf_mlp_dact_floats(int64_t n_points) {
-    const int64_t a = n_points * mlp::DACT_PER_POINT, b = mlp::sdact_total_floats(n_points);
+    const int64_t a = n_points * mlp::DACT_PER_POINT, b = mlp::sdact22_total_floats(n_points);   // sdact22 >= sdact
     return (size_t)(a > b ? a : b);
 }
 extern "C" size_t benerf_mlp_dw_workspace_floats(int64_t n_points) {

@@ -164,7 +164,17 @@ __host__ __device__ inline int64_t sact_info(int64_t Mp) { return sact_mask(Mp) 
 __host__ __device__ inline int64_t sact_total_floats(int64_t M) { return sact_info(m_pad(M)) + 16; }
 // info words (uint32) at sact_info: [SI_TAG] arithmetic mode that wrote the buffer (the backward launches check it)
 enum { SI_TAG = 0, SI_COUNT = 16 };
-constexpr uint32_t SACT_TAG_SPLIT = 0x53504c54u;   // 'SPLT'
+constexpr uint32_t SACT_TAG_SPLIT = 0x53504c54u;   // 'SPLT': f16 halves only (BENERF_MLP_SPLIT_F16BWD)
+constexpr uint32_t SACT_TAG_SPLIT22 = 0x53504c32u; // 'SPL2': hi + lo (BENERF_MLP_SPLIT, the 22-bit backward)
+// BENERF_MLP_SPLIT (22-bit backward, mlp_bwd_s.hip / mlp_dw_s.hip): every SH array above has a twin holding the LOW halves
+// lo = rn16(x - hi), UNSCALED (the backward GEMMs add hi x hi, hi x lo and lo x hi into ONE accumulator; f16 subnormals give
+// lo an absolute floor of 2^-25, i.e. x keeps 22 bits down to |x| = 2^-3 and >= 17 bits down to 2^-8), in a second region
+// behind the info words with the same internal order: offset(lo array) = offset(hi array) + sact_lo_delta.
+__host__ __device__ inline int64_t sact_lo_delta(int64_t Mp) { return sact_info(Mp) + SI_COUNT - sact_h(Mp, 0); }
+__host__ __device__ inline int64_t sact22_total_floats(int64_t M) {
+    const int64_t Mp = m_pad(M);
+    return sact_info(Mp) + SI_COUNT + (sact_mask(Mp) - sact_h(Mp, 0));
+}
 // activation gradients: SH arrays holding dY * s_s (s_s = power-of-two scale of this backward call from max|d_raw|,
 // pow2_scale6), then 16 info words: [SD_DRAW] max|d_raw| (float bits, grad_absmax_kernel)
 __host__ __device__ inline int64_t sdact_h(int64_t Mp, int l) { return (int64_t)l * Mp * 128; }
@@ -173,6 +183,9 @@ __host__ __device__ inline int64_t sdact_hv(int64_t Mp) { return 9 * Mp * 128; }
 __host__ __device__ inline int64_t sdact_info(int64_t Mp) { return 9 * Mp * 128 + Mp * (ACT_HV_W / 2); }
 __host__ __device__ inline int64_t sdact_total_floats(int64_t M) { return sdact_info(m_pad(M)) + 16; }
 enum { SD_DRAW = 0, SD_COUNT = 16 };
+// 22-bit backward: the low halves of the gradient arrays (same scale s_s, unscaled lo) behind the info words
+__host__ __device__ inline int64_t sdact_lo_delta(int64_t Mp) { return sdact_info(Mp) + SD_COUNT; }
+__host__ __device__ inline int64_t sdact22_total_floats(int64_t M) { return 2 * sdact_info(m_pad(M)) + SD_COUNT; }
 
 // Gradients are far outside f16's range (d_raw ~ 1/n_rays) but the backward chain is LINEAR in d_raw: power-of-two
 // scale s = 2^(6 - exponent(mx)) brings values of magnitude <= mx to < 2^7 (2^9 of head room below f16's maximum

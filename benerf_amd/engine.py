@@ -164,7 +164,7 @@ class RenderRays(torch.autograd.Function):
     def forward(ctx, poses, ray_idx, cam, ndc, n_samples, n_importance, draws, net_c, net_f, *params):
         poses_c = poses.detach().contiguous()
         need_grad = any(ctx.needs_input_grad)
-        if need_grad and K.get_mlp_precision() == "split":
+        if need_grad and K.is_split():
             # range guard of the autograd path: the previous backward posted the device's status words to pinned host memory;
             # gradients that left the f16 range (inf / NaN into torch.optim) are reported here, without a synchronisation
             K.range_guard(poses_c.device).poll()
@@ -197,7 +197,7 @@ class RenderRays(torch.autograd.Function):
             gf = ([torch.empty_like(w) for w in net_f.weights], [torch.empty_like(b) for b in net_f.biases])
         d_poses = _render_backward(ctx.cam, ctx.ndc, ctx.draws, ctx.poses, ctx.ray_idx, net_c, net_f, ctx.saved_k, g,
                                    gc, gf, False)
-        if K.get_mlp_precision() == "split":
+        if K.is_split():
             K.range_guard(d_poses.device).post()
         ctx.saved_k = None
         grads = list(gc[0]) + list(gc[1])

@@ -221,17 +221,23 @@ def _param_struct(cls, tensors_w, tensors_b):
     return s
 
 
-MLP_PRECISIONS = {"f32": 0, "split": 1}
+MLP_PRECISIONS = {"f32": 0, "split": 1, "split_f16bwd": 3}
 _MLP_AUTO = 2
 _default_precision = os.environ.get("BENERF_MLP_PRECISION", "split")
 if _default_precision not in MLP_PRECISIONS:
-    raise _lib.BenerfHipError("BENERF_MLP_PRECISION must be 'f32' or 'split', not %r" % _default_precision)
+    raise _lib.BenerfHipError("BENERF_MLP_PRECISION must be one of %s, not %r" % (sorted(MLP_PRECISIONS), _default_precision))
+
+
+def is_split(mode=None):
+    """True for the modes whose GEMM operands are f16 pairs (range guard, BENERF_MLP_AUTO inference launches)."""
+    return (mode or _default_precision) != "f32"
 
 
 def set_mlp_precision(mode):
     """Default arithmetic of the MLP launches issued through this module (the C ABI takes it per call):
-    'f32': exact f32 MFMA;  'split': forward 3 x f16 MFMA on hi/lo-split operands, backward f16 operands, f32
-    accumulate (include/benerf_hip.h)."""
+    'f32': exact f32 MFMA;  'split' (default): 3 x f16 MFMA on hi/lo-split operands in the forward pass and in both backward
+    GEMMs, f32 accumulate - fp32-equivalent;  'split_f16bwd': the split forward with a reduced-precision (f16-operand)
+    backward, opt-in (include/benerf_hip.h)."""
     global _default_precision
     if mode not in MLP_PRECISIONS:
         raise ValueError("unknown MLP precision %r" % (mode,))
@@ -423,7 +429,7 @@ def mlp_fwd(net, rays_o, rays_d, viewdirs, z, save_acts, precision=None, status=
         acts.benerf_pe_weights = net.pe_weights       # the backward of THIS forward uses the same column weights
     s = net.struct()
     code = MLP_PRECISIONS[mode]
-    if code == 1 and not save_acts:
+    if code != 0 and not save_acts:
         code = _MLP_AUTO
         status = _auto_status(z.device)
     if status is None:

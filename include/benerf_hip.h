@@ -163,13 +163,16 @@ size_t benerf_workspace_bytes(int which, int64_t n_points, int n_poses, int n_pi
 
 /* MFMA arithmetic of the fused MLP kernels - a PER-CALL argument (the library keeps no mode state):
  *   BENERF_MLP_F32    exact f32 MFMA (v_mfma_f32_32x32x2_f32) in forward and backward, bit-for-bit f32 products;
- *   BENERF_MLP_SPLIT  forward: every f32 operand as two f16 numbers (hi + lo*2^-11), three f16 MFMAs per product
- *                     block, f32 accumulation - 22-bit operands, measured error equal to the f32 path;
- *                     backward (dX chain and dW): f16 operands (11-bit; gradients rescaled by exact powers of
- *                     two), one f16 MFMA per product block, f32 accumulation - the deviation of the gradients stays
- *                     inside the spread f32 itself shows against f64 (tools/experiments/lowprec_backward.py; every
- *                     parity test runs in both modes with the same tolerances).  Activations must stay below 65504
- *                     in magnitude (f16 range): see `status`;
+ *   BENERF_MLP_SPLIT  every GEMM operand (activations, weights, gradients) as two f16 numbers hi + lo, three f16 MFMAs
+ *                     per product block (hi x hi, hi x lo, lo x hi), f32 accumulation - 22-bit operands, in the forward pass
+ *                     AND in both backward GEMMs (dX chain, dW).  Measured against float64 the outputs and every gradient
+ *                     carry the error of the BENERF_MLP_F32 path (tests/test_f64_truth_gpu.py holds both modes to the same
+ *                     bounds): fp32-equivalent, the default.  Gradients are rescaled by exact powers of two into f16's
+ *                     range.  Activations must stay below 65504 in magnitude (f16 range): see `status`;
+ *   BENERF_MLP_SPLIT_F16BWD  the forward of BENERF_MLP_SPLIT with a REDUCED-PRECISION backward: dX takes the gradient as one
+ *                     f16 (weights hi + lo), dW takes f16 dY and f16 X, one MFMA per block.  Gradients sit 2-8e-4 of their
+ *                     largest entry from the fp32 result (inside SURVEY 8c's 1e-3 contract on the mean-squared losses, not
+ *                     fp32-equivalent); ~25 % faster steps.  Opt-in;
  *   BENERF_MLP_AUTO   inference only (acts == NULL): BENERF_MLP_SPLIT, followed by a BENERF_MLP_F32 launch whose
  *                     workgroups exit at once unless the split launch reported an activation outside the f16 range
  *                     - the output is always valid, at the price of one (normally empty) extra launch.
@@ -187,7 +190,7 @@ size_t benerf_workspace_bytes(int which, int64_t n_points, int n_poses, int n_pi
  * training steps were skipped since the words were last zeroed, BENERF_EBADARG for [MODE].
  * benerf_adam_step takes the same pointer and leaves the parameters untouched when [SKIP] is set or [ACT] / [GRAD]
  * show a violation. */
-enum { BENERF_MLP_F32 = 0, BENERF_MLP_SPLIT = 1, BENERF_MLP_AUTO = 2 };
+enum { BENERF_MLP_F32 = 0, BENERF_MLP_SPLIT = 1, BENERF_MLP_AUTO = 2, BENERF_MLP_SPLIT_F16BWD = 3 };
 enum { BENERF_ST_ACT = 0, BENERF_ST_GRAD = 1, BENERF_ST_MODE = 2, BENERF_ST_AUTO = 3, BENERF_ST_SKIP = 4, BENERF_ST_SKIPPED = 5,
        BENERF_ST_CONSECUTIVE = 6, BENERF_ST_STEPS = 7, BENERF_ST_LAST_ACT = 8, BENERF_ST_LAST_GRAD = 9,
        BENERF_ST_STEP_SCRATCH = 10,     /* [10], [11]: max |d_raw| of the step's (up to) two networks - benerf_composite_bwd's
@@ -223,7 +226,7 @@ int benerf_mlp_fwd(const BenerfMlpParams* params, const float* packed, int chann
  *   _dw: weight gradients from acts + dacts; dw_ws scratch [benerf_mlp_dw_workspace_floats(n_points)];
  *        grads: overwritten when accumulate == 0, added to otherwise; pe_weights: the forward call's
  *        BenerfMlpParams.pe_weights (the saved encodings are unweighted; the columns are scaled in the reduce).
- * precision: BENERF_MLP_F32 or BENERF_MLP_SPLIT, the mode of the forward launch that wrote acts.
+ * precision: BENERF_MLP_F32, BENERF_MLP_SPLIT or BENERF_MLP_SPLIT_F16BWD, the mode of the forward launch that wrote acts.
  * d_raw_absmax (_dx): NULL, or the device float benerf_composite_bwd filled with max |d_raw| for exactly this d_raw. */
 int benerf_mlp_bwd_dx(const BenerfMlpParams* params, const float* packed, int channels,
                       int n_rays, int n_samples, const float* d_raw, const float* acts,
