@@ -35,15 +35,21 @@ sys.path.insert(0, ROOT)
 F32_MFMA_PEAK_TFLOPS = 157.3    # MI355X f32 matrix peak (MI355X_MICROARCH.md)
 F16_MFMA_PEAK_TFLOPS = 2516.6   # dense f16 matrix peak: 256 CUs x 4 SIMDs x 1024 flop/clk x 2.4 GHz
 HBM_PEAK_GBS = 8000.0
-# f16 MFMAs the split-mode kernels execute per algorithmic product block: forward 3 (hi/lo-split
-# operands), dX chain 2 (f16 gradient x hi/lo weight), dW 1 (f16 x f16); exact-f32 mode: 1 f32 MFMA chain everywhere
-EXECUTED_PER_PRODUCT = {"mlp_fwd": 3, "mlp_bwd_dx": 2, "mlp_bwd_dw": 1}
-# bytes per sample point the split-mode dW launch streams once (f16 saved activations h0..h7, feature, hv
-# and as many gradients, f32 PE / PE(dir) rows, one d_raw row)
-DW_SPLIT_BYTES_PER_POINT = 2 * ((8 * 256 + 256 + 128) + (8 * 256 + 256 + 128)) + 4 * (64 + 32) + 8
-# what a saved-activation design moves per point and network pass besides that: forward writes (f16 arrays, PE rows, ReLU
-# sign-bit words), dX reads (PE rows, sign bits) and writes (f16 gradients)
-FWD_SPLIT_WRITE_BYTES_PER_POINT = 2 * (8 * 256 + 256 + 128) + 4 * (64 + 32) + 9 * 256 * 8 // 64
+# f16 MFMAs the split-mode kernels execute per algorithmic product block: hi/lo-split operands, hi x hi + hi x lo +
+# lo x hi, in the forward pass and in both backward GEMMs; the opt-in reduced-precision backward (split_f16bwd): dX chain 2 (f16
+# gradient x hi/lo weight), dW 1 (f16 x f16); exact-f32 mode: 1 f32 MFMA chain everywhere
+EXECUTED_PER_PRODUCT = {"split": {"mlp_fwd": 3, "mlp_bwd_dx": 3, "mlp_bwd_dw": 3},
+                        "split_f16bwd": {"mlp_fwd": 3, "mlp_bwd_dx": 2, "mlp_bwd_dw": 1}}
+# bytes per sample point the split-mode dW launch streams once (saved activations h0..h7, feature, hv and as many
+# gradients - hi + lo f16 pairs, 4 bytes per value (split_f16bwd: 2) -, f32 PE / PE(dir) rows, one d_raw row)
+DW_BYTES_PER_POINT = {"split": 4 * ((8 * 256 + 256 + 128) + (8 * 256 + 256 + 128)) + 4 * (64 + 32) + 8,
+                      "split_f16bwd": 2 * ((8 * 256 + 256 + 128) + (8 * 256 + 256 + 128)) + 4 * (64 + 32) + 8}
+DTYPE_NOTE = {
+    "split": "f32 storage; every MLP GEMM (forward, dX, dW) as 3 f16 MFMAs on hi/lo-split operands (22-bit), f32 accumulate: "
+             "fp32-equivalent, measured against float64 (tests/test_f64_truth_gpu.py)",
+    "split_f16bwd": "f32 storage; forward 3 f16 MFMAs on hi/lo-split operands (22-bit); REDUCED-PRECISION backward: f16 gradient x "
+                    "hi/lo weight (dX), f16 x f16 (dW), f32 accumulate",
+    "f32": "f32 (v_mfma_f32_32x32x2_f32: bit-exact f32 products, f32 accumulate)"}
 
 
 def algorithmic_bytes_per_step(wl, C):
@@ -84,7 +90,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--primary-only", action="store_true", help="timed training steps only (profiling runs): no secondary legs")
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--mlp-precision", default="split", choices=["f32", "split"],
+    ap.add_argument("--mlp-precision", default="split", choices=["f32", "split", "split_f16bwd"],
                     help="arithmetic of the fused MLP kernels (include/benerf_hip.h, K3 `precision`)")
     a = ap.parse_args()
     if a.scaling is None:
@@ -187,7 +193,7 @@ def power_leg(one_step, device_index, seconds):
 
 
 def split_mode(a):
-    return a.mlp_precision == "split"
+    return a.mlp_precision != "f32"
 
 
 def build_graph(args_ns, device, seed):
@@ -493,9 +499,11 @@ def main():
     power = None
     if world == 1 and not a.primary_only:
         power = power_leg(one_step, device.index or 0, 1.5)
-    exact = roof_f32 = None
-    if world == 1 and split_mode(a) and not a.primary_only:
-        K.set_mlp_precision("f32")
+    exact = roof_f32 = reduced = None
+
+    def other_mode_leg(mode, peak_tf):
+        """the same training step in another arithmetic mode: >= 20 timed steps, its own per-kernel HIP-event durations"""
+        K.set_mlp_precision(mode)
         K.TIMERS.records.clear()
         K.TIMERS.enabled = True
         for _ in range(3):
@@ -510,23 +518,34 @@ def main():
         dt_o = (time.perf_counter() - to) / n_other
         K.TIMERS.enabled = False
         step.check_range()
-        exact = {"value": round(WL.rays_per_step(wl) / dt_o, 1), "unit": "rays/s", "ms_per_step": round(dt_o * 1e3, 3), "steps": n_other,
-                 "dtype": "f32 (v_mfma_f32_32x32x2_f32: bit-exact f32 products, f32 accumulate) in forward and backward"}
+        leg = {"value": round(WL.rays_per_step(wl) / dt_o, 1), "unit": "rays/s", "ms_per_step": round(dt_o * 1e3, 3), "steps": n_other,
+               "dtype": DTYPE_NOTE[mode]}
         fpp_ = WL.mlp_flops_per_point(wl["channels"])
         per = {}
         for name, (n_, ms_, pts_) in K.TIMERS.summary().items():
             tf_ = pts_ * fpp_ / (ms_ * 1e-3) / 1e12 if ms_ > 0 else 0.0
             per[name] = {"launches": n_, "avg_ms": round(ms_ / n_, 4), "points_per_launch": int(pts_ / n_), "tflops_algorithmic": round(tf_, 2),
-                         "frac_of_mfma_peak": round(tf_ / F32_MFMA_PEAK_TFLOPS, 4)}
+                         "frac_of_mfma_peak": round(tf_ / peak_tf, 4)}
+        roof_ = None
         if per:
             dom_ = max(per.items(), key=lambda kv: kv[1]["avg_ms"] * kv[1]["launches"])[0]
             pts_step_ = WL.rays_per_step(wl) * (wl["S"] + wl["S"] + wl["Ni"])
-            roof_f32 = {"bound": "mfma", "kernel": dom_, "achieved": per[dom_]["tflops_algorithmic"], "peak": F32_MFMA_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": per[dom_]["frac_of_mfma_peak"], "avg_launch_ms": per[dom_]["avg_ms"],
-                        "step_tflops_algorithmic": round(pts_step_ * fpp_ * 3 / dt_o / 1e12, 2),
-                        "step_frac_of_mfma_peak": round(pts_step_ * fpp_ * 3 / dt_o / 1e12 / F32_MFMA_PEAK_TFLOPS, 4), "per_kernel": per}
+            roof_ = {"bound": "mfma", "kernel": dom_, "achieved": per[dom_]["tflops_algorithmic"], "peak": peak_tf,
+                     "unit": "TFLOP/s", "frac": per[dom_]["frac_of_mfma_peak"], "avg_launch_ms": per[dom_]["avg_ms"],
+                     "step_tflops_algorithmic": round(pts_step_ * fpp_ * 3 / dt_o / 1e12, 2),
+                     "step_frac_of_mfma_peak": round(pts_step_ * fpp_ * 3 / dt_o / 1e12 / peak_tf, 4), "per_kernel": per}
         K.TIMERS.records.clear()
         K.set_mlp_precision(a.mlp_precision)
+        return leg, roof_
+
+    if world == 1 and split_mode(a) and not a.primary_only:
+        exact, roof_f32 = other_mode_leg("f32", F32_MFMA_PEAK_TFLOPS)
+        if a.mlp_precision == "split":
+            # NOT the headline: the opt-in mode whose backward GEMMs take f16 operands (round 3's default) - narrower arithmetic than
+            # the reference's fp32, reported for scale only
+            reduced, _ = other_mode_leg("split_f16bwd", F16_MFMA_PEAK_TFLOPS)
+            reduced["note"] = ("reduced-precision backward (gradients 2-8e-4 of their largest entry from the fp32 result): not the "
+                               "reference's precision, not the headline")
     other = exact["value"] if exact else None
 
     rays_step = WL.rays_per_step(wl) * world
@@ -536,14 +555,14 @@ def main():
     # ---- roofline: the fused MLP (K3) against the MFMA roof, algorithmic FLOPs / HIP-event-timed duration --
     fpp = WL.mlp_flops_per_point(wl["channels"])
     summ = summ_main
-    split = a.mlp_precision == "split"
+    split = a.mlp_precision != "f32"
     peak = F16_MFMA_PEAK_TFLOPS if split else F32_MFMA_PEAK_TFLOPS
     roof = None
     kern = {}
     for name, (n, ms, pts) in summ.items():
         # algorithmic flops: fwd = fpp/point; dx chain = fpp/point; dW = fpp/point (training = 3 x fwd)
         tf = pts * fpp / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        ex = EXECUTED_PER_PRODUCT[name] if split else 1
+        ex = EXECUTED_PER_PRODUCT[a.mlp_precision][name] if split else 1
         kern[name] = {"launches": n, "avg_ms": round(ms / n, 4), "points_per_launch": int(pts / n), "tflops_algorithmic": round(tf, 2),
                       "frac_of_mfma_peak": round(tf / peak, 4), "mfma_per_product": ex, "frac_executed": round(ex * tf / peak, 4)}
     pmc = {}
@@ -588,9 +607,9 @@ def main():
             # the bandwidth-bound launch (dW) and the step's HBM traffic: design bytes (saved activations) vs the bytes any
             # implementation must move
             n_dw, ms_dw, pts_dw = summ["mlp_bwd_dw"]
-            gbs = pts_dw * DW_SPLIT_BYTES_PER_POINT / (ms_dw * 1e-3) / 1e9
+            gbs = pts_dw * DW_BYTES_PER_POINT[a.mlp_precision] / (ms_dw * 1e-3) / 1e9
             hbm = {"kernel": "mlp_bwd_dw", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "frac": round(gbs / HBM_PEAK_GBS, 4), "design_bytes_per_launch": int(pts_dw / n_dw * DW_SPLIT_BYTES_PER_POINT),
+                   "frac": round(gbs / HBM_PEAK_GBS, 4), "design_bytes_per_launch": int(pts_dw / n_dw * DW_BYTES_PER_POINT[a.mlp_precision]),
                    "traffic": traffic_of("mlp_bwd_dw"),
                    "algorithmic_bytes_per_step": algorithmic_bytes_per_step(wl, wl["channels"])}
             tr = [traffic_of(k) for k in ("mlp_fwd", "mlp_bwd_dx", "mlp_bwd_dw")]
@@ -604,8 +623,7 @@ def main():
         "value": round(value, 1), "unit": "rays/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": a.scaling,
         "vs_baseline": None,
-        "dtype": ("f32 storage; MLP GEMMs on f16 MFMA with f32 accumulate: forward 3 MFMAs on hi/lo-split operands (22-bit), "
-                  "backward f16 gradient x hi/lo weight (dX) and f16 x f16 (dW)") if split else "f32",
+        "dtype": DTYPE_NOTE[a.mlp_precision],
         "data": "synthetic",
         "config": {"workload": "%s: %s" % (a.workload, wl["name"]), "rays_per_step_per_gpu": WL.rays_per_step(wl),
                    "samples": "%d+%d" % (wl["S"], wl["S"] + wl["Ni"]), "channels": wl["channels"],
@@ -618,6 +636,8 @@ def main():
     }
     if exact is not None:
         out["exact_f32"], out["roofline_f32"] = exact, roof_f32
+    if reduced is not None:
+        out["reduced_precision"] = reduced
     if power and out.get("roofline"):
         out["roofline"]["power"] = power
     if comm is not None:

@@ -283,7 +283,9 @@ __device__ __forceinline__ void epilogue3(f32x16 (&acc)[4], const uint32_t (&bit
                         const int e = (ep * 2 + h) * 4 + jp * 2 + t;
                         const int o = tb[((e >> 1) & 1) | (((e >> 2) & 1) << 1)][rt >> 1] + ((rt & 1) * 32 + (e & 3) + 8 * (e >> 2)) * LD;
                         Th[o] = hv[t];
+#ifndef BWS_SKIP_PLANE_LO
                         Tl[o] = lv[t];
+#endif
                     }
                     wh[jp] = __builtin_bit_cast(uint32_t, hv);
                     wl[jp] = __builtin_bit_cast(uint32_t, lv);
@@ -302,8 +304,10 @@ __device__ __forceinline__ void epilogue3(f32x16 (&acc)[4], const uint32_t (&bit
                 ol[i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2v, ulw[i]) * g2);
             }
             // vector offset + zero scalar offset (mlp_bwd_h.hip: the scalar-offset form of a 16-byte store reads its data late)
+#ifndef BWS_SKIP_STORE      // timing variants only (tools/experiments/build_variant.sh)
             __builtin_amdgcn_raw_buffer_store_b128(oh, rs_hi, st_lane + (rt * 4 + ep * 2) * 256 * 8 * 2, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b128(ol, rs_lo, st_lane + (rt * 4 + ep * 2) * 256 * 8 * 2, 0, 0);
+#endif
         }
 }
 

@@ -258,6 +258,181 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int64_t 
     }
 }
 
+// ---- LDS-DMA variant of dw_gemm for the big instances -----------------------------------------------------------------
+// The chunk image IS the global layout (16-byte units, contiguous per array and chunk), so the copy needs no registers at all:
+// `buffer_load_dwordx4 ... lds` moves 1 KiB per wave-instruction straight into the ring slot.  Ring of DMA_RING slots,
+// DMA_RING - 1 chunks in flight (96 KiB per CU against ~50 KiB of bandwidth-delay product at 6 TB/s), one barrier per chunk:
+//   acquire(j): wait for this wave's own pieces of chunk j (vector-memory operations retire in order: only the pieces of the
+//   chunks requested behind j may still be outstanding), barrier -> every piece of j has landed AND every wave is done with
+//   chunk j - 1, whose slot the next request (chunk j + DMA_RING - 1) overwrites.
+// Every wave issues the same number PW of pieces per chunk, so the wait counts are compile-time constants.
+#ifndef DMA_RING
+#define DMA_RING 4
+#endif
+template <int N, bool ALPHA>
+struct DmaGeom {
+    static constexpr int K = 256;
+    static constexpr int YU = CHB * N, XU = CHB * K;                 // 16-byte units per chunk and plane
+    static constexpr int YP = YU / 64, XP = XU / 64;                 // 1-KiB pieces per plane
+    static_assert(XP == 8 && (YP == 8 || YP == 4), "eight waves share the pieces evenly");
+    static constexpr int PW = (YP == 8 ? 2 : 1) + 2 + (ALPHA ? 1 : 0);
+    static constexpr int SIG = (2 * YU + 2 * XU) * 16;               // byte offset of the d_raw rows (one 256-byte copy per wave)
+    static constexpr int SLOT = SIG + (ALPHA ? 8 * 256 : 0);
+};
+template <int CNT>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT) : "memory"); }
+
+template <int N, int WN, int TR, int TC, bool ALPHA>
+__device__ __forceinline__ void dw_gemm_dma(const DwArgs& a, const Src src, int64_t chunk_begin, int64_t chunk_end,
+                                            float* __restrict__ part, char* __restrict__ smem) {
+    typedef DmaGeom<N, ALPHA> G;
+    constexpr int K = G::K, YU = G::YU, XU = G::XU, PW = G::PW, AHEAD = DMA_RING - 1;
+    static_assert(WN * TR * 32 == N && (8 / WN) * TC * 32 == K, "tiling");
+    static_assert(AHEAD * PW < 64, "vmcnt field");
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+    const int wn = wave % WN, wk = wave / WN;
+    auto rsrc_of = [](const void* p, uint32_t bytes) {
+        const uint64_t wa = reinterpret_cast<uint64_t>(p);
+        const uint64_t wau = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(wa >> 32)) << 32) |
+                             (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)wa);
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(wau), 0, bytes, 0x00020000);
+    };
+    // descriptors on this workgroup's first chunk: per-chunk offsets stay below 2^31 (a split covers a few MB per array)
+    const __amdgpu_buffer_rsrc_t rs_yh = rsrc_of(src.y + chunk_begin * YU, 0x7fffffff);
+    const __amdgpu_buffer_rsrc_t rs_yl = rsrc_of(src.y + src.ylo + chunk_begin * YU, 0x7fffffff);
+    const __amdgpu_buffer_rsrc_t rs_xh = rsrc_of(src.x + chunk_begin * XU, 0x7fffffff);
+    const __amdgpu_buffer_rsrc_t rs_xl = rsrc_of(src.x + src.xlo + chunk_begin * XU, 0x7fffffff);
+    // d_raw rows of a chunk (ALPHA: the alpha head's d_sigma): [M][C + 1] floats; rows past M read as zero (range check on the
+    // VECTOR offset, which therefore carries the chunk's position)
+    const int row_dw = a.C + 1;
+    const __amdgpu_buffer_rsrc_t rs_sig = rsrc_of(a.d_raw, (uint32_t)(a.M * row_dw * 4));
+    const int lane16 = lane * 16;
+
+    auto request = [&](int64_t j) {
+        char* slot = smem + (int)(j % DMA_RING) * G::SLOT;
+        const int rel = (int)(j - chunk_begin);
+        if (G::YP == 8) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_yh, (lds_ptr)(slot + wave * 1024), 16, lane16, rel * (YU * 16) + wave * 1024, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_yl, (lds_ptr)(slot + YU * 16 + wave * 1024), 16, lane16, rel * (YU * 16) + wave * 1024, 0, 0);
+        } else {    // 4 pieces per plane: waves 0..3 take the hi plane, 4..7 the lo plane
+            if (wave < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_yh, (lds_ptr)(slot + wave * 1024), 16, lane16, rel * (YU * 16) + wave * 1024, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_yl, (lds_ptr)(slot + YU * 16 + (wave - 4) * 1024), 16, lane16, rel * (YU * 16) + (wave - 4) * 1024, 0, 0);
+        }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_xh, (lds_ptr)(slot + 2 * YU * 16 + wave * 1024), 16, lane16, rel * (XU * 16) + wave * 1024, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_xl, (lds_ptr)(slot + (2 * YU + XU) * 16 + wave * 1024), 16, lane16, rel * (XU * 16) + wave * 1024, 0, 0);
+        if (ALPHA) {    // 16 rows x (C + 1) floats <= 64 dwords: one dword per lane, one copy per wave (uniform piece count)
+            const int voff = ((int)j * CHP * row_dw + (lane < CHP * row_dw ? lane : 0)) * 4;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_sig, (lds_ptr)(slot + G::SIG + wave * 256), 4, voff, 0, 0, 0);
+        }
+    };
+    auto acquire = [&](int newer) {
+        if (newer >= 2) wait_vm<2 * PW>();
+        else if (newer == 1) wait_vm<PW>();
+        else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+    };
+    static_assert(AHEAD == 3, "acquire() enumerates newer = 0, 1, 2");
+
+    f32x16 acc[TR][TC];
+#pragma unroll
+    for (int r = 0; r < TR; ++r)
+#pragma unroll
+        for (int c = 0; c < TC; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[r][c][e] = 0.f;
+    float bsum = 0.f, asum = 0.f, absum = 0.f;
+
+    for (int i = 0; i < AHEAD; ++i)
+        if (chunk_begin + i < chunk_end) request(chunk_begin + i);
+    for (int64_t j = chunk_begin; j < chunk_end; ++j) {
+        const int64_t behind = chunk_end - 1 - j;
+        acquire(behind >= AHEAD - 1 ? AHEAD - 1 : (int)behind);
+        if (j + AHEAD < chunk_end) request(j + AHEAD);
+        __builtin_amdgcn_sched_barrier(0);      // requests first, then the chunk's MFMAs
+        const char* slot = smem + (int)(j % DMA_RING) * G::SLOT;
+        const u32x4* Yl = reinterpret_cast<const u32x4*>(slot);
+        const u32x4* Xl = Yl + 2 * YU;
+        {
+            half8 ayh[TR], ayl[TR];
+#pragma unroll
+            for (int r = 0; r < TR; ++r) {
+                ayh[r] = __builtin_bit_cast(half8, Yl[lh * N + (wn * TR + r) * 32 + lr]);
+                ayl[r] = __builtin_bit_cast(half8, Yl[YU + lh * N + (wn * TR + r) * 32 + lr]);
+            }
+            constexpr int CG = 2;
+#pragma unroll
+            for (int c0 = 0; c0 < TC; c0 += CG) {
+                half8 bxh[CG], bxl[CG];
+#pragma unroll
+                for (int c = 0; c < CG; ++c) {
+                    bxh[c] = __builtin_bit_cast(half8, Xl[lh * K + (wk * TC + c0 + c) * 32 + lr]);
+                    bxl[c] = __builtin_bit_cast(half8, Xl[XU + lh * K + (wk * TC + c0 + c) * 32 + lr]);
+                }
+#pragma unroll
+                for (int r = 0; r < TR; ++r)
+#pragma unroll
+                    for (int c = 0; c < CG; ++c) acc[r][c0 + c] = mfma16(ayh[r], bxh[c], acc[r][c0 + c]);
+#pragma unroll
+                for (int r = 0; r < TR; ++r)
+#pragma unroll
+                    for (int c = 0; c < CG; ++c) acc[r][c0 + c] = mfma16(ayh[r], bxl[c], acc[r][c0 + c]);
+#pragma unroll
+                for (int r = 0; r < TR; ++r)
+#pragma unroll
+                    for (int c = 0; c < CG; ++c) acc[r][c0 + c] = mfma16(ayl[r], bxh[c], acc[r][c0 + c]);
+            }
+        }
+        if (src.bias && tid < N) {
+            float s = 0.f;
+#pragma unroll
+            for (int mb = 0; mb < CHB; ++mb) {
+                const half8 h = __builtin_bit_cast(half8, Yl[mb * N + tid]);
+                const half8 l = __builtin_bit_cast(half8, Yl[YU + mb * N + tid]);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) s += (float)h[q] + (float)l[q];
+            }
+            bsum += s;
+        }
+        if (ALPHA && tid >= DWT - K) {      // waves 4..7: column tid - 256 (mlp_dw_h.hip); each reads its own wave's d_raw copy
+            const int ka = tid - (DWT - K);
+            const float* da = reinterpret_cast<const float*>(slot + G::SIG + wave * 256);
+            float s = 0.f, sb = 0.f;
+#pragma unroll
+            for (int mb = 0; mb < CHB; ++mb) {
+                const half8 h = __builtin_bit_cast(half8, Xl[mb * K + ka]);
+                const half8 l = __builtin_bit_cast(half8, Xl[XU + mb * K + ka]);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const float d = da[(mb * 8 + q) * row_dw + a.C];
+                    s += d * ((float)h[q] + (float)l[q]);
+                    sb += d;
+                }
+            }
+            asum += s;
+            absum += sb;
+        }
+    }
+
+    // partial block -> workspace (dw_gemm's layout)
+#pragma unroll
+    for (int r = 0; r < TR; ++r)
+#pragma unroll
+        for (int c = 0; c < TC; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (wn * TR + r) * 32 + acc_row(e, lane);
+                part[(int64_t)row * K + (wk * TC + c) * 32 + lr] = acc[r][c][e];
+            }
+    if (tid < N) part[(int64_t)N * K + tid] = src.bias ? bsum : 0.f;
+    if (ALPHA && tid >= DWT - K) {
+        part[(int64_t)N * K + N + tid - (DWT - K)] = asum;
+        if (tid == DWT - K) part[(int64_t)N * K + N + 256] = absum;
+    }
+}
+
 // rgb head: dW_rgb[c][j] = sum_pt d_rgb[pt][c] * hv[pt][j], db_rgb[c] = sum_pt d_rgb[pt][c]   (unscaled d_raw, f32; hv = hi + lo).
 // Batches of 256 points: d_raw staged in LDS, then every thread (column j, phase ph) streams 8 blocks of hv (hi and lo) with
 // all its loads independent.
@@ -340,7 +515,11 @@ __device__ __forceinline__ void dw_rgb(const DwArgs& a, int64_t blk_begin, int64
     }
 }
 
+#ifdef DWS_NO_DMA
 constexpr size_t DWS_SMEM = 3 * (size_t)(2 * CHB * 256 + 2 * CHB * 256 + CHP / 4) * 16;       // three chunk images of the 256 x 256 block: 98 496 B
+#else
+constexpr size_t DWS_SMEM = (size_t)DMA_RING * DmaGeom<256, true>::SLOT;                        // four ring slots of 32 KiB + d_raw copies: 139 264 B
+#endif
 constexpr size_t DWS_SMEM_SMALL = 3 * (size_t)(2 * CHB * 256 + 2 * CHB * 64 + CHP / 4) * 16;  // 256 x 64 block: 61 632 B
 static_assert(DWS_SMEM_SMALL >= (32 * 8 * 4 + 18 * 128) * sizeof(float), "rgb head scratch fits the thin image");
 
@@ -370,9 +549,16 @@ __global__ __launch_bounds__(DWT, 2) void mlp_dw_split_big_kernel(DwArgs a) {
     chunk_range(a, inst, split, cb, ce);
     float* part = a.ws + dwh_inst_offset(inst) + (int64_t)split * dw_inst_floats(inst);
     const Src src = inst_src(a, inst);
+#ifdef DWS_NO_DMA      // register-staged copies (the f16 kernel's scheme): kept for A/B runs
     if (inst == DW_FEAT) dw_gemm<256, 256, 4, 2, 4, true>(a, src, cb, ce, part, smem_u);
     else if (inst <= DW_L7) dw_gemm<256, 256, 4, 2, 4, false>(a, src, cb, ce, part, smem_u);
     else dw_gemm<128, 256, 2, 2, 2, false>(a, src, cb, ce, part, smem_u);
+#else
+    char* smem_c = reinterpret_cast<char*>(smem_u);
+    if (inst == DW_FEAT) dw_gemm_dma<256, 4, 2, 4, true>(a, src, cb, ce, part, smem_c);
+    else if (inst <= DW_L7) dw_gemm_dma<256, 4, 2, 4, false>(a, src, cb, ce, part, smem_c);
+    else dw_gemm_dma<128, 2, 2, 2, false>(a, src, cb, ce, part, smem_c);
+#endif
     DW_TRACE(1, 1);
 }
 

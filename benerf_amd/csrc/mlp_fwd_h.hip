@@ -217,7 +217,9 @@ __device__ __forceinline__ void save_pair_lo(const _Float16* __restrict__ Tl, in
         q[k] = unscale_lo4(__builtin_bit_cast(uint2, v));
     }
     const uint4 u = sh_pair_unit(q[0], q[1]);
+#ifndef FWD_SKIP_LO_STORE    // timing variants only (tools/experiments/build_variant.sh)
     __builtin_amdgcn_raw_buffer_store_b128(u32x4{u.x, u.y, u.z, u.w}, rs, (((2 * bp + hf) * W + n) * 8) * 2, 0, 0);
+#endif
 }
 template <int W, int NBLK>
 __device__ __forceinline__ void save_tile_lo(const _Float16* __restrict__ Tl, int ct, int lane, const _Float16* __restrict__ st_tile) {
@@ -360,9 +362,16 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
                 for (int i = 0; i < 4; ++i) save_pair<256, true, 16>(Th, wave, (ks - (last - 1)) * 4 + i, lane, prs, pbits);
                 if (ks == last) store_bits(l - 1, pbits);
             }
-            if (SAVE == 2 && ks >= last - 3 && ks < last - 1) {
+#ifndef FWD_LO_AT
+#define FWD_LO_AT 0
+#endif
+            if (SAVE == 2 && FWD_LO_AT == 0 && ks >= last - 3 && ks < last - 1) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) save_pair_lo<256>(Tl, wave, (ks - (last - 3)) * 4 + i, lane, prs_lo);
+            }
+            if (SAVE == 2 && FWD_LO_AT == 1 && ks >= last - 1) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) save_pair_lo<256>(Tl, wave, (ks - (last - 1)) * 4 + i, lane, prs_lo);
             }
         };
         acc_init_bias(acc1, bq);
@@ -371,6 +380,10 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
                                                     [&](int ks) { save_at(ks, 19); });
         else gemm_stage<16, 1, FPF, true, 4>(Th, Tl, 0, a.packed + fwd_layer_offset(l), wave, lane, acc1, acc2, NoAfterHead(),
                                              [&](int ks) { save_at(ks, 15); });
+        if (SAVE == 2 && FWD_LO_AT == 2) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) save_pair_lo<256>(Tl, wave, i, lane, prs_lo);
+        }
         lds_barrier();
         load_bias<1>(a.bias[l < 7 ? l + 1 : BENERF_L_FEAT], wave, lane, bq);
         epilogue_t<1, true, 4>(acc1, acc2, Th, Tl, wave, lane, amax);

@@ -95,6 +95,70 @@ def step_grads(cfg, pc, pf, knots, transform, evt_ts, rgb_ts, idx_evt, idx_rgb, 
     return {"loss": total, "grads": grads, "z": z_out}
 
 
+def step_grads_vjp(cfg, pc, pf, knots, transform, evt_ts, rgb_ts, idx_evt, idx_rgb, target_acc, target_rgb, draws_evt, draws_rgb,
+                   dtype=torch.float32, n_chunks=8):
+    """One training step's loss and gradients in `dtype`, in pixel chunks, for ANY loss - also the L2-normalised event loss
+    (train.py:238-292), which is not a sum over pixels and which step_grads therefore refuses to chunk.  Two passes:
+      1. without autograd, chunk by chunk: the four rendered colour arrays (rgb_map / rgb0 of the event and of the blur render)
+         and the depths of both renders;
+      2. the loss on those arrays (tiny graph) gives d loss / d colours; then chunk by chunk WITH autograd the same render (the
+         depths of pass 1 forced in, so sample_pdf is not re-drawn) is back-propagated with its slice of those vectors.
+    By the chain rule the accumulated parameter gradients are the gradients of the whole step (a chunk's colours depend on the
+    chunk's rays and the parameters only).  Returns the dict of step_grads."""
+    Re, Rr, P, C = idx_evt.shape[0], idx_rgb.shape[0], cfg.n_poses, cfg.channels
+    S, F = cfg.n_samples, cfg.n_samples + cfg.n_importance
+    K = cfg.K()
+    with default_dtype(dtype):
+        leaf = lambda t: t.detach().to(dtype).clone().requires_grad_(True)   # noqa: E731
+        qc = {k: leaf(v) for k, v in pc.items()}
+        qf = {k: leaf(v) for k, v in pf.items()}
+        kn, tr = leaf(knots), leaf(transform)
+        z_out = {k: tuple(torch.empty(shape, dtype=torch.float32) for shape in ((n, S), (n, F)))
+                 for k, n in (("evt", 2 * Re), ("rgb", P * Rr))}
+        col = {k: torch.empty((n, C), dtype=dtype) for k, n in (("e1", 2 * Re), ("e0", 2 * Re), ("r1", P * Rr), ("r0", P * Rr))}
+        eb = np.linspace(0, Re, n_chunks + 1).astype(int)
+        rb = np.linspace(0, Rr, n_chunks + 1).astype(int)
+
+        def renders(c, forced):
+            e0, e1, r0, r1 = int(eb[c]), int(eb[c + 1]), int(rb[c]), int(rb[c + 1])
+            rows_e, rows_r = pose_major_rows(2, Re, e0, e1), pose_major_rows(P, Rr, r0, r1)
+            poses_e = O.trajectory_poses(kn, None, evt_ts.to(dtype), 2, cfg.traj)
+            poses_r = O.trajectory_poses(kn, tr, rgb_ts.to(dtype), P, cfg.traj)
+            zf_e = zf_r = None
+            if forced:
+                zf_e = tuple(t[rows_e].to(dtype) for t in z_out["evt"])
+                zf_r = tuple(t[rows_r].to(dtype) for t in z_out["rgb"])
+            ret_e, ex_e = O.render(qc, qf, poses_e, idx_evt[e0:e1], cfg.H, cfg.W, K, C, S, cfg.n_importance,
+                                   _chunk_draws(draws_evt, rows_e, dtype), z_forced=zf_e, want_extras=True)
+            ret_r, ex_r = O.render(qc, qf, poses_r, idx_rgb[r0:r1], cfg.H, cfg.W, K, C, S, cfg.n_importance,
+                                   _chunk_draws(draws_rgb, rows_r, dtype), z_forced=zf_r, want_extras=True)
+            return rows_e, rows_r, ret_e, ret_r, ex_e, ex_r
+
+        with torch.no_grad():
+            for c in range(n_chunks):
+                rows_e, rows_r, ret_e, ret_r, ex_e, ex_r = renders(c, False)
+                col["e1"][rows_e], col["e0"][rows_e] = ret_e["rgb_map"], ret_e["rgb0"]
+                col["r1"][rows_r], col["r0"][rows_r] = ret_r["rgb_map"], ret_r["rgb0"]
+                for key, rows, ex in (("evt", rows_e, ex_e), ("rgb", rows_r, ex_r)):
+                    z_out[key][0][rows] = ex["z_coarse"].float()
+                    z_out[key][1][rows] = ex["z_fine"].float()
+        lv = {k: v.clone().requires_grad_(True) for k, v in col.items()}
+        le, _, _ = O.event_loss(lv["e1"], lv["e0"], Re, target_acc.to(torch.float64), C, cfg.dataset, cfg.threshold, cfg.coeff_syn,
+                                cfg.coeff_real)
+        lr_, _, _ = O.blur_loss(lv["r1"], lv["r0"], target_rgb.to(dtype), P, cfg.rgb_coeff)
+        loss = le + lr_
+        loss.backward()
+        for c in range(n_chunks):
+            rows_e, rows_r, ret_e, ret_r, _, _ = renders(c, True)
+            torch.autograd.backward([ret_e["rgb_map"], ret_e["rgb0"], ret_r["rgb_map"], ret_r["rgb0"]],
+                                    [lv["e1"].grad[rows_e], lv["e0"].grad[rows_e], lv["r1"].grad[rows_r], lv["r0"].grad[rows_r]])
+        grads = {"knots": kn.grad.double(), "transform": tr.grad.double()}
+        for tag, q in (("nerf", qc), ("nerf_fine", qf)):
+            for k, v in q.items():
+                grads[tag + "." + k] = v.grad.double()
+    return {"loss": float(loss.detach()), "grads": grads, "z": z_out}
+
+
 def error_table(truth, candidates):
     """truth: {name: f64 tensor}; candidates: {label: {name: tensor}} -> {name: {label: (max_err / max|truth|,
     | ||x|| / ||truth|| - 1 |, ||x - truth|| / ||truth||)}}."""

@@ -43,8 +43,11 @@ def test_bench_bookkeeping_helpers():
     import bench
     from benerf_amd import workloads as WL
     wl = WL.WORKLOADS["C2"] if hasattr(WL, "WORKLOADS") else WL.get("C2")
-    # training = 3 x forward FLOPs; executed MFMAs per product in split mode: 3 (fwd) + 2 (dX) + 1 (dW)
-    assert bench.EXECUTED_PER_PRODUCT == {"mlp_fwd": 3, "mlp_bwd_dx": 2, "mlp_bwd_dw": 1}
+    # training = 3 x forward FLOPs; executed MFMAs per product in split mode: 3 in each of fwd / dX / dW (hi/lo-split
+    # operands everywhere); the opt-in reduced-precision backward: 3 + 2 + 1
+    assert bench.EXECUTED_PER_PRODUCT["split"] == {"mlp_fwd": 3, "mlp_bwd_dx": 3, "mlp_bwd_dw": 3}
+    assert bench.EXECUTED_PER_PRODUCT["split_f16bwd"] == {"mlp_fwd": 3, "mlp_bwd_dx": 2, "mlp_bwd_dw": 1}
+    assert bench.DW_BYTES_PER_POINT["split"] == 4 * 2 * 2432 + 4 * 96 + 8
     b = bench.algorithmic_bytes_per_step(wl, wl["channels"])
     assert 3e7 < b < 1e8          # weights + gradients + Adam state + per-ray I/O: tens of MB, not the GBs of saved activations
 

@@ -4,10 +4,9 @@ backward GEMMs take f16 operands and are therefore not the reference's fp32 arit
 1. test_step_gradients_vs_float64: one training step (train.py:160-340).  For every gradient (knots, transform, every weight
    and bias of both networks) the error of the HIP path against the float64 evaluation of the same step is compared with
    the error of the float32 oracle (= the reference's arithmetic, torch CPU) against the same float64 evaluation:
-       err(HIP vs f64) <= CONTRACT + 1.5 * err(float32 oracle vs f64)
-   with CONTRACT = SURVEY 8c's gradient tolerances (1e-3 of the largest entry, 1e-4 on norms).  The bound is what "HIP
-   within CONTRACT of the reference" implies against the truth (triangle inequality, 1.5 instead of 1 for the scatter of a
-   single draw), but it does not depend on which ReLU masks flip between two float32 implementations: two float32
+       err(HIP vs f64) <= 1.5 * err(float32 oracle vs f64)
+   (1.5 instead of 1 for the scatter of a single draw; no additive floor).  The bound says "no further from the truth than the
+   reference's own fp32 arithmetic", and it does not depend on which ReLU masks flip between two float32 implementations: two float32
    evaluations of this path differ from each other by about the contract's 1e-3 already (an ulp in pts = o + d z is amplified
    2^9 times by the positional encoding) - the exact-f32 mode, held to the same bound, is the control.
    tools/experiments/f64_truth.py prints the full decomposition (profiles/r03_f64_truth_*.log).
@@ -37,10 +36,11 @@ G8_SPECS = [
     ("e2syn_C3", "e2nerf_syn", 3, "E2NeRF_Synthetic", 0.2, 7, 32, 32, 16, 5),
     ("e2real_C3", "e2nerf_real", 3, "E2NeRF_Real", -1.0, 31, 16, 32, 16, 2),
 ]
-# err(HIP vs f64) <= FLOOR + FACTOR * err(float32 oracle vs f64); FLOOR = the contract: 1e-3 of the largest entry
-# (also for the relative L2 error), 1e-4 on norms
+# err(HIP vs f64) <= FACTOR * err(float32 oracle vs f64): no additive floor (round 3 had the contract's 1e-3 / 1e-4 in front; every
+# mode sat at 0.4-0.85 of that bound without needing it).  The norm statistic keeps an absolute 2e-6: where the float32 oracle's
+# own norm error happens to be ~1e-8 (a difference of two nearly equal norms), 1.5 x that is below float32 round-off.
 FACTOR = {"L2": 1.5, "max": 1.5, "norm": 1.5}
-FLOOR = {"L2": 1e-3, "max": 1e-3, "norm": 1e-4}
+FLOOR = {"L2": 0.0, "max": 0.0, "norm": 2e-6}
 
 
 def _case(name):
@@ -52,13 +52,13 @@ def _case(name):
         cam = GI.CAMERAS[cname]
         window, chunks = (0.1 if "unreal" in tag else 0.25), 1
     else:
-        wl = WL.WORKLOADS["C2"]
+        wl = WL.WORKLOADS[name[:2]]
         frac = 8 if name.endswith("eighth") else 1
         cname, C, dataset, thr, P, S, Ni = wl["cam"], wl["channels"], wl["dataset"], wl["threshold"], wl["n"], wl["S"], wl["Ni"]
         Re, Rr = wl["Re"] // frac, max(wl["Rr"] // frac, 1)
-        rng = np.random.default_rng(2024)
+        rng = np.random.default_rng(2024 + int(name[1]) - 2)
         cam = WL.CAMERAS[cname]
-        window, chunks = wl["window"], (2 if frac == 8 else 12)
+        window, chunks = wl["window"], (2 if frac == 8 else {"C2": 12, "C3": 12, "C4": 24, "C5": 32}[name[:2]])
     pc, pf = O.xavier_params(rng, C), O.xavier_params(rng, C)
     pc["alpha_linear.bias"] += 1.0
     pf["alpha_linear.bias"] += 1.0
@@ -90,8 +90,8 @@ def _hip_step(x, mode, z_forced):
     K.set_mlp_precision(mode)
     try:
         cam = x["cam"]
-        wl = dict(cam="_t", channels=x["C"], dataset=x["dataset"], threshold=x["thr"], window=0.1, n=x["P"], S=x["S"], Ni=x["Ni"],
-                  Re=x["Re"], Rr=x["Rr"])
+        wl = dict(cam="_t", channels=x["C"], dataset=x["dataset"], threshold=x["thr"], window=float(x["evt_ts"][1] - x["evt_ts"][0]),
+                  n=x["P"], S=x["S"], Ni=x["Ni"], Re=x["Re"], Rr=x["Rr"])
         WL.CAMERAS["_t"] = cam
         args = WL.make_args(wl, optimize_trans=True)
         model = optimize.Model(args)
@@ -166,9 +166,11 @@ def test_step_gradients_vs_float64(case):
 def test_full_size_step_vs_oracle():
     """The C2 step of BASELINE.json on explicit draws, HIP (both modes) against the float32 oracle itself: loss, pose
     gradients, 64 sampled entries and the norm of every weight gradient.  Fine depths forced to the oracle's (sample_pdf's
-    conditioning is tested by itself, test_kernels_gpu K5).  Tolerances: loss 2e-5; gradients SURVEY 8c's 1e-3 of the largest
-    entry / 1e-4 on norms, times the factor two float32 implementations of this step are apart at this size anyway
-    (test_step_gradients_vs_float64 holds both modes to the float64 yardstick; measured: profiles/r03_f64_truth_*.log)."""
+    conditioning is tested by itself, test_kernels_gpu K5).  Tolerances = SURVEY 8c's contract, the same for both modes: loss 2e-5,
+    pose gradients 1e-3 of the largest entry, norms 1e-4; sampled entries 1.25e-3 - two float32 evaluations of this step are
+    that far apart at this size whatever their arithmetic (ReLU-kink flips behind the 2^9 x positional encoding: the exact-f32
+    mode itself shows 1.11e-3 on one sampled bias entry and 0.8e-3 on the pose gradients, profiles/r03_gpu_parity_report.txt:238;
+    test_step_gradients_vs_float64 holds both modes to the float64 yardstick)."""
     x = _case("C2")
     a = _oracle_args(x)
     o32 = T.step_grads(*a, dtype=torch.float32, z_forced=None, n_chunks=x["chunks"])
@@ -183,16 +185,52 @@ def test_full_size_step_vs_oracle():
             if name in ("knots", "transform"):
                 e = float((got - ref).abs().max()) / mx
                 REPORT.append("full-size C2 vs oracle, %-5s d%-36s max err %.2e of the largest entry" % (mode, name, e))
-                if e > 2e-3:
+                if e > 1e-3:
                     bad.append("%s: %.2e" % (name, e))
                 continue
             idx = torch.from_numpy(rng.integers(0, ref.numel(), 64))
             e = float((got.reshape(-1)[idx] - ref.reshape(-1)[idx]).abs().max()) / mx
             en = abs(float(got.norm() / ref.norm()) - 1.0)
             REPORT.append("full-size C2 vs oracle, %-5s d%-36s sampled entries %.2e  norm %.2e" % (mode, name, e, en))
-            if e > 2e-3 or en > 2e-4:
+            if e > 1.25e-3 or en > 1e-4:
                 bad.append("%s: entries %.2e norm %.2e" % (name, e, en))
         assert not bad, "mode %s:\n%s" % (mode, "\n".join(bad))
+
+
+@pytest.mark.parametrize("case", ["C3", "C4", "C5"])
+def test_full_size_step_vs_oracle_colour_configs(case):
+    """The full-size steps of the other BASELINE.json GPU configurations, HIP (both modes) against the float32 oracle on explicit
+    draws with the oracle's fine depths forced in: C3 (colour kernels, 0.78 M points), C4 (800 x 800 camera, lin-log brightness,
+    8181 rays, 1.57 M points) and C5 (31 poses, 64 + 192 samples, 2.1 M points, the L2-NORMALISED event loss, train.py:238-292 -
+    the configuration where round 3's f16 backward needed a widened tolerance already at G8 size).  The oracle evaluates the
+    step in pixel chunks by a two-pass vector-Jacobian product (f64_truth.step_grads_vjp: any loss, bounded memory).
+    Tolerances: test_full_size_step_vs_oracle's (loss 2e-5, pose gradients 1e-3 of the largest entry, 64 sampled entries per
+    gradient 1.25e-3, norms 1e-4), the same for both modes."""
+    x = _case(case)
+    cfg, pc, pf, kn, tr, ets, rts, idx_e, idx_r, tacc, timg, d_e, d_r = _oracle_args(x)
+    o32 = T.step_grads_vjp(cfg, pc, pf, kn, tr, ets, rts, idx_e, idx_r, tacc, timg, d_e, d_r, dtype=torch.float32, n_chunks=x["chunks"])
+    rng = np.random.default_rng(7)
+    picks = {name: torch.from_numpy(rng.integers(0, ref.numel(), 64)) for name, ref in o32["grads"].items()}
+    for mode in ("f32", "split"):
+        loss, g = _hip_step(x, mode, {k: (None, v[1]) for k, v in o32["z"].items()})
+        assert abs(loss - o32["loss"]) <= 2e-5 * max(1.0, abs(o32["loss"])), (mode, loss, o32["loss"])
+        bad = []
+        for name, ref in o32["grads"].items():
+            got = g[name].double().reshape(ref.shape)
+            mx = float(ref.abs().max())
+            if name in ("knots", "transform"):
+                e = float((got - ref).abs().max()) / mx
+                REPORT.append("full-size %s vs oracle, %-5s d%-36s max err %.2e of the largest entry" % (case, mode, name, e))
+                if e > 1e-3:
+                    bad.append("%s: %.2e" % (name, e))
+                continue
+            idx = picks[name]
+            e = float((got.reshape(-1)[idx] - ref.reshape(-1)[idx]).abs().max()) / mx
+            en = abs(float(got.norm() / ref.norm()) - 1.0)
+            REPORT.append("full-size %s vs oracle, %-5s d%-36s sampled entries %.2e  norm %.2e" % (case, mode, name, e, en))
+            if e > 1.25e-3 or en > 1e-4:
+                bad.append("%s: entries %.2e norm %.2e" % (name, e, en))
+        assert not bad, "%s, mode %s:\n%s" % (case, mode, "\n".join(bad))
 
 
 @pytest.mark.parametrize("n_rays", [8, 1020])

@@ -45,6 +45,7 @@ def main():
         return ts[len(ts) // 2]
 
     t_f = timed(lambda: K.mlp_fwd(packed, ro, rd, rd, z, True))
+    t_i = timed(lambda: K.mlp_fwd(packed, ro, rd, rd, z, False))
     dacts = [None]
 
     def dx():
@@ -53,7 +54,8 @@ def main():
     gw = [torch.zeros_like(w) for w in packed.weights]
     gb = [torch.zeros_like(b) for b in packed.biases]
     t_w = timed(lambda: K.mlp_bwd_dw(packed, d_raw.view(-1, raw.shape[-1]), acts, dacts[0], n_rays, n_samples, gw, gb, False))
-    print("lib=%s M=%d fwd %.3f ms  dx %.3f ms  dw %.3f ms" % (os.environ.get("BENERF_HIP_LIB", "default"), M, t_f, t_x, t_w))
+    print("lib=%s mode=%s M=%d fwd %.3f ms (inference launch %.3f)  dx %.3f ms  dw %.3f ms"
+          % (os.environ.get("BENERF_HIP_LIB", "default"), K.get_mlp_precision(), M, t_f, t_i, t_x, t_w))
 
 
 if __name__ == "__main__":
