@@ -24,13 +24,13 @@ import os
 import sys
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before the HIP runtime initialises: one hardware queue per stream (benerf_amd/__init__.py)
-
 import numpy as np      # noqa: E402
 import torch            # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+import benerf_amd       # noqa: E402
+benerf_amd.configure_runtime()      # GPU_MAX_HW_QUEUES = 8 unless the user chose a value; before the HIP runtime initialises (no device call yet)
 
 F32_MFMA_PEAK_TFLOPS = 157.3    # MI355X f32 matrix peak (MI355X_MICROARCH.md)
 F16_MFMA_PEAK_TFLOPS = 2516.6   # dense f16 matrix peak: 256 CUs x 4 SIMDs x 1024 flop/clk x 2.4 GHz

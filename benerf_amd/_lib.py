@@ -17,6 +17,7 @@ LOSS_NSTATS = 16
 # status words of the split-f16 range guard (include/benerf_hip.h)
 ST_ACT, ST_GRAD, ST_MODE, ST_AUTO, ST_SKIP, ST_SKIPPED, ST_CONSECUTIVE, ST_STEPS, ST_LAST_ACT, ST_LAST_GRAD, ST_STEP_SCRATCH, ST_WORDS = \
     0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 16
+ST_SKIPPED_TOTAL, ST_MAX_CONSECUTIVE = 12, 13
 
 
 class MlpParams(Structure):

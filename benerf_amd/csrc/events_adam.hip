@@ -55,12 +55,24 @@ __global__ void gather_rows_kernel(const float* __restrict__ src, const int64_t*
 
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, int64_t n, float step_size, float omb1, float beta2, float omb2,
-                            float eps, float bc2_sqrt, float grad_scale, const uint32_t* __restrict__ skip_if_range) {
+                            float eps, float bc2_sqrt, float grad_scale, const uint32_t* __restrict__ skip_if_range,
+                            double lr, double beta1_d, double beta2_d, int step) {
     // status words of the split-f16 MLP mode (include/benerf_hip.h): a step whose activations or scaled gradients left
     // the f16 range carries inf / NaN gradients - leave parameters and moments untouched, the host reports it
     // ([4]: the verdict of benerf_step_gate for this step - identical on every data-parallel rank)
     if (skip_if_range && (skip_if_range[BENERF_ST_SKIP] != 0u || skip_if_range[BENERF_ST_ACT] >= 0x477fe000u ||
                           skip_if_range[BENERF_ST_GRAD] >= 0x477fe000u)) return;   // 65504.f
+    // Bias correction counts APPLIED steps: steps the range guard skipped did not update the moments (torch's GradScaler does
+    // not advance a skipped step either).  The host computed step_size / bc2_sqrt for t = step; with skipped steps on record
+    // (rare) they are recomputed here for t = step - [SKIPPED_TOTAL].
+    if (skip_if_range) {
+        const uint32_t sk = skip_if_range[BENERF_ST_SKIPPED_TOTAL];
+        if (sk != 0u) {
+            const double t = (double)((int64_t)step - (int64_t)sk < 1 ? 1 : (int64_t)step - (int64_t)sk);
+            step_size = (float)(lr / (1.0 - pow(beta1_d, t)));
+            bc2_sqrt = (float)sqrt(1.0 - pow(beta2_d, t));
+        }
+    }
     int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         float gi = g[i] * grad_scale;
@@ -90,7 +102,9 @@ __global__ void step_gate_kernel(uint32_t* __restrict__ st, float* __restrict__ 
     }
     st[BENERF_ST_SKIP] = skip ? 1u : 0u;
     st[BENERF_ST_SKIPPED] += skip ? 1u : 0u;
+    st[BENERF_ST_SKIPPED_TOTAL] += skip ? 1u : 0u;
     st[BENERF_ST_CONSECUTIVE] = skip ? st[BENERF_ST_CONSECUTIVE] + 1u : 0u;
+    if (st[BENERF_ST_CONSECUTIVE] > st[BENERF_ST_MAX_CONSECUTIVE]) st[BENERF_ST_MAX_CONSECUTIVE] = st[BENERF_ST_CONSECUTIVE];
     st[BENERF_ST_STEPS] += 1u;
     st[BENERF_ST_ACT] = 0u;    // the next step starts clean: one violation does not disable training for good
     st[BENERF_ST_GRAD] = 0u;
@@ -200,7 +214,7 @@ extern "C" int benerf_adam_step(float* param, const float* grad, float* exp_avg,
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq, n,
                        step_size, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps, bc2_sqrt,
-                       (float)grad_scale, skip_if_range);
+                       (float)grad_scale, skip_if_range, lr, beta1, beta2, step);
     BENERF_LAUNCH_CHECK("adam_step");
     return BENERF_OK;
 }

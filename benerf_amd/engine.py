@@ -245,16 +245,20 @@ def getattr_path(obj, dotted):
 
 
 class TrainStep:
-    MAX_SKIPPED_IN_A_ROW = 3     # consecutive range-guard skips after which step() raises (checked without synchronising)
-    GUARD_POST_EVERY = 8         # steps between two copies of the guard's counters to the host
-
     """One full training iteration (train.py:153-394 semantics) as a fixed kernel sequence.
 
     Per rank it renders its shard of the event pixels (2 poses) and blur pixels (n poses) in one
     batched launch sequence, computes loss + gradients (K6), backpropagates through both MLPs,
     rays and the trajectory, all-reduces the flat gradient buffer (when world_size > 1) and
     applies Adam with the exponential LR schedule.
+
+    Range guard (split arithmetic modes): a step whose activations / scaled gradients left the f16 range, or whose loss gradient
+    is not finite, leaves parameters and Adam moments untouched on every rank and is counted on the device; Adam's bias
+    correction counts APPLIED steps only (t = iteration - skipped steps, like torch's GradScaler), the LR schedule follows the
+    iteration count like the reference's (train.py:355-394).
     """
+    MAX_SKIPPED_IN_A_ROW = 3     # consecutive range-guard skips after which step() raises (checked without synchronising)
+    GUARD_POST_EVERY = 8         # steps between two copies of the guard's counters to the host
 
     def __init__(self, graph, cfg, cam_rgb, cam_evt, device, world_size=1, rank=0, process_group=None, seed=0):
         # switches of train.py:180-352 this fused sequence does not implement are refused, not ignored
@@ -271,6 +275,9 @@ class TrainStep:
             raise ValueError("TrainStep: event_loss and rgb_loss are both off - nothing to optimise")
         self.g, self.cfg, self.cam_rgb, self.cam_evt = graph, cfg, cam_rgb, cam_evt
         self.dev, self.world, self.rank, self.pg = device, world_size, rank, process_group
+        if process_group is not None:      # RCCL's streams join the step's: GPU_MAX_HW_QUEUES matters (benerf_amd.configure_runtime)
+            import benerf_amd
+            benerf_amd.warn_if_few_hw_queues()
         self.seed = seed
         self.dw_stream = torch.cuda.Stream(device=device)    # weight-gradient launches (step(): backward)
         self.C = cfg.channels
@@ -301,6 +308,9 @@ class TrainStep:
         self.transform = self.flat_p[o + 24:o + 30].view(1, 6)
         self.transform.copy_(tr.detach())
         tr.data = self.transform
+        # the nn.Parameters alias the flat buffer through `.data = view`, which does NOT share version counters: a torch-side
+        # write through graph.evt_knot_pose_se3 / graph.transform bumps THEIR counters, not flat_p's (_param_versions)
+        self._traj_params = (kn, tr)
         self.g_knots = self.flat_g[o:o + 24].view(4, 6)
         self.g_transform = self.flat_g[o + 24:o + 30].view(1, 6)
         self.off_pose = o
@@ -358,12 +368,14 @@ class TrainStep:
     def export_optimizer_state(self, optimizers):
         """Fills the Adam objects of Model.setup_optimizer (nerf, pose, transform, ...) with this step's moments, step
         count and current learning rates, ready for checkpoint.save (the tone-mapper optimisers too, when they are trained)."""
+        # Adam's step count = APPLIED steps (a step the range guard skipped did not touch the moments); synchronises
+        applied = self.global_step - int(self.guard.words[_lib.ST_SKIPPED_TOTAL].item())
         for opt, lr in self._trained_optimizers(optimizers):
             for group in opt.param_groups:
                 group["lr"] = lr
                 for p in group["params"]:
                     off, n = self._flat_slice(p)
-                    opt.state[p] = {"step": torch.tensor(float(self.global_step), device="cpu"),
+                    opt.state[p] = {"step": torch.tensor(float(applied), device="cpu"),
                                     "exp_avg": self.flat_m[off:off + n].view_as(p).clone(),
                                     "exp_avg_sq": self.flat_v[off:off + n].view_as(p).clone()}
 
@@ -380,9 +392,21 @@ class TrainStep:
                     self.flat_m[off:off + n].copy_(st["exp_avg"].reshape(-1))
                     self.flat_v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
         self.global_step = int(global_step)
+        self.guard.words[_lib.ST_SKIPPED_TOTAL:_lib.ST_SKIPPED_TOTAL + 1].zero_()     # the imported step count IS the applied count
         self._prefetched = None
         self.net_c.packed.pack()
         self.net_f.packed.pack()
+
+    def _param_versions(self):
+        """Version counters that a torch-side write to the trajectory parameters bumps, whichever alias it goes through: the flat
+        buffer's (step.knots / step.transform are true views of it) and the two nn.Parameters' own (their `.data` was re-pointed
+        at those views; set_data does not share counters).  The fused Adam writes through raw pointers and bumps none of them."""
+        return (self.flat_p._version, self._traj_params[0]._version, self._traj_params[1]._version)
+
+    def invalidate_prefetch(self):
+        """Drop the next step's prefetched poses / rays / depths.  Needed only after a write to the trajectory parameters that
+        torch's version counters cannot see: through `param.data` (every access makes a fresh counter) or through a raw pointer."""
+        self._prefetched = None
 
     def check_range(self, reset=True):
         """Synchronises.  Raises kernels.BenerfRangeError if a step since the last reset left the f16 range of the split mode
@@ -412,8 +436,22 @@ class TrainStep:
         z = K.stratified_z(N, S, dev, t_rand, sd, off)
         return poses_e, poses_r, ro, rd, vd, z
 
-    def step(self, evt_ts2, rgb_ts2, idx_evt_global, idx_rgb_global, events_accu, image, draws_evt=None,
-             draws_rgb=None, z_fine_forced=None, overlap=None):
+    def step(self, *args, **kwargs):
+        """One training iteration: see _step for the arguments.  If anything raises between the compositing backward and the
+        step gate, the two per-step maxima of |d_raw| (atomic maxima in the guard's scratch words, zeroed by the gate) would
+        stay behind and scale the next step's dX chain - they are cleared here, with the prefetched ray set-up."""
+        try:
+            return self._step(*args, **kwargs)
+        except BaseException:
+            self._prefetched = None
+            try:
+                self.amax.zero_()
+            except Exception:      # noqa: BLE001 - the device may be the thing that failed; the original error matters
+                pass
+            raise
+
+    def _step(self, evt_ts2, rgb_ts2, idx_evt_global, idx_rgb_global, events_accu, image, draws_evt=None,
+              draws_rgb=None, z_fine_forced=None, overlap=None):
         """evt_ts2/rgb_ts2: [2] device floats; idx_*_global: int64 device pixel indices (global batch,
         identical on every rank); events_accu [H_e*W_e] float32 device; image [H*W, C] float32 device.
         z_fine_forced [N, S+Ni]: parity runs may supply the merged fine depths instead of K5's (sample_pdf is
@@ -448,7 +486,7 @@ class TrainStep:
             d = Draws(seed=self.seed + self.rank * 7919, offset=step_id)
         pre, self._prefetched = self._prefetched, None
         if (pre is not None and draws_evt is None and pre["step_id"] == step_id and
-                pre["versions"] == (self.flat_p._version, evt_ts2._version, rgb_ts2._version, idx_evt_global._version, idx_rgb_global._version) and
+                pre["versions"] == self._param_versions() + (evt_ts2._version, rgb_ts2._version, idx_evt_global._version, idx_rgb_global._version) and
                 all(x is y for x, y in zip(pre["inputs"], (evt_ts2, rgb_ts2, idx_evt_global, idx_rgb_global)))):
             poses_e, poses_r, ro, rd, vd, z = pre["rays"]      # set up in the previous step's slack (see the end of this method)
         else:
@@ -587,7 +625,7 @@ class TrainStep:
             # torch-side writes to the parameters (a checkpoint load, a test poking a weight) or to the inputs before the next
             # call bump these version counters - the set-up is then recomputed (the fused Adam writes through raw pointers)
             self._prefetched = {"inputs": nxt, "step_id": step_id + 1,
-                                "versions": (self.flat_p._version,) + tuple(t_._version for t_ in nxt),
+                                "versions": self._param_versions() + tuple(t_._version for t_ in nxt),
                                 "rays": self._ray_setup(nxt[0], nxt[1], self.shard(nxt[2]), self.shard(nxt[3]), dn)}
         with torch.cuda.stream(side):
             for w in pending[:2]:

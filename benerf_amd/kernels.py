@@ -206,7 +206,9 @@ _struct_cache = {}
 def _param_struct(cls, tensors_w, tensors_b):
     """Pointer table of one network's 12 weights + 12 biases (or their gradients).  The tables of a training run never
     change (parameters and gradients are views of flat buffers): validated once per distinct set of pointers."""
-    key = (cls,) + tuple(t.data_ptr() for t in tensors_w) + tuple(t.data_ptr() for t in tensors_b)
+    # dtype / shape / stride / device belong to the key: w.t() shares its pointer with w, a reallocated tensor may recycle an address
+    key = (cls,) + tuple((t.data_ptr(), t.dtype, t.shape, t.stride(), t.device) for t in tensors_w) + \
+        tuple((t.data_ptr(), t.dtype, t.shape, t.stride(), t.device) for t in tensors_b)
     hit = _struct_cache.get(key)
     if hit is None:
         if len(_struct_cache) > 64:
@@ -293,7 +295,9 @@ class RangeGuard:
         self._posted = False
         h = [int(v) & 0xffffffff for v in self._mirror.tolist()]
         lim = 0x477fe000
-        if h[_lib.ST_CONSECUTIVE] >= max_consecutive or h[_lib.ST_ACT] >= lim or h[_lib.ST_GRAD] >= lim:
+        # [MAX_CONSECUTIVE]: the longest run of skipped steps since the host last cleared the counters - a run that ended between
+        # two posts is seen too
+        if max(h[_lib.ST_CONSECUTIVE], h[_lib.ST_MAX_CONSECUTIVE]) >= max_consecutive or h[_lib.ST_ACT] >= lim or h[_lib.ST_GRAD] >= lim:
             self._raise(h)
 
     def check(self, reset=True):
@@ -302,7 +306,8 @@ class RangeGuard:
         rc = _lib.load().benerf_mlp_status_check(self.words.data_ptr(), _stream())
         self._posted = False            # whatever an earlier post() copied is older than this synchronous look
         if rc != 0 and reset:
-            self.words.zero_()
+            self.words[:_lib.ST_SKIPPED_TOTAL].zero_()      # [SKIPPED_TOTAL] stays: Adam's bias correction counts applied steps
+            self.words[_lib.ST_MAX_CONSECUTIVE:].zero_()
         _lib.check(rc, "mlp_status_check")
 
 

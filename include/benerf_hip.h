@@ -196,6 +196,11 @@ enum { BENERF_ST_ACT = 0, BENERF_ST_GRAD = 1, BENERF_ST_MODE = 2, BENERF_ST_AUTO
        BENERF_ST_STEP_SCRATCH = 10,     /* [10], [11]: max |d_raw| of the step's (up to) two networks - benerf_composite_bwd's
                                          * d_raw_absmax, NaN recorded as +inf; zeroed by benerf_step_gate phase 1, which treats a
                                          * non-finite value as a violation (the loss gradient of the step is not finite) */
+       BENERF_ST_SKIPPED_TOTAL = 12,    /* skipped steps since the words were created (never cleared by benerf_mlp_status_check's callers'
+                                         * resets of [SKIPPED]): benerf_adam_step counts only APPLIED steps in its bias correction,
+                                         * t = step - [SKIPPED_TOTAL] (torch's GradScaler does not advance a skipped step either) */
+       BENERF_ST_MAX_CONSECUTIVE = 13,  /* longest run of skipped steps since the host last cleared it (a run that ends between two
+                                         * host polls is still seen) */
        BENERF_ST_WORDS = 16 };
 int benerf_mlp_status_check(const uint32_t* status, benerf_stream_t stream);
 /* Per-step verdict of the range guard, on the device (no synchronisation), between the backward pass and the
@@ -204,7 +209,8 @@ int benerf_mlp_status_check(const uint32_t* status, benerf_stream_t stream);
  *            callers SUM it over the ranks together with the gradients, so that every replica takes the same decision
  *            (a rank that overflowed contributes inf / NaN to everybody's gradient sum);
  *   phase 1: [SKIP] = violation (reduce_flag[0] > 0 when reduce_flag != NULL, this rank's words otherwise), counters
- *            [SKIPPED] (total), [CONSECUTIVE], [STEPS] updated, the tripping maxima kept in [LAST_ACT] / [LAST_GRAD],
+ *            [SKIPPED] (total), [SKIPPED_TOTAL], [CONSECUTIVE], [MAX_CONSECUTIVE], [STEPS] updated, the tripping maxima kept in
+ *            [LAST_ACT] / [LAST_GRAD],
  *            [ACT] / [GRAD] / [MODE] and the two [STEP_SCRATCH] words cleared for the next step: one violation costs one step,
  *            not the rest of the run. */
 int benerf_step_gate(uint32_t* status, float* reduce_flag, int phase, benerf_stream_t stream);

@@ -547,6 +547,26 @@ def test_train_step_overlap_slot():
             a_ = step.step(stale[0], stale[1], stale[2], stale[3], accus[0], img)
             b_ = ref_step.step(ets, rts, idxs[0][0], idxs[0][1], accus[0], img)
             assert torch.equal(a_, b_) and torch.equal(step.flat_p, ref_step.flat_p)
+            # ... and so is one made stale by a write THROUGH THE nn.Parameters (pose re-initialisation, load_state_dict): their
+            # `.data` aliases the flat buffer, but set_data does not share version counters - the snapshot holds theirs too
+            stale2 = (ets.clone(), rts, idxs[1][0], idxs[1][1])
+            step.step(ets, rts, idxs[0][0], idxs[0][1], accus[0], img, overlap=lambda: stale2)
+            assert step._prefetched is not None
+            ref2 = engine.TrainStep(_graph(args, seed=23)[1], args, cam_o, cam_o, torch.device(DEV), seed=5)
+            with torch.no_grad():
+                for buf in ("flat_p", "flat_m", "flat_v"):
+                    getattr(ref2, buf).copy_(getattr(step, buf))
+                ref2.global_step = step.global_step
+                g.evt_knot_pose_se3.params.weight.mul_(0.5)
+                g.transform.params.weight.add_(0.01)
+                ref2.knots.mul_(0.5)
+                ref2.transform.add_(0.01)
+            assert torch.equal(step.knots, ref2.knots) and torch.equal(step.transform, ref2.transform), "the Parameters alias the flat buffer"
+            ref2.net_c.packed.pack()
+            ref2.net_f.packed.pack()
+            a_ = step.step(stale2[0], stale2[1], stale2[2], stale2[3], accus[1], img)
+            b_ = ref2.step(ets, rts, idxs[1][0], idxs[1][1], accus[1], img)
+            assert torch.equal(a_, b_) and torch.equal(step.flat_p, ref2.flat_p)
         elif not use_slot:
             l0 = step.step(ets, rts, idxs[0][0], idxs[0][1], accus[0], img)
             l1 = step.step(ets, rts, idxs[1][0], idxs[1][1], accus[1], img)
