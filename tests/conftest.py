@@ -69,7 +69,7 @@ def pytest_sessionfinish(session, exitstatus):
     out = os.path.join(ROOT, "gpurun_out")
     try:
         os.makedirs(out, exist_ok=True)
-        with open(os.path.join(out, "parity_report.txt"), "w") as f:
+        with open(os.path.join(out, "parity_report.txt"), "a") as f:      # several pytest sessions of one GPU call share the file
             f.write("\n".join(REPORT) + "\n")
     except OSError:
         pass

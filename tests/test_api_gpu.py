@@ -748,3 +748,32 @@ def test_barf_c2f_through_render_and_fused_step():
     report("barf fused step d knots", step.g_knots, ko.grad, atol=2e-3 * float(ko.grad.abs().max()), rtol=2e-3)
     r0 = pc["pts_linears.0.weight"].grad
     report("barf fused step d nerf.pts_linears.0.weight", step.net_c.gviews_w[0], r0, atol=2e-3 * float(r0.abs().max()), rtol=2e-3)
+
+
+def test_bench_two_ranks_end_to_end():
+    """The multi-rank training path of bench.py, end to end, on the one-GPU box: `python bench.py --gpus 2 --oversubscribe` spawns
+    its two ranks under torch.distributed.run (both on device 0, gloo transport - the same launch, sharding, bucketed exchange,
+    guard verdict and Adam code an 8-GPU run takes; RCCL itself is exercised by test_step_over_rccl_communicator_of_one).  C4 is
+    strong-scaled: the two ranks split ONE 8181-ray batch, so after the same number of steps from the same
+    initialisation the loss agrees with the one-rank run of that batch (the ranks' Philox jitter streams differ from the
+    one-rank run's: agreement to a percent, not bit for bit - test_sharded_step_equals_single_rank is the exact test)."""
+    import json
+    import subprocess
+    import sys
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+
+    def run(extra):
+        res = subprocess.run([sys.executable, bench, "--steps", "3", "--warmup", "1", "--workload", "C4", "--no-cpu-baseline"] + extra,
+                             env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+        assert res.returncode == 0, res.stderr[-3000:]
+        return json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+
+    two = run(["--gpus", "2", "--oversubscribe"])
+    assert two["n_gpus"] == 2 and two["rccl_ranks_seen"] == 2 and two["scaling"] == "strong" and two["allreduce_ms"] > 0
+    assert two["config"]["parallelism"] == "dp2" and two["config"]["rays_per_step_per_gpu"] == 2 * (2048 // 2) + 19 * (215 // 2)
+    assert np.isfinite(two["config"]["final_loss"]) and two["value"] > 0
+    one = run(["--gpus", "1", "--primary-only"])
+    assert one["n_gpus"] == 1 and np.isfinite(one["config"]["final_loss"])
+    assert abs(two["config"]["final_loss"] - one["config"]["final_loss"]) <= 2e-2 * abs(one["config"]["final_loss"]), \
+        (two["config"]["final_loss"], one["config"]["final_loss"])
