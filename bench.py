@@ -41,12 +41,12 @@ HBM_PEAK_GBS = 8000.0
 EXECUTED_PER_PRODUCT = {"split": {"mlp_fwd": 3, "mlp_bwd_dx": 3, "mlp_bwd_dw": 3},
                         "split_f16bwd": {"mlp_fwd": 3, "mlp_bwd_dx": 2, "mlp_bwd_dw": 1}}
 # bytes per sample point the split-mode dW launch streams once (saved activations h0..h7, feature, hv and as many
-# gradients - hi + lo f16 pairs, 4 bytes per value (split_f16bwd: 2) -, f32 PE / PE(dir) rows, one d_raw row)
-DW_BYTES_PER_POINT = {"split": 4 * ((8 * 256 + 256 + 128) + (8 * 256 + 256 + 128)) + 4 * (64 + 32) + 8,
+# gradients - f16 + 8-bit residual code, 3 bytes per value (split_f16bwd: one f16) -, f32 PE / PE(dir) rows, one d_raw row)
+DW_BYTES_PER_POINT = {"split": 3 * ((8 * 256 + 256 + 128) + (8 * 256 + 256 + 128)) + 4 * (64 + 32) + 8,
                       "split_f16bwd": 2 * ((8 * 256 + 256 + 128) + (8 * 256 + 256 + 128)) + 4 * (64 + 32) + 8}
 DTYPE_NOTE = {
-    "split": "f32 storage; every MLP GEMM (forward, dX, dW) as 3 f16 MFMAs on hi/lo-split operands (22-bit), f32 accumulate: "
-             "fp32-equivalent, measured against float64 (tests/test_f64_truth_gpu.py)",
+    "split": "f32 storage; every MLP GEMM (forward, dX, dW) as 3 f16 MFMAs on hi/lo-split operands (22-bit in flight, 19-bit saved "
+             "operands), f32 accumulate: fp32-equivalent, measured against float64 (tests/test_f64_truth_gpu.py)",
     "split_f16bwd": "f32 storage; forward 3 f16 MFMAs on hi/lo-split operands (22-bit); REDUCED-PRECISION backward: f16 gradient x "
                     "hi/lo weight (dX), f16 x f16 (dW), f32 accumulate",
     "f32": "f32 (v_mfma_f32_32x32x2_f32: bit-exact f32 products, f32 accumulate)"}

@@ -10,8 +10,9 @@
 //
 // Range: gradients are far outside f16's range (d_raw ~ 1/n_rays), but the chain is LINEAR in d_raw: each 128-point tile
 // multiplies its d_raw by a power of two s (pow2_scale6: tile maximum -> [2^6, 2^7)), runs the chain on the scaled values and
-// multiplies every output by 1/s - both exact.  The dY arrays for the dW kernel (hi and lo twins, SH layout, mlp_split.h)
-// carry ONE power-of-two scale per call (s_s from max|d_raw| of the launch), divided out by the dW reduce kernel.
+// multiplies every output by 1/s - both exact.  The dY arrays for the dW kernel (f16 hi halves in SH layout + 8-bit residual codes,
+// "lo8" twins: 19-bit operands, mlp_split.h) carry ONE power-of-two scale per call (s_s from max|d_raw| of the launch), divided
+// out by the dW reduce kernel.  Inside the chain (LDS planes) the gradient stays an f16 pair.
 //
 // Tiling (the split forward kernel's): one workgroup of 8 waves per 128 points, two f16 planes Th / Tl [128][320] = the CU's
 // whole 160 KiB; wave w owns the 32 input features of column tile w x all four point tiles (one accumulator set of 64
@@ -240,7 +241,7 @@ __device__ __forceinline__ void split2(float v0, float v1, half2v& hi, half2v& l
 // by gf = s_call / s_tile (a power of two <= 1; exact), the SH gradient arrays `st_hi` / `st_lo` of width 256 (tile part).
 template <bool MASK>
 __device__ __forceinline__ void epilogue3(f32x16 (&acc)[4], const uint32_t (&bits)[2], _Float16* __restrict__ Th, _Float16* __restrict__ Tl,
-                                          int ct, int lane, const _Float16* __restrict__ st_hi, const _Float16* __restrict__ st_lo, float gf,
+                                          int ct, int lane, const _Float16* __restrict__ st_hi, const uint8_t* __restrict__ st_lo, float gf,
                                           float& amax) {
     lane = stage_local(lane);
     const int lr = lane & 31, r4 = 4 * (lane >> 5);
@@ -248,6 +249,8 @@ __device__ __forceinline__ void epilogue3(f32x16 (&acc)[4], const uint32_t (&bit
     const __amdgpu_buffer_rsrc_t rs_lo = uniform_rsrc(st_lo);
     const _Float16 gh = (_Float16)gf;             // a power of two (or 0 below 2^-24: such a tile's gradients are below f16 anyway)
     const half2v g2 = {gh, gh};
+    const _Float16 gl = (_Float16)(gf * 4096.f);  // the residual goes into the encoder as lo * gf * 2^12 (h8_encode_unit<12>)
+    const half2v g2l = {gl, gl};
     const int n = ct * 32 + lr;
     const int ns = (n >> 3) ^ ((lane >> 5) << 1);
     // plane element offsets: 4 swizzle variants x {rows 0-63, rows 64-127}; the rest are immediate offsets (mlp_bwd_h.hip)
@@ -293,20 +296,22 @@ __device__ __forceinline__ void epilogue3(f32x16 (&acc)[4], const uint32_t (&bit
                 qh[h] = uint2{wh[0], wh[1]};
                 ql[h] = uint2{wl[0], wl[1]};
             }
-            // lanes exchange halves, then the exact rescale (v_pk_mul_f16 by a power of two)
+            // lanes exchange halves, then the exact rescale (v_pk_mul_f16 by a power of two) and the residual codes
             const uint4 uh = sh_pair_unit(qh[0], qh[1]);
             const uint4 ul = sh_pair_unit(ql[0], ql[1]);
             const uint32_t uhw[4] = {uh.x, uh.y, uh.z, uh.w}, ulw[4] = {ul.x, ul.y, ul.z, ul.w};
-            u32x4 oh, ol;
+            uint32_t oh[4], ol[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 oh[i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2v, uhw[i]) * g2);
-                ol[i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2v, ulw[i]) * g2);
+                ol[i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2v, ulw[i]) * g2l);
             }
+            const uint2 code = h8_encode_unit<12>(oh, ol);
             // vector offset + zero scalar offset (mlp_bwd_h.hip: the scalar-offset form of a 16-byte store reads its data late)
 #ifndef BWS_SKIP_STORE      // timing variants only (tools/experiments/build_variant.sh)
-            __builtin_amdgcn_raw_buffer_store_b128(oh, rs_hi, st_lane + (rt * 4 + ep * 2) * 256 * 8 * 2, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(ol, rs_lo, st_lane + (rt * 4 + ep * 2) * 256 * 8 * 2, 0, 0);
+            typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{oh[0], oh[1], oh[2], oh[3]}, rs_hi, st_lane + (rt * 4 + ep * 2) * 256 * 8 * 2, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{code.x, code.y}, rs_lo, st_lane / 2 + (rt * 4 + ep * 2) * 256 * 8, 0, 0);
 #endif
         }
 }
@@ -327,7 +332,7 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
     const float* packed_h = a.packed + PACKED_FLOATS;
     const int ct = wave;                                         // this wave's column tile in the 256-wide stages
     const int64_t Mp = m_pad(M);
-    const int64_t dlo = 2 * sdact_lo_delta(Mp);                  // half offset from a gradient SH array to its lo twin
+    uint8_t* st8 = reinterpret_cast<uint8_t*>(dacts + sdact_lo8_base(Mp));      // lo8 region: byte i <-> half i of the SH region
     // ReLU sign-bit words of the two 64-point forward tiles this workgroup covers: uint64 [layer][tile][4 x 64 threads]; this
     // wave's column tile ct is the forward thread (ct >> 1) * 64 + lane, 32-bit half ct & 1 (mlp_common.h / mlp_fwd_h.hip)
     const __amdgpu_buffer_rsrc_t mask_rsrc =
@@ -341,6 +346,7 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
     };
     _Float16* st_dyh = reinterpret_cast<_Float16*>(dacts + sdact_h(Mp, 0));      // layer l: + l * Mp * 256 halfs
     auto st_tile = [&](int l) { return st_dyh + ((int64_t)l * Mp + m0) * 256; };   // tile's part of layer l's SH array (hi)
+    auto st8_tile = [&](int l) { return st8 + ((int64_t)l * Mp + m0) * 256; };      // ... and of its lo8 twin
     float s_g, inv_s_g;
     const float mx_call = a.absmax ? *a.absmax : dacts[sdact_info(Mp) + SD_DRAW];
     if (a.absmax && blockIdx.x == 0 && tid == 0) dacts[sdact_info(Mp) + SD_DRAW] = mx_call;   // the dW reduce reads it there
@@ -386,6 +392,7 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
 #pragma unroll
         for (int c = 0; c < C; ++c) wr[c] = a.w_rgb[c * 128 + col];
         _Float16* st_lane = reinterpret_cast<_Float16*>(dacts + sdact_hv(Mp)) + (((m0 >> 3) + (lane >> 5)) * ACT_HV_W + col) * 8;
+        uint8_t* st8_lane = st8 + 2 * sdact_hv(Mp) + (((m0 >> 3) + (lane >> 5)) * ACT_HV_W + col) * 8;
 #pragma unroll
         for (int rtl = 0; rtl < 2; ++rtl)
 #pragma unroll
@@ -410,10 +417,13 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
                         const float sv = v * gf;
                         amax = fmaxf(amax, fabsf(v));
                         qh[h].v[j] = (_Float16)sv;
-                        ql[h].v[j] = (_Float16)(sv - (float)qh[h].v[j]);
+                        ql[h].v[j] = (_Float16)((sv - (float)qh[h].v[j]) * 4096.f);       // encoder input: residual * 2^12
                     }
-                *reinterpret_cast<uint4*>(st_lane + (int64_t)(rt * 4 + ep * 2) * ACT_HV_W * 8) = sh_pair_unit(qh[0], qh[1]);
-                *reinterpret_cast<uint4*>(st_lane + dlo + (int64_t)(rt * 4 + ep * 2) * ACT_HV_W * 8) = sh_pair_unit(ql[0], ql[1]);
+                const uint4 uh = sh_pair_unit(qh[0], qh[1]);
+                const uint4 ul = sh_pair_unit(ql[0], ql[1]);
+                const uint32_t uhw[4] = {uh.x, uh.y, uh.z, uh.w}, ulw[4] = {ul.x, ul.y, ul.z, ul.w};
+                *reinterpret_cast<uint4*>(st_lane + (int64_t)(rt * 4 + ep * 2) * ACT_HV_W * 8) = uh;
+                *reinterpret_cast<uint2*>(st8_lane + (int64_t)(rt * 4 + ep * 2) * ACT_HV_W * 8) = h8_encode_unit<12>(uhw, ulw);
             }
     }
     lds_barrier();
@@ -439,7 +449,7 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
     lds_barrier();   // dYv fully consumed; dPE(dir) visible
     {
         _Float16* stf = reinterpret_cast<_Float16*>(dacts + sdact_feat(Mp)) + m0 * 256;
-        epilogue3<false>(acc, bits, Th, Tl, ct, lane, stf, stf + dlo, gf, amax);
+        epilogue3<false>(acc, bits, Th, Tl, ct, lane, stf, st8 + 2 * sdact_feat(Mp) + m0 * 256, gf, amax);
     }
     if (tid < TMB && m0 + tid < M) {   // d viewdirs (per point) through PE(dir)
         const int64_t m = m0 + tid;
@@ -479,7 +489,7 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
     WRing<BWS_PF> ring;
     load_bits(6, bits_n);
     gemm3_head<16, BWS_PF>(packed_h + pack_offset(PB_L7), ct, lane, ring);
-    epilogue3<true>(acc, bits, Th, Tl, ct, lane, st_tile(7), st_tile(7) + dlo, gf, amax);
+    epilogue3<true>(acc, bits, Th, Tl, ct, lane, st_tile(7), st8_tile(7), gf, amax);
     lds_barrier();
 
     // ---- P4: L7 .. L1: dY_l x W_l, mask h_{l-1} -> dY_{l-1} ----------------------------------------------
@@ -493,7 +503,7 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
             load_bits(l - 2, bits_n);
             gemm3_head<16, BWS_PF>(packed_h + bwd_layer_offset(l - 1), ct, lane, ring);
         }
-        epilogue3<true>(acc, bits, Th, Tl, ct, lane, st_tile(l - 1), st_tile(l - 1) + dlo, gf, amax);
+        epilogue3<true>(acc, bits, Th, Tl, ct, lane, st_tile(l - 1), st8_tile(l - 1), gf, amax);
         lds_barrier();
     };
 #pragma unroll 1

@@ -1,16 +1,21 @@
-// K3 backward part 2, BENERF_MLP_SPLIT (the 22-bit backward): dW_l = dY_l^T X_l over all sample points with BOTH operands as
-// hi + lo f16 pairs (the SH arrays and their lo twins the split forward / mlp_bwd_s.hip save, mlp_split.h):
+// K3 backward part 2, BENERF_MLP_SPLIT (the fp32-equivalent backward): dW_l = dY_l^T X_l over all sample points with BOTH operands as
+// f16 pairs hi + lo:
 //     dY^T X  =  dY_hi^T X_hi + dY_hi^T X_lo + dY_lo^T X_hi      (three v_mfma_f32_32x32x16_f16 per block, ONE f32 accumulator)
-// + bias sums and the alpha / rgb heads on the VALU from hi + lo.  Why both lo halves: tools/experiments/
+// + bias sums and the alpha / rgb heads on the VALU from hi + lo.  Why both low halves: tools/experiments/
 // backward_format_study.py - with an f16 X or an f16 dY the weight gradients sit 2-3e-4 of the largest entry from float64
-// (same ReLU masks) where the exact-f32 kernel sits at 1e-6; with hi + lo on both they carry float32's own error.
+// (same ReLU masks) where the exact-f32 kernel sits at 1e-6.
+// In HBM the low halves are 8-BIT RESIDUAL CODES (lo8 twins of the SH arrays the split forward / mlp_bwd_s.hip save,
+// mlp_split.h: 19-bit operands, 3 bytes per value): this kernel is bound by exactly those bytes.  A code unit (8 bytes = 8 points
+// of one feature) is decoded to its f16 low halves on the way from the load registers to LDS (h8_decode_unit: 6 packed VALU
+// operations per pair, next to an idle VALU), so the MFMA side sees plain f16 pairs.
 //
 // Structure = mlp_dw_h.hip's: an SH array is blocks of 8 points, feature-major, one 16-byte unit per (block, feature) = the
-// MFMA fragment of a contraction over points, copied verbatim into a triple-buffered LDS image with three chunks in flight in
-// registers and one LDS-only barrier per chunk; a workgroup (8 waves, one per CU) holds a whole 256 x 256 output block (128
+// MFMA fragment of a contraction over points, staged through registers into a triple-buffered LDS image with three chunks in
+// flight and one LDS-only barrier per chunk; a workgroup (8 waves, one per CU) holds a whole 256 x 256 output block (128
 // accumulator registers per wave), so every operand byte is read exactly once.  A chunk is 16 points (ONE MFMA k-step) of the
-// four arrays = 32 KiB, the same bytes per barrier and per register set as the f16 kernel's 32-point chunk of two arrays.
-// HBM-bound: 19.5 KB per point against 24 MFMAs per wave and chunk.
+// four arrays = 24 KiB from HBM, 32 KiB in LDS.  HBM-bound: 14.6 KB per point against 24 MFMAs per wave and chunk.
+// (An LDS-DMA variant of the copy - ring of four slots, no staging registers - measured 5 % faster on f16 pairs in HBM, commit
+// caf2f65; it cannot decode on the way and went with the 4-byte format.)
 #include "mlp_split.h"
 
 namespace {
@@ -31,26 +36,29 @@ struct DwArgs {
 };
 
 struct Src {
-    const u32x4* y;    // SH array of width N (16-byte units), hi halves; lo twin at + ylo units
-    const u32x4* x;    // SH array of width K ... or, for the thin instances (XROWS), f32 rows [Mp][K]
-    int64_t ylo, xlo;  // unit offsets of the lo twins
+    const u32x4* y;     // SH array of width N (16-byte units), hi halves
+    const uint2* y8;    // its lo8 twin (8-byte units)
+    const u32x4* x;     // SH array of width K ... or, for the thin instances (XROWS), f32 rows [Mp][K]
+    const uint2* x8;
     bool bias;
 };
 
 __device__ __forceinline__ Src inst_src(const DwArgs& a, int inst) {
     const int64_t Mp = m_pad(a.M);
-    auto U = [](const float* p) { return reinterpret_cast<const u32x4*>(p); };
     const float* A = a.acts;
     const float* D = a.dacts;
-    const int64_t yl = sdact_lo_delta(Mp) / 4, xl = sact_lo_delta(Mp) / 4;        // floats -> 16-byte units
+    auto Y = [&](int64_t off, int64_t xoff, bool xsh, bool bias) {
+        return Src{reinterpret_cast<const u32x4*>(D + off), reinterpret_cast<const uint2*>(sdact_lo8(D, Mp, off)),
+                   reinterpret_cast<const u32x4*>(A + xoff), xsh ? reinterpret_cast<const uint2*>(sact_lo8(A, Mp, xoff)) : nullptr, bias};
+    };
     switch (inst) {
         case DW_L1: case DW_L2: case DW_L3: case DW_L4: case DW_L5H: case DW_L6: case DW_L7:
-            return {U(D + sdact_h(Mp, 1 + (inst - DW_L1))), U(A + sact_h(Mp, inst - DW_L1)), yl, xl, true};
-        case DW_FEAT: return {U(D + sdact_feat(Mp)), U(A + sact_h(Mp, 7)), yl, xl, true};
-        case DW_VIEWSF: return {U(D + sdact_hv(Mp)), U(A + sact_feat(Mp)), yl, xl, true};
-        case DW_L0: return {U(D + sdact_h(Mp, 0)), U(A + sact_pe32(Mp)), yl, 0, true};       // X = PE as f32 rows
-        case DW_L5P: return {U(D + sdact_h(Mp, 5)), U(A + sact_pe32(Mp)), yl, 0, false};
-        default: return {U(D + sdact_hv(Mp)), U(A + sact_ped32(Mp)), yl, 0, false};          // DW_VIEWSP: PE(dir) rows
+            return Y(sdact_h(Mp, 1 + (inst - DW_L1)), sact_h(Mp, inst - DW_L1), true, true);
+        case DW_FEAT: return Y(sdact_feat(Mp), sact_h(Mp, 7), true, true);
+        case DW_VIEWSF: return Y(sdact_hv(Mp), sact_feat(Mp), true, true);
+        case DW_L0: return Y(sdact_h(Mp, 0), sact_pe32(Mp), false, true);        // X = PE as f32 rows
+        case DW_L5P: return Y(sdact_h(Mp, 5), sact_pe32(Mp), false, false);
+        default: return Y(sdact_hv(Mp), sact_ped32(Mp), false, false);           // DW_VIEWSP: PE(dir) rows
     }
 }
 
@@ -81,78 +89,95 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int64_t 
             for (int e = 0; e < 16; ++e) acc[r][c][e] = 0.f;
     float bsum = 0.f, asum = 0.f, absum = 0.f;
 
-    u32x4 ryA[2][NY], rxA[2][NX], ryB[2][NY], rxB[2][NX], ryC[2][NY], rxC[2][NX];
-    float rdaA = 0.f, rdaB = 0.f, rdaC = 0.f;
+    // per chunk and thread: hi unit (16 bytes) + code unit (8 bytes) of Y and of X
+    struct Regs { u32x4 y[NY]; uint2 y8[NY]; u32x4 x[NX]; uint2 x8[NX]; float da; };
+    Regs rA, rB, rC;
+    rA.da = rB.da = rC.da = 0.f;
     // Loads are UNCONDITIONAL (a chunk index past the range is clamped to the last chunk and its staged dY zeroed): with the
     // loads under branches the compiler's waitcnt bookkeeping falls back to vmcnt(0) at every stage (mlp_dw_h.hip)
-#define DW_PREFETCH(RY, RX, RDA, CHUNK)                                                                   \
+#define DW_PREFETCH(R, CHUNK)                                                                             \
     {                                                                                                     \
         const int64_t cc = (CHUNK) < chunk_end ? (CHUNK) : chunk_end - 1;                                 \
-        const u32x4* py = src.y + cc * YU + tid;                                                          \
-        const u32x4* px = src.x + cc * XU + tid;                                                          \
         _Pragma("unroll") for (int j = 0; j < NY; ++j)                                                    \
             if (YFULL || tid + j * DWT < YU) {                                                            \
-                RY[0][j] = py[j * DWT];                                                                   \
-                RY[1][j] = py[src.ylo + j * DWT];                                                         \
+                R.y[j] = src.y[cc * YU + tid + j * DWT];                                                  \
+                R.y8[j] = src.y8[cc * YU + tid + j * DWT];                                                \
             }                                                                                             \
         if (XROWS) {   /* f32 rows [point][K]: one float4 (4 features of a point) per thread */                \
             if (tid < CHP * K / 4)                                                                        \
-                RX[0][0] = reinterpret_cast<const u32x4*>(reinterpret_cast<const float*>(src.x) + cc * (CHP * K))[tid]; \
+                R.x[0] = reinterpret_cast<const u32x4*>(reinterpret_cast<const float*>(src.x) + cc * (CHP * K))[tid]; \
         } else {                                                                                          \
             _Pragma("unroll") for (int j = 0; j < NX; ++j)                                                \
                 if (XFULL || tid + j * DWT < XU) {                                                        \
-                    RX[0][j] = px[j * DWT];                                                               \
-                    RX[1][j] = px[src.xlo + j * DWT];                                                     \
+                    R.x[j] = src.x[cc * XU + tid + j * DWT];                                              \
+                    R.x8[j] = src.x8[cc * XU + tid + j * DWT];                                            \
                 }                                                                                         \
         }                                                                                                 \
         if (ALPHA) {                                                                                      \
             const int64_t row = cc * CHP + (tid & (CHP - 1));                                             \
-            RDA = a.d_raw[(row < M ? row : M - 1) * (a.C + 1) + a.C];                                     \
-            if (row >= M) RDA = 0.f;                                                                      \
+            R.da = a.d_raw[(row < M ? row : M - 1) * (a.C + 1) + a.C];                                    \
+            if (row >= M) R.da = 0.f;                                                                     \
         }                                                                                                 \
     }
-    // global unit u = block * W + w of the chunk is unit u of the LDS image [block][w] (16-byte writes, conflict free)
-#define DW_STAGE(RY, RX, RDA, B, VALID)                                                                   \
+    // global unit u = block * W + w of the chunk is unit u of the LDS image [block][w] (16-byte writes, conflict free); the
+    // low halves are decoded from the codes here, between the load registers and LDS
+    auto put_pair = [&](u32x4* img_hi, u32x4* img_lo, int u, const u32x4 hi, const uint2 code, bool valid) {
+        const uint32_t h4[4] = {hi[0], hi[1], hi[2], hi[3]};
+        uint32_t l4[4];
+        h8_decode_unit(h4, code, l4);
+        img_hi[u] = valid ? hi : u32x4{0u, 0u, 0u, 0u};
+        img_lo[u] = valid ? u32x4{l4[0], l4[1], l4[2], l4[3]} : u32x4{0u, 0u, 0u, 0u};
+    };
+    auto stage_y = [&](const Regs& R, int b, bool valid) {     // past the range: contributes nothing
+        u32x4* Ys_ = smem + b * BUF;
+#pragma unroll
+        for (int j = 0; j < NY; ++j) {
+            const int u = tid + j * DWT;
+            if (YFULL || u < YU) put_pair(Ys_, Ys_ + YU, u, R.y[j], R.y8[j], valid);
+        }
+    };
+    auto stage_x = [&](const Regs& R, int b, bool valid) {
+        u32x4* Xs_ = smem + b * BUF + 2 * YU;
+        if (XROWS) {   // split into hi + lo and scatter the 4 features of this thread's point into their fragments
+            if (tid < CHP * K / 4) {
+                const int p = tid / (K / 4), w0 = (tid % (K / 4)) * 4;
+                _Float16* img = reinterpret_cast<_Float16*>(Xs_);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float v = __uint_as_float(R.x[0][i]);
+                    const _Float16 hi = (_Float16)v;
+                    img[((p >> 3) * K + w0 + i) * 8 + (p & 7)] = hi;
+                    img[XU * 8 + ((p >> 3) * K + w0 + i) * 8 + (p & 7)] = (_Float16)(v - (float)hi);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                const int u = tid + j * DWT;
+                if (XFULL || u < XU) put_pair(Xs_, Xs_ + XU, u, R.x[j], R.x8[j], true);
+            }
+        }
+        if (ALPHA && tid < CHP) reinterpret_cast<float*>(Xs_ + 2 * XU)[tid] = valid ? R.da : 0.f;
+    };
+    // one LDS-only barrier per chunk.  The image written before it (chunk j + 1) was last read two barriers earlier (three images)
+#define DW_BARRIER()                                                                                      \
     {                                                                                                     \
-        u32x4* Ys_ = smem + (B) * BUF;                                                                    \
-        u32x4* Xs_ = Ys_ + 2 * YU;                                                                        \
-        _Pragma("unroll") for (int j = 0; j < NY; ++j) {                                                  \
-            const int u = tid + j * DWT;                                                                  \
-            if (YFULL || u < YU) {   /* past the range: contributes nothing */                            \
-                Ys_[u] = (VALID) ? RY[0][j] : u32x4{0u, 0u, 0u, 0u};                                      \
-                Ys_[YU + u] = (VALID) ? RY[1][j] : u32x4{0u, 0u, 0u, 0u};                                 \
-            }                                                                                             \
-        }                                                                                                 \
-        if (XROWS) {   /* split into hi + lo and scatter the 4 features of this thread's point into their fragments */ \
-            if (tid < CHP * K / 4) {                                                                      \
-                const int p = tid / (K / 4), w0 = (tid % (K / 4)) * 4;                                    \
-                _Float16* img = reinterpret_cast<_Float16*>(Xs_);                                         \
-                _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
-                    const float v = __uint_as_float(RX[0][0][i]);                                         \
-                    const _Float16 hi = (_Float16)v;                                                      \
-                    img[((p >> 3) * K + w0 + i) * 8 + (p & 7)] = hi;                                      \
-                    img[XU * 8 + ((p >> 3) * K + w0 + i) * 8 + (p & 7)] = (_Float16)(v - (float)hi);      \
-                }                                                                                         \
-            }                                                                                             \
-        } else                                                                                            \
-        _Pragma("unroll") for (int j = 0; j < NX; ++j) {                                                  \
-            const int u = tid + j * DWT;                                                                  \
-            if (XFULL || u < XU) {                                                                        \
-                Xs_[u] = RX[0][j];                                                                        \
-                Xs_[XU + u] = RX[1][j];                                                                   \
-            }                                                                                             \
-        }                                                                                                 \
-        if (ALPHA && tid < CHP) reinterpret_cast<float*>(Xs_ + 2 * XU)[tid] = (VALID) ? RDA : 0.f;        \
-        /* buffer B was last read three chunks ago, and every wave has passed two barriers in between */ \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");                                   \
         __builtin_amdgcn_s_barrier();                                                                     \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");                                   \
     }
-    auto compute = [&](int b) {
+    // every wave of the grid multiplies (the big instances, L0 / L5P): the staging of the NEXT chunk goes INTO the MFMA block
+    constexpr bool ALLMMA = (8 / WN - 1) * TC * 32 < K;
+    // Chunk b's MFMAs with the decode + staging of the next chunk (register set Rn -> image bn) between them: ONE basic block,
+    // so the VALU / LDS-write instructions of the staging issue in the shadow of the MFMAs (an MFMA holds the matrix pipe for
+    // 32 cycles, the in-order wave would otherwise just wait for it) - first half of the column tiles, Y staging, second half,
+    // X staging.  With the staging as its own phase in front of the barrier (the f16 kernel's order, where it is a plain copy)
+    // the decode sat on the critical path of every chunk: 2.25 ms per 522 k-point launch against 1.99 ms for f16 pairs.
+    auto compute = [&](int b, const Regs& Rn, int bn, bool vn) {
         const u32x4* Yl = smem + b * BUF;
         const u32x4* Xl = Yl + 2 * YU;
         const float* da = reinterpret_cast<const float*>(Xl + 2 * XU);
-        if (mma_wave) {
+        if (ALLMMA || mma_wave) {
             half8 ayh[TR], ayl[TR];
 #pragma unroll
             for (int r = 0; r < TR; ++r) {
@@ -161,7 +186,10 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int64_t 
             }
             // column tiles in groups of CG: the three MFMAs of one accumulator are TR * CG issue slots apart, and only CG
             // fragment pairs of X are live at a time (all TC at once spilled)
-            constexpr int CG = TC >= 2 ? 2 : 1;
+#ifndef DWS_CG
+#define DWS_CG 2
+#endif
+            constexpr int CG = TC >= DWS_CG ? DWS_CG : 1;
 #pragma unroll
             for (int c0 = 0; c0 < TC; c0 += CG) {
                 half8 bxh[CG], bxl[CG];
@@ -182,7 +210,13 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int64_t 
                 for (int r = 0; r < TR; ++r)
 #pragma unroll
                     for (int c = 0; c < CG; ++c) acc[r][c0 + c] = mfma16(ayl[r], bxh[c], acc[r][c0 + c]);
+                if (ALLMMA && c0 == 0) stage_y(Rn, bn, vn);
+                if (ALLMMA && c0 + CG >= TC) stage_x(Rn, bn, vn);
             }
+        }
+        if (!ALLMMA) {
+            stage_y(Rn, bn, vn);
+            stage_x(Rn, bn, vn);
         }
         if (src.bias && tid < N) {
             float s = 0.f;
@@ -215,28 +249,34 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int64_t 
         }
     };
 
+    // Three register sets in flight, three LDS images.  (Four sets / two images / one column tile at a time - 96 KiB in flight
+    // per CU instead of 72 - measured the same or 3 % slower: with 3 bytes per value the kernel is no longer bound by the bytes in
+    // flight but by its per-chunk schedule, MFMA pipe busy ~55 %, like the forward and dX kernels.)
     if (chunk_begin < chunk_end) {
-        DW_PREFETCH(ryA, rxA, rdaA, chunk_begin);
-        DW_PREFETCH(ryB, rxB, rdaB, chunk_begin + 1);
-        DW_PREFETCH(ryC, rxC, rdaC, chunk_begin + 2);
+        DW_PREFETCH(rA, chunk_begin);
+        DW_PREFETCH(rB, chunk_begin + 1);
+        DW_PREFETCH(rC, chunk_begin + 2);
+        stage_y(rA, 0, true);
+        stage_x(rA, 0, true);
+        DW_BARRIER();
         for (int64_t chunk = chunk_begin; chunk < chunk_end; chunk += 3) {
-            DW_STAGE(ryA, rxA, rdaA, 0, true);
-            DW_PREFETCH(ryA, rxA, rdaA, chunk + 3);
+            const bool v1 = chunk + 1 < chunk_end, v2 = chunk + 2 < chunk_end, v3 = chunk + 3 < chunk_end;
+            DW_PREFETCH(rA, chunk + 3);
             __builtin_amdgcn_sched_barrier(0);   // keep the loads HERE: the scheduler otherwise sinks them below the MFMAs
-            compute(0);
-            const bool v1 = chunk + 1 < chunk_end, v2 = chunk + 2 < chunk_end;
-            DW_STAGE(ryB, rxB, rdaB, 1, v1);
-            DW_PREFETCH(ryB, rxB, rdaB, chunk + 4);
+            compute(0, rB, 1, v1);
+            DW_BARRIER();
+            DW_PREFETCH(rB, chunk + 4);
             __builtin_amdgcn_sched_barrier(0);
-            compute(1);
-            DW_STAGE(ryC, rxC, rdaC, 2, v2);
-            DW_PREFETCH(ryC, rxC, rdaC, chunk + 5);
+            compute(1, rC, 2, v2);
+            DW_BARRIER();
+            DW_PREFETCH(rC, chunk + 5);
             __builtin_amdgcn_sched_barrier(0);
-            compute(2);
+            compute(2, rA, 0, v3);
+            DW_BARRIER();
         }
     }
+#undef DW_BARRIER
 #undef DW_PREFETCH
-#undef DW_STAGE
 
     // partial block -> workspace: [N][K] then bias [N] (then alpha row [256] + alpha bias).  Block and bias stay at the
     // gradient scale s_s (the reduce kernel divides it out); the alpha row is unscaled (d_raw is)
@@ -258,181 +298,6 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int64_t 
     }
 }
 
-// ---- LDS-DMA variant of dw_gemm for the big instances -----------------------------------------------------------------
-// The chunk image IS the global layout (16-byte units, contiguous per array and chunk), so the copy needs no registers at all:
-// `buffer_load_dwordx4 ... lds` moves 1 KiB per wave-instruction straight into the ring slot.  Ring of DMA_RING slots,
-// DMA_RING - 1 chunks in flight (96 KiB per CU against ~50 KiB of bandwidth-delay product at 6 TB/s), one barrier per chunk:
-//   acquire(j): wait for this wave's own pieces of chunk j (vector-memory operations retire in order: only the pieces of the
-//   chunks requested behind j may still be outstanding), barrier -> every piece of j has landed AND every wave is done with
-//   chunk j - 1, whose slot the next request (chunk j + DMA_RING - 1) overwrites.
-// Every wave issues the same number PW of pieces per chunk, so the wait counts are compile-time constants.
-#ifndef DMA_RING
-#define DMA_RING 4
-#endif
-template <int N, bool ALPHA>
-struct DmaGeom {
-    static constexpr int K = 256;
-    static constexpr int YU = CHB * N, XU = CHB * K;                 // 16-byte units per chunk and plane
-    static constexpr int YP = YU / 64, XP = XU / 64;                 // 1-KiB pieces per plane
-    static_assert(XP == 8 && (YP == 8 || YP == 4), "eight waves share the pieces evenly");
-    static constexpr int PW = (YP == 8 ? 2 : 1) + 2 + (ALPHA ? 1 : 0);
-    static constexpr int SIG = (2 * YU + 2 * XU) * 16;               // byte offset of the d_raw rows (one 256-byte copy per wave)
-    static constexpr int SLOT = SIG + (ALPHA ? 8 * 256 : 0);
-};
-template <int CNT>
-__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CNT) : "memory"); }
-
-template <int N, int WN, int TR, int TC, bool ALPHA>
-__device__ __forceinline__ void dw_gemm_dma(const DwArgs& a, const Src src, int64_t chunk_begin, int64_t chunk_end,
-                                            float* __restrict__ part, char* __restrict__ smem) {
-    typedef DmaGeom<N, ALPHA> G;
-    constexpr int K = G::K, YU = G::YU, XU = G::XU, PW = G::PW, AHEAD = DMA_RING - 1;
-    static_assert(WN * TR * 32 == N && (8 / WN) * TC * 32 == K, "tiling");
-    static_assert(AHEAD * PW < 64, "vmcnt field");
-    typedef __attribute__((address_space(3))) void* lds_ptr;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lr = lane & 31, lh = lane >> 5;
-    const int wn = wave % WN, wk = wave / WN;
-    auto rsrc_of = [](const void* p, uint32_t bytes) {
-        const uint64_t wa = reinterpret_cast<uint64_t>(p);
-        const uint64_t wau = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(wa >> 32)) << 32) |
-                             (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)wa);
-        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(wau), 0, bytes, 0x00020000);
-    };
-    // descriptors on this workgroup's first chunk: per-chunk offsets stay below 2^31 (a split covers a few MB per array)
-    const __amdgpu_buffer_rsrc_t rs_yh = rsrc_of(src.y + chunk_begin * YU, 0x7fffffff);
-    const __amdgpu_buffer_rsrc_t rs_yl = rsrc_of(src.y + src.ylo + chunk_begin * YU, 0x7fffffff);
-    const __amdgpu_buffer_rsrc_t rs_xh = rsrc_of(src.x + chunk_begin * XU, 0x7fffffff);
-    const __amdgpu_buffer_rsrc_t rs_xl = rsrc_of(src.x + src.xlo + chunk_begin * XU, 0x7fffffff);
-    // d_raw rows of a chunk (ALPHA: the alpha head's d_sigma): [M][C + 1] floats; rows past M read as zero (range check on the
-    // VECTOR offset, which therefore carries the chunk's position)
-    const int row_dw = a.C + 1;
-    const __amdgpu_buffer_rsrc_t rs_sig = rsrc_of(a.d_raw, (uint32_t)(a.M * row_dw * 4));
-    const int lane16 = lane * 16;
-
-    auto request = [&](int64_t j) {
-        char* slot = smem + (int)(j % DMA_RING) * G::SLOT;
-        const int rel = (int)(j - chunk_begin);
-        if (G::YP == 8) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_yh, (lds_ptr)(slot + wave * 1024), 16, lane16, rel * (YU * 16) + wave * 1024, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_yl, (lds_ptr)(slot + YU * 16 + wave * 1024), 16, lane16, rel * (YU * 16) + wave * 1024, 0, 0);
-        } else {    // 4 pieces per plane: waves 0..3 take the hi plane, 4..7 the lo plane
-            if (wave < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_yh, (lds_ptr)(slot + wave * 1024), 16, lane16, rel * (YU * 16) + wave * 1024, 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_yl, (lds_ptr)(slot + YU * 16 + (wave - 4) * 1024), 16, lane16, rel * (YU * 16) + (wave - 4) * 1024, 0, 0);
-        }
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_xh, (lds_ptr)(slot + 2 * YU * 16 + wave * 1024), 16, lane16, rel * (XU * 16) + wave * 1024, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_xl, (lds_ptr)(slot + (2 * YU + XU) * 16 + wave * 1024), 16, lane16, rel * (XU * 16) + wave * 1024, 0, 0);
-        if (ALPHA) {    // 16 rows x (C + 1) floats <= 64 dwords: one dword per lane, one copy per wave (uniform piece count)
-            const int voff = ((int)j * CHP * row_dw + (lane < CHP * row_dw ? lane : 0)) * 4;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_sig, (lds_ptr)(slot + G::SIG + wave * 256), 4, voff, 0, 0, 0);
-        }
-    };
-    auto acquire = [&](int newer) {
-        if (newer >= 2) wait_vm<2 * PW>();
-        else if (newer == 1) wait_vm<PW>();
-        else wait_vm<0>();
-        __builtin_amdgcn_s_barrier();
-    };
-    static_assert(AHEAD == 3, "acquire() enumerates newer = 0, 1, 2");
-
-    f32x16 acc[TR][TC];
-#pragma unroll
-    for (int r = 0; r < TR; ++r)
-#pragma unroll
-        for (int c = 0; c < TC; ++c)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[r][c][e] = 0.f;
-    float bsum = 0.f, asum = 0.f, absum = 0.f;
-
-    for (int i = 0; i < AHEAD; ++i)
-        if (chunk_begin + i < chunk_end) request(chunk_begin + i);
-    for (int64_t j = chunk_begin; j < chunk_end; ++j) {
-        const int64_t behind = chunk_end - 1 - j;
-        acquire(behind >= AHEAD - 1 ? AHEAD - 1 : (int)behind);
-        if (j + AHEAD < chunk_end) request(j + AHEAD);
-        __builtin_amdgcn_sched_barrier(0);      // requests first, then the chunk's MFMAs
-        const char* slot = smem + (int)(j % DMA_RING) * G::SLOT;
-        const u32x4* Yl = reinterpret_cast<const u32x4*>(slot);
-        const u32x4* Xl = Yl + 2 * YU;
-        {
-            half8 ayh[TR], ayl[TR];
-#pragma unroll
-            for (int r = 0; r < TR; ++r) {
-                ayh[r] = __builtin_bit_cast(half8, Yl[lh * N + (wn * TR + r) * 32 + lr]);
-                ayl[r] = __builtin_bit_cast(half8, Yl[YU + lh * N + (wn * TR + r) * 32 + lr]);
-            }
-            constexpr int CG = 2;
-#pragma unroll
-            for (int c0 = 0; c0 < TC; c0 += CG) {
-                half8 bxh[CG], bxl[CG];
-#pragma unroll
-                for (int c = 0; c < CG; ++c) {
-                    bxh[c] = __builtin_bit_cast(half8, Xl[lh * K + (wk * TC + c0 + c) * 32 + lr]);
-                    bxl[c] = __builtin_bit_cast(half8, Xl[XU + lh * K + (wk * TC + c0 + c) * 32 + lr]);
-                }
-#pragma unroll
-                for (int r = 0; r < TR; ++r)
-#pragma unroll
-                    for (int c = 0; c < CG; ++c) acc[r][c0 + c] = mfma16(ayh[r], bxh[c], acc[r][c0 + c]);
-#pragma unroll
-                for (int r = 0; r < TR; ++r)
-#pragma unroll
-                    for (int c = 0; c < CG; ++c) acc[r][c0 + c] = mfma16(ayh[r], bxl[c], acc[r][c0 + c]);
-#pragma unroll
-                for (int r = 0; r < TR; ++r)
-#pragma unroll
-                    for (int c = 0; c < CG; ++c) acc[r][c0 + c] = mfma16(ayl[r], bxh[c], acc[r][c0 + c]);
-            }
-        }
-        if (src.bias && tid < N) {
-            float s = 0.f;
-#pragma unroll
-            for (int mb = 0; mb < CHB; ++mb) {
-                const half8 h = __builtin_bit_cast(half8, Yl[mb * N + tid]);
-                const half8 l = __builtin_bit_cast(half8, Yl[YU + mb * N + tid]);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) s += (float)h[q] + (float)l[q];
-            }
-            bsum += s;
-        }
-        if (ALPHA && tid >= DWT - K) {      // waves 4..7: column tid - 256 (mlp_dw_h.hip); each reads its own wave's d_raw copy
-            const int ka = tid - (DWT - K);
-            const float* da = reinterpret_cast<const float*>(slot + G::SIG + wave * 256);
-            float s = 0.f, sb = 0.f;
-#pragma unroll
-            for (int mb = 0; mb < CHB; ++mb) {
-                const half8 h = __builtin_bit_cast(half8, Xl[mb * K + ka]);
-                const half8 l = __builtin_bit_cast(half8, Xl[XU + mb * K + ka]);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const float d = da[(mb * 8 + q) * row_dw + a.C];
-                    s += d * ((float)h[q] + (float)l[q]);
-                    sb += d;
-                }
-            }
-            asum += s;
-            absum += sb;
-        }
-    }
-
-    // partial block -> workspace (dw_gemm's layout)
-#pragma unroll
-    for (int r = 0; r < TR; ++r)
-#pragma unroll
-        for (int c = 0; c < TC; ++c)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = (wn * TR + r) * 32 + acc_row(e, lane);
-                part[(int64_t)row * K + (wk * TC + c) * 32 + lr] = acc[r][c][e];
-            }
-    if (tid < N) part[(int64_t)N * K + tid] = src.bias ? bsum : 0.f;
-    if (ALPHA && tid >= DWT - K) {
-        part[(int64_t)N * K + N + tid - (DWT - K)] = asum;
-        if (tid == DWT - K) part[(int64_t)N * K + N + 256] = absum;
-    }
-}
-
 // rgb head: dW_rgb[c][j] = sum_pt d_rgb[pt][c] * hv[pt][j], db_rgb[c] = sum_pt d_rgb[pt][c]   (unscaled d_raw, f32; hv = hi + lo).
 // Batches of 256 points: d_raw staged in LDS, then every thread (column j, phase ph) streams 8 blocks of hv (hi and lo) with
 // all its loads independent.
@@ -442,7 +307,7 @@ __device__ __forceinline__ void dw_rgb(const DwArgs& a, int64_t blk_begin, int64
     const int tid = threadIdx.x, j = tid & 127, ph = tid >> 7;     // ph: block phase 0..3
     const int64_t Mp = m_pad(a.M);
     const u32x4* hv = reinterpret_cast<const u32x4*>(a.acts + sact_hv(Mp));
-    const int64_t lo = sact_lo_delta(Mp) / 4;
+    const uint2* hv8 = reinterpret_cast<const uint2*>(sact_lo8(a.acts, Mp, sact_hv(Mp)));
     const int C = a.C;
     const int64_t M = a.M;
     float* dr = smem;                                                // [BB*8][4]
@@ -461,19 +326,24 @@ __device__ __forceinline__ void dw_rgb(const DwArgs& a, int64_t blk_begin, int64
             reinterpret_cast<float4*>(dr)[tid] = g;
         }
         __syncthreads();
-        u32x4 hh[BB / 4], hl[BB / 4];
+        u32x4 hh[BB / 4];
+        uint2 h8c[BB / 4];
 #pragma unroll
         for (int i = 0; i < BB / 4; ++i) {
             const int64_t mb = b0 + ph + 4 * i;
-            hh[i] = hl[i] = u32x4{0u, 0u, 0u, 0u};
+            hh[i] = u32x4{0u, 0u, 0u, 0u};
+            h8c[i] = uint2{0x80808080u, 0x80808080u};
             if (mb < blk_end) {
                 hh[i] = hv[mb * ACT_HV_W + j];     // 8 points of column j
-                hl[i] = hv[lo + mb * ACT_HV_W + j];
+                h8c[i] = hv8[mb * ACT_HV_W + j];
             }
         }
 #pragma unroll
         for (int i = 0; i < BB / 4; ++i) {
-            const half8 pq = __builtin_bit_cast(half8, hh[i]), pl = __builtin_bit_cast(half8, hl[i]);
+            const uint32_t h4[4] = {hh[i][0], hh[i][1], hh[i][2], hh[i][3]};
+            uint32_t l4[4];
+            h8_decode_unit(h4, h8c[i], l4);
+            const half8 pq = __builtin_bit_cast(half8, hh[i]), pl = __builtin_bit_cast(half8, u32x4{l4[0], l4[1], l4[2], l4[3]});
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const float x = (float)pq[q] + (float)pl[q];
@@ -515,11 +385,7 @@ __device__ __forceinline__ void dw_rgb(const DwArgs& a, int64_t blk_begin, int64
     }
 }
 
-#ifdef DWS_NO_DMA
 constexpr size_t DWS_SMEM = 3 * (size_t)(2 * CHB * 256 + 2 * CHB * 256 + CHP / 4) * 16;       // three chunk images of the 256 x 256 block: 98 496 B
-#else
-constexpr size_t DWS_SMEM = (size_t)DMA_RING * DmaGeom<256, true>::SLOT;                        // four ring slots of 32 KiB + d_raw copies: 139 264 B
-#endif
 constexpr size_t DWS_SMEM_SMALL = 3 * (size_t)(2 * CHB * 256 + 2 * CHB * 64 + CHP / 4) * 16;  // 256 x 64 block: 61 632 B
 static_assert(DWS_SMEM_SMALL >= (32 * 8 * 4 + 18 * 128) * sizeof(float), "rgb head scratch fits the thin image");
 
@@ -549,16 +415,9 @@ __global__ __launch_bounds__(DWT, 2) void mlp_dw_split_big_kernel(DwArgs a) {
     chunk_range(a, inst, split, cb, ce);
     float* part = a.ws + dwh_inst_offset(inst) + (int64_t)split * dw_inst_floats(inst);
     const Src src = inst_src(a, inst);
-#ifdef DWS_NO_DMA      // register-staged copies (the f16 kernel's scheme): kept for A/B runs
     if (inst == DW_FEAT) dw_gemm<256, 256, 4, 2, 4, true>(a, src, cb, ce, part, smem_u);
     else if (inst <= DW_L7) dw_gemm<256, 256, 4, 2, 4, false>(a, src, cb, ce, part, smem_u);
     else dw_gemm<128, 256, 2, 2, 2, false>(a, src, cb, ce, part, smem_u);
-#else
-    char* smem_c = reinterpret_cast<char*>(smem_u);
-    if (inst == DW_FEAT) dw_gemm_dma<256, 4, 2, 4, true>(a, src, cb, ce, part, smem_c);
-    else if (inst <= DW_L7) dw_gemm_dma<256, 4, 2, 4, false>(a, src, cb, ce, part, smem_c);
-    else dw_gemm_dma<128, 2, 2, 2, false>(a, src, cb, ce, part, smem_c);
-#endif
     DW_TRACE(1, 1);
 }
 

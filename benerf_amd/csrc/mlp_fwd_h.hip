@@ -193,39 +193,50 @@ __device__ __forceinline__ uint64_t save_tile(const _Float16* __restrict__ Th, i
     return bits;
 }
 
-// BENERF_MLP_SPLIT (SAVE == 2, the 22-bit backward): the LOW halves leave too, as a second SH array of the same shape.  The lo
-// plane holds (x - hi) * 2^11; the backward GEMMs add hi x lo into the hi x hi accumulator, so the saved copy is unscaled
-// again by an exact v_pk_mul_f16 with 2^-11 (results below 2^-14 round into f16's subnormals: absolute floor 2^-25).
-__device__ __forceinline__ uint2 unscale_lo4(uint2 q) {
-    const half2v k = {(_Float16)LO_INV, (_Float16)LO_INV};
-    return uint2{__builtin_bit_cast(uint32_t, __builtin_bit_cast(half2v, q.x) * k), __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2v, q.y) * k)};
-}
-template <int W>
-__device__ __forceinline__ void save_pair_lo(const _Float16* __restrict__ Tl, int ct, int bp, int lane, __amdgpu_buffer_rsrc_t rs) {
-    asm volatile("" : "+v"(lane));
+// BENERF_MLP_SPLIT (SAVE == 2, the fp32-equivalent backward): the low halves leave too - as 8-bit residual codes (lo8 twin of
+// the SH array, mlp_split.h): the same transpose read on the lo plane (which holds (x - hi) * 2^11), the lane pair forms the
+// unit like the hi halves, h8_encode_unit<11> turns the 8 + 8 halfs into 8 bytes: one 8-byte store per lane.
+template <int W, bool MASK, int NBLK>
+__device__ __forceinline__ void save_pair22(const _Float16* __restrict__ Th, const _Float16* __restrict__ Tl, int ct, int bp, int lane,
+                                            __amdgpu_buffer_rsrc_t rs, __amdgpu_buffer_rsrc_t rs8, uint64_t& bits) {
+    asm volatile("" : "+v"(lane));      // addresses recomputed per call, not hoisted out of the layer loop and spilled
     const int t = lane & 15, g = lane >> 4, hf = lane >> 5, pl = lane & 31;
     const int n = ct * 32 + pl;
     const int col = ct * 32 + 16 * (g & 1) + 4 * (t & 3);
     const int rsub = 4 * (g >> 1) + (t >> 2);
-    uint2 q[2];
+    uint2 q[2], ql[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const int b = 2 * bp + k, row = b * 8 + rsub;
-        const _Float16* src = Tl + row * LD + ((((col >> 3) ^ hsw(row)) << 3) | (col & 7));
+        const int off = row * LD + ((((col >> 3) ^ hsw(row)) << 3) | (col & 7));
         const short4v v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (short4v __attribute__((address_space(3)))*)(reinterpret_cast<const short4v*>(src)));
-        q[k] = unscale_lo4(__builtin_bit_cast(uint2, v));
+            (short4v __attribute__((address_space(3)))*)(reinterpret_cast<const short4v*>(Th + off)));
+        const short4v vl = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (short4v __attribute__((address_space(3)))*)(reinterpret_cast<const short4v*>(Tl + off)));
+        q[k] = __builtin_bit_cast(uint2, v);
+        ql[k] = __builtin_bit_cast(uint2, vl);
+        if (MASK) bits |= (uint64_t)nonzero4(q[k]) << (b * 4);        // post-ReLU: > 0 <=> != 0
     }
     const uint4 u = sh_pair_unit(q[0], q[1]);
+    const uint4 ul = sh_pair_unit(ql[0], ql[1]);
+    const uint32_t uh4[4] = {u.x, u.y, u.z, u.w}, ul4[4] = {ul.x, ul.y, ul.z, ul.w};
+    const uint2 code = h8_encode_unit<11>(uh4, ul4);
+    const int unit = (2 * bp + hf) * W + n;
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{u.x, u.y, u.z, u.w}, rs, unit * 16, 0, 0);
 #ifndef FWD_SKIP_LO_STORE    // timing variants only (tools/experiments/build_variant.sh)
-    __builtin_amdgcn_raw_buffer_store_b128(u32x4{u.x, u.y, u.z, u.w}, rs, (((2 * bp + hf) * W + n) * 8) * 2, 0, 0);
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2{code.x, code.y}, rs8, unit * 8, 0, 0);
 #endif
 }
-template <int W, int NBLK>
-__device__ __forceinline__ void save_tile_lo(const _Float16* __restrict__ Tl, int ct, int lane, const _Float16* __restrict__ st_tile) {
-    const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(st_tile);
+// a whole tile part (column tile ct, NBLK blocks): hi array at `st_tile` (halfs), codes at `st8_tile` (bytes)
+template <int W, bool MASK, int NBLK>
+__device__ __forceinline__ uint64_t save_tile22(const _Float16* __restrict__ Th, const _Float16* __restrict__ Tl, int ct, int lane,
+                                                const _Float16* __restrict__ st_tile, const uint8_t* __restrict__ st8_tile) {
+    const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(st_tile), rs8 = uniform_rsrc(st8_tile);
+    uint64_t bits = 0;
 #pragma unroll
-    for (int bp = 0; bp < NBLK / 2; ++bp) save_pair_lo<W>(Tl, ct, bp, lane, rs);
+    for (int bp = 0; bp < NBLK / 2; ++bp) save_pair22<W, MASK, NBLK>(Th, Tl, ct, bp, lane, rs, rs8, bits);
+    return bits;
 }
 
 // offset of the forward block of hidden layer l (1..7, l != 5 at the call site) without the generic pack_offset() summation,
@@ -275,7 +286,8 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
     };
     const bool live = m < M;
     if (SAVE && blockIdx.x == 0 && tid == 0) reinterpret_cast<uint32_t*>(acts + sact_info(Mp))[SI_TAG] = SAVE == 2 ? SACT_TAG_SPLIT22 : SACT_TAG_SPLIT;
-    const int64_t lo_halfs = 2 * sact_lo_delta(Mp);                 // SAVE == 2: half offset from an SH array to its lo twin
+    // SAVE == 2: byte i of the lo8 region <-> half i of the SH region (mlp_split.h)
+    uint8_t* st8_h = SAVE == 2 ? reinterpret_cast<uint8_t*>(acts + sact_lo8_base(Mp)) : nullptr;          // layer l: + l * Mp * 256 bytes
     float amax = 0.f;        // running max |activation| of this thread (range guard)
     // f32 scratch in the dead PE columns [288,320) of the lo plane: logical slot 36 + j of this thread's row
     const int psw = hsw(pt);
@@ -352,26 +364,23 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
         // between the MFMAs.  The next requests (the following layer's) come an epilogue later.
         uint64_t pbits = 0;
         const __amdgpu_buffer_rsrc_t prs = uniform_rsrc(SAVE ? st_h + ((int64_t)(l - 1) * Mp + m0) * 256 : nullptr);
-        const __amdgpu_buffer_rsrc_t prs_lo = uniform_rsrc(SAVE == 2 ? st_h + ((int64_t)(l - 1) * Mp + m0) * 256 + lo_halfs : nullptr);
-        // `last` = the loop's final k-step.  SAVE == 1: the hi halves in its last two k-steps; SAVE == 2: the lo halves in the
-        // two k-steps before those (behind the loop's last fragment request with FPF = 2 only for the final pair of k-steps -
-        // the lo stores of k-steps last - 3 / last - 2 sit in front of one / no later fragment request)
+        const __amdgpu_buffer_rsrc_t prs8 = uniform_rsrc(SAVE == 2 ? st8_h + ((int64_t)(l - 1) * Mp + m0) * 256 : nullptr);
+#ifndef FWD_SAVE_KS
+#define FWD_SAVE_KS 8        // k-steps the SAVE == 2 work is spread over (8 block pairs per layer)
+#endif
+        // `last` = the loop's final k-step.  SAVE == 1: the hi halves in its last two k-steps (four block pairs each); SAVE == 2:
+        // hi halves + residual codes together, one block pair in each of the last eight k-steps
         auto save_at = [&](int ks, int last) {
-            if (SAVE && ks >= last - 1) {
+            if (SAVE == 1 && ks >= last - 1) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) save_pair<256, true, 16>(Th, wave, (ks - (last - 1)) * 4 + i, lane, prs, pbits);
                 if (ks == last) store_bits(l - 1, pbits);
             }
-#ifndef FWD_LO_AT
-#define FWD_LO_AT 0
-#endif
-            if (SAVE == 2 && FWD_LO_AT == 0 && ks >= last - 3 && ks < last - 1) {
+            if (SAVE == 2 && ks >= last - (FWD_SAVE_KS - 1)) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) save_pair_lo<256>(Tl, wave, (ks - (last - 3)) * 4 + i, lane, prs_lo);
-            }
-            if (SAVE == 2 && FWD_LO_AT == 1 && ks >= last - 1) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) save_pair_lo<256>(Tl, wave, (ks - (last - 1)) * 4 + i, lane, prs_lo);
+                for (int i = 0; i < 8 / FWD_SAVE_KS; ++i)
+                    save_pair22<256, true, 16>(Th, Tl, wave, (ks - (last - (FWD_SAVE_KS - 1))) * (8 / FWD_SAVE_KS) + i, lane, prs, prs8, pbits);
+                if (ks == last) store_bits(l - 1, pbits);
             }
         };
         acc_init_bias(acc1, bq);
@@ -380,17 +389,14 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
                                                     [&](int ks) { save_at(ks, 19); });
         else gemm_stage<16, 1, FPF, true, 4>(Th, Tl, 0, a.packed + fwd_layer_offset(l), wave, lane, acc1, acc2, NoAfterHead(),
                                              [&](int ks) { save_at(ks, 15); });
-        if (SAVE == 2 && FWD_LO_AT == 2) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) save_pair_lo<256>(Tl, wave, i, lane, prs_lo);
-        }
         lds_barrier();
         load_bias<1>(a.bias[l < 7 ? l + 1 : BENERF_L_FEAT], wave, lane, bq);
         epilogue_t<1, true, 4>(acc1, acc2, Th, Tl, wave, lane, amax);
         lds_barrier();
     }
-    if (SAVE) store_bits(7, save_tile<1, 256, true, 16>(Th, wave, lane, st_h + ((int64_t)7 * Mp + m0) * 256));
-    if (SAVE == 2) save_tile_lo<256, 16>(Tl, wave, lane, st_h + ((int64_t)7 * Mp + m0) * 256 + lo_halfs);
+    if (SAVE == 1) store_bits(7, save_tile<1, 256, true, 16>(Th, wave, lane, st_h + ((int64_t)7 * Mp + m0) * 256));
+    if (SAVE == 2) store_bits(7, save_tile22<256, true, 16>(Th, Tl, wave, lane, st_h + ((int64_t)7 * Mp + m0) * 256,
+                                                           st8_h + ((int64_t)7 * Mp + m0) * 256));
 
     // ---- alpha partials (reads h7) + PE(viewdir) into columns [256,288) ---------------------------
     {
@@ -451,8 +457,9 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
         a.raw[m * (C + 1) + C] = ((p.x + p.y) + (p.z + p.w)) + a.b_alpha[0];
     }
     lds_barrier();
-    if (SAVE) save_tile<1, 256, false, 16>(Th, wave, lane, reinterpret_cast<_Float16*>(acts + sact_feat(Mp)) + m0 * 256);
-    if (SAVE == 2) save_tile_lo<256, 16>(Tl, wave, lane, reinterpret_cast<_Float16*>(acts + sact_feat(Mp)) + m0 * 256 + lo_halfs);
+    if (SAVE == 1) save_tile<1, 256, false, 16>(Th, wave, lane, reinterpret_cast<_Float16*>(acts + sact_feat(Mp)) + m0 * 256);
+    if (SAVE == 2) save_tile22<256, false, 16>(Th, Tl, wave, lane, reinterpret_cast<_Float16*>(acts + sact_feat(Mp)) + m0 * 256,
+                                               st8_h + (int64_t)8 * Mp * 256 + m0 * 256);
 
     // ---- VIEWS: [feature | PE(dir)] (288) -> 128: wave w computes column tile w & 3 for the point half w >> 2 -------------
     {
@@ -467,11 +474,11 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
         epilogue_t<1, true, 2>(av1, av2, Thh, Tlh, vct, lane, amax);
         lds_barrier();
         if (SAVE) {  // sign bits of hv: bit b*4 + j = point 8b + 4 (lane >> 5) + j of this half, column tile = wave & 3
-            const uint64_t bits = save_tile<1, ACT_HV_W, true, 8>(Thh, vct, lane, reinterpret_cast<_Float16*>(acts + sact_hv(Mp)) +
-                                                                                      (m0 + vrh * 64) * ACT_HV_W);
+            _Float16* sthv = reinterpret_cast<_Float16*>(acts + sact_hv(Mp)) + (m0 + vrh * 64) * ACT_HV_W;
+            const uint64_t bits = SAVE == 2 ? save_tile22<ACT_HV_W, true, 8>(Thh, Tlh, vct, lane, sthv, st8_h + (int64_t)9 * Mp * 256 + (m0 + vrh * 64) * ACT_HV_W)
+                                            : save_tile<1, ACT_HV_W, true, 8>(Thh, vct, lane, sthv);
             reinterpret_cast<uint64_t*>(acts + sact_mask(Mp))[8 * (Mp / TM) * NTHREADS + ((int64_t)blockIdx.x * 2 + vrh) * NTHREADS + vct * 64 + lane] = bits;
         }
-        if (SAVE == 2) save_tile_lo<ACT_HV_W, 8>(Tlh, vct, lane, reinterpret_cast<_Float16*>(acts + sact_hv(Mp)) + (m0 + vrh * 64) * ACT_HV_W + lo_halfs);
     }
 
     // ---- rgb: 128 -> C on the VALU; partials of channel c in scratch slot 1 + c ------------------------

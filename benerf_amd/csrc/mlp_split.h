@@ -166,14 +166,70 @@ __host__ __device__ inline int64_t sact_total_floats(int64_t M) { return sact_in
 enum { SI_TAG = 0, SI_COUNT = 16 };
 constexpr uint32_t SACT_TAG_SPLIT = 0x53504c54u;   // 'SPLT': f16 halves only (BENERF_MLP_SPLIT_F16BWD)
 constexpr uint32_t SACT_TAG_SPLIT22 = 0x53504c32u; // 'SPL2': hi + lo (BENERF_MLP_SPLIT, the 22-bit backward)
-// BENERF_MLP_SPLIT (22-bit backward, mlp_bwd_s.hip / mlp_dw_s.hip): every SH array above has a twin holding the LOW halves
-// lo = rn16(x - hi), UNSCALED (the backward GEMMs add hi x hi, hi x lo and lo x hi into ONE accumulator; f16 subnormals give
-// lo an absolute floor of 2^-25, i.e. x keeps 22 bits down to |x| = 2^-3 and >= 17 bits down to 2^-8), in a second region
-// behind the info words with the same internal order: offset(lo array) = offset(hi array) + sact_lo_delta.
-__host__ __device__ inline int64_t sact_lo_delta(int64_t Mp) { return sact_info(Mp) + SI_COUNT - sact_h(Mp, 0); }
+// BENERF_MLP_SPLIT (the fp32-equivalent backward, mlp_bwd_s.hip / mlp_dw_s.hip): every SH array above has a twin of 8-BIT RESIDUAL
+// CODES ("lo8": one byte per value, same element order: an 8-byte unit per (block, feature)) in a second region behind the info
+// words.  With hi = rn16(x), E = max(exponent(hi), -6):
+//     code = clamp(rn((x - hi) * 2^(18 - E)) + 128, 0, 255)          x ~ hi + (code - 128) * 2^(E - 18)
+// i.e. the residual in units of ulp(hi) / 256: x keeps 19 significant bits (absolute floor 2^-25, the f16 subnormal grid the
+// decoded low half lives on).  3 bytes per value instead of the 4 of an f16 pair: the dW kernels are HBM-bound on exactly these
+// bytes, the forward / dX kernels pay for every byte they store.  tools/experiments/backward_format_study.py: 19-bit stored
+// operands ("h8") leave the weight gradients 2.5e-6 of the largest entry from float64 on identical masks (f16 pairs 1.2e-6,
+// exact f32 0.8e-6, 15 bits 3.7e-5, one f16 6e-4) - inside float32's own error band; the dX CHAIN keeps f16 pairs (LDS only).
+// Element i of a hi array (half index) <-> byte i of its lo8 twin.
+__host__ __device__ inline int64_t sact_lo8_base(int64_t Mp) { return sact_info(Mp) + SI_COUNT; }      // float offset of the lo8 region
 __host__ __device__ inline int64_t sact22_total_floats(int64_t M) {
     const int64_t Mp = m_pad(M);
-    return sact_info(Mp) + SI_COUNT + (sact_mask(Mp) - sact_h(Mp, 0));
+    return sact_lo8_base(Mp) + (sact_mask(Mp) - sact_h(Mp, 0)) / 2;
+}
+// lo8 twin (byte pointer) of the hi array at float offset `hi_off` of the activation buffer
+__host__ __device__ inline const uint8_t* sact_lo8(const float* acts, int64_t Mp, int64_t hi_off) {
+    return reinterpret_cast<const uint8_t*>(acts + sact_lo8_base(Mp)) + 2 * (hi_off - sact_h(Mp, 0));
+}
+
+// ---- lo8 codec on packed f16 pairs (one 32-bit register = two values) ----------------------------------------------------
+typedef unsigned short h8_ushort2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h8_half2 __attribute__((ext_vector_type(2)));
+// per half: max(biased exponent of hi, 9) << 10   (E = max(exponent, -6))
+__device__ __forceinline__ uint32_t h8_exp(uint32_t hi_pair) {
+    const h8_ushort2 lim = {9 << 10, 9 << 10};
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(h8_ushort2, hi_pair & 0x7C007C00u), lim));
+}
+// codes of one pair as the low bytes of the two halves of the result.  lo_pair holds (x - hi) * 2^S as f16 (the forward
+// kernel's lo plane: S = 11; an unscaled residual pre-multiplied by 4096: S = 12).  One packed FMA does scale, + 128 and the
+// rounding: 1024 + 128 + r lands where f16's spacing is 1 (round-to-nearest-even), the code is the low byte of the result.
+template <int S>
+__device__ __forceinline__ uint32_t h8_code_pair(uint32_t hi_pair, uint32_t lo_pair) {
+    const uint32_t sc = (uint32_t)(((48 - S) << 10) * 0x10001u) - h8_exp(hi_pair);                     // 2^(18 - S - E) per half
+    const h8_half2 c = __builtin_elementwise_min(
+        __builtin_bit_cast(h8_half2, lo_pair) * __builtin_bit_cast(h8_half2, sc) + h8_half2{(_Float16)1152.f, (_Float16)1152.f},
+        h8_half2{(_Float16)1279.f, (_Float16)1279.f});
+    return __builtin_bit_cast(uint32_t, c);
+}
+// 8 codes of a unit (hi: 8 halfs as 4 pairs, lo likewise) -> 8 bytes
+template <int S>
+__device__ __forceinline__ uint2 h8_encode_unit(const uint32_t (&hi)[4], const uint32_t (&lo)[4]) {
+    const uint32_t c0 = h8_code_pair<S>(hi[0], lo[0]), c1 = h8_code_pair<S>(hi[1], lo[1]);
+    const uint32_t c2 = h8_code_pair<S>(hi[2], lo[2]), c3 = h8_code_pair<S>(hi[3], lo[3]);
+    return uint2{__builtin_amdgcn_perm(c1, c0, 0x06040200u), __builtin_amdgcn_perm(c3, c2, 0x06040200u)};
+}
+// low halves (unscaled f16: lo = (code - 128) * 2^(E - 18)) of one unit from its hi halves and its 8 codes
+__device__ __forceinline__ void h8_decode_unit(const uint32_t (&hi)[4], const uint2 code, uint32_t (&lo)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t w = j < 2 ? code.x : code.y;
+        // [0x64, c(2j+1), 0x64, c(2j)]: the f16 numbers 1024 + code
+        const uint32_t v = __builtin_amdgcn_perm(0x64646464u, w, (j & 1) ? 0x04030402u : 0x04010400u);
+        const h8_half2 t = __builtin_bit_cast(h8_half2, v) * h8_half2{(_Float16)0x1p-10f, (_Float16)0x1p-10f} -
+                           h8_half2{(_Float16)1.125f, (_Float16)1.125f};                                  // (code - 128) * 2^-10, exact
+        const uint32_t sc = h8_exp(hi[j]) - (uint32_t)((8 << 10) * 0x10001u);                               // 2^(E - 8) per half
+        lo[j] = __builtin_bit_cast(uint32_t, t * __builtin_bit_cast(h8_half2, sc));
+    }
+}
+// one value (heads on the VALU, tests of the codec)
+__device__ __forceinline__ float h8_decode_one(_Float16 hi, uint32_t code) {
+    int e5 = (int)((__builtin_bit_cast(unsigned short, hi) >> 10) & 31u);
+    e5 = e5 < 9 ? 9 : e5;
+    return (float)((int)code - 128) * __uint_as_float((uint32_t)(127 + (e5 - 15) - 18) << 23);
 }
 // activation gradients: SH arrays holding dY * s_s (s_s = power-of-two scale of this backward call from max|d_raw|,
 // pow2_scale6), then 16 info words: [SD_DRAW] max|d_raw| (float bits, grad_absmax_kernel)
@@ -183,9 +239,12 @@ __host__ __device__ inline int64_t sdact_hv(int64_t Mp) { return 9 * Mp * 128; }
 __host__ __device__ inline int64_t sdact_info(int64_t Mp) { return 9 * Mp * 128 + Mp * (ACT_HV_W / 2); }
 __host__ __device__ inline int64_t sdact_total_floats(int64_t M) { return sdact_info(m_pad(M)) + 16; }
 enum { SD_DRAW = 0, SD_COUNT = 16 };
-// 22-bit backward: the low halves of the gradient arrays (same scale s_s, unscaled lo) behind the info words
-__host__ __device__ inline int64_t sdact_lo_delta(int64_t Mp) { return sdact_info(Mp) + SD_COUNT; }
-__host__ __device__ inline int64_t sdact22_total_floats(int64_t M) { return 2 * sdact_info(m_pad(M)) + SD_COUNT; }
+// fp32-equivalent backward: the lo8 twins of the gradient arrays (same scale s_s; mlp_split.h above) behind the info words
+__host__ __device__ inline int64_t sdact_lo8_base(int64_t Mp) { return sdact_info(Mp) + SD_COUNT; }
+__host__ __device__ inline int64_t sdact22_total_floats(int64_t M) { const int64_t Mp = m_pad(M); return sdact_lo8_base(Mp) + sdact_info(Mp) / 2; }
+__host__ __device__ inline const uint8_t* sdact_lo8(const float* dacts, int64_t Mp, int64_t hi_off) {
+    return reinterpret_cast<const uint8_t*>(dacts + sdact_lo8_base(Mp)) + 2 * hi_off;
+}
 
 // Gradients are far outside f16's range (d_raw ~ 1/n_rays) but the backward chain is LINEAR in d_raw: power-of-two
 // scale s = 2^(6 - exponent(mx)) brings values of magnitude <= mx to < 2^7 (2^9 of head room below f16's maximum

@@ -30,18 +30,18 @@ def test_size_queries(lib):
     assert lib.benerf_version() >= 100
     # sized for every arithmetic mode.  f32: rows of 2528 / 2432 floats per point + 8 layers of ReLU sign-bit words per
     # 64-point tile; split: points padded to 128, PE rows (64 + 32 floats) + f16 arrays (9 x 256 + 128 halfs), 9 mask layers,
-    # 16 info words, then the twin arrays of low halves (the 22-bit backward)
+    # 16 info words, then the twin arrays of 8-bit residual codes (one byte per saved value: the fp32-equivalent backward)
     def f32_act(m):
         return m * ((64 + 32) + 8 * 256 + 256 + 128) + 8 * ((m + 63) // 64) * 256 * 2
 
     def split_act(m):
         mp = (m + 127) // 128 * 128
-        return mp * (64 + 32) + mp * (9 * 256 + 128) // 2 + 9 * (mp // 64) * 256 * 2 + 16 + mp * (9 * 256 + 128) // 2
+        return mp * (64 + 32) + mp * (9 * 256 + 128) // 2 + 9 * (mp // 64) * 256 * 2 + 16 + mp * (9 * 256 + 128) // 4
 
     for m in (640, 641, 100000):
         assert lib.benerf_mlp_act_floats(m) == max(f32_act(m), split_act(m))
         mp = (m + 127) // 128 * 128
-        assert lib.benerf_mlp_dact_floats(m) == max(m * (8 * 256 + 256 + 128), 2 * (mp * (9 * 256 + 128) // 2) + 16)
+        assert lib.benerf_mlp_dact_floats(m) == max(m * (8 * 256 + 256 + 128), mp * (9 * 256 + 128) // 2 + 16 + mp * (9 * 256 + 128) // 4)
     assert lib.benerf_mlp_dact_floats_per_point() == 8 * 256 + 256 + 128
     assert lib.benerf_mlp_packed_floats() > 2 * 593920 - 200000
     assert lib.benerf_mlp_dw_workspace_floats(1000) > 0
