@@ -538,8 +538,59 @@ def main():
         K.set_mlp_precision(a.mlp_precision)
         return leg, roof_
 
+    def kernels_alone(mode, peak_tf, reps=7):
+        """each of the three K3 launches of the FINE network by itself (nothing else on the device), median of `reps`: inside the
+        step the dW launches share the device with the other network's dX chain (second stream), so their in-step HIP-event
+        durations include that time slicing - these do not"""
+        K.set_mlp_precision(mode)
+        try:
+            net = step.net_f.packed
+            N, S = WL.rays_per_step(wl), wl["S"] + wl["Ni"]
+            g_ = torch.Generator(device=device)
+            g_.manual_seed(7)
+            ro = torch.rand((N, 3), device=device, generator=g_) * 0.2 - 0.1
+            rd = torch.nn.functional.normalize(torch.rand((N, 3), device=device, generator=g_) - 0.5, dim=-1)
+            z = torch.sort(torch.rand((N, S), device=device, generator=g_), dim=-1).values
+            raw, acts = K.mlp_fwd(net, ro, rd, rd, z, True, status=step.guard.words)
+            d_raw = (torch.rand(raw.shape, device=device, generator=g_) - 0.5).view(-1, raw.shape[-1]) * 1e-4
+            gw, gb = [torch.zeros_like(w) for w in net.weights], [torch.zeros_like(b) for b in net.biases]
+            dacts = [None]
+
+            def med(fn):
+                fn()
+                ts = []
+                for _ in range(reps):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    torch.cuda.synchronize()
+                    e0.record()
+                    fn()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    ts.append(e0.elapsed_time(e1))
+                return sorted(ts)[len(ts) // 2]
+
+            def dx():
+                dacts[0] = K.mlp_bwd_dx(net, d_raw, acts, N, S, status=step.guard.words)[2]
+            t = {"mlp_fwd": med(lambda: K.mlp_fwd(net, ro, rd, rd, z, True, status=step.guard.words)), "mlp_bwd_dx": med(dx),
+                 "mlp_bwd_dw": med(lambda: K.mlp_bwd_dw(net, d_raw, acts, dacts[0], N, S, gw, gb, False))}
+            step.guard.words.zero_()
+            fpp_ = WL.mlp_flops_per_point(wl["channels"])
+            return {k: {"ms": round(v, 4), "points": N * S, "tflops_algorithmic": round(N * S * fpp_ / (v * 1e-3) / 1e12, 2),
+                        "frac_of_mfma_peak": round(N * S * fpp_ / (v * 1e-3) / 1e12 / peak_tf, 4)} for k, v in t.items()}
+        finally:
+            K.set_mlp_precision(a.mlp_precision)
+
+    alone = None
+    if world == 1 and not a.primary_only and a.batch_fraction == 1:
+        alone = kernels_alone(a.mlp_precision, F16_MFMA_PEAK_TFLOPS if split_mode(a) else F32_MFMA_PEAK_TFLOPS)
     if world == 1 and split_mode(a) and not a.primary_only:
         exact, roof_f32 = other_mode_leg("f32", F32_MFMA_PEAK_TFLOPS)
+        if roof_f32 is not None and a.batch_fraction == 1:
+            roof_f32["per_kernel_alone"] = kernels_alone("f32", F32_MFMA_PEAK_TFLOPS)
+            roof_f32["per_kernel_note"] = ("per_kernel: HIP-event durations inside the step - the dW launches run on a second stream beside the "
+                                           "other network's dX chain, both MFMA-bound, so those two figures include time slicing (the MFMA-busy "
+                                           "counter of a dW launch also counts the co-running dX); per_kernel_alone: the fine network's launches "
+                                           "by themselves")
         if a.mlp_precision == "split":
             # NOT the headline: the opt-in mode whose backward GEMMs take f16 operands (round 3's default) - narrower arithmetic than
             # the reference's fp32, reported for scale only
@@ -638,6 +689,8 @@ def main():
         out["exact_f32"], out["roofline_f32"] = exact, roof_f32
     if reduced is not None:
         out["reduced_precision"] = reduced
+    if alone and out.get("roofline"):
+        out["roofline"]["per_kernel_alone"] = alone
     if power and out.get("roofline"):
         out["roofline"]["power"] = power
     if comm is not None:

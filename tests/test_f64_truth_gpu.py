@@ -19,6 +19,8 @@ backward GEMMs take f16 operands and are therefore not the reference's fp32 arit
    and backward, against torch float64 evaluating the SAME piecewise-linear branch (the HIP forward's own ReLU masks), at 1 024
    and 130 560 points: what the MFMA arithmetic itself contributes, with the ReLU-flip lottery taken out.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -179,13 +181,16 @@ def test_full_size_step_vs_oracle():
 
 # SURVEY 8c's contract at FULL size, in 8c's own terms: loss 2e-5; gradients "1e-3 of the largest entry, 1e-4 on norms" TIMES
 # TWO, for both arithmetic modes alike - because that is what the reference's own arithmetic can hold against itself at these
-# sizes: the exact-f32 mode (bit-exact f32 products, the oracle's arithmetic on another summation order) measures, against the
-# float32 oracle (round 4; pose gradients / worst sampled entry / worst norm):
-#     C2 0.80e-3 / 1.1e-3 / 4e-5     C3 0.47e-3 / .. / ..     C4 1.29e-3 / .. / ..     C5 1.41e-3 / 3.6e-4 / 1.02e-4
+# sizes.  Measured against the float32 oracle (round 4, profiles/r04_gpu_parity_report_full_suite.txt; worst pose gradient /
+# worst of 64 sampled entries per gradient / worst norm, each relative as in 8c):
+#                exact-f32 mode (bit-exact f32 products, the oracle's arithmetic on another summation order)      split mode
+#     C2         0.80e-3 / 1.11e-3 / 0.97e-4                                                                     0.94e-3 / 0.54e-3 / 0.40e-4
+#     C3         0.47e-3 / 0.25e-3 / 0.44e-4                                                                     1.04e-3 / 0.31e-3 / 0.58e-4
+#     C4         1.29e-3 / 0.46e-3 / 0.58e-4                                                                     1.07e-3 / 0.50e-3 / 0.34e-4
+#     C5         1.41e-3 / 0.72e-3 / 1.02e-4                                                                     1.57e-3 / 0.62e-3 / 0.53e-4
 # (ReLU-kink flips behind the 2^9 x positional encoding; C5's L2-normalised loss makes every gradient the remainder of cancelling
-# sums).  The split mode sits in the same band (C2 0.94e-3, C3 1.04e-3 on the pose gradients).  What the ARITHMETIC contributes
-# is held to float32's own error by test_mlp_backward_arithmetic_vs_float64, the whole step to the float64 yardstick by
-# test_step_gradients_vs_float64.
+# sums).  Neither mode is systematically closer.  What the ARITHMETIC contributes is held to float32's own error by
+# test_mlp_backward_arithmetic_vs_float64, the whole step to the float64 yardstick by test_step_gradients_vs_float64.
 FULL_SIZE_TOL = {"pose": 2e-3, "entries": 2e-3, "norm": 2e-4}
 
 
@@ -220,7 +225,9 @@ def _full_size_vs_oracle(case, x, o32):
     assert not bad, "%s:\n%s" % (case, "\n".join(bad))
 
 
-@pytest.mark.parametrize("case", ["C3", "C4", "C5"])
+# C4 (1.57 M points: ~2.5 minutes of oracle time on the host) runs with BENERF_FULL_TESTS=1; its figures of round 4 are in the table
+# above and in profiles/r04_gpu_parity_report_full_suite.txt (passed, both modes)
+@pytest.mark.parametrize("case", ["C3", "C5"] + (["C4"] if os.environ.get("BENERF_FULL_TESTS") == "1" else []))
 def test_full_size_step_vs_oracle_colour_configs(case):
     """The full-size steps of the other BASELINE.json GPU configurations, HIP (both modes) against the float32 oracle on explicit
     draws with the oracle's fine depths forced in: C3 (colour kernels, 0.78 M points), C4 (800 x 800 camera, lin-log brightness,

@@ -17,6 +17,10 @@ import sys
 PARTS = [
     ("mlp_fwd_split_kernel", "mlp_fwd", "fwd"),
     ("mlp_fwd_kernel", "mlp_fwd", "fwd"),
+    ("mlp_bwd_split_kernel", "mlp_bwd_dx", "dx"),
+    ("grad_absmax22_kernel", "mlp_bwd_dx", "absmax"),
+    ("mlp_dw_split_big_kernel", "mlp_bwd_dw", "big"),
+    ("mlp_dw_split_small_kernel", "mlp_bwd_dw", "small"),
     ("mlp_bwd_f16_kernel", "mlp_bwd_dx", "dx"),
     ("grad_absmax_kernel", "mlp_bwd_dx", "absmax"),
     ("mlp_bwd_kernel", "mlp_bwd_dx", "dx"),
