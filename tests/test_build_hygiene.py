@@ -11,7 +11,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = "/opt/rocm/bin/hipcc"
 # kernel-name fragment -> most VGPRs the compiler may spill (none: the dX kernel's last 33 went in round 3)
-LIMITS = {"mlp_fwd_h.hip": {"mlp_fwd_split_kernel": 0}, "mlp_dw_h.hip": {"mlp_dw_f16_big_kernel": 0, "mlp_dw_f16_small_kernel": 0},
+# mlp_fwd_split_kernel: the SAVE = 2 instantiations keep ONE value (thread index x 4) in scratch across the layer loop - stored once in
+# the prologue, reloaded in the per-tile tail; test_no_scratch_traffic_inside_loops checks that no loop touches scratch
+LIMITS = {"mlp_fwd_h.hip": {"mlp_fwd_split_kernel": 1}, "mlp_dw_h.hip": {"mlp_dw_f16_big_kernel": 0, "mlp_dw_f16_small_kernel": 0},
           "mlp_bwd_h.hip": {"mlp_bwd_f16_kernel": 0}, "mlp_bwd_s.hip": {"mlp_bwd_split_kernel": 0},
           "mlp_dw_s.hip": {"mlp_dw_split_big_kernel": 0, "mlp_dw_split_small_kernel": 0}}
 
@@ -40,3 +42,28 @@ def test_split_kernels_do_not_spill(src, tmp_path):
         assert hits, "kernel %s not found in the compiler remarks" % frag
         for k, v in hits.items():
             assert v <= limit, "%s spills %d VGPRs (limit %d)" % (k, v, limit)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+@pytest.mark.parametrize("src", sorted(LIMITS))
+def test_no_scratch_traffic_inside_loops(src, tmp_path):
+    """What makes a spill expensive is its reload inside a hot loop (every scratch_load drains the in-order vector-memory queue).
+    In the ISA of every kernel of the file: no scratch_* instruction between a label and a branch back to it."""
+    asm = tmp_path / "x.s"
+    res = subprocess.run([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-o", str(asm),
+                          os.path.join(ROOT, "benerf_amd", "csrc", src)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:]
+    lines = asm.read_text().splitlines()
+    labels = {}
+    for i, ln in enumerate(lines):
+        m = re.match(r"^(\.LBB\d+_\d+):", ln)
+        if m:
+            labels[m.group(1)] = i
+    loops = []
+    for i, ln in enumerate(lines):
+        m = re.search(r"s_c?branch\S*\s+(\.LBB\d+_\d+)", ln)
+        if m and labels.get(m.group(1), i + 1) < i:
+            loops.append((labels[m.group(1)], i))
+    assert loops, "no loops found - parser out of date?"
+    bad = [(a, b, j) for a, b in loops for j in range(a, b) if "scratch_" in lines[j]]
+    assert not bad, "scratch traffic inside a loop: " + "; ".join("%s (loop lines %d-%d)" % (lines[j].strip(), a, b) for a, b, j in bad[:5])
