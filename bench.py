@@ -300,7 +300,7 @@ def torch_gpu_baseline(wl, seed, device):
         accu = torch.from_numpy(rng.integers(-3, 4, (HW, 1)).astype(np.float64)).to(device)
         img = torch.from_numpy(rng.random((HW, C)).astype(np.float32)).to(device)
         times = []
-        n_steps = 3
+        n_steps = 5
         for it in range(n_steps + 1):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -699,7 +699,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline and not a.primary_only:
             # the workload the metric is quoted on, full size (one step is ~10-20 s of CPU work), and C1, the reference's
             # own CPU-runnable case (BASELINE.json configs[0])
-            out["cpu_baseline"] = cpu_baseline(a.workload, a.seed, n_steps=1, warm_fraction=16)
+            out["cpu_baseline"] = cpu_baseline(a.workload, a.seed, n_steps=2, warm_fraction=16)
             out["cpu_baseline_c1"] = cpu_baseline("C1", a.seed, n_steps=3)
             try:
                 del step, g

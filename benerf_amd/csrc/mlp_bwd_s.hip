@@ -14,13 +14,13 @@
 // "lo8" twins: 19-bit operands, mlp_split.h) carry ONE power-of-two scale per call (s_s from max|d_raw| of the launch), divided
 // out by the dW reduce kernel.  Inside the chain (LDS planes) the gradient stays an f16 pair.
 //
-// Tiling (the split forward kernel's): one workgroup of 8 waves per 128 points, two f16 planes Th / Tl [128][320] = the CU's
-// whole 160 KiB; wave w owns the 32 input features of column tile w x all four point tiles (one accumulator set of 64
+// Tiling (the split forward kernel's): one workgroup of 8 waves per 128 points, two f16 planes Th / Tl (FEATURE-major,
+// [320][128]: see fidx) = the CU's whole 160 KiB; wave w owns the 32 input features of column tile w x all four point tiles (one accumulator set of 64
 // registers): a weight-fragment pair (hi, lo: 2 KiB from L2) feeds 12 MFMAs.  Un-transposed product (activations as the MFMA A
 // operand): an accumulator lane holds 4 consecutive points of one feature, so the lane pair (l, l + 32) forms whole 16-byte SH
 // units in registers (v_permlane32_swap) and the ReLU sign-bit words the forward pass saved line up with the accumulators.
-// The planes' PE columns [256,320) are never a GEMM operand here: f32 scratch (hi plane: dPE(dir) at floats [0,27), the tile's
-// maximum at [26] of rows 0 / 1 during P0, scaled d_raw at [28,32)), later the layer-5 skip's dPE block as hi + lo.
+// The planes' PE feature rows [256,320) are never a GEMM operand here: f32 scratch (hi plane: dPE(dir) at floats [0,27) of a
+// point, the tile's maximum at [26] of points 0 / 1 during P0, scaled d_raw at [28,32)), later the layer-5 skip's dPE block as hi + lo.
 #include "mlp_split.h"
 
 namespace {
@@ -50,9 +50,35 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float float2v __attribute__((ext_vector_type(2)));
 
-// f32 scratch float i (0..31) of `row` in the hi plane's PE columns: slot 32 + i/4, swizzled like everything else
+// ---- LDS planes, FEATURE-MAJOR: plane[feature 0..319][128 points] f16 (256 bytes per feature row) -----------------------------
+// An accumulator lane of the un-transposed product holds 4 consecutive points of one feature = 8 contiguous bytes of this layout:
+// the epilogue writes whole quads (ds_write_b64, 32 per wave and stage for both planes) where a point-major plane needs 128
+// two-byte writes; the K-loop gets its A fragments (row = point, 8 consecutive features) with two ds_read_b64_tr_b16 each
+// (tools/hwprobe/tr_read.hip: within a 16-lane group lane t supplies the address of row t >> 2, halfs 4 (t & 3) .. + 3 of a
+// 4 x 16 block and receives column t: here rows = features, columns = points).  Swizzle: the 64-byte segment (32 points) of a
+// row is XORed with feature & 3, the 16-byte slot (8 points) inside it with (feature >> 2) & 3 - the four feature rows of a
+// transpose read land in four different bank quarters, eight consecutive features of a quad write in eight different slots.
+constexpr int PROW = 128;                                               // halfs per feature row
+__device__ __forceinline__ int fidx(int f, int p) {
+    return f * PROW + ((((p >> 5) ^ (f & 3)) << 5) | ((((p >> 3) & 3) ^ ((f >> 2) & 3)) << 3) | (p & 7));
+}
+// f32 scratch float i (0..31) of point `row`: the feature rows [256,320) of the hi plane (never a GEMM operand here) as 4096
+// floats, 32 per point, groups of four floats XOR-swizzled by the point
 __device__ __forceinline__ float* fscr1(_Float16* T, int row, int i) {
-    return reinterpret_cast<float*>(T + row * LD + (((32 + (i >> 2)) ^ hsw(row)) << 3)) + (i & 3);
+    return reinterpret_cast<float*>(T + 256 * PROW) + row * 32 + (i ^ ((row & 7) << 2));
+}
+// A fragment pieces of this lane: half offsets at k-step 0 for piece j (features 8 (lane >> 5) + 4 j + ((lane & 15) >> 2)) and row
+// tile rt (points rt * 32 + 16 ((lane >> 4) & 1) + 4 (lane & 3)); a k-step further is 16 feature rows = 16 * PROW halfs
+__device__ __forceinline__ int frag_off(int lane, int j, int rt) {
+    const int t = lane & 15;
+    return fidx(8 * (lane >> 5) + 4 * j + (t >> 2), rt * 32 + 16 * ((lane >> 4) & 1) + 4 * (t & 3));
+}
+typedef short short4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ half8 frag_read(const _Float16* __restrict__ T, int off0, int off1) {
+    const short4v a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3)))*)(reinterpret_cast<const short4v*>(T + off0)));
+    const short4v b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3)))*)(reinterpret_cast<const short4v*>(T + off1)));
+    typedef short short8v __attribute__((ext_vector_type(8)));
+    return __builtin_bit_cast(half8, short8v{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]});
 }
 
 // buffer descriptor on a wave-uniform base address (per-lane addresses become ONE 32-bit VGPR offset: mlp_bwd_h.hip)
@@ -116,20 +142,18 @@ template <int KS, int PF>
 __device__ __forceinline__ void gemm3_body(const _Float16* __restrict__ Th, const _Float16* __restrict__ Tl, const float* __restrict__ wp,
                                            int ct, int lane, WRing<PF>& r, f32x16 (&acc)[4]) {
     lane = stage_local(lane);
-    const int row = lane & 31, lh = lane >> 5;
-    const int sw = hsw(row);                        // rows row + 32 * rt share the swizzle
-    const int rbase = row * LD;
     const WFrag wf(wp, lane);
     const int ctu = __builtin_amdgcn_readfirstlane(ct);
-    int abase[4];
+    int ao[2][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) abase[j] = rbase + (((2 * j + lh) ^ sw) << 3);
-    auto a_off = [&](int ks) { return abase[ks & 3] + ((((2 * ks) & ~7)) << 3); };
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) ao[j][rt] = frag_off(lane, j, rt);
     half8 ah[4], al[4];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
-        ah[rt] = *reinterpret_cast<const half8*>(Th + a_off(0) + rt * 32 * LD);
-        al[rt] = *reinterpret_cast<const half8*>(Tl + a_off(0) + rt * 32 * LD);
+        ah[rt] = frag_read(Th, ao[0][rt], ao[1][rt]);
+        al[rt] = frag_read(Tl, ao[0][rt], ao[1][rt]);
     }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -144,12 +168,12 @@ __device__ __forceinline__ void gemm3_body(const _Float16* __restrict__ Th, cons
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
             acc[rt] = mfma16(ah[rt], bl, acc[rt]);
-            if (ks + 1 < KS) ah[rt] = *reinterpret_cast<const half8*>(Th + a_off(ks + 1) + rt * 32 * LD);
+            if (ks + 1 < KS) ah[rt] = frag_read(Th + (ks + 1) * 16 * PROW, ao[0][rt], ao[1][rt]);
         }
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
             acc[rt] = mfma16(al[rt], bh, acc[rt]);
-            if (ks + 1 < KS) al[rt] = *reinterpret_cast<const half8*>(Tl + a_off(ks + 1) + rt * 32 * LD);
+            if (ks + 1 < KS) al[rt] = frag_read(Tl + (ks + 1) * 16 * PROW, ao[0][rt], ao[1][rt]);
         }
         __builtin_amdgcn_sched_barrier(0);          // one k-step per scheduling region: keeps the prefetch distances as written
     }
@@ -169,9 +193,7 @@ template <int KS, int PF = 4>
 __device__ __forceinline__ void gemm_row3(const _Float16* __restrict__ Th, const _Float16* __restrict__ Tl, const float* __restrict__ wp,
                                           int tile, int rt, int lane, f32x16& out) {
     lane = stage_local(lane);
-    const int row = rt * 32 + (lane & 31), lh = lane >> 5;
-    const int sw = hsw(row);
-    const int rbase = row * LD;
+    const int o0 = frag_off(lane, 0, rt), o1 = frag_off(lane, 1, rt);
     const WFrag wf(wp, lane);
     const int tu = __builtin_amdgcn_readfirstlane(tile);
     u32x4 bq[PF + 1][2];
@@ -181,8 +203,8 @@ __device__ __forceinline__ void gemm_row3(const _Float16* __restrict__ Th, const
             bq[p][0] = wf.load(tu, p, KS, 0);
             bq[p][1] = wf.load(tu, p, KS, 1);
         }
-    half8 ahn = *reinterpret_cast<const half8*>(Th + rbase + ((lh ^ sw) << 3));
-    half8 aln = *reinterpret_cast<const half8*>(Tl + rbase + ((lh ^ sw) << 3));
+    half8 ahn = frag_read(Th, o0, o1);
+    half8 aln = frag_read(Tl, o0, o1);
     // two partial accumulators (even / odd k-steps) halve the dependent chain
     f32x16 o2;
 #pragma unroll
@@ -195,8 +217,8 @@ __device__ __forceinline__ void gemm_row3(const _Float16* __restrict__ Th, const
             bq[(ks + PF) % (PF + 1)][1] = wf.load(tu, ks + PF, KS, 1);
         }
         if (ks + 1 < KS) {
-            ahn = *reinterpret_cast<const half8*>(Th + rbase + ((((ks + 1) * 2 + lh) ^ sw) << 3));
-            aln = *reinterpret_cast<const half8*>(Tl + rbase + ((((ks + 1) * 2 + lh) ^ sw) << 3));
+            ahn = frag_read(Th + (ks + 1) * 16 * PROW, o0, o1);
+            aln = frag_read(Tl + (ks + 1) * 16 * PROW, o0, o1);
         }
         const half8 bh = __builtin_bit_cast(half8, bq[ks % (PF + 1)][0]);
         const half8 bl = __builtin_bit_cast(half8, bq[ks % (PF + 1)][1]);
@@ -252,14 +274,10 @@ __device__ __forceinline__ void epilogue3(f32x16 (&acc)[4], const uint32_t (&bit
     const _Float16 gl = (_Float16)(gf * 4096.f);  // the residual goes into the encoder as lo * gf * 2^12 (h8_encode_unit<12>)
     const half2v g2l = {gl, gl};
     const int n = ct * 32 + lr;
-    const int ns = (n >> 3) ^ ((lane >> 5) << 1);
-    // plane element offsets: 4 swizzle variants x {rows 0-63, rows 64-127}; the rest are immediate offsets (mlp_bwd_h.hip)
-    int tb[4][2];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        tb[q][0] = r4 * LD + ((((ns ^ ((q & 1) | ((q >> 1) << 2)))) << 3) | (n & 7));
-        tb[q][1] = tb[q][0] + 64 * LD;
-    }
+    // plane offset of this lane's quad (4 points r4 .. r4 + 3 of an 8-point block) in row tile 0, block 0; row tile rt and block q
+    // enter through the swizzle: + (((rt ^ (n & 3)) << 5) | ((q ^ ((n >> 2) & 3)) << 3))
+    const int tq = n * PROW + r4;
+    const int sw_seg = n & 3, sw_slot = (n >> 2) & 3;
     const int st_lane = (((lane >> 5) * 256 + n) * 8) * 2;   // byte offset of unit (block, n); lanes 32-63: the odd block of a pair
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
@@ -281,17 +299,15 @@ __device__ __forceinline__ void epilogue3(f32x16 (&acc)[4], const uint32_t (&bit
                     amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])));   // v_max3_f32
                     half2v hv, lv;
                     split2(v[0], v[1], hv, lv);
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        const int e = (ep * 2 + h) * 4 + jp * 2 + t;
-                        const int o = tb[((e >> 1) & 1) | (((e >> 2) & 1) << 1)][rt >> 1] + ((rt & 1) * 32 + (e & 3) + 8 * (e >> 2)) * LD;
-                        Th[o] = hv[t];
-#ifndef BWS_SKIP_PLANE_LO
-                        Tl[o] = lv[t];
-#endif
-                    }
                     wh[jp] = __builtin_bit_cast(uint32_t, hv);
                     wl[jp] = __builtin_bit_cast(uint32_t, lv);
+                }
+                {   // this quad (block q = 2 ep + h of row tile rt) -> both planes, 8 bytes each
+                    const int o = tq + (((rt ^ sw_seg) << 5) | ((((ep * 2 + h) ^ sw_slot)) << 3));
+                    *reinterpret_cast<uint2*>(Th + o) = uint2{wh[0], wh[1]};
+#ifndef BWS_SKIP_PLANE_LO
+                    *reinterpret_cast<uint2*>(Tl + o) = uint2{wl[0], wl[1]};
+#endif
                 }
                 qh[h] = uint2{wh[0], wh[1]};
                 ql[h] = uint2{wl[0], wl[1]};
@@ -412,8 +428,8 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
                         for (int c = 0; c < C; ++c) g += drv[c] * wr[c];
                         const float v = ((hvbits >> (rtl * 16 + e)) & 1u) ? g : 0.f;
                         const _Float16 vh = (_Float16)v;
-                        Th[hidx(p, col)] = vh;
-                        Tl[hidx(p, col)] = (_Float16)(v - (float)vh);
+                        Th[fidx(col, p)] = vh;
+                        Tl[fidx(col, p)] = (_Float16)(v - (float)vh);
                         const float sv = v * gf;
                         amax = fmaxf(amax, fabsf(v));
                         qh[h].v[j] = (_Float16)sv;
@@ -521,7 +537,7 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
         for (int e = 0; e < 16; ++e) {
             amax = __builtin_fmaxf(amax, __builtin_fabsf(dpe[e]));
             const _Float16 vh = (_Float16)dpe[e];
-            const int o = hidx(prt * 32 + acc_row(e, ln), 256 + pct * 32 + (ln & 31));
+            const int o = fidx(256 + pct * 32 + (ln & 31), prt * 32 + acc_row(e, ln));
             Th[o] = vh;
             Tl[o] = (_Float16)(dpe[e] - (float)vh);
         }
@@ -549,7 +565,7 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
         const int ln = stage_local(lane);
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const int o = hidx(prt * 32 + acc_row(e, ln), 256 + pct * 32 + (ln & 31));
+            const int o = fidx(256 + pct * 32 + (ln & 31), prt * 32 + acc_row(e, ln));
             dpe[e] = (float)Th[o] + (float)Tl[o];
         }
     }

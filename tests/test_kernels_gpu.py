@@ -356,7 +356,9 @@ def test_mlp_fwd_golden(K, mlp_mode, golden, C, variant, S):
         assert float(av["pe"][:, 63].abs().max()) == 0.0
         # split mode saves the f16 operand of the backward GEMMs (11-bit significand: 2^-11 relative); the full-precision
         # forward path is what `raw` checks below
-        rt = 2.0 ** -11 if mlp_mode == "split_f16bwd" else 1e-4      # hi + 8-bit residual code: 19 bits
+        # split: hi + 8-bit residual code = 19 bits (2e-6), held to 2e-5 - tighter than the f32 mode's 1e-4 so that a wrong code
+        # (one unit of the residual = 2^-18 relative) cannot hide; split_f16bwd: the f16 half alone
+        rt = {"split_f16bwd": 2.0 ** -11, "split": 2e-5, "f32": 1e-4}[mlp_mode]
         for name in ("h0", "h4", "h7", "feat", "hv"):
             r = g[tag + "_" + name]
             report("K3 act %s %s" % (name, tag), av[name], r, atol=2e-5 * float(np.abs(r).max()), rtol=rt)
