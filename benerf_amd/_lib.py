@@ -59,6 +59,7 @@ _SIGNATURES = {
     "benerf_mlp_dw_workspace_floats": (c_size_t, [c_int64]),
     "benerf_mlp_fwd": (c_int, [POINTER(MlpParams), P, c_int, c_int, c_int, P, P, P, P, P, P, c_int, P, P]),
     "benerf_mlp_status_check": (c_int, [P, P]),
+    "benerf_mlp_h8_roundtrip": (c_int, [P, c_int64, c_int, P, P, P, P]),
     "benerf_step_gate": (c_int, [P, P, c_int, P]),
     "benerf_mlp_bwd_dx": (c_int, [POINTER(MlpParams), P, c_int, c_int, c_int, P, P, P, P, P, c_int, P, P, P]),
     "benerf_mlp_bwd_dw": (c_int, [c_int, c_int, c_int, P, P, P, P, c_size_t, POINTER(MlpGrads), c_int, c_int, P, P]),

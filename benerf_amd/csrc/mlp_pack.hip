@@ -120,7 +120,48 @@ __device__ __forceinline__ void pack_body(const PackArgs& a) {
     }
 }
 
+// known-answer access to the lo8 codec of the saved operands (mlp_split.h): one thread per unit of 8 values
+template <int S>
+__global__ void h8_roundtrip_kernel(const float* __restrict__ x, int64_t units, uint16_t* __restrict__ hi_out, uint8_t* __restrict__ code_out,
+                                    float* __restrict__ dec_out) {
+    const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= units) return;
+    uint32_t hi[4], lo[4], dl[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float a = x[u * 8 + 2 * j], b = x[u * 8 + 2 * j + 1];
+        const _Float16 ha = (_Float16)a, hb = (_Float16)b;
+        const h8_half2 h = {ha, hb};
+        const h8_half2 l = {(_Float16)((a - (float)ha) * (float)(1 << S)), (_Float16)((b - (float)hb) * (float)(1 << S))};
+        hi[j] = __builtin_bit_cast(uint32_t, h);
+        lo[j] = __builtin_bit_cast(uint32_t, l);
+    }
+    const uint2 code = h8_encode_unit<S>(hi, lo);
+    h8_decode_unit(hi, code, dl);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const h8_half2 h = __builtin_bit_cast(h8_half2, hi[j]), d = __builtin_bit_cast(h8_half2, dl[j]);
+        hi_out[u * 8 + 2 * j] = (uint16_t)(hi[j] & 0xffffu);
+        hi_out[u * 8 + 2 * j + 1] = (uint16_t)(hi[j] >> 16);
+        dec_out[u * 8 + 2 * j] = (float)h[0] + (float)d[0];
+        dec_out[u * 8 + 2 * j + 1] = (float)h[1] + (float)d[1];
+    }
+    reinterpret_cast<uint2*>(code_out)[u] = code;
+}
+
 }  // namespace
+
+extern "C" int benerf_mlp_h8_roundtrip(const float* x, int64_t n, int residual_log2_scale, uint16_t* hi_bits, uint8_t* codes,
+                                       float* decoded, benerf_stream_t stream) {
+    BENERF_REQUIRE(x && hi_bits && codes && decoded && n > 0 && n % 8 == 0, "mlp_h8_roundtrip: bad args (n must be a multiple of 8)");
+    BENERF_REQUIRE(residual_log2_scale == 11 || residual_log2_scale == 12, "mlp_h8_roundtrip: residual scale must be 2^11 (forward planes) or 2^12 (dX)");
+    const int64_t units = n / 8;
+    const dim3 grid((unsigned)((units + 255) / 256)), block(256);
+    if (residual_log2_scale == 11) hipLaunchKernelGGL(h8_roundtrip_kernel<11>, grid, block, 0, as_stream(stream), x, units, hi_bits, codes, decoded);
+    else hipLaunchKernelGGL(h8_roundtrip_kernel<12>, grid, block, 0, as_stream(stream), x, units, hi_bits, codes, decoded);
+    BENERF_LAUNCH_CHECK("mlp_h8_roundtrip");
+    return BENERF_OK;
+}
 
 extern "C" size_t benerf_mlp_packed_floats(void) { return (size_t)(2 * mlp::PACKED_FLOATS); }   // f32 blocks | split-f16 blocks
 // buffers are sized for either arithmetic mode (the split mode pads the point count to whole 128-point tiles)

@@ -447,6 +447,19 @@ def mlp_fwd(net, rays_o, rays_d, viewdirs, z, save_acts, precision=None, status=
     return raw, acts
 
 
+def mlp_h8_roundtrip(x, residual_log2_scale=12):
+    """The lo8 codec of the split mode's saved operands on x (float32, numel a multiple of 8): returns (hi as float16 tensor,
+    codes uint8, decoded float32) - include/benerf_hip.h: benerf_mlp_h8_roundtrip."""
+    lib = _lib.load()
+    n = x.numel()
+    hi = torch.empty(n, dtype=torch.float16, device=x.device)
+    codes = torch.empty(n, dtype=torch.uint8, device=x.device)
+    dec = torch.empty(n, dtype=torch.float32, device=x.device)
+    _lib.check(lib.benerf_mlp_h8_roundtrip(_chk(x, name="x"), n, residual_log2_scale, hi.data_ptr(), codes.data_ptr(), dec.data_ptr(),
+                                           _stream()), "mlp_h8_roundtrip")
+    return hi, codes, dec
+
+
 def mlp_bwd_dx(net, d_raw, acts, n_rays, n_samples, slot="", status=None, d_raw_absmax=None):
     """Activation-gradient chain of one network: returns per-point (d_pts [M,3], d_vdir [M,3]) and the per-layer
     activation gradients (scratch buffer `slot`: give the two networks different slots when the weight-gradient launch

@@ -243,6 +243,15 @@ int benerf_mlp_bwd_dw(int channels, int n_rays, int n_samples, const float* d_ra
                       const BenerfMlpGrads* grads, int accumulate, int precision, const float* pe_weights,
                       benerf_stream_t stream);
 
+/* Known-answer access to the format of the saved operands of BENERF_MLP_SPLIT (csrc/mlp_split.h): every activation / activation
+ * gradient the forward and dX kernels save for the dW kernel is an f16 hi = rn16(x) plus an 8-bit residual code
+ *     code = clamp(rn((x - hi) * 2^(18 - E)) + 128, 0, 255),  E = max(exponent(hi), -6)     x ~ hi + (code - 128) * 2^(E - 18).
+ * Encodes and decodes n values (a multiple of 8) with the kernels' own device functions; residual_log2_scale = 11 (the forward
+ * kernel's path: residual carried as (x - hi) * 2^11 in f16) or 12 (the dX kernel's).  Test infrastructure of the format, not a
+ * step of the path: hi_bits [n] f16 bit patterns, codes [n], decoded [n]. */
+int benerf_mlp_h8_roundtrip(const float* x, int64_t n, int residual_log2_scale, uint16_t* hi_bits, uint8_t* codes, float* decoded,
+                            benerf_stream_t stream);
+
 /* ---------------------------------------------------------------- K4: compositing -- */
 /* Alpha compositing, one wavefront per ray.  Replaces NeRF.raw2output
  * (model/nerf.py:118-148).  noise [n_rays,n_samples] = randn*raw_noise_std, or NULL with

@@ -889,3 +889,50 @@ def test_composite_bwd_reports_max_d_raw(K):
         assert all(torch.equal(x, y) for x, y in zip(*grads))
     finally:
         K.set_mlp_precision(prev)
+
+
+@pytest.mark.parametrize("scale_log2", [11, 12])
+def test_saved_operand_codec_known_answers(K, scale_log2):
+    """The 3-byte format of the split mode's saved operands (mlp_split.h: f16 hi + 8-bit residual code in units of ulp(hi) / 256,
+    E clamped at -6) through the kernels' own encode / decode device functions, against a numpy model: zeros, f16-exact values,
+    both signs, magnitudes from 1e-7 to 6e4 (f16 subnormal hi, the E clamp, the largest exponent), values half-way between
+    two f16 (residual = +-ulp/2 -> code 0 / 255 after the clamp)."""
+    rng = np.random.default_rng(512)
+    mags = np.exp(rng.uniform(np.log(1e-7), np.log(6e4), 40000))
+    x = (mags * rng.choice([-1.0, 1.0], mags.shape)).astype(np.float32)
+    special = np.array([0.0, -0.0, 1.0, -1.0, 0.5, 1024.0, 65504.0, -65504.0, 2.0 ** -14, 2.0 ** -6, 2.0 ** -7, 1.0 + 2.0 ** -11,
+                        1.0 - 2.0 ** -12, 3.0 + 2.0 ** -10, -(3.0 + 2.0 ** -10), 2.0 ** -24, 1e-8, 100.03125, 0.1, -0.1], np.float32)
+    x = np.concatenate([special, x])
+    x = np.concatenate([x, np.zeros((-len(x)) % 8, np.float32)])
+    hi, codes, dec = K.mlp_h8_roundtrip(dev(torch.from_numpy(x)), scale_log2)
+    hi, codes, dec = hi.cpu().numpy(), codes.cpu().numpy().astype(np.int64), dec.cpu().numpy().astype(np.float64)
+    hi_ref = x.astype(np.float16)
+    assert np.array_equal(hi.view(np.uint16), hi_ref.view(np.uint16)), "hi = round-to-nearest-even f16"
+    e5 = np.maximum((hi_ref.view(np.uint16).astype(np.int64) >> 10) & 31, 9)
+    unit = np.exp2((e5 - 15 - 18).astype(np.float64))                       # 2^(E - 18)
+    r = x.astype(np.float64) - hi_ref.astype(np.float64)
+    code_ref = np.clip(np.rint(r / unit) + 128, 0, 255)
+    # the kernels carry the residual through ONE f16 rounding before the encoder (exact unless it is subnormal there): a code may
+    # differ from the model's by one unit at a tie, never more
+    assert int(np.abs(codes - code_ref).max()) <= 1, int(np.abs(codes - code_ref).max())
+    frac_exact = float((codes == code_ref).mean())
+    assert frac_exact > 0.99, frac_exact
+    # decoded = hi + (code - 128) * 2^(E - 18), computed in f16 arithmetic that is exact above the subnormal grid (2^-24)
+    dec_ref = hi_ref.astype(np.float64) + (codes - 128) * unit
+    assert float(np.abs(dec - dec_ref).max()) <= 2.0 ** -24, float(np.abs(dec - dec_ref).max())
+    # the format's promise: 19 significant bits above |x| = 2^-6 (a residual within ulp/512 of +ulp/2 clamps to code 255: 18 bits there),
+    # an absolute 2^-24 below
+    err = np.abs(dec - x.astype(np.float64))
+    big = np.abs(x) >= 2.0 ** -6
+    tie = np.abs(r / unit) > 127.5          # residual within ulp/512 of +ulp/2: rounds to code 256, clamped to 255
+    rel = err[big & ~tie] / np.abs(x[big & ~tie].astype(np.float64))
+    iw = np.flatnonzero(big & ~tie)[int(np.argmax(rel))]
+    print("worst: x=%r hi=%r e5=%d code=%d model=%d r/unit=%.4f dec=%r" % (float(x[iw]), float(hi_ref[iw]), int(e5[iw]), int(codes[iw]), int(code_ref[iw]),
+                                                                        float(r[iw] / unit[iw]), float(dec[iw])))
+    rel_tie = err[big & tie] / np.abs(x[big & tie].astype(np.float64))
+    print("lo8 codec (S=%d): max relative error above 2^-6: %.3e (2^-19 = %.3e; at %d clamped residuals %.3e), max absolute error below: %.3e"
+          % (scale_log2, float(rel.max()), 2.0 ** -19, int((big & tie).sum()), float(rel_tie.max()) if rel_tie.size else 0.0, float(err[~big].max())))
+    # (half a code unit + the f16 rounding of the residual in front of the encoder: 1/32 unit at most)
+    assert float(rel.max()) <= 2.0 ** -19 * (1 + 1 / 16) + 2.0 ** -24 and float(err[~big].max()) <= 2.0 ** -24
+    assert rel_tie.size == 0 or float(rel_tie.max()) <= 2.0 ** -18
+    assert codes[0] == 128 and codes[1] == 128 and dec[0] == 0.0, "zero encodes as code 128 and decodes to zero"
