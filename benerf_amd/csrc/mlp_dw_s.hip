@@ -95,13 +95,18 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int64_t 
     rA.da = rB.da = rC.da = 0.f;
     // Loads are UNCONDITIONAL (a chunk index past the range is clamped to the last chunk and its staged dY zeroed): with the
     // loads under branches the compiler's waitcnt bookkeeping falls back to vmcnt(0) at every stage (mlp_dw_h.hip)
+#ifdef DWS_NO_CODES      /* timing variant: what do the 8-byte code loads cost? */
+#define DWS_CODE_LOAD(expr) (uint2{0x80808080u, 0x80808080u})
+#else
+#define DWS_CODE_LOAD(expr) (expr)
+#endif
 #define DW_PREFETCH(R, CHUNK)                                                                             \
     {                                                                                                     \
         const int64_t cc = (CHUNK) < chunk_end ? (CHUNK) : chunk_end - 1;                                 \
         _Pragma("unroll") for (int j = 0; j < NY; ++j)                                                    \
             if (YFULL || tid + j * DWT < YU) {                                                            \
                 R.y[j] = src.y[cc * YU + tid + j * DWT];                                                  \
-                R.y8[j] = src.y8[cc * YU + tid + j * DWT];                                                \
+                R.y8[j] = DWS_CODE_LOAD(src.y8[cc * YU + tid + j * DWT]);                                 \
             }                                                                                             \
         if (XROWS) {   /* f32 rows [point][K]: one float4 (4 features of a point) per thread */                \
             if (tid < CHP * K / 4)                                                                        \
@@ -110,7 +115,7 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int64_t 
             _Pragma("unroll") for (int j = 0; j < NX; ++j)                                                \
                 if (XFULL || tid + j * DWT < XU) {                                                        \
                     R.x[j] = src.x[cc * XU + tid + j * DWT];                                              \
-                    R.x8[j] = src.x8[cc * XU + tid + j * DWT];                                            \
+                    R.x8[j] = DWS_CODE_LOAD(src.x8[cc * XU + tid + j * DWT]);                             \
                 }                                                                                         \
         }                                                                                                 \
         if (ALPHA) {                                                                                      \
