@@ -467,9 +467,10 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
         _Float16* stf = reinterpret_cast<_Float16*>(dacts + sdact_feat(Mp)) + m0 * 256;
         epilogue3<false>(acc, bits, Th, Tl, ct, lane, stf, st8 + 2 * sdact_feat(Mp) + m0 * 256, gf, amax);
     }
-    if (tid < TMB && m0 + tid < M) {   // d viewdirs (per point) through PE(dir)
+    if (tid < TMB && m0 + tid < M) {   // d viewdirs (per point) through PE(dir): sin / cos recomputed from the saved direction
         const int64_t m = m0 + tid;
-        const float* ped = acts + sact_ped32(Mp) + m * ACT_PED_W;
+        const float4 vd4 = reinterpret_cast<const float4*>(acts + sact22_pts(Mp))[m * 2 + 1];
+        const float vd[3] = {vd4.x, vd4.y, vd4.z};
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             float sv = *fscr1(Th, tid, d);
@@ -477,7 +478,8 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
                 const int es = 3 + f * 6 + d, ec = es + 3;
-                const float sn = ped[es], cs = ped[ec];
+                float sn, cs;
+                pe_sincos(vd[d] * (float)(1 << f), sn, cs);       // the forward's own evaluation (mlp_fwd_h.hip): identical values
                 const float ws = a.pe_w ? a.pe_w[64 + es] : 1.f, wc = a.pe_w ? a.pe_w[64 + ec] : 1.f;
                 sv += (float)(1 << f) * (cs * (ws * *fscr1(Th, tid, es)) - sn * (wc * *fscr1(Th, tid, ec)));
             }
@@ -552,14 +554,9 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
     }
 
     // ---- P5: L0^T: dPE += dY0 x W0 -----------------------------------------------------------------------
-    // The tile's saved PE rows (f32 [128][64] = 32 KiB, contiguous) are requested here as coalesced 16-byte loads, so that their
-    // HBM round trip hides under the L0 GEMM; P6 reads them from LDS.
-    float4 per[4];
-    {
-        const float4* pe_tile = reinterpret_cast<const float4*>(acts + sact_pe32(Mp) + m0 * ACT_PE_W);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) per[k] = pe_tile[tid + k * BNT];
-    }
+    // The point itself (saved by the forward as f32, 16 bytes) is requested here, its HBM round trip hides under the L0 GEMM; P6
+    // recomputes sin / cos from it (the forward's own pe_sincos: identical values) instead of reading 256 bytes of saved rows.
+    const float4 x4 = reinterpret_cast<const float4*>(acts + sact22_pts(Mp))[(m0 + (tid & (TMB - 1))) * 2];
     f32x16 dpe;
     {
         const int ln = stage_local(lane);
@@ -570,60 +567,50 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
         }
     }
     gemm_row3<16>(Th, Tl, packed_h + pack_offset(PB_L0), pct, prt, lane, dpe);
-    lds_barrier();      // every wave is done reading dY0: the planes become f32 scratch, 133 floats per point:
-    // [0,64) dPE, [64,68) the odd-frequency partial sums, [68,132) PE.  The odd row stride keeps P6's per-point walks
+    lds_barrier();      // every wave is done reading dY0: the planes become f32 scratch, 77 floats per point:
+    // [0,64) dPE, [64,73) the partial sums of the other three frequency groups.  The odd row stride keeps P6's per-point walks
     // (lane = point, same column) free of bank conflicts.
     float* F = reinterpret_cast<float*>(Tsm);
-    constexpr int FLD = 133;
+    constexpr int FLD = 77;
     static_assert((size_t)TMB * FLD * sizeof(float) <= BWD_SMEM, "P6 scratch fits the planes");
     {
         const int ln = stage_local(lane);
 #pragma unroll
         for (int e = 0; e < 16; ++e) F[(prt * 32 + acc_row(e, ln)) * FLD + pct * 32 + (ln & 31)] = dpe[e];
     }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int u = tid + k * BNT;                              // float4 u of the tile: point u / 16, floats 4 (u % 16) ..
-        float* dst = F + (u >> 4) * FLD + 68 + (u & 15) * 4;
-        dst[0] = per[k].x;
-        dst[1] = per[k].y;
-        dst[2] = per[k].z;
-        dst[3] = per[k].w;
-    }
     lds_barrier();
 
-    // ---- P6: dPE -> d_pts through the saved PE values; two threads per point (even / odd frequencies) ------------
+    // ---- P6: dPE -> d_pts; sin / cos recomputed from the point; four threads per point (frequencies g, g + 4, g + 8) ------------
     {
-        const int pt = tid & (TMB - 1), g = tid >> 7;            // g = 0, 1 compute; 2, 3 idle
+        const int pt = tid & (TMB - 1), g = tid >> 7;
         const int64_t m = m0 + pt;
         const float* dp = F + pt * FLD;
-        const float* pe = dp + 68;
+        const float x[3] = {x4.x, x4.y, x4.z};
         float sp[3] = {0.f, 0.f, 0.f};
-        if (g == 0) {
+        for (int f = g; f < 10; f += 4) {
+            const float sc = (float)(1 << f);
 #pragma unroll
-            for (int d = 0; d < 3; ++d) sp[d] = a.pe_w ? a.pe_w[d] * dp[d] : dp[d];
-        }
-        if (g < 2) {
-            for (int f = g; f < 10; f += 2) {
-                const float sc = (float)(1 << f);
-#pragma unroll
-                for (int d = 0; d < 3; ++d) {
-                    const int es = 3 + f * 6 + d, ec = es + 3;
-                    const float sn = pe[es], cs = pe[ec];
-                    const float ws = a.pe_w ? a.pe_w[es] : 1.f, wc = a.pe_w ? a.pe_w[ec] : 1.f;
-                    sp[d] += sc * (cs * (ws * dp[es]) - sn * (wc * dp[ec]));
-                }
+            for (int d = 0; d < 3; ++d) {
+                const int es = 3 + f * 6 + d, ec = es + 3;
+                float sn, cs;
+                pe_sincos(x[d] * sc, sn, cs);
+                const float ws = a.pe_w ? a.pe_w[es] : 1.f, wc = a.pe_w ? a.pe_w[ec] : 1.f;
+                sp[d] += sc * (cs * (ws * dp[es]) - sn * (wc * dp[ec]));
             }
         }
-        float* part = F + pt * FLD + 64;                          // floats [64,68) of the row: past the dPE block
-        if (g == 1) {
+        // fixed summation order: ((identity + group 0) + group 1) + group 2) + group 3
+        float* part = F + pt * FLD + 64;                          // floats [64,73) of the row: past the dPE block
+        if (g > 0) {
 #pragma unroll
-            for (int d = 0; d < 3; ++d) part[d] = sp[d];
+            for (int d = 0; d < 3; ++d) part[(g - 1) * 3 + d] = sp[d];
         }
         lds_barrier();
         if (g == 0 && m < M) {
 #pragma unroll
-            for (int d = 0; d < 3; ++d) a.d_pts[m * 3 + d] = (sp[d] + part[d]) * inv_s;
+            for (int d = 0; d < 3; ++d) {
+                const float id = a.pe_w ? a.pe_w[d] * dp[d] : dp[d];
+                a.d_pts[m * 3 + d] = ((((id + sp[d]) + part[d]) + part[3 + d]) + part[6 + d]) * inv_s;
+            }
         }
     }
 }

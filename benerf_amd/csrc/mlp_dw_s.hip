@@ -16,6 +16,8 @@
 // four arrays = 24 KiB from HBM, 32 KiB in LDS.  HBM-bound: 14.6 KB per point against 24 MFMAs per wave and chunk.
 // (An LDS-DMA variant of the copy - ring of four slots, no staging registers - measured 5 % faster on f16 pairs in HBM, commit
 // caf2f65; it cannot decode on the way and went with the 4-byte format.)
+// The thin instances (X = positional encoding: L0, the PE part of L5, the PE(dir) part of the views layer) stream WITHOUT LDS:
+// see thin_stream below.
 #include "mlp_split.h"
 
 namespace {
@@ -38,7 +40,7 @@ struct DwArgs {
 struct Src {
     const u32x4* y;     // SH array of width N (16-byte units), hi halves
     const uint2* y8;    // its lo8 twin (8-byte units)
-    const u32x4* x;     // SH array of width K ... or, for the thin instances (XROWS), f32 rows [Mp][K]
+    const u32x4* x;     // SH array of width K
     const uint2* x8;
     bool bias;
 };
@@ -47,31 +49,26 @@ __device__ __forceinline__ Src inst_src(const DwArgs& a, int inst) {
     const int64_t Mp = m_pad(a.M);
     const float* A = a.acts;
     const float* D = a.dacts;
-    auto Y = [&](int64_t off, int64_t xoff, bool xsh, bool bias) {
+    auto Y = [&](int64_t off, int64_t xoff) {
         return Src{reinterpret_cast<const u32x4*>(D + off), reinterpret_cast<const uint2*>(sdact_lo8(D, Mp, off)),
-                   reinterpret_cast<const u32x4*>(A + xoff), xsh ? reinterpret_cast<const uint2*>(sact_lo8(A, Mp, xoff)) : nullptr, bias};
+                   reinterpret_cast<const u32x4*>(A + xoff), reinterpret_cast<const uint2*>(sact_lo8(A, Mp, xoff)), true};
     };
-    switch (inst) {
-        case DW_L1: case DW_L2: case DW_L3: case DW_L4: case DW_L5H: case DW_L6: case DW_L7:
-            return Y(sdact_h(Mp, 1 + (inst - DW_L1)), sact_h(Mp, inst - DW_L1), true, true);
-        case DW_FEAT: return Y(sdact_feat(Mp), sact_h(Mp, 7), true, true);
-        case DW_VIEWSF: return Y(sdact_hv(Mp), sact_feat(Mp), true, true);
-        case DW_L0: return Y(sdact_h(Mp, 0), sact_pe32(Mp), false, true);        // X = PE as f32 rows
-        case DW_L5P: return Y(sdact_h(Mp, 5), sact_pe32(Mp), false, false);
-        default: return Y(sdact_hv(Mp), sact_ped32(Mp), false, false);           // DW_VIEWSP: PE(dir) rows
+    switch (inst) {     // the big kernel's instances
+        case DW_FEAT: return Y(sdact_feat(Mp), sact_h(Mp, 7));
+        case DW_VIEWSF: return Y(sdact_hv(Mp), sact_feat(Mp));
+        default: return Y(sdact_h(Mp, 1 + (inst - DW_L1)), sact_h(Mp, inst - DW_L1));     // DW_L1 .. DW_L7 (DW_L5H: the h4 part of layer 5)
     }
 }
 
 // Output block N x K (the whole instance: K = width of X).  Waves form a WN x (8/WN) grid; each owns TR x TC MFMA tiles: per
 // 16-point chunk acc += Yh^T Xh + Yh^T Xl + Yl^T Xh.  Three chunks are in flight in registers (sets A, B, C) and the LDS image
 // is triple-buffered, so there is one LDS-only barrier per chunk.
-template <int N, int K, int WN, int TR, int TC, bool ALPHA, bool XROWS = false>
+template <int N, int K, int WN, int TR, int TC, bool ALPHA>
 __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int64_t chunk_begin, int64_t chunk_end,
                                         float* __restrict__ part, u32x4* __restrict__ smem) {
     static_assert(WN * TR * 32 == N, "row tiling");
     constexpr int YU = CHB * N, XU = CHB * K;                  // 16-byte units per chunk and plane
-    static_assert(!XROWS || (CHP * K / 4 <= DWT), "one float4 of the f32 rows per thread");
-    constexpr int NY = (YU + DWT - 1) / DWT, NX = XROWS ? 1 : (XU + DWT - 1) / DWT;
+    constexpr int NY = (YU + DWT - 1) / DWT, NX = (XU + DWT - 1) / DWT;
     constexpr bool YFULL = YU % DWT == 0, XFULL = XU % DWT == 0;
     constexpr int BUF = 2 * YU + 2 * XU + CHP / 4;             // Yh | Yl | Xh | Xl | CHP floats of d_sigma
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -108,16 +105,11 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int64_t 
                 R.y[j] = src.y[cc * YU + tid + j * DWT];                                                  \
                 R.y8[j] = DWS_CODE_LOAD(src.y8[cc * YU + tid + j * DWT]);                                 \
             }                                                                                             \
-        if (XROWS) {   /* f32 rows [point][K]: one float4 (4 features of a point) per thread */                \
-            if (tid < CHP * K / 4)                                                                        \
-                R.x[0] = reinterpret_cast<const u32x4*>(reinterpret_cast<const float*>(src.x) + cc * (CHP * K))[tid]; \
-        } else {                                                                                          \
-            _Pragma("unroll") for (int j = 0; j < NX; ++j)                                                \
-                if (XFULL || tid + j * DWT < XU) {                                                        \
-                    R.x[j] = src.x[cc * XU + tid + j * DWT];                                              \
-                    R.x8[j] = DWS_CODE_LOAD(src.x8[cc * XU + tid + j * DWT]);                             \
-                }                                                                                         \
-        }                                                                                                 \
+        _Pragma("unroll") for (int j = 0; j < NX; ++j)                                                    \
+            if (XFULL || tid + j * DWT < XU) {                                                            \
+                R.x[j] = src.x[cc * XU + tid + j * DWT];                                                  \
+                R.x8[j] = DWS_CODE_LOAD(src.x8[cc * XU + tid + j * DWT]);                                 \
+            }                                                                                             \
         if (ALPHA) {                                                                                      \
             const int64_t row = cc * CHP + (tid & (CHP - 1));                                             \
             R.da = a.d_raw[(row < M ? row : M - 1) * (a.C + 1) + a.C];                                    \
@@ -143,24 +135,10 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int64_t 
     };
     auto stage_x = [&](const Regs& R, int b, bool valid) {
         u32x4* Xs_ = smem + b * BUF + 2 * YU;
-        if (XROWS) {   // split into hi + lo and scatter the 4 features of this thread's point into their fragments
-            if (tid < CHP * K / 4) {
-                const int p = tid / (K / 4), w0 = (tid % (K / 4)) * 4;
-                _Float16* img = reinterpret_cast<_Float16*>(Xs_);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float v = __uint_as_float(R.x[0][i]);
-                    const _Float16 hi = (_Float16)v;
-                    img[((p >> 3) * K + w0 + i) * 8 + (p & 7)] = hi;
-                    img[XU * 8 + ((p >> 3) * K + w0 + i) * 8 + (p & 7)] = (_Float16)(v - (float)hi);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < NX; ++j) {
-                const int u = tid + j * DWT;
-                if (XFULL || u < XU) put_pair(Xs_, Xs_ + XU, u, R.x[j], R.x8[j], true);
-            }
+        for (int j = 0; j < NX; ++j) {
+            const int u = tid + j * DWT;
+            if (XFULL || u < XU) put_pair(Xs_, Xs_ + XU, u, R.x[j], R.x8[j], true);
         }
         if (ALPHA && tid < CHP) reinterpret_cast<float*>(Xs_ + 2 * XU)[tid] = valid ? R.da : 0.f;
     };
@@ -391,9 +369,6 @@ __device__ __forceinline__ void dw_rgb(const DwArgs& a, int64_t blk_begin, int64
 }
 
 constexpr size_t DWS_SMEM = 3 * (size_t)(2 * CHB * 256 + 2 * CHB * 256 + CHP / 4) * 16;       // three chunk images of the 256 x 256 block: 98 496 B
-constexpr size_t DWS_SMEM_SMALL = 3 * (size_t)(2 * CHB * 256 + 2 * CHB * 64 + CHP / 4) * 16;  // 256 x 64 block: 61 632 B
-static_assert(DWS_SMEM_SMALL >= (32 * 8 * 4 + 18 * 128) * sizeof(float), "rgb head scratch fits the thin image");
-
 __device__ __forceinline__ void chunk_range(const DwArgs& a, int inst, int split, int64_t& cb, int64_t& ce) {
     const int64_t nchunks = m_pad(a.M) / CHP;
     const int64_t per = (nchunks + dwh_splits(inst) - 1) / dwh_splits(inst);
@@ -426,22 +401,171 @@ __global__ __launch_bounds__(DWT, 2) void mlp_dw_split_big_kernel(DwArgs a) {
     DW_TRACE(1, 1);
 }
 
-// the thin instances: L0 and L5P (256 x 64, X = PE), VIEWSP (128 x 32, X = PE(dir)), rgb head (VALU)
-__global__ __launch_bounds__(DWT, 4) void mlp_dw_split_small_kernel(DwArgs a) {
-    extern __shared__ __attribute__((aligned(16))) u32x4 smem_u[];
-    DW_TRACE(0, 0);
-    const int inst = dwh_thin_inst(blockIdx.x), split = dwh_thin_split(blockIdx.x);
-    int64_t cb, ce;
-    chunk_range(a, inst, split, cb, ce);
-    float* part = a.ws + dwh_inst_offset(inst) + (int64_t)split * dw_inst_floats(inst);
-    if (inst == DW_RGB) {
-        dw_rgb(a, cb * CHB, ce * CHB, part, reinterpret_cast<float*>(smem_u));
-        DW_TRACE(0, 1);
-        return;
+// ---- the thin instances: L0 and the PE part of L5 (256 x 64 each, X = PE), the PE(dir) part of the views layer (128 x 32), rgb head -----
+// X is 64 / 32 features wide, so ONE wave can own a 32-row tile of dY against ALL of X (2 / 1 accumulator tiles) and nothing of
+// the heavy operand (dY: 768 of the 960 bytes per point and instance) is shared between waves.  SH units ARE the MFMA fragments of
+// a contraction over points (mlp_split.h), so a wave loads its fragments straight from global memory - lane (lr, lh) takes unit
+// (block 2 k + lh, feature 32 rt + lr): 16 bytes of hi halves + 8 bytes of codes, 512 / 256 contiguous bytes per half wave -
+// decodes the low halves in registers and multiplies: no LDS, no barrier, no staging pass; every wave streams at its own pace
+// with TS_DEPTH k-steps (16 points each) in flight.  The X fragments (3 KiB per k-step against 24 of dY) are requested by all
+// eight waves of a workgroup and come out of the vector L1 / L2.  L0 and L5P share X: one wave carries row tile rt of dY0 AND of
+// dY5 (four accumulator tiles), so the encoding is fetched once for both.
+// Before (round 4's first version): the dw_gemm structure above with X split from f32 rows while staging - six MFMAs per wave and
+// barrier, 2.7 TB/s; 0.96 ms per C2 step for 6 % of the dW FLOPs.
+#ifndef TS_DEPTH
+#define TS_DEPTH 4
+#endif
+template <int NYA, int TC>
+struct ThinRegs {
+    u32x4 y[NYA];
+    uint2 yc[NYA];
+    u32x4 x[TC];
+    uint2 xc[TC];
+};
+
+__device__ __forceinline__ half8 h8_lo_of(const u32x4 hi, const uint2 code) {
+    const uint32_t h4[4] = {hi[0], hi[1], hi[2], hi[3]};
+    uint32_t l4[4];
+    h8_decode_unit(h4, code, l4);
+    return __builtin_bit_cast(half8, u32x4{l4[0], l4[1], l4[2], l4[3]});
+}
+// sum of the 8 + 8 halfs of a unit in f32 (v_dot2_f32_f16 against (1, 1))
+__device__ __forceinline__ float h8_sum_unit(const half8 h, const half8 l) {
+    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    const half2v one = {(_Float16)1.f, (_Float16)1.f};
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        s = __builtin_amdgcn_fdot2(half2v{h[2 * j], h[2 * j + 1]}, one, s, false);
+        s = __builtin_amdgcn_fdot2(half2v{l[2 * j], l[2 * j + 1]}, one, s, false);
     }
-    const Src src = inst_src(a, inst);
-    if (inst == DW_VIEWSP) dw_gemm<128, 32, 4, 1, 1, false, true>(a, src, cb, ce, part, smem_u);
-    else dw_gemm<256, 64, 4, 2, 1, false, true>(a, src, cb, ce, part, smem_u);   // DW_L0, DW_L5P
+    return s;
+}
+
+// NYA dY arrays of width YW (row tile rt of each) x the X array of width 32 TC, k-steps [kb, ke).  part[i]: this split's partial
+// block of dY array i ([YW][32 TC] then bias [YW]); bias sums for array 0 only when BIAS0.
+template <int NYA, int YW, int TC, bool BIAS0>
+__device__ __forceinline__ void thin_stream(const u32x4* const (&yh)[NYA], const uint2* const (&y8)[NYA], const u32x4* __restrict__ xh,
+                                            const uint2* __restrict__ x8, int rt, int64_t kb, int64_t ke, int lane,
+                                            float* const (&part)[NYA]) {
+    constexpr int XW = 32 * TC;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int yo = lh * YW + rt * 32 + lr;            // unit of this lane inside k-step 0 (a k-step = 2 blocks = 2 YW units)
+    const int xo = lh * XW + lr;
+    f32x16 acc[NYA][TC];
+#pragma unroll
+    for (int i = 0; i < NYA; ++i)
+#pragma unroll
+        for (int c = 0; c < TC; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][c][e] = 0.f;
+    float bsum = 0.f;
+    typedef ThinRegs<NYA, TC> Regs;
+    Regs r[TS_DEPTH];
+    // unconditional loads (a k-step past the range is clamped to the last one and not multiplied): loads under branches make
+    // the compiler's waitcnt bookkeeping fall back to vmcnt(0) (mlp_dw_h.hip)
+    auto load = [&](Regs& R, int64_t k) {
+        const int64_t kk = k < ke ? k : ke - 1;
+#pragma unroll
+        for (int i = 0; i < NYA; ++i) {
+            R.y[i] = yh[i][kk * (2 * YW) + yo];
+            R.yc[i] = y8[i][kk * (2 * YW) + yo];
+        }
+#pragma unroll
+        for (int c = 0; c < TC; ++c) {
+            R.x[c] = xh[kk * (2 * XW) + xo + c * 32];
+            R.xc[c] = x8[kk * (2 * XW) + xo + c * 32];
+        }
+    };
+    // vm: all ones for a k-step inside the range, zero past it (wave-uniform): the dY fragments of a clamped k-step are zeroed -
+    // a branch around the MFMAs instead would cost the ring its wait counts (the compiler merges them to vmcnt(0) at the join)
+    auto compute = [&](const Regs& R, uint32_t vm) {
+        half8 bh[TC], bl[TC];
+#pragma unroll
+        for (int c = 0; c < TC; ++c) {
+            bh[c] = __builtin_bit_cast(half8, R.x[c]);
+            bl[c] = h8_lo_of(R.x[c], R.xc[c]);
+        }
+#pragma unroll
+        for (int i = 0; i < NYA; ++i) {
+            const u32x4 yv = R.y[i] & vm;
+            const half8 ah = __builtin_bit_cast(half8, yv);
+            const half8 al = __builtin_bit_cast(half8, __builtin_bit_cast(u32x4, h8_lo_of(R.y[i], R.yc[i])) & vm);
+#pragma unroll
+            for (int c = 0; c < TC; ++c) acc[i][c] = mfma16(ah, bh[c], acc[i][c]);
+#pragma unroll
+            for (int c = 0; c < TC; ++c) acc[i][c] = mfma16(ah, bl[c], acc[i][c]);
+#pragma unroll
+            for (int c = 0; c < TC; ++c) acc[i][c] = mfma16(al, bh[c], acc[i][c]);
+            if (BIAS0 && i == 0) bsum += h8_sum_unit(ah, al);
+        }
+    };
+    if (kb < ke) {
+#pragma unroll
+        for (int d = 0; d < TS_DEPTH; ++d) {
+            load(r[d], kb + d);
+            // in ring order: left alone the scheduler requests stage 0 LAST, and the wait counts of the loop header (merged from
+            // this block and the loop's own back edge) degrade to vmcnt(0) - no prefetch distance left
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        for (int64_t k = kb; k < ke; k += TS_DEPTH) {
+#pragma unroll
+            for (int d = 0; d < TS_DEPTH; ++d) {
+                compute(r[d], k + d < ke ? 0xffffffffu : 0u);
+                load(r[d], k + d + TS_DEPTH);
+                __builtin_amdgcn_sched_barrier(0);      // keep the ring as written: stage d's loads stay behind its own MFMAs
+            }
+        }
+    }
+    // partial blocks at the gradient scale s_s (the reduce kernel divides it out)
+#pragma unroll
+    for (int i = 0; i < NYA; ++i) {
+#pragma unroll
+        for (int c = 0; c < TC; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) part[i][(int64_t)(rt * 32 + acc_row(e, lane)) * XW + c * 32 + lr] = acc[i][c][e];
+        float b = (BIAS0 && i == 0) ? bsum : 0.f;
+        b += __shfl_xor(b, 32);                         // the two blocks of a k-step sit in the two half waves
+        if (lh == 0) part[i][(int64_t)YW * XW + rt * 32 + lr] = b;
+    }
+}
+
+// Workgroups [0, DWH_T0): split b of L0 + L5P, wave w = row tile w; [DWH_T0, + DWH_T1 / 2): VIEWSP, two splits per workgroup (waves
+// 0-3 / 4-7, row tile w & 3); then DWH_T2 workgroups of the rgb head.
+constexpr int DWS_SMALL_BLOCKS = DWH_T0 + DWH_T1 / 2 + DWH_T2;
+static_assert(DWH_T1 % 2 == 0 && dwh_splits(DW_L0) == dwh_splits(DW_L5P), "thin split tables");
+__global__ __launch_bounds__(DWT, 2) void mlp_dw_split_small_kernel(DwArgs a) {
+    __shared__ __attribute__((aligned(16))) float rgb_smem[32 * 8 * 4 + 18 * 128];
+    DW_TRACE(0, 0);
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t Mp = m_pad(a.M);
+    const float* A = a.acts;
+    const float* D = a.dacts;
+    auto dy = [&](int64_t off) { return reinterpret_cast<const u32x4*>(D + off); };
+    auto dy8 = [&](int64_t off) { return reinterpret_cast<const uint2*>(sdact_lo8(D, Mp, off)); };
+    int64_t cb, ce;
+    if (b < DWH_T0) {
+        chunk_range(a, DW_L0, b, cb, ce);
+        const u32x4* const yh[2] = {dy(sdact_h(Mp, 0)), dy(sdact_h(Mp, 5))};
+        const uint2* const y8[2] = {dy8(sdact_h(Mp, 0)), dy8(sdact_h(Mp, 5))};
+        float* const part[2] = {a.ws + dwh_inst_offset(DW_L0) + (int64_t)b * dw_inst_floats(DW_L0),
+                                a.ws + dwh_inst_offset(DW_L5P) + (int64_t)b * dw_inst_floats(DW_L5P)};
+        thin_stream<2, 256, 2, true>(yh, y8, reinterpret_cast<const u32x4*>(A + sact22_pe_hi(Mp)),
+                                     reinterpret_cast<const uint2*>(A + sact22_pe_lo8(Mp)), wave, cb, ce, lane, part);
+    } else if (b < DWH_T0 + DWH_T1 / 2) {
+        const int split = 2 * (b - DWH_T0) + (wave >> 2);
+        chunk_range(a, DW_VIEWSP, split, cb, ce);
+        const u32x4* const yh[1] = {dy(sdact_hv(Mp))};
+        const uint2* const y8[1] = {dy8(sdact_hv(Mp))};
+        float* const part[1] = {a.ws + dwh_inst_offset(DW_VIEWSP) + (int64_t)split * dw_inst_floats(DW_VIEWSP)};
+        thin_stream<1, 128, 1, false>(yh, y8, reinterpret_cast<const u32x4*>(A + sact22_ped_hi(Mp)),
+                                      reinterpret_cast<const uint2*>(A + sact22_ped_lo8(Mp)), wave & 3, cb, ce, lane, part);
+    } else {
+        const int split = b - (DWH_T0 + DWH_T1 / 2);
+        chunk_range(a, DW_RGB, split, cb, ce);
+        dw_rgb(a, cb * CHB, ce * CHB, a.ws + dwh_inst_offset(DW_RGB) + (int64_t)split * dw_inst_floats(DW_RGB), rgb_smem);
+    }
     DW_TRACE(0, 1);
 }
 
@@ -459,16 +583,15 @@ int benerf_mlp_dw_split22_launch(int channels, int64_t M, const float* d_raw, co
     a.ws = dw_ws;
     a.M = M;
     a.C = channels;
-    static_assert(DW_L0 + 1 == DW_L5P && DW_L5P + 1 == DW_VIEWSP && DW_VIEWSP + 1 == DW_RGB, "small-kernel instance order");
-    static BenerfLdsAttr attr_big, attr_small;      // once per device
-    if (!benerf_lds_attr(attr_big, (const void*)mlp_dw_split_big_kernel, (int)DWS_SMEM) ||
-        !benerf_lds_attr(attr_small, (const void*)mlp_dw_split_small_kernel, (int)DWS_SMEM_SMALL)) {
+    static BenerfLdsAttr attr_big;      // once per device
+    if (!benerf_lds_attr(attr_big, (const void*)mlp_dw_split_big_kernel, (int)DWS_SMEM)) {
         benerf_set_error("mlp_bwd(dw, split): cannot reserve LDS");
         return BENERF_EHIP;
     }
-    hipLaunchKernelGGL(mlp_dw_split_small_kernel, dim3(mlp::DWH_SMALL_BLOCKS), dim3(DWT), DWS_SMEM_SMALL, stream, a);
+    (void)pe_weights;       // the saved encodings carry the BARF column weights already (mlp_split.h: sact22_*)
+    hipLaunchKernelGGL(mlp_dw_split_small_kernel, dim3(DWS_SMALL_BLOCKS), dim3(DWT), 0, stream, a);
     BENERF_LAUNCH_CHECK("mlp_bwd(dw small, split)");
     hipLaunchKernelGGL(mlp_dw_split_big_kernel, dim3(mlp::DWH_BIG_BLOCKS), dim3(DWT), DWS_SMEM, stream, a);
     BENERF_LAUNCH_CHECK("mlp_bwd(dw, split)");
-    return benerf_mlp_dw_reduce_launch(dw_ws, grads, channels, accumulate, 1, dacts + mlp::sdact_info(mlp::m_pad(M)), pe_weights, stream);
+    return benerf_mlp_dw_reduce_launch(dw_ws, grads, channels, accumulate, 1, dacts + mlp::sdact_info(mlp::m_pad(M)), nullptr, stream);
 }

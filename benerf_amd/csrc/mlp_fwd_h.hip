@@ -196,13 +196,14 @@ __device__ __forceinline__ uint64_t save_tile(const _Float16* __restrict__ Th, i
 // BENERF_MLP_SPLIT (SAVE == 2, the fp32-equivalent backward): the low halves leave too - as 8-bit residual codes (lo8 twin of
 // the SH array, mlp_split.h): the same transpose read on the lo plane (which holds (x - hi) * 2^11), the lane pair forms the
 // unit like the hi halves, h8_encode_unit<11> turns the 8 + 8 halfs into 8 bytes: one 8-byte store per lane.
-template <int W, bool MASK, int NBLK>
+// COL0: first plane column of the array's feature 0 (the encodings sit in columns [COL_PE, COL_PE + 64) of the planes)
+template <int W, bool MASK, int NBLK, int COL0 = 0>
 __device__ __forceinline__ void save_pair22(const _Float16* __restrict__ Th, const _Float16* __restrict__ Tl, int ct, int bp, int lane,
                                             __amdgpu_buffer_rsrc_t rs, __amdgpu_buffer_rsrc_t rs8, uint64_t& bits) {
     asm volatile("" : "+v"(lane));      // addresses recomputed per call, not hoisted out of the layer loop and spilled
     const int t = lane & 15, g = lane >> 4, hf = lane >> 5, pl = lane & 31;
     const int n = ct * 32 + pl;
-    const int col = ct * 32 + 16 * (g & 1) + 4 * (t & 3);
+    const int col = COL0 + ct * 32 + 16 * (g & 1) + 4 * (t & 3);
     const int rsub = 4 * (g >> 1) + (t >> 2);
     uint2 q[2], ql[2];
 #pragma unroll
@@ -299,13 +300,13 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
         float x[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) x[c] = __fadd_rn(a.rays_o[ray * 3 + c], __fmul_rn(a.rays_d[ray * 3 + c], zz));
-        // training: PE as f32 rows (sin/cos derivatives in dX; dW operand of the thin instances), all Mp rows.  Staged in
+        // training, SAVE == 1: PE as f32 rows (sin/cos derivatives in dX; dW operand of the thin instances), all Mp rows.  Staged in
         // the still unused columns [0,128) of this point's hi-plane row and written out below as whole 16-byte units
         // (a 4-byte store per thread and column touches 64 cache lines per instruction); the columns are rotated by
         // 4 * point so that the 64 lanes of a staging write do not all hit one bank.
         float* stage = reinterpret_cast<float*>(Th) + pt * (LD / 2);
         auto put = [&](int col, float v) {
-            if (SAVE) stage[(col + 4 * pt) & 63] = v;                // saved UNWEIGHTED (dX needs sin / cos themselves)
+            if (SAVE == 1) stage[(col + 4 * pt) & 63] = v;           // saved UNWEIGHTED (dX needs sin / cos themselves)
             if (a.pe_w) v *= a.pe_w[col];
             const _Float16 hi = (_Float16)v;
             const _Float16 lo = (_Float16)((v - (float)hi) * LO_SCALE);
@@ -331,7 +332,26 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
         }
     }
     lds_barrier();
-    if (SAVE) {
+    if (SAVE == 2) {
+        // the 22-bit backward: the encoding leaves as an SH array + lo8 twin straight from the planes' PE columns (the thin dW
+        // instances load MFMA fragments from it like from every other saved operand), and the point itself (+ its view
+        // direction) as f32 for the dX kernel, which recomputes sin / cos (mlp_split.h: sact22_*).  Wave w: column tile w & 1,
+        // block pairs 2 (w >> 1), + 1.  The PE columns stay untouched until the views stage: no barrier behind this.
+        const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(reinterpret_cast<_Float16*>(acts + sact22_pe_hi(Mp)) + m0 * ACT_PE_W);
+        const __amdgpu_buffer_rsrc_t rs8 = uniform_rsrc(reinterpret_cast<uint8_t*>(acts + sact22_pe_lo8(Mp)) + m0 * ACT_PE_W);
+        uint64_t nobits = 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) save_pair22<ACT_PE_W, false, 16, COL_PE>(Th, Tl, wave & 1, (wave >> 1) * 2 + i, lane, rs, rs8, nobits);
+        if (grp == 0) {
+            const float zz = a.z[mc];
+            float4* dst = reinterpret_cast<float4*>(acts + sact22_pts(Mp)) + m * 2;
+            dst[0] = make_float4(__fadd_rn(a.rays_o[ray * 3 + 0], __fmul_rn(a.rays_d[ray * 3 + 0], zz)),
+                                 __fadd_rn(a.rays_o[ray * 3 + 1], __fmul_rn(a.rays_d[ray * 3 + 1], zz)),
+                                 __fadd_rn(a.rays_o[ray * 3 + 2], __fmul_rn(a.rays_d[ray * 3 + 2], zz)), 0.f);
+            dst[1] = make_float4(a.viewdirs[ray * 3 + 0], a.viewdirs[ray * 3 + 1], a.viewdirs[ray * 3 + 2], 0.f);
+        }
+    }
+    if (SAVE == 1) {
         float4* pe_tile = reinterpret_cast<float4*>(acts + sact_pe32(Mp) + m0 * ACT_PE_W);
 #pragma unroll
         for (int k = 0; k < FTM * ACT_PE_W / 4 / FNT; ++k) {
@@ -415,9 +435,9 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
         float vd[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) vd[c] = a.viewdirs[ray * 3 + c];
-        float* aped = SAVE ? acts + sact_ped32(Mp) + m * ACT_PED_W : nullptr;
+        float* aped = SAVE == 1 ? acts + sact_ped32(Mp) + m * ACT_PED_W : nullptr;
         auto put = [&](int col, float v) {
-            if (SAVE) {
+            if (SAVE == 1) {
                 aped[col] = v;
             }
             if (a.pe_w) v *= a.pe_w[64 + col];
@@ -458,8 +478,16 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
     }
     lds_barrier();
     if (SAVE == 1) save_tile<1, 256, false, 16>(Th, wave, lane, reinterpret_cast<_Float16*>(acts + sact_feat(Mp)) + m0 * 256);
-    if (SAVE == 2) save_tile22<256, false, 16>(Th, Tl, wave, lane, reinterpret_cast<_Float16*>(acts + sact_feat(Mp)) + m0 * 256,
-                                               st8_h + (int64_t)8 * Mp * 256 + m0 * 256);
+    if (SAVE == 2) {
+        save_tile22<256, false, 16>(Th, Tl, wave, lane, reinterpret_cast<_Float16*>(acts + sact_feat(Mp)) + m0 * 256,
+                                    st8_h + (int64_t)8 * Mp * 256 + m0 * 256);
+        // PE(dir) (planes' columns [256,288), visible since the barrier behind the FEAT GEMM) as an SH array of width 32 + lo8
+        // twin: one block pair per wave
+        const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(reinterpret_cast<_Float16*>(acts + sact22_ped_hi(Mp)) + m0 * ACT_PED_W);
+        const __amdgpu_buffer_rsrc_t rs8 = uniform_rsrc(reinterpret_cast<uint8_t*>(acts + sact22_ped_lo8(Mp)) + m0 * ACT_PED_W);
+        uint64_t nobits = 0;
+        save_pair22<ACT_PED_W, false, 16, COL_PE>(Th, Tl, 0, wave, lane, rs, rs8, nobits);
+    }
 
     // ---- VIEWS: [feature | PE(dir)] (288) -> 128: wave w computes column tile w & 3 for the point half w >> 2 -------------
     {

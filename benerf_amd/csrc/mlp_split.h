@@ -186,6 +186,19 @@ __host__ __device__ inline const uint8_t* sact_lo8(const float* acts, int64_t Mp
     return reinterpret_cast<const uint8_t*>(acts + sact_lo8_base(Mp)) + 2 * (hi_off - sact_h(Mp, 0));
 }
 
+// BENERF_MLP_SPLIT also re-uses the two f32 regions at the head of the buffer (sact_pe32 / sact_ped32: f32 rows in the
+// BENERF_MLP_SPLIT_F16BWD layout).  The thin dW instances (X = positional encoding) want X as MFMA fragments like every other
+// operand, and the dX kernel recomputes sin / cos from the point (12 bytes) instead of reading them back (256 bytes), so:
+//   pe region  (256 B / point): SH array W = 64 of PE(pts) [128 B] | its lo8 twin [64 B] | f32 [Mp][8]: pts xyz, 0, viewdir xyz, 0 [32 B]
+//   ped region (128 B / point): SH array W = 32 of PE(dir) [64 B]  | its lo8 twin [32 B]
+// The encodings are saved AS THE FORWARD PLANES HOLD THEM (BARF column weights applied: the dW reduce must not apply them again).
+__host__ __device__ inline int64_t sact22_pe_hi(int64_t Mp) { return sact_pe32(Mp); }
+__host__ __device__ inline int64_t sact22_pe_lo8(int64_t Mp) { return sact_pe32(Mp) + Mp * 32; }
+__host__ __device__ inline int64_t sact22_pts(int64_t Mp) { return sact_pe32(Mp) + Mp * 48; }
+__host__ __device__ inline int64_t sact22_ped_hi(int64_t Mp) { return sact_ped32(Mp); }
+__host__ __device__ inline int64_t sact22_ped_lo8(int64_t Mp) { return sact_ped32(Mp) + Mp * 16; }
+static_assert(48 + 8 <= ACT_PE_W && 16 + 8 <= ACT_PED_W, "the split22 encodings fit the f32 regions");
+
 // ---- lo8 codec on packed f16 pairs (one 32-bit register = two values) ----------------------------------------------------
 typedef unsigned short h8_ushort2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h8_half2 __attribute__((ext_vector_type(2)));

@@ -14,6 +14,7 @@ Random draws follow the reference order per render: stratified j
 sigma noise (coarse), importance u, sigma noise (fine).
 """
 import math
+import os
 
 import torch
 
@@ -280,6 +281,8 @@ class TrainStep:
             benerf_amd.warn_if_few_hw_queues()
         self.seed = seed
         self.dw_stream = torch.cuda.Stream(device=device)    # weight-gradient launches (step(): backward)
+        # BENERF_DW_STREAM=main keeps them on the step's own stream (measurement knob: what the second stream buys)
+        self.dw_on_side_stream = os.environ.get("BENERF_DW_STREAM", "side") != "main"
         self.C = cfg.channels
         wc, bc = nerf_param_lists(graph.nerf)
         wf, bf = nerf_param_lists(graph.nerf_fine)
@@ -559,7 +562,8 @@ class TrainStep:
         # a second stream and run beside the other network's activation-gradient chain and the trajectory tail
         # (MFMA-bound, little HBM traffic); the two networks keep separate activation-gradient buffers for that.
         n = self.n_net
-        main, side = torch.cuda.current_stream(dev), self.dw_stream
+        main = torch.cuda.current_stream(dev)
+        side = self.dw_stream if self.dw_on_side_stream else main
         # max |d_raw| of both networks comes out of the compositing backward (the split-f16 dX chain scales by it)
         amax = self.amax
         d_raw1, _ = K.composite_bwd(raw1, z_fine, rd, nz1[0], nz1[1], nz1[2], nz1[3], g_rgb, d_rays_d=d_d, absmax_out=amax[0:1])

@@ -332,8 +332,23 @@ def _act_views(acts, M, mode="f32"):
     def sh(off, W):
         return sh1(off, W)
 
-    out["pe"] = a[0:Mp * 64].reshape(Mp, 64)[:M]
-    out["ped"] = a[Mp * 64:Mp * 96].reshape(Mp, 32)[:M]
+    if mode == "split":
+        # mlp_split.h, sact22_*: the two f32 regions hold the encodings as SH arrays + lo8 twins (19 bits, like every other saved
+        # operand) and the point / view direction as f32 [Mp][8] for the dX kernel, which recomputes sin / cos
+        raw8 = a.numpy().view(np.uint8)
+
+        def sh_at(hi_off, lo8_off, W):
+            h16 = halfs[hi_off * 2: hi_off * 2 + Mp * W]
+            code = raw8[lo8_off * 4: lo8_off * 4 + Mp * W].reshape(Mp // 8, W, 8).astype(np.float32)
+            e5 = np.maximum((h16.view(np.uint16).reshape(Mp // 8, W, 8) >> 10) & 31, 9).astype(np.float32)
+            blk = h16.reshape(Mp // 8, W, 8).astype(np.float32) + (code - 128.0) * np.exp2(e5 - 15.0 - 18.0)
+            return torch.from_numpy(np.ascontiguousarray(blk.transpose(0, 2, 1)).reshape(Mp, W)[:M])
+        out["pe"] = sh_at(0, Mp * 32, 64)
+        out["ped"] = sh_at(Mp * 64, Mp * 64 + Mp * 16, 32)
+        out["pts"] = a[Mp * 48:Mp * 56].reshape(Mp, 8)[:M]
+    else:
+        out["pe"] = a[0:Mp * 64].reshape(Mp, 64)[:M]
+        out["ped"] = a[Mp * 64:Mp * 96].reshape(Mp, 32)[:M]
     for l in range(8):
         out["h%d" % l] = sh(Mp * 96 + l * Mp * 128, 256)
     out["feat"] = sh(Mp * 96 + 8 * Mp * 128, 256)
@@ -352,8 +367,12 @@ def test_mlp_fwd_golden(K, mlp_mode, golden, C, variant, S):
     sc = float(np.abs(ref).max())
     if tag + "_h0" in g:
         av = _act_views(acts, M, mlp_mode)
-        report("K3 PE " + tag, av["pe"][:, :63], g[tag + "_pe"], atol=2e-6)
+        # split: the encoding is saved at 19 bits (relative 2^-19; the identity columns reach |x| ~ 4) - and the point itself as f32
+        report("K3 PE " + tag, av["pe"][:, :63], g[tag + "_pe"], atol=2e-6, rtol=2e-6 if mlp_mode == "split" else 0.0)
         assert float(av["pe"][:, 63].abs().max()) == 0.0
+        if mlp_mode == "split":
+            report("K3 saved point " + tag, av["pts"][:, :3], g[tag + "_pe"][:, :3], atol=2e-6)
+            assert float(av["pts"][:, 3].abs().max()) == 0.0 and float(av["pts"][:, 7].abs().max()) == 0.0
         # split mode saves the f16 operand of the backward GEMMs (11-bit significand: 2^-11 relative); the full-precision
         # forward path is what `raw` checks below
         # split: hi + 8-bit residual code = 19 bits (2e-6), held to 2e-5 - tighter than the f32 mode's 1e-4 so that a wrong code
