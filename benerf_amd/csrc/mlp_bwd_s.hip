@@ -361,8 +361,14 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
         b[1] = __builtin_amdgcn_raw_buffer_load_b32(mask_rsrc, vo + NTHREADS * 8, so, 0);
     };
     _Float16* st_dyh = reinterpret_cast<_Float16*>(dacts + sdact_h(Mp, 0));      // layer l: + l * Mp * 256 halfs
-    auto st_tile = [&](int l) { return st_dyh + ((int64_t)l * Mp + m0) * 256; };   // tile's part of layer l's SH array (hi)
-    auto st8_tile = [&](int l) { return st8 + ((int64_t)l * Mp + m0) * 256; };      // ... and of its lo8 twin
+    // timing variant (-DBWS_STORE_WINDOW=256): every tile stores into the first WINDOW points - same instructions, bytes stay in L2
+#ifdef BWS_STORE_WINDOW
+    const int64_t ms0 = m0 & (int64_t)(BWS_STORE_WINDOW - 1);
+#else
+    const int64_t ms0 = m0;
+#endif
+    auto st_tile = [&](int l) { return st_dyh + ((int64_t)l * Mp + ms0) * 256; };   // tile's part of layer l's SH array (hi)
+    auto st8_tile = [&](int l) { return st8 + ((int64_t)l * Mp + ms0) * 256; };      // ... and of its lo8 twin
     float s_g, inv_s_g;
     const float mx_call = a.absmax ? *a.absmax : dacts[sdact_info(Mp) + SD_DRAW];
     if (a.absmax && blockIdx.x == 0 && tid == 0) dacts[sdact_info(Mp) + SD_DRAW] = mx_call;   // the dW reduce reads it there
@@ -464,8 +470,8 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
     gemm3<8>(Th, Tl, packed_h + pack_offset(PB_VIEWS), ct, lane, acc);
     lds_barrier();   // dYv fully consumed; dPE(dir) visible
     {
-        _Float16* stf = reinterpret_cast<_Float16*>(dacts + sdact_feat(Mp)) + m0 * 256;
-        epilogue3<false>(acc, bits, Th, Tl, ct, lane, stf, st8 + 2 * sdact_feat(Mp) + m0 * 256, gf, amax);
+        _Float16* stf = reinterpret_cast<_Float16*>(dacts + sdact_feat(Mp)) + ms0 * 256;
+        epilogue3<false>(acc, bits, Th, Tl, ct, lane, stf, st8 + 2 * sdact_feat(Mp) + ms0 * 256, gf, amax);
     }
     if (tid < TMB && m0 + tid < M) {   // d viewdirs (per point) through PE(dir): sin / cos recomputed from the saved direction
         const int64_t m = m0 + tid;
