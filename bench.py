@@ -192,6 +192,59 @@ def power_leg(one_step, device_index, seconds):
             "note": "socket power / shader clock sampled every 10 ms over back-to-back training steps (small-kernel phases included)"}
 
 
+def hbm_traffic_leg(a, timeout_s=240):
+    """HBM bytes of the K3 launches, measured in THIS run: rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE, one pass each, with
+    --kernel-trace only - the combination the GPU guide prescribes) over two training steps of this very command
+    (`bench.py --primary-only`, same workload / batch / arithmetic mode) in a child process, reduced like tools/summarize_profile.py
+    does for the committed summaries: per launch = sum over the launch's kernels, averaged over the coarse and the fine launch;
+    FETCH_SIZE x 2 (gfx950 counts 64 B per 128-B request on wide streaming reads: MI355X_MICROARCH.md) and x 1024 (KB units).
+    Returns ({group: {"hbm_read_bytes_per_launch", "hbm_write_bytes_per_launch"}}, seconds) or (None, reason)."""
+    import collections
+    import csv
+    import glob
+    import importlib.util
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if rp is None:
+        return None, "rocprofv3 not found"
+    spec = importlib.util.spec_from_file_location("summarize_profile", os.path.join(ROOT, "tools", "summarize_profile.py"))
+    sp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sp)
+    t0 = time.perf_counter()
+    tmp = tempfile.mkdtemp(prefix="benerf_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", BENERF_BENCH_NO_PMC="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--primary-only", "--no-cpu-baseline", "--steps", "2", "--warmup", "1",
+           "--workload", a.workload, "--batch-fraction", str(a.batch_fraction), "--mlp-precision", a.mlp_precision, "--seed", str(a.seed),
+           "--n-events", str(a.n_events)]
+    tot = collections.defaultdict(lambda: collections.defaultdict(list))      # (group, part) -> counter -> per-dispatch values
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out_dir = os.path.join(tmp, counter)
+            r = subprocess.run([rp, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out_dir, "-o", "p", "--"] + cmd,
+                               cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            hits = glob.glob(os.path.join(out_dir, "**", "p_counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not hits:
+                return None, "rocprofv3 --pmc %s failed (rc %d)" % (counter, r.returncode)
+            for row in csv.DictReader(open(hits[0])):
+                c = sp.classify(row["Kernel_Name"])
+                if c and row["Counter_Name"] == counter:
+                    tot[c][counter].append(float(row["Counter_Value"]))
+    except (subprocess.TimeoutExpired, OSError, KeyError, ValueError) as e:
+        return None, "PMC leg: %s" % type(e).__name__
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    res = {}
+    for g in ("mlp_fwd", "mlp_bwd_dx", "mlp_bwd_dw"):
+        rd = sum(sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"]) for c, v in tot.items() if c[0] == g and v.get("FETCH_SIZE"))
+        wr = sum(sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"]) for c, v in tot.items() if c[0] == g and v.get("WRITE_SIZE"))
+        if rd == 0 and wr == 0:
+            return None, "no %s dispatches in the PMC passes" % g
+        res[g] = {"hbm_read_bytes_per_launch": 2 * rd * 1024, "hbm_write_bytes_per_launch": wr * 1024}
+    return res, time.perf_counter() - t0
+
+
 def split_mode(a):
     return a.mlp_precision != "f32"
 
@@ -617,7 +670,8 @@ def main():
         kern[name] = {"launches": n, "avg_ms": round(ms / n, 4), "points_per_launch": int(pts / n), "tflops_algorithmic": round(tf, 2),
                       "frac_of_mfma_peak": round(tf / peak, 4), "mfma_per_product": ex, "frac_executed": round(ex * tf / peak, 4)}
     pmc = {}
-    try:    # per-launch PMC figures of the same command from the committed rocprofv3 passes (profiles/README.md)
+    try:    # per-launch PMC figures of the same command from the committed rocprofv3 passes (profiles/README.md): MFMA utilisation,
+        # and the HBM bytes when this run cannot measure them itself
         import glob
         latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc_summary.json" % a.mlp_precision)))[-1]
         if a.workload == "C2" and world == 1 and a.batch_fraction == 1:
@@ -625,6 +679,18 @@ def main():
             pmc_src = os.path.relpath(latest, ROOT)
     except (IndexError, KeyError, OSError, ValueError):
         pmc = {}
+    # HBM traffic of the K3 launches measured by THIS run (two rocprofv3 --pmc passes over a two-step child run of this command)
+    pmc_live_note = None
+    if world == 1 and not a.primary_only and not a.oversubscribe and not os.environ.get("BENERF_BENCH_NO_PMC"):
+        torch.cuda.synchronize()
+        live, info = hbm_traffic_leg(a)
+        if live is not None:
+            for k_, v_ in live.items():
+                pmc.setdefault(k_, {}).update(v_)
+            pmc_src = "this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace) over 2 steps of `bench.py " \
+                      "--primary-only` in a child process, %.0f s" % info
+        else:
+            pmc_live_note = info
 
     def traffic_of(k):
         try:
@@ -648,6 +714,8 @@ def main():
                 "per_kernel": kern}
         if pmc:
             roof["traffic_source"] = pmc_src
+            if pmc_live_note:
+                roof["traffic_source"] += " (in-run PMC passes unavailable: %s)" % pmc_live_note
             if "mfma_util" in pmc.get(dom, {}):
                 roof["mfma_util_profiled"] = round(pmc[dom]["mfma_util"], 4)
         # whole training step against the same roof: 3 x forward FLOPs per point

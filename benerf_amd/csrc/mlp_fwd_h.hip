@@ -403,11 +403,16 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
                 for (int i = 0; i < 4; ++i) save_pair<256, true, 16>(Th, wave, (ks - (last - 1)) * 4 + i, lane, prs, pbits);
                 if (ks == last) store_bits(l - 1, pbits);
             }
-            if (SAVE == 2 && ks >= last - (FWD_SAVE_KS - 1)) {
+#ifdef FWD_SAVE_SKEW     /* timing variant: the two waves of a SIMD (w, w + 4) save in different halves of the K-loop */
+            const int first = wave >= 4 ? last - (FWD_SAVE_KS - 1) : 0;
+#else
+            const int first = last - (FWD_SAVE_KS - 1);
+#endif
+            if (SAVE == 2 && ks >= first && ks < first + FWD_SAVE_KS) {
 #pragma unroll
                 for (int i = 0; i < 8 / FWD_SAVE_KS; ++i)
-                    save_pair22<256, true, 16>(Th, Tl, wave, (ks - (last - (FWD_SAVE_KS - 1))) * (8 / FWD_SAVE_KS) + i, lane, prs, prs8, pbits);
-                if (ks == last) store_bits(l - 1, pbits);
+                    save_pair22<256, true, 16>(Th, Tl, wave, (ks - first) * (8 / FWD_SAVE_KS) + i, lane, prs, prs8, pbits);
+                if (ks == first + FWD_SAVE_KS - 1) store_bits(l - 1, pbits);
             }
         };
         acc_init_bias(acc1, bq);
