@@ -571,8 +571,14 @@ class TrainStep:
                                     absmax_out=amax[1:2])
         d_pts1, d_vp1, dacts1 = K.mlp_bwd_dx(self.net_f.packed, d_raw1.view(-1, C + 1), acts1, N, S + Ni, slot="_fine", status=st,
                                              d_raw_absmax=amax[0:1])
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
+        # Exact-f32 mode: every K3 launch is bound by the matrix pipes, so the fine network's weight gradients beside the coarse
+        # network's dX chain are pure time slicing (same span, both launches stretched: the in-step dW duration read 0.56 of the
+        # f32 roof against 0.77 alone) - they stay on the main stream; only the LAST weight-gradient launch goes to the side
+        # stream, where it hides the trajectory tail.  Split modes: the dW launch is bound by its HBM bytes and the pair runs
+        # ~3 % under the sum of its parts (profiles/r04_overlap_probe.log): both on the side stream.
+        side_f = side if K.is_split(getattr(acts1, "benerf_precision", None)) else main
+        side_f.wait_stream(main)
+        with torch.cuda.stream(side_f):
             K.mlp_bwd_dw(self.net_f.packed, d_raw1.view(-1, C + 1), acts1, dacts1, N, S + Ni, self.net_f.gviews_w,
                          self.net_f.gviews_b, False)
             # gradient exchange, bucket 1 of 3: the fine network's gradients are final - their all-reduce (RCCL over
