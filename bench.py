@@ -192,7 +192,7 @@ def power_leg(one_step, device_index, seconds):
             "note": "socket power / shader clock sampled every 10 ms over back-to-back training steps (small-kernel phases included)"}
 
 
-def hbm_traffic_leg(a, timeout_s=240):
+def hbm_traffic_leg(a, timeout_s=120):
     """HBM bytes of the K3 launches, measured in THIS run: rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE, one pass each, with
     --kernel-trace only - the combination the GPU guide prescribes) over two training steps of this very command
     (`bench.py --primary-only`, same workload / batch / arithmetic mode) in a child process, reduced like tools/summarize_profile.py
