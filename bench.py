@@ -640,10 +640,8 @@ def main():
         exact, roof_f32 = other_mode_leg("f32", F32_MFMA_PEAK_TFLOPS)
         if roof_f32 is not None and a.batch_fraction == 1:
             roof_f32["per_kernel_alone"] = kernels_alone("f32", F32_MFMA_PEAK_TFLOPS)
-            roof_f32["per_kernel_note"] = ("per_kernel: HIP-event durations inside the step - the dW launches run on a second stream beside the "
-                                           "other network's dX chain, both MFMA-bound, so those two figures include time slicing (the MFMA-busy "
-                                           "counter of a dW launch also counts the co-running dX); per_kernel_alone: the fine network's launches "
-                                           "by themselves")
+            roof_f32["per_kernel_note"] = ("per_kernel: HIP-event durations inside the step (only the last, coarse dW launch runs on the second "
+                                           "stream, beside small kernels); per_kernel_alone: the fine network's launches by themselves")
         if a.mlp_precision == "split":
             # NOT the headline: the opt-in mode whose backward GEMMs take f16 operands (round 3's default) - narrower arithmetic than
             # the reference's fp32, reported for scale only
@@ -708,9 +706,9 @@ def main():
                 "peak_note": "dense %s MFMA peak at 2.4 GHz; the K3 kernels run at the board's power cap (`power` below, "
                              "profiles/r03_power_trace.log) and are clocked at 1.7-2.1 GHz, the isolated MFMA K-loop at 1.5-1.7 GHz "
                              "(tools/hwprobe/kloop_bound.hip): DESIGN.md 4" % ("f16" if split else "f32"),
-                "per_kernel_note": "mlp_bwd_dw launches run on a second stream beside mlp_bwd_dx of the other network "
-                                   "(engine.TrainStep): the HIP-event durations of these two include that time slicing; "
-                                   "mlp_fwd, the dominant kernel, runs alone",
+                "per_kernel_note": "HIP-event durations on the launching stream; only the step's LAST weight-gradient launch (coarse network) "
+                                   "runs on the second stream, beside the small kernels of the trajectory tail (engine.TrainStep), so the six K3 "
+                                   "launches of a step add up to its duration",
                 "per_kernel": kern}
         if pmc:
             roof["traffic_source"] = pmc_src

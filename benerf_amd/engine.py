@@ -281,8 +281,14 @@ class TrainStep:
             benerf_amd.warn_if_few_hw_queues()
         self.seed = seed
         self.dw_stream = torch.cuda.Stream(device=device)    # weight-gradient launches (step(): backward)
-        # BENERF_DW_STREAM=main keeps them on the step's own stream (measurement knob: what the second stream buys)
-        self.dw_on_side_stream = os.environ.get("BENERF_DW_STREAM", "side") != "main"
+        # BENERF_DW_STREAM (measurement knob): "last" - only the LAST weight-gradient launch of the step (the coarse
+        # network's) goes to the side stream; "both" - the fine network's too, beside the coarse dX chain; "main" - none; "auto"
+        # (default) - "last" when the fine launch fills the device many times over, "both" for small per-rank batches (step())
+        mode = os.environ.get("BENERF_DW_STREAM", "auto")
+        if mode not in ("auto", "last", "both", "main"):
+            raise ValueError("BENERF_DW_STREAM must be auto, last, both or main, not %r" % mode)
+        self.dw_stream_mode = mode
+        self.dw_on_side_stream = mode != "main"
         self.C = cfg.channels
         wc, bc = nerf_param_lists(graph.nerf)
         wf, bf = nerf_param_lists(graph.nerf_fine)
@@ -571,12 +577,16 @@ class TrainStep:
                                     absmax_out=amax[1:2])
         d_pts1, d_vp1, dacts1 = K.mlp_bwd_dx(self.net_f.packed, d_raw1.view(-1, C + 1), acts1, N, S + Ni, slot="_fine", status=st,
                                              d_raw_absmax=amax[0:1])
-        # Exact-f32 mode: every K3 launch is bound by the matrix pipes, so the fine network's weight gradients beside the coarse
-        # network's dX chain are pure time slicing (same span, both launches stretched: the in-step dW duration read 0.56 of the
-        # f32 roof against 0.77 alone) - they stay on the main stream; only the LAST weight-gradient launch goes to the side
-        # stream, where it hides the trajectory tail.  Split modes: the dW launch is bound by its HBM bytes and the pair runs
-        # ~3 % under the sum of its parts (profiles/r04_overlap_probe.log): both on the side stream.
-        side_f = side if K.is_split(getattr(acts1, "benerf_precision", None)) else main
+        # At full batch two K3 launches side by side are time slicing (0.91-1.00 of the sum of their times alone,
+        # profiles/r04_overlap_probe.log: each fills the CUs' LDS or registers by itself), so the fine network's weight gradients
+        # stay on the main stream and only the LAST weight-gradient launch goes to the side stream, where it hides the trajectory
+        # tail and the loss values.  With the fine launch on the side stream too the C2 step measured 0.3 % shorter (9.07 vs 9.10 ms;
+        # the same in the exact-f32 mode) at the price of HIP-event durations that count the co-running launch (dX read 2.40 instead
+        # of 1.51 ms, the f32 dW 0.56 instead of 0.77 of its roof): not worth a roofline nobody can add up.  A small per-rank batch
+        # is different - its launches are one or two waves of workgroups, the device is not full for long and the pair does
+        # overlap: 1/8 of C2 1.45 vs 1.54 ms, C4 2.51 vs 2.70, C5 3.26 vs 3.38 - so below 2048 fine tiles (8 per CU) both go there.
+        fine_on_side = self.dw_stream_mode == "both" or (self.dw_stream_mode == "auto" and N * (S + Ni) < 2048 * 128)
+        side_f = side if fine_on_side else main
         side_f.wait_stream(main)
         with torch.cuda.stream(side_f):
             K.mlp_bwd_dw(self.net_f.packed, d_raw1.view(-1, C + 1), acts1, dacts1, N, S + Ni, self.net_f.gviews_w,
