@@ -269,9 +269,9 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
     // timing variant (tools/experiments/build_variant.sh -DFWD_STORE_WINDOW=256): every tile saves into the first WINDOW points of
     // the arrays - same instructions, the bytes stay in L2: separates the cost of ISSUING the stores from the HBM write path
 #ifdef FWD_STORE_WINDOW
-#define MS0 (m0 & (int64_t)(FWD_STORE_WINDOW - 1))
+    const int64_t ms0 = m0 & (int64_t)(FWD_STORE_WINDOW - 1);
 #else
-#define MS0 m0
+    const int64_t ms0 = m0;
 #endif
     const int64_t M = a.M;
     const int pt = tid & (FTM - 1);
@@ -344,8 +344,8 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
         // instances load MFMA fragments from it like from every other saved operand), and the point itself (+ its view
         // direction) as f32 for the dX kernel, which recomputes sin / cos (mlp_split.h: sact22_*).  Wave w: column tile w & 1,
         // block pairs 2 (w >> 1), + 1.  The PE columns stay untouched until the views stage: no barrier behind this.
-        const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(reinterpret_cast<_Float16*>(acts + sact22_pe_hi(Mp)) + MS0 * ACT_PE_W);
-        const __amdgpu_buffer_rsrc_t rs8 = uniform_rsrc(reinterpret_cast<uint8_t*>(acts + sact22_pe_lo8(Mp)) + MS0 * ACT_PE_W);
+        const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(reinterpret_cast<_Float16*>(acts + sact22_pe_hi(Mp)) + ms0 * ACT_PE_W);
+        const __amdgpu_buffer_rsrc_t rs8 = uniform_rsrc(reinterpret_cast<uint8_t*>(acts + sact22_pe_lo8(Mp)) + ms0 * ACT_PE_W);
         uint64_t nobits = 0;
 #pragma unroll
         for (int i = 0; i < 2; ++i) save_pair22<ACT_PE_W, false, 16, COL_PE>(Th, Tl, wave & 1, (wave >> 1) * 2 + i, lane, rs, rs8, nobits);
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
         }
     }
     if (SAVE == 1) {
-        float4* pe_tile = reinterpret_cast<float4*>(acts + sact_pe32(Mp) + MS0 * ACT_PE_W);
+        float4* pe_tile = reinterpret_cast<float4*>(acts + sact_pe32(Mp) + ms0 * ACT_PE_W);
 #pragma unroll
         for (int k = 0; k < FTM * ACT_PE_W / 4 / FNT; ++k) {
             const int u = tid + k * FNT, row = u >> 4, c4 = u & 15;
@@ -390,8 +390,8 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
         // weight-fragment request, so that no fragment is queued behind a store (in-order retirement), and in the gaps
         // between the MFMAs.  The next requests (the following layer's) come an epilogue later.
         uint64_t pbits = 0;
-        const __amdgpu_buffer_rsrc_t prs = uniform_rsrc(SAVE ? st_h + ((int64_t)(l - 1) * Mp + MS0) * 256 : nullptr);
-        const __amdgpu_buffer_rsrc_t prs8 = uniform_rsrc(SAVE == 2 ? st8_h + ((int64_t)(l - 1) * Mp + MS0) * 256 : nullptr);
+        const __amdgpu_buffer_rsrc_t prs = uniform_rsrc(SAVE ? st_h + ((int64_t)(l - 1) * Mp + ms0) * 256 : nullptr);
+        const __amdgpu_buffer_rsrc_t prs8 = uniform_rsrc(SAVE == 2 ? st8_h + ((int64_t)(l - 1) * Mp + ms0) * 256 : nullptr);
 #ifndef FWD_SAVE_KS
 #define FWD_SAVE_KS 8        // k-steps the SAVE == 2 work is spread over (8 block pairs per layer)
 #endif
@@ -426,9 +426,9 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
         epilogue_t<1, true, 4>(acc1, acc2, Th, Tl, wave, lane, amax);
         lds_barrier();
     }
-    if (SAVE == 1) store_bits(7, save_tile<1, 256, true, 16>(Th, wave, lane, st_h + ((int64_t)7 * Mp + MS0) * 256));
-    if (SAVE == 2) store_bits(7, save_tile22<256, true, 16>(Th, Tl, wave, lane, st_h + ((int64_t)7 * Mp + MS0) * 256,
-                                                           st8_h + ((int64_t)7 * Mp + MS0) * 256));
+    if (SAVE == 1) store_bits(7, save_tile<1, 256, true, 16>(Th, wave, lane, st_h + ((int64_t)7 * Mp + ms0) * 256));
+    if (SAVE == 2) store_bits(7, save_tile22<256, true, 16>(Th, Tl, wave, lane, st_h + ((int64_t)7 * Mp + ms0) * 256,
+                                                           st8_h + ((int64_t)7 * Mp + ms0) * 256));
 
     // ---- alpha partials (reads h7) + PE(viewdir) into columns [256,288) ---------------------------
     {
@@ -489,14 +489,14 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
         a.raw[m * (C + 1) + C] = ((p.x + p.y) + (p.z + p.w)) + a.b_alpha[0];
     }
     lds_barrier();
-    if (SAVE == 1) save_tile<1, 256, false, 16>(Th, wave, lane, reinterpret_cast<_Float16*>(acts + sact_feat(Mp)) + MS0 * 256);
+    if (SAVE == 1) save_tile<1, 256, false, 16>(Th, wave, lane, reinterpret_cast<_Float16*>(acts + sact_feat(Mp)) + ms0 * 256);
     if (SAVE == 2) {
-        save_tile22<256, false, 16>(Th, Tl, wave, lane, reinterpret_cast<_Float16*>(acts + sact_feat(Mp)) + MS0 * 256,
-                                    st8_h + (int64_t)8 * Mp * 256 + MS0 * 256);
+        save_tile22<256, false, 16>(Th, Tl, wave, lane, reinterpret_cast<_Float16*>(acts + sact_feat(Mp)) + ms0 * 256,
+                                    st8_h + (int64_t)8 * Mp * 256 + ms0 * 256);
         // PE(dir) (planes' columns [256,288), visible since the barrier behind the FEAT GEMM) as an SH array of width 32 + lo8
         // twin: one block pair per wave
-        const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(reinterpret_cast<_Float16*>(acts + sact22_ped_hi(Mp)) + MS0 * ACT_PED_W);
-        const __amdgpu_buffer_rsrc_t rs8 = uniform_rsrc(reinterpret_cast<uint8_t*>(acts + sact22_ped_lo8(Mp)) + MS0 * ACT_PED_W);
+        const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(reinterpret_cast<_Float16*>(acts + sact22_ped_hi(Mp)) + ms0 * ACT_PED_W);
+        const __amdgpu_buffer_rsrc_t rs8 = uniform_rsrc(reinterpret_cast<uint8_t*>(acts + sact22_ped_lo8(Mp)) + ms0 * ACT_PED_W);
         uint64_t nobits = 0;
         save_pair22<ACT_PED_W, false, 16, COL_PE>(Th, Tl, 0, wave, lane, rs, rs8, nobits);
     }
@@ -514,8 +514,8 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
         epilogue_t<1, true, 2>(av1, av2, Thh, Tlh, vct, lane, amax);
         lds_barrier();
         if (SAVE) {  // sign bits of hv: bit b*4 + j = point 8b + 4 (lane >> 5) + j of this half, column tile = wave & 3
-            _Float16* sthv = reinterpret_cast<_Float16*>(acts + sact_hv(Mp)) + (MS0 + vrh * 64) * ACT_HV_W;
-            const uint64_t bits = SAVE == 2 ? save_tile22<ACT_HV_W, true, 8>(Thh, Tlh, vct, lane, sthv, st8_h + (int64_t)9 * Mp * 256 + (MS0 + vrh * 64) * ACT_HV_W)
+            _Float16* sthv = reinterpret_cast<_Float16*>(acts + sact_hv(Mp)) + (ms0 + vrh * 64) * ACT_HV_W;
+            const uint64_t bits = SAVE == 2 ? save_tile22<ACT_HV_W, true, 8>(Thh, Tlh, vct, lane, sthv, st8_h + (int64_t)9 * Mp * 256 + (ms0 + vrh * 64) * ACT_HV_W)
                                             : save_tile<1, ACT_HV_W, true, 8>(Thh, vct, lane, sthv);
             reinterpret_cast<uint64_t*>(acts + sact_mask(Mp))[8 * (Mp / TM) * NTHREADS + ((int64_t)blockIdx.x * 2 + vrh) * NTHREADS + vct * 64 + lane] = bits;
         }
