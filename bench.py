@@ -679,7 +679,11 @@ def main():
         pmc = {}
     # HBM traffic of the K3 launches measured by THIS run (two rocprofv3 --pmc passes over a two-step child run of this command)
     pmc_live_note = None
-    if world == 1 and not a.primary_only and not a.oversubscribe and not os.environ.get("BENERF_BENCH_NO_PMC"):
+    # (not when this process is itself running under a profiler: nested counter collection is asking for trouble)
+    under_profiler = any(k.startswith(("ROCPROF", "ROCPROFILER", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
+    if under_profiler:
+        pmc_live_note = "this process runs under a profiler"
+    if world == 1 and not a.primary_only and not a.oversubscribe and not os.environ.get("BENERF_BENCH_NO_PMC") and not under_profiler:
         torch.cuda.synchronize()
         live, info = hbm_traffic_leg(a)
         if live is not None:
