@@ -132,10 +132,12 @@ __device__ __forceinline__ void epilogue_t(f32x16 (&acc1)[NR][NCT], f32x16 (&acc
 // NBLK = 8 that is the accumulator layout of the un-transposed 64-point product the dX kernel reads (mlp_common.h).
 // bit j = (half j of the four f16 in q != 0): two v_pk_min_u16 against 1, then three bit operations
 __device__ __forceinline__ uint32_t nonzero4(uint2 q) {
-    typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
-    const ushort2v one = {1, 1};
-    const uint32_t t0 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(ushort2v, q.x), one));
-    const uint32_t t1 = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(ushort2v, q.y), one));
+    // asm: written with __builtin_elementwise_min the compiler turns "min(x, 1)" into per-half compares and selects
+    // (v_cmp_ne_u16 + v_cndmask, ~25 VALU instructions per block pair instead of 12)
+    uint32_t t0, t1;
+    const uint32_t one = 0x00010001u;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(t0) : "v"(q.x), "v"(one));
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(t1) : "v"(q.y), "v"(one));
     const uint32_t u = t0 | (t1 << 2);            // bits 0, 16, 2, 18
     return (u | (u >> 15)) & 0xFu;
 }

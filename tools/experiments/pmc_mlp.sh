@@ -11,10 +11,20 @@ acc=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/pmc_dx/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k=r["Kernel_Name"]
-        name = "dx" if "mlp_bwd_f16" in k else "fwd" if "mlp_fwd_split" in k else "dw_big" if "dw_f16_big" in k else None
+        name = ("dx" if ("mlp_bwd_split" in k or "mlp_bwd_f16" in k) else "fwd (training launch)" if ("mlp_fwd_split_kernel<1, 2>" in k or "mlp_fwd_split_kernel<1, 1>" in k)
+                else "fwd (inference launch)" if "mlp_fwd_split_kernel<1, 0>" in k else "dw_big" if ("dw_split_big" in k or "dw_f16_big" in k)
+                else "dw_small" if ("dw_split_small" in k or "dw_f16_small" in k) else None)
         if name: acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
-for name,d in acc.items():
+for name,d in sorted(acc.items()):
+    m = {c: sum(v)/len(v) for c,v in d.items()}
     print(name)
-    for c,v in sorted(d.items()): print("   %-34s %14.0f  (n=%d)"%(c, sum(v)/len(v), len(v)))
+    for c,v in sorted(m.items()): print("   %-34s %14.0f  (n=%d)"%(c, v, len(d[c])))
+    wc = m.get("SQ_WAVE_CYCLES")
+    if wc:     # per-wave-cycle fractions (SQ_WAVE_CYCLES: resident-wave cycles summed over the chip; SQ_BUSY_CYCLES x SIMDs: cycles the kernel ran)
+        for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VMEM"):
+            if c in m: print("   %-34s %14.3f  of the waves' cycles" % (c + " / WAVE_CYCLES", m[c] / wc))
+    if "SQ_INSTS_MFMA" in m:
+        for c in ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SALU"):
+            if c in m: print("   %-34s %14.2f  per MFMA instruction" % (c, m[c] / m["SQ_INSTS_MFMA"]))
 P
 find $O -name "*.csv" | xargs rm -f
