@@ -41,8 +41,9 @@ HBM_PEAK_GBS = 8000.0
 EXECUTED_PER_PRODUCT = {"split": {"mlp_fwd": 3, "mlp_bwd_dx": 3, "mlp_bwd_dw": 3},
                         "split_f16bwd": {"mlp_fwd": 3, "mlp_bwd_dx": 2, "mlp_bwd_dw": 1}}
 # bytes per sample point the split-mode dW launch streams once (saved activations h0..h7, feature, hv and as many
-# gradients - f16 + 8-bit residual code, 3 bytes per value (split_f16bwd: one f16) -, f32 PE / PE(dir) rows, one d_raw row)
-DW_BYTES_PER_POINT = {"split": 3 * ((8 * 256 + 256 + 128) + (8 * 256 + 256 + 128)) + 4 * (64 + 32) + 8,
+# gradients - f16 + 8-bit residual code, 3 bytes per value (split_f16bwd: one f16) -, the PE / PE(dir) operands (split: saved like
+# every other operand, 3 bytes per value; split_f16bwd: f32 rows), one d_raw row)
+DW_BYTES_PER_POINT = {"split": 3 * ((8 * 256 + 256 + 128) + (8 * 256 + 256 + 128)) + 3 * (64 + 32) + 8,
                       "split_f16bwd": 2 * ((8 * 256 + 256 + 128) + (8 * 256 + 256 + 128)) + 4 * (64 + 32) + 8}
 DTYPE_NOTE = {
     "split": "f32 storage; every MLP GEMM (forward, dX, dW) as 3 f16 MFMAs on hi/lo-split operands (22-bit in flight, 19-bit saved "
@@ -86,8 +87,15 @@ def parse():
                          "without wire time")
     ap.add_argument("--batch-fraction", type=int, default=1,
                     help="render 1/F of the workload's pixels per rank (F = 8 on one GPU: the per-rank step of a strong-scaled 8-GPU run)")
+    ap.add_argument("--event-bins", type=int, default=1,
+                    help="dense event bins (BASELINE.json configs[4]; an extension, the reference has one bin per step): the event "
+                         "window is cut into B contiguous equal bins, the event pixels are rendered at the B + 1 bin boundaries, every "
+                         "bin contributes the reference's event-loss term on its pose pair (engine.TrainStep(event_bins=B))")
     ap.add_argument("--n-events", type=int, default=2_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", default="sweep",
+                    help="host threads of the cpu_baseline leg: 'sweep' (default: one warm full-size step at 16, 64 and the physical core "
+                         "count, the best is timed and reported with the sweep) or a number")
     ap.add_argument("--primary-only", action="store_true", help="timed training steps only (profiling runs): no secondary legs")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--mlp-precision", default="split", choices=["f32", "split", "split_f16bwd"],
@@ -217,7 +225,7 @@ def hbm_traffic_leg(a, timeout_s=120):
     env = dict(os.environ, TMPDIR="/tmp", BENERF_BENCH_NO_PMC="1")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--primary-only", "--no-cpu-baseline", "--steps", "2", "--warmup", "1",
            "--workload", a.workload, "--batch-fraction", str(a.batch_fraction), "--mlp-precision", a.mlp_precision, "--seed", str(a.seed),
-           "--n-events", str(a.n_events)]
+           "--n-events", str(a.n_events), "--event-bins", str(a.event_bins)]
     tot = collections.defaultdict(lambda: collections.defaultdict(list))      # (group, part) -> counter -> per-dispatch values
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -273,9 +281,28 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(wl, seed, n_steps, warm_fraction=1):
+def physical_cores():
+    """Physical cores of the host (distinct (package, core) pairs of /proc/cpuinfo); os.cpu_count() if that cannot be read."""
+    try:
+        seen, pkg = set(), None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                pkg = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                seen.add((pkg, line.split(":", 1)[1].strip()))
+        if seen:
+            return len(seen)
+    except OSError:
+        pass
+    return os.cpu_count() or 1
+
+
+def cpu_baseline(wl, seed, n_steps, warm_fraction=1, threads="sweep"):
     """Oracle training step (torch CPU) at the FULL size of workload `wl`: `n_steps` timed steps after one warm-up step
-    (the warm-up runs on 1/warm_fraction of the pixels when a full step takes many seconds)."""
+    (the warm-up runs on 1/warm_fraction of the pixels when a full step takes many seconds).
+    threads: a number, or "sweep" - after the warm-up ONE full-size step is timed at each of {16, 64, physical cores} host threads
+    (those the host has), the timed steps then run at the best count; `cores` = that count, `sweep` = what each one measured
+    ("using all host cores" - the honest baseline is the best the host does, not a guess)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import benerf_oracle as O
     import golden_inputs as GI
@@ -295,11 +322,11 @@ def cpu_baseline(wl, seed, n_steps, warm_fraction=1):
     state = [(torch.zeros_like(p), torch.zeros_like(p)) for p in params]
     ev = GI.synthetic_events(rng, cam, 200000)
     img = torch.from_numpy(rng.random((cam["H"] * cam["W"], C)).astype(np.float32))
-    times = []
-    # many small ops: a moderate thread count beats one thread per core of a 128-core host
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
-    for it in range(n_steps + 1):
-        frac = warm_fraction if it == 0 else 1
+    counter = [0]
+
+    def one(frac):
+        it = counter[0]
+        counter[0] += 1
         Re, Rr = max(w["Re"] // frac, 8), max(w["Rr"] // frac, 1)
         t0 = time.perf_counter()
         low_t = float(rng.random() * (1 - w["window"]))
@@ -316,13 +343,33 @@ def cpu_baseline(wl, seed, n_steps, warm_fraction=1):
         with torch.no_grad():
             for p, (m, v) in zip(params, state):
                 O.adam_update(p, p.grad, m, v, it + 1, 5e-4)
-        if it > 0:
-            times.append(time.perf_counter() - t0)
+        return time.perf_counter() - t0
+
+    host = os.cpu_count() or 1
+    sweep = None
+    if threads == "sweep":
+        cands = sorted({min(c, host) for c in (16, 64, physical_cores())})
+        torch.set_num_threads(cands[0])
+        one(warm_fraction)                       # warm-up: allocator, thread pool
+        sweep = {}
+        for c in cands:
+            torch.set_num_threads(c)
+            sweep[str(c)] = round(one(1), 3)
+        best = min(sweep, key=sweep.get)
+        torch.set_num_threads(int(best))
+    else:
+        torch.set_num_threads(max(1, min(int(threads), host)))
+        one(warm_fraction)
+    times = [one(1) for _ in range(n_steps)]
     rays = 2 * w["Re"] + P * w["Rr"]
-    return {"value": round(rays / (sum(times) / len(times)), 1), "unit": "rays/s", "cores": torch.get_num_threads(),
-            "host_cores": os.cpu_count(), "cpu": cpu_model(), "kind": "port", "s_per_step": round(sum(times) / len(times), 3),
-            "sample": "%d full-size step(s) of %s (%d rays/step, %d+%d samples), oracle torch-CPU step incl. backward + Adam"
-                      % (n_steps, wl, rays, S, S + Ni)}
+    out = {"value": round(rays / (sum(times) / len(times)), 1), "unit": "rays/s", "cores": torch.get_num_threads(),
+           "host_cores": host, "host_physical_cores": physical_cores(), "cpu": cpu_model(), "kind": "port",
+           "s_per_step": round(sum(times) / len(times), 3),
+           "sample": "%d full-size step(s) of %s (%d rays/step, %d+%d samples), oracle torch-CPU step incl. backward + Adam"
+                     % (n_steps, wl, rays, S, S + Ni)}
+    if sweep is not None:
+        out["sweep"] = {"s_per_step_by_threads": sweep, "note": "one warm full-size step per thread count; `cores` = the fastest, used for the timed steps"}
+    return out
 
 
 def torch_gpu_baseline(wl, seed, device):
@@ -443,16 +490,35 @@ def main():
 
     from benerf_amd import engine, workloads as WL, kernels as K
     K.set_mlp_precision(a.mlp_precision)
+    from benerf_amd import dist as D
     wl = dict(WL.WORKLOADS[a.workload])
-    # per-rank pixel counts.  weak: the workload's batch per rank (global = world x that); strong: the workload's batch IS
-    # the global batch (C4 / C5 are 8192 rays in total), every rank renders 1/world of it
-    div = a.batch_fraction * (world if a.scaling == "strong" else 1)
-    wl["Re"], wl["Rr"] = max(wl["Re"] // div, 1), max(wl["Rr"] // div, 1)
+    wl["bins"] = a.event_bins
+    # Pixel counts.  weak: the workload's batch per rank (global = world x that); strong: the workload's batch IS the global batch
+    # (C4 / C5 are 8192 rays in total) and every rank renders its contiguous share - the left-over pixels of a batch
+    # the ranks cannot split evenly (C4: 215 blur pixels over 8 ranks) go one each to the low ranks (dist.shard_bounds), nothing is
+    # dropped.  --batch-fraction F (one-GPU proxy of a strong-scaled rank): the share of rank 0 of F, i.e. the LARGEST share.
+    def share(n, parts):
+        lo, hi = D.shard_bounds(n, 0, parts, uneven=True)
+        return max(hi - lo, 1)
+    Re_n, Rr_n = share(wl["Re"], a.batch_fraction), share(wl["Rr"], a.batch_fraction)
+    if a.scaling == "strong":
+        Re_g, Rr_g = Re_n, Rr_n
+        (e0, e1), (r0, r1) = D.shard_bounds(Re_g, rank, world, uneven=True), D.shard_bounds(Rr_g, rank, world, uneven=True)
+        wl["Re"], wl["Rr"] = e1 - e0, r1 - r0
+        if min(wl["Re"], wl["Rr"]) < 1:
+            sys.exit("bench.py: rank %d would render no pixels (%d event / %d blur pixels over %d ranks)" % (rank, Re_g, Rr_g, world))
+    else:
+        wl["Re"], wl["Rr"] = Re_n, Rr_n
+        Re_g, Rr_g = Re_n * world, Rr_n * world
+    rays_global = (a.event_bins + 1) * Re_g + wl["n"] * Rr_g
     cam = WL.CAMERAS[wl["cam"]]
     args_ns = WL.make_args(wl)
     g = build_graph(args_ns, device, a.seed)     # identical on every rank (same seed)
     cam_o = engine.Camera(cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"])
-    step = engine.TrainStep(g, args_ns, cam_o, cam_o, device, world_size=world, rank=rank, process_group=pg, seed=a.seed)
+    step = engine.TrainStep(g, args_ns, cam_o, cam_o, device, world_size=world, rank=rank, process_group=pg, seed=a.seed,
+                            event_bins=a.event_bins, uneven_shards=a.scaling == "strong")
+    if world > 1 or a.rccl_loopback:
+        step.wait_events = []                    # HIP-event brackets around every wait for a gradient bucket (engine._timed_wait)
 
     # ---- synthetic inputs, resident in HBM ------------------------------------------------------------
     rng = np.random.default_rng(a.seed)
@@ -465,8 +531,7 @@ def main():
     rgb_ts = torch.tensor([0.0, 1.0], device=device)
     gen = torch.Generator(device=device)
     gen.manual_seed(a.seed + 1234)               # same pixel draws on every rank, sharded by TrainStep
-    accu = torch.zeros((cam["H"], cam["W"]), dtype=torch.float32, device=device)
-    Re_g, Rr_g = wl["Re"] * world, wl["Rr"] * world
+    accu = torch.zeros((a.event_bins, cam["H"], cam["W"]), dtype=torch.float32, device=device)
 
     # Inputs of a step - event-window accumulation (K7), window times, pixel draws - are a data loader's job: step k + 1's are
     # prepared inside step k, in TrainStep.step's `overlap` slot (main stream, behind the last backward launch, while the
@@ -479,7 +544,12 @@ def main():
         low_t = float(rng.random() * (1 - wl["window"]))
         up_t = low_t + wl["window"]
         accu.zero_()
-        K.event_window_accumulate(ev_x, ev_y, ev_p, ev_t, low_t, up_t, cam["H"], cam["W"], out=accu)
+        if a.event_bins == 1:
+            K.event_window_accumulate(ev_x, ev_y, ev_p, ev_t, low_t, up_t, cam["H"], cam["W"], out=accu[0])
+        else:       # one K7 pass per bin over the device-resident sorted stream; bin edges = the f32 linspace the poses are evaluated at
+            edges = torch.linspace(low_t, up_t, a.event_bins + 1, dtype=torch.float32).tolist()
+            for b in range(a.event_bins):
+                K.event_window_accumulate(ev_x, ev_y, ev_p, ev_t, edges[b], edges[b + 1], cam["H"], cam["W"], out=accu[b])
         evt_ts = torch.full((2,), low_t, dtype=torch.float32, device=device)      # scalars by value: no host buffer to keep alive
         evt_ts[1:].fill_(up_t)
         idx_e = K.sample_pixels(HW, Re_g, a.seed + 1234, 2 * k + 2, device)
@@ -491,7 +561,8 @@ def main():
         if not queue:
             prepare(0)
         k, evt_ts, idx_e, idx_r = queue.pop(0)
-        return step.step(evt_ts, rgb_ts, idx_e, idx_r, accu.view(-1), image, overlap=lambda: prepare(k + 1))
+        return step.step(evt_ts, rgb_ts, idx_e, idx_r, accu.view(a.event_bins, -1) if a.event_bins > 1 else accu.view(-1), image,
+                         overlap=lambda: prepare(k + 1))
 
     def sync():
         if world > 1:
@@ -522,18 +593,44 @@ def main():
         print("fwd launch ms:", " ".join("%.2f" % x[2].elapsed_time(x[3]) for x in K.TIMERS.records if x[0] == "mlp_fwd"), file=sys.stderr)
     step_ms = sorted(step_series)
     median_ms = step_ms[len(step_ms) // 2]
+    per_rank = None
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device if a.backend == "nccl" else "cpu")
+        cdev = device if a.backend == "nccl" else "cpu"
+        # every rank's own wall time and median step (HIP events) next to the MAX the metric uses: a straggler shows as a spread
+        mine = torch.tensor([dt / a.steps * 1e3, median_ms, float(WL.rays_per_step(wl))], dtype=torch.float64, device=cdev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(allr, mine)
+        rows = [x.tolist() for x in allr]
+        per_rank = {"ms_per_step_min": round(min(r[0] for r in rows), 3), "ms_per_step_max": round(max(r[0] for r in rows), 3),
+                    "median_ms_min": round(min(r[1] for r in rows), 3), "median_ms_max": round(max(r[1] for r in rows), 3),
+                    "ms_per_step_by_rank": [round(r[0], 3) for r in rows], "rays_per_step_by_rank": [int(r[2]) for r in rows]}
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+    # how long the step's streams actually stall on each gradient bucket (HIP events around the waits, rank 0; warm-up excluded)
+    bucket_wait = None
+    if step.wait_events:
+        ev_ = step.wait_events[-3 * a.steps:]
+        bucket_wait = {}
+        for nm in ("fine_net", "coarse_net", "trajectory"):
+            ts_ = [e0.elapsed_time(e1) for n_, e0, e1 in ev_ if n_ == nm]
+            if ts_:
+                bucket_wait[nm] = {"avg_ms": round(sum(ts_) / len(ts_), 4), "max_ms": round(max(ts_), 4)}
+        bucket_wait["note"] = ("HIP events around the wait for each all-reduce bucket inside the timed steps: fine_net / coarse_net on the "
+                               "weight-gradient stream (issued as soon as each network's dW reduce is done), trajectory (+ range-guard "
+                               "verdict) on the main stream before Adam; `allreduce_ms` is the three buckets alone, back to back")
+        step.wait_events = None
 
-    # ---- secondary: forward-only (inference) rays/s of the same ray batch, no activation saving ----------------------
+    # ---- secondary: forward-only (inference) rays/s: (i) the training ray batch without activation saving, (ii) chunks of
+    # args.chunk = 4096 rays of ONE pose, as Graph.render_video / render_image_test call it (model/nerf.py:353-390) - SURVEY 8d's
+    # secondary metric, with its own HIP-event per-launch durations -> `roofline_inference` ------------------------------------
     infer = None
+    roof_inf = None
     if world == 1 and not a.primary_only:
         with torch.no_grad():
             idx_e = torch.randperm(HW, device=device, generator=gen)[:wl["Re"]]
             poses = K.spline_poses_fwd(step.knots, None, torch.tensor([0.2, 0.3], device=device), 2, 0)
-            idx_all = torch.randperm(HW, device=device, generator=gen)[:WL.rays_per_step(wl) // 2]
+            idx_all = torch.randperm(HW, device=device, generator=gen)[:(2 * wl["Re"] + wl["n"] * wl["Rr"]) // 2]
             d_inf = engine.Draws(seed=a.seed, offset=12345)
             for i in range(a.steps + 2):
                 if i == 2:
@@ -543,6 +640,39 @@ def main():
             torch.cuda.synchronize()
             n_inf = 2 * idx_all.shape[0]
             infer = round(n_inf / ((time.perf_counter() - ti) / a.steps), 1)
+            # (ii) render_video's call shape
+            chunk = int(getattr(args_ns, "chunk", 4096))
+            pose1 = poses[:1].contiguous()
+            idx_c = torch.randperm(HW, device=device, generator=gen)[:chunk]
+            K.TIMERS.records.clear()
+            n_chunks = max(a.steps, 20)
+            for i in range(n_chunks + 3):
+                if i == 3:
+                    torch.cuda.synchronize()
+                    K.TIMERS.records.clear()
+                    K.TIMERS.enabled = True
+                    ti = time.perf_counter()
+                engine._render_forward(cam_o, True, wl["S"], wl["Ni"], d_inf, pose1, idx_c, step.net_c.packed, step.net_f.packed, False)
+            torch.cuda.synchronize()
+            dt_c = (time.perf_counter() - ti) / n_chunks
+            K.TIMERS.enabled = False
+            n_l, ms_l, pts_l = K.TIMERS.summary().get("mlp_fwd", (0, 0.0, 0))
+            K.TIMERS.records.clear()
+            if n_l:
+                fpp_i = WL.mlp_flops_per_point(wl["channels"])
+                pk_i = F16_MFMA_PEAK_TFLOPS if split_mode(a) else F32_MFMA_PEAK_TFLOPS
+                tf_i = pts_l * fpp_i / (ms_l * 1e-3) / 1e12
+                ex_i = 3 if split_mode(a) else 1
+                roof_inf = {"bound": "mfma", "kernel": "mlp_fwd (inference launch: no activation saving)", "achieved": round(tf_i, 2), "peak": pk_i,
+                            "unit": "TFLOP/s", "frac": round(tf_i / pk_i, 4), "frac_executed": round(ex_i * tf_i / pk_i, 4),
+                            "avg_launch_ms": round(ms_l / n_l, 4), "points_per_launch": int(pts_l / n_l), "launches": n_l,
+                            "rays_per_s": round(chunk / dt_c, 1), "ms_per_chunk": round(dt_c * 1e3, 3), "chunk_rays": chunk,
+                            "mlp_ms_per_chunk": round(ms_l / n_chunks, 3),
+                            "note": "Graph.render_video's call shape: chunks of args.chunk rays of one pose through the whole forward "
+                                    "(rays, coarse MLP, compositing, sample_pdf, fine MLP, compositing); HIP events around the two MLP "
+                                    "launches of a chunk (coarse %d + fine %d samples per ray), averaged; in the split mode an inference "
+                                    "launch is BENERF_MLP_AUTO: the split launch + the normally empty exact-f32 fallback launch"
+                                    % (wl["S"], wl["S"] + wl["Ni"])}
 
     # ---- secondary: the same training step with exact-f32 MFMA products (the strict arithmetic mode), >= 20 timed steps,
     # its own per-kernel HIP-event durations -> `exact_f32` + `roofline_f32` in the JSON line --------------------------------
@@ -626,7 +756,9 @@ def main():
                 dacts[0] = K.mlp_bwd_dx(net, d_raw, acts, N, S, status=step.guard.words)[2]
             t = {"mlp_fwd": med(lambda: K.mlp_fwd(net, ro, rd, rd, z, True, status=step.guard.words)), "mlp_bwd_dx": med(dx),
                  "mlp_bwd_dw": med(lambda: K.mlp_bwd_dw(net, d_raw, acts, dacts[0], N, S, gw, gb, False))}
-            step.guard.words.zero_()
+            from benerf_amd import _lib as L_
+            step.guard.words[:L_.ST_SKIPPED_TOTAL].zero_()      # [SKIPPED_TOTAL] stays: Adam's bias correction counts applied steps
+            step.guard.words[L_.ST_MAX_CONSECUTIVE:].zero_()
             fpp_ = WL.mlp_flops_per_point(wl["channels"])
             return {k: {"ms": round(v, 4), "points": N * S, "tflops_algorithmic": round(N * S * fpp_ / (v * 1e-3) / 1e12, 2),
                         "frac_of_mfma_peak": round(N * S * fpp_ / (v * 1e-3) / 1e12 / peak_tf, 4)} for k, v in t.items()}
@@ -650,7 +782,7 @@ def main():
                                "reference's precision, not the headline")
     other = exact["value"] if exact else None
 
-    rays_step = WL.rays_per_step(wl) * world
+    rays_step = rays_global              # what all ranks rendered per step (uneven strong-scaled shards included)
     ms_step = dt / a.steps * 1e3
     value = rays_step / (dt / a.steps)
 
@@ -708,8 +840,8 @@ def main():
                 "traffic": traffic_of(dom), "avg_launch_ms": kern[dom]["avg_ms"],
                 "flops_per_point": fpp, "points_per_launch": kern[dom]["points_per_launch"],
                 "peak_note": "dense %s MFMA peak at 2.4 GHz; the K3 kernels run at the board's power cap (`power` below, "
-                             "profiles/r03_power_trace.log) and are clocked at 1.7-2.1 GHz, the isolated MFMA K-loop at 1.5-1.7 GHz "
-                             "(tools/hwprobe/kloop_bound.hip): DESIGN.md 4" % ("f16" if split else "f32"),
+                             "profiles/r04_mfma_power_probe.log: a pure MFMA stream is clocked at 1.9 GHz by the 1400 W cap) and are clocked at "
+                             "1.7-2.1 GHz: DESIGN.md 4" % ("f16" if split else "f32"),
                 "per_kernel_note": "HIP-event durations on the launching stream; only the step's LAST weight-gradient launch (coarse network) "
                                    "runs on the second stream, beside the small kernels of the trajectory tail (engine.TrainStep), so the six K3 "
                                    "launches of a step add up to its duration",
@@ -721,7 +853,7 @@ def main():
             if "mfma_util" in pmc.get(dom, {}):
                 roof["mfma_util_profiled"] = round(pmc[dom]["mfma_util"], 4)
         # whole training step against the same roof: 3 x forward FLOPs per point
-        pts_step = rays_step / world * (wl["S"] + wl["S"] + wl["Ni"])
+        pts_step = WL.rays_per_step(wl) * (wl["S"] + wl["S"] + wl["Ni"])
         roof["step_tflops_algorithmic"] = round(pts_step * fpp * 3 / (dt / a.steps) / 1e12, 2)
         roof["step_frac_of_mfma_peak"] = round(roof["step_tflops_algorithmic"] / peak, 4)
         if split and "mlp_bwd_dw" in summ:
@@ -746,7 +878,10 @@ def main():
         "vs_baseline": None,
         "dtype": DTYPE_NOTE[a.mlp_precision],
         "data": "synthetic",
-        "config": {"workload": "%s: %s" % (a.workload, wl["name"]), "rays_per_step_per_gpu": WL.rays_per_step(wl),
+        "config": {"workload": "%s: %s%s" % (a.workload, wl["name"], "" if a.event_bins == 1 else
+                                             " + %d dense event bins (%d event poses per pixel)" % (a.event_bins, a.event_bins + 1)),
+                   "rays_global": rays_global, "event_pixels_global": Re_g, "blur_pixels_global": Rr_g, "event_bins": a.event_bins,
+                   "rays_per_step_per_gpu": WL.rays_per_step(wl),
                    "samples": "%d+%d" % (wl["S"], wl["S"] + wl["Ni"]), "channels": wl["channels"],
                    "parallelism": "dp%d" % world, "batch_fraction": a.batch_fraction,
                    "median_ms_per_step": round(median_ms, 3), "median_rays_per_s": round(rays_step / world / (median_ms * 1e-3) * world, 1),
@@ -763,19 +898,26 @@ def main():
         out["roofline"]["per_kernel_alone"] = alone
     if power and out.get("roofline"):
         out["roofline"]["power"] = power
+    if roof_inf is not None:
+        out["roofline_inference"] = roof_inf
     if comm is not None:
         out.update(comm)
+    if per_rank is not None:
+        out["per_rank"] = per_rank
+    if bucket_wait is not None:
+        out["bucket_wait"] = bucket_wait
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline and not a.primary_only:
             # the workload the metric is quoted on, full size (one step is ~10-20 s of CPU work), and C1, the reference's
             # own CPU-runnable case (BASELINE.json configs[0])
-            out["cpu_baseline"] = cpu_baseline(a.workload, a.seed, n_steps=2, warm_fraction=16)
-            out["cpu_baseline_c1"] = cpu_baseline("C1", a.seed, n_steps=3)
+            out["cpu_baseline"] = cpu_baseline(a.workload, a.seed, n_steps=2, warm_fraction=16, threads=a.cpu_threads)
+            out["cpu_baseline_c1"] = cpu_baseline("C1", a.seed, n_steps=3, threads=a.cpu_threads)
             try:
                 del step, g
                 torch.cuda.empty_cache()
                 out["torch_gpu_baseline"] = torch_gpu_baseline(a.workload, a.seed, device)
-                out["torch_gpu_baseline"]["speedup_vs_it"] = round(out["value"] / out["torch_gpu_baseline"]["value"], 2)
+                if a.event_bins == 1:      # the baselines run the reference's one-bin step
+                    out["torch_gpu_baseline"]["speedup_vs_it"] = round(out["value"] / out["torch_gpu_baseline"]["value"], 2)
             except Exception as e:   # informational leg only: never fail the bench line on it
                 out["torch_gpu_baseline"] = {"error": repr(e)[:200]}
         else:

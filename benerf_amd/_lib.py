@@ -56,6 +56,8 @@ _SIGNATURES = {
     "benerf_mlp_act_floats": (c_size_t, [c_int64]),
     "benerf_mlp_dact_floats_per_point": (c_size_t, []),
     "benerf_mlp_dact_floats": (c_size_t, [c_int64]),
+    "benerf_mlp_act_floats_for": (c_size_t, [c_int64, c_int]),
+    "benerf_mlp_dact_floats_for": (c_size_t, [c_int64, c_int]),
     "benerf_mlp_dw_workspace_floats": (c_size_t, [c_int64]),
     "benerf_mlp_fwd": (c_int, [POINTER(MlpParams), P, c_int, c_int, c_int, P, P, P, P, P, P, c_int, P, P]),
     "benerf_mlp_status_check": (c_int, [P, P]),

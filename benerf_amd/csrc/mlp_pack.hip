@@ -174,6 +174,24 @@ extern "C" size_t benerf_mlp_dact_floats(int64_t n_points) {
     const int64_t a = n_points * mlp::DACT_PER_POINT, b = mlp::sdact22_total_floats(n_points);   // sdact22 >= sdact
     return (size_t)(a > b ? a : b);
 }
+// the same two buffers sized for ONE arithmetic mode (`precision`: the K3 launch argument): the lo8 twins of BENERF_MLP_SPLIT add a
+// third to the activations and half to the gradients, which the other modes never touch.  0 for an unknown mode.
+extern "C" size_t benerf_mlp_act_floats_for(int64_t n_points, int precision) {
+    switch (precision) {
+        case BENERF_MLP_F32: return (size_t)mlp::act_total_floats(n_points);
+        case BENERF_MLP_SPLIT: return (size_t)mlp::sact22_total_floats(n_points);
+        case BENERF_MLP_SPLIT_F16BWD: return (size_t)mlp::sact_total_floats(n_points);
+        default: return 0;
+    }
+}
+extern "C" size_t benerf_mlp_dact_floats_for(int64_t n_points, int precision) {
+    switch (precision) {
+        case BENERF_MLP_F32: return (size_t)(n_points * mlp::DACT_PER_POINT);
+        case BENERF_MLP_SPLIT: return (size_t)mlp::sdact22_total_floats(n_points);
+        case BENERF_MLP_SPLIT_F16BWD: return (size_t)mlp::sdact_total_floats(n_points);
+        default: return 0;
+    }
+}
 extern "C" size_t benerf_mlp_dw_workspace_floats(int64_t n_points) {
     (void)n_points;
 #ifdef BENERF_TRACE_DW

@@ -1,8 +1,10 @@
-// Shared pieces of the split-f16 MLP kernels (mlp_fwd_h.hip, mlp_bwd_h.hip, mlp_dw_h.hip).  Forward: an f32 value x
-// is carried as two f16 numbers x = hi + lo * 2^-11 and a product block is three f16 MFMAs (hi*hi, hi*lo, lo*hi)
-// with f32 accumulation; LDS holds two f16 planes Th/Tl[128][LD] (forward: one workgroup of 8 waves per CU).  Backward (dX chain, dW): f16 operands, one MFMA
-// per product block, f32 accumulation.  16-byte LDS slots (8 halfs) are XOR-swizzled: element (row, col) lives in
-// slot (col>>3) ^ ((row>>1)&7) of its row.
+// Shared pieces of the split-f16 MLP kernels (mlp_fwd_h.hip; mlp_bwd_s.hip / mlp_dw_s.hip: BENERF_MLP_SPLIT; mlp_bwd_h.hip /
+// mlp_dw_h.hip: BENERF_MLP_SPLIT_F16BWD).  An f32 value x is carried as two f16 numbers x = hi + lo * 2^-11 and a product block
+// is THREE f16 MFMAs (hi*hi, hi*lo, lo*hi) with f32 accumulation - in the forward pass and, in BENERF_MLP_SPLIT (the default),
+// in both backward GEMMs too (dX chain: gradient and transposed weight as f16 pairs; dW: 19-bit saved operands = f16 hi +
+// 8-bit residual code).  Only the opt-in BENERF_MLP_SPLIT_F16BWD backward takes single-f16 operands (dW 1 MFMA, dX 2).
+// LDS holds two f16 planes Th/Tl[128][LD] (forward: one workgroup of 8 waves per CU).  16-byte LDS slots (8 halfs) are
+// XOR-swizzled: element (row, col) lives in slot (col>>3) ^ ((row>>1)&7) of its row.
 #pragma once
 #include "mlp_common.h"
 
@@ -138,16 +140,16 @@ __device__ __forceinline__ void load8(const _Float16* __restrict__ Th, const _Fl
 
 
 // ---- saved activations / activation gradients in split mode ("SH" arrays) -------------------------------------
-// The backward GEMMs (dX chain, dW) take f16 operands with f32 accumulation (one MFMA per product block; the forward
-// pass keeps the hi/lo split).  What the forward / dX kernels save for them is therefore the f16 value (the hi half)
-// only: an SH array of width W over Mp points stores element (m, w) at
+// What the forward / dX kernels save for the dW kernels: the f16 hi half of every value in an "SH" array (described here) and,
+// in BENERF_MLP_SPLIT, an 8-bit residual code in the array's lo8 twin (further down: 3 bytes, 19 bits per saved value; three
+// MFMAs per dW block).  BENERF_MLP_SPLIT_F16BWD saves and multiplies the hi halves only (one MFMA per block).
+// An SH array of width W over Mp points stores element (m, w) at
 //   half index  ((m >> 3) * W + w) * 8 + (m & 7)
 // i.e. blocks of 8 points, feature-major, one 16-byte unit per (block, feature) = the MFMA A/B fragment of a
 // contraction over points (dW = dY^T X), so the dW kernel copies chunks straight into LDS.  A lane of the forward /
 // dX epilogue holds 4 consecutive points of one feature = one 8-byte store; a wave covers 512 B contiguous.
 // Mp = M rounded up to 128 points (rows m >= M: copies of the last point for activations, exact zeros for gradients),
-// so no store is masked and no dW chunk is ragged.  2 bytes per element: 5.5 KB (activations + masks) + 4.9 KB
-// (gradients) per point, half of the f32 layout.
+// so no store is masked and no dW chunk is ragged.  2 bytes per element (+ 1 for the code in BENERF_MLP_SPLIT).
 constexpr int SM_PAD = 128;
 __host__ __device__ inline int64_t sh_half_index(int64_t m, int W, int w) { return ((m >> 3) * W + w) * 8 + (m & 7); }
 __host__ __device__ inline int64_t m_pad(int64_t M) { return (M + SM_PAD - 1) / SM_PAD * SM_PAD; }

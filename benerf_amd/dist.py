@@ -21,13 +21,20 @@ def _active(world):
     return world > 1 or (ALWAYS_COMMUNICATE and torch.distributed.is_initialized())
 
 
-def shard_indices(idx, rank, world):
-    """Contiguous slice [rank*n/world, (rank+1)*n/world) of a global index vector."""
-    n = idx.shape[0]
-    if n % world != 0:
+def shard_bounds(n, rank, world, uneven=False):
+    """[lo, hi) of rank `rank`'s contiguous slice of n items.  uneven: the n % world left-over items go one each to the low ranks
+    (a strong-scaled batch that the ranks cannot split evenly - C4's 215 blur pixels over 8 GPUs - is rendered whole)."""
+    if n % world != 0 and not uneven:
         raise ValueError("global batch (%d) must be divisible by world size (%d)" % (n, world))
-    per = n // world
-    return idx[rank * per:(rank + 1) * per].contiguous()
+    per, rem = divmod(n, world)
+    lo = rank * per + min(rank, rem)
+    return lo, lo + per + (1 if rank < rem else 0)
+
+
+def shard_indices(idx, rank, world, uneven=False):
+    """Contiguous slice of a global index vector for this rank (shard_bounds)."""
+    lo, hi = shard_bounds(idx.shape[0], rank, world, uneven)
+    return idx[lo:hi].contiguous()
 
 
 def _through_host(t, group):

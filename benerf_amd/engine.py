@@ -261,7 +261,24 @@ class TrainStep:
     MAX_SKIPPED_IN_A_ROW = 3     # consecutive range-guard skips after which step() raises (checked without synchronising)
     GUARD_POST_EVERY = 8         # steps between two copies of the guard's counters to the host
 
-    def __init__(self, graph, cfg, cam_rgb, cam_evt, device, world_size=1, rank=0, process_group=None, seed=0):
+    def __init__(self, graph, cfg, cam_rgb, cam_evt, device, world_size=1, rank=0, process_group=None, seed=0, event_bins=1,
+                 uneven_shards=False):
+        # Dense event bins (BASELINE.json configs[4]; SURVEY 8, note under the config table: an extension, the reference has one
+        # bin per step): the event span [evt_ts2[0], evt_ts2[1]] is cut into `event_bins` contiguous equal bins, the event batch
+        # is rendered ONCE at the event_bins + 1 bin boundaries (get_pose_evt(args, ts, seg_num=B + 1), model/optimize.py:58-82)
+        # and every bin contributes the reference's event-loss term (train.py:204-292) on its pose pair and its own accumulated
+        # polarity image; event_bins = 1 is the reference's step.
+        # uneven_shards: a global batch the ranks cannot split evenly is rendered whole - the left-over pixels go one each to the
+        # low ranks (dist.shard_bounds) - instead of being refused; the loss means use the true global counts either way
+        self.uneven_shards = bool(uneven_shards)
+        # wait_events: when a list, every wait of the main / side stream for a gradient bucket is bracketed by HIP events
+        # (bucket name, before, after) - bench.py reports how long a step actually stalls on each exchange
+        self.wait_events = None
+        self.event_bins = int(event_bins)
+        if self.event_bins < 1:
+            raise ValueError("TrainStep: event_bins must be >= 1")
+        if self.event_bins > 1 and (getattr(cfg, "optimize_event_crf", False) or getattr(cfg, "optimize_rgb_crf", False)):
+            raise NotImplementedError("TrainStep: event_bins > 1 with the CRF tone-mappers is not built (they are off in every shipped config)")
         # switches of train.py:180-352 this fused sequence does not implement are refused, not ignored
         self.use_rgb_crf = bool(getattr(cfg, "optimize_rgb_crf", False))
         self.use_evt_crf = bool(getattr(cfg, "optimize_event_crf", False))
@@ -390,7 +407,11 @@ class TrainStep:
 
     def import_optimizer_state(self, optimizers, global_step):
         """Inverse of export_optimizer_state after checkpoint.load: parameters were restored in place (they alias the
-        flat buffer); moments and the step counter come from the Adam objects; weights are re-packed."""
+        flat buffer); moments and the step counter come from the Adam objects; weights are re-packed.  Adam's `step` in the
+        checkpoint counts APPLIED steps (export_optimizer_state); the difference to the iteration count - steps the range guard
+        skipped before the checkpoint - goes back into the device's [SKIPPED_TOTAL] word, so that the resumed run's bias
+        correction continues exactly where the saved one stopped."""
+        applied = None
         for opt, _ in self._trained_optimizers(optimizers):
             for group in opt.param_groups:
                 for p in group["params"]:
@@ -400,8 +421,12 @@ class TrainStep:
                     off, n = self._flat_slice(p)
                     self.flat_m[off:off + n].copy_(st["exp_avg"].reshape(-1))
                     self.flat_v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                    if "step" in st:
+                        a_ = int(float(st["step"]))
+                        applied = a_ if applied is None else max(applied, a_)
         self.global_step = int(global_step)
-        self.guard.words[_lib.ST_SKIPPED_TOTAL:_lib.ST_SKIPPED_TOTAL + 1].zero_()     # the imported step count IS the applied count
+        skipped = 0 if applied is None else max(self.global_step - applied, 0)
+        self.guard.words[_lib.ST_SKIPPED_TOTAL:_lib.ST_SKIPPED_TOTAL + 1].fill_(skipped)
         self._prefetched = None
         self.net_c.packed.pack()
         self.net_f.packed.pack()
@@ -424,17 +449,18 @@ class TrainStep:
 
     def shard(self, idx):
         """Contiguous slice of a global pixel-index vector for this rank."""
-        return dist.shard_indices(idx, self.rank, self.world)
+        return dist.shard_indices(idx, self.rank, self.world, self.uneven_shards)
 
     def _ray_setup(self, evt_ts2, rgb_ts2, idx_e, idx_r, d):
         """Poses of both trajectories (K1), rays of both batches (K2), stratified coarse depths: everything in front of the
         first MLP launch.  idx_*: this rank's shard; d: the step's Draws."""
         cfg, dev = self.cfg, self.dev
         P, S = cfg.num_interpolated_pose, cfg.N_samples
-        Ne, Nr = 2 * idx_e.shape[0], P * idx_r.shape[0]
+        Pe = self.event_bins + 1
+        Ne, Nr = Pe * idx_e.shape[0], P * idx_r.shape[0]
         N = Ne + Nr
         traj = 1 if cfg.traj == "linear" else 0
-        poses_e, poses_r = K.spline_poses_fwd_pair(self.knots, self.transform.view(6), evt_ts2, 2, rgb_ts2, P, traj)
+        poses_e, poses_r = K.spline_poses_fwd_pair(self.knots, self.transform.view(6), evt_ts2, Pe, rgb_ts2, P, traj)
         ro = torch.empty((N, 3), dtype=torch.float32, device=dev)
         rd = torch.empty_like(ro)
         vd = torch.empty_like(ro)
@@ -444,6 +470,17 @@ class TrainStep:
         t_rand, sd, off = d.jitter_args()
         z = K.stratified_z(N, S, dev, t_rand, sd, off)
         return poses_e, poses_r, ro, rd, vd, z
+
+    def _timed_wait(self, name, handle):
+        """handle.wait() on the current stream; bracketed by events when self.wait_events is a list (bench.py)."""
+        if self.wait_events is None:
+            handle.wait()
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        handle.wait()
+        e1.record()
+        self.wait_events.append((name, e0, e1))
 
     def step(self, *args, **kwargs):
         """One training iteration: see _step for the arguments.  If anything raises between the compositing backward and the
@@ -462,7 +499,8 @@ class TrainStep:
     def _step(self, evt_ts2, rgb_ts2, idx_evt_global, idx_rgb_global, events_accu, image, draws_evt=None,
               draws_rgb=None, z_fine_forced=None, overlap=None):
         """evt_ts2/rgb_ts2: [2] device floats; idx_*_global: int64 device pixel indices (global batch,
-        identical on every rank); events_accu [H_e*W_e] float32 device; image [H*W, C] float32 device.
+        identical on every rank); events_accu [H_e*W_e] float32 device ([event_bins, H_e*W_e] with dense event bins: row b = the
+        polarity sum of bin b, K7 over [t_b, t_b+1]); image [H*W, C] float32 device.
         z_fine_forced [N, S+Ni]: parity runs may supply the merged fine depths instead of K5's (sample_pdf is
         ill-conditioned in the coarse weights: isolates everything behind it).
         overlap: optional callable, run on the main stream behind the step's last backward launch and before the step waits
@@ -481,10 +519,14 @@ class TrainStep:
         S, Ni = cfg.N_samples, cfg.N_importance
         idx_e, idx_r = self.shard(idx_evt_global), self.shard(idx_rgb_global)
         Re, Rr = idx_e.shape[0], idx_r.shape[0]
-        Ne, Nr = 2 * Re, P * Rr
+        B = self.event_bins
+        Pe = B + 1
+        Ne, Nr = Pe * Re, P * Rr
         N = Ne + Nr
         traj = 1 if cfg.traj == "linear" else 0
         step_id = self.global_step
+        if B > 1 and events_accu.numel() != B * ce_hw(self.cam_evt):
+            raise ValueError("TrainStep: event_bins = %d needs events_accu of shape [%d, H_e * W_e]" % (B, B))
 
         # ---- forward ---------------------------------------------------------------------------
         ce, cr = self.cam_evt, self.cam_rgb
@@ -515,12 +557,11 @@ class TrainStep:
         rgb_map, rgb0 = c1["rgb_map"], c0["rgb_map"]
 
         # ---- loss + gradient w.r.t. rendered colours (K6) ------------------------------------------
-        target_acc = K.gather_rows(events_accu.view(-1, 1), idx_e).view(-1)
         target_rgb = K.gather_rows(image, idx_r)
         syn = cfg.event_threshold > 0
         lcfg = K.make_loss_cfg(C, cfg.dataset.startswith("E2NeRF"), Re, Rr, P, cfg.event_threshold,
                                cfg.event_coeff_syn if syn else cfg.event_coeff_real, cfg.rgb_coeff,
-                               Re * self.world, Rr * self.world)
+                               idx_evt_global.shape[0], idx_rgb_global.shape[0])
         # args.event_loss / args.rgb_loss (train.py:201,299): a disabled term contributes neither loss nor gradient
         use_e, use_r = getattr(cfg, "event_loss", True), getattr(cfg, "rgb_loss", True)
         crf = self.use_rgb_crf or self.use_evt_crf
@@ -534,22 +575,75 @@ class TrainStep:
                     mapped.append(torch.cat([e_part, r_part], 0))
             raw_maps = (rgb_map, rgb0)
             rgb_map, rgb0 = mapped[0].detach(), mapped[1].detach()
-        largs = ((rgb_map[:Ne], rgb0[:Ne], target_acc) if use_e else (None, None, None)) + \
-                ((rgb_map[Ne:], rgb0[Ne:], target_rgb) if use_r else (None, None, None))
         # The L2-normalised event loss (train.py:238-292) needs the sums of squares - GLOBAL ones when data-parallel: a blocking
         # 16-double exchange - before its gradient.  The mean-squared losses do not: their gradients use the global COUNTS only,
         # so the gradient launch goes first and the sums + loss values follow behind the backward launches, off the critical
         # path (values are linear in the sums: every rank computes its part, the 8 numbers are summed asynchronously).
         stats_first = use_e and not syn
-        if stats_first:
-            stats = K.loss_stats(lcfg, *largs)
-            dist.allreduce_sum_(stats, self.world, self.pg)
         g_rgb = torch.empty_like(rgb_map) if (use_e and use_r) else torch.zeros_like(rgb_map)
         g_rgb0 = torch.empty_like(rgb0) if (use_e and use_r) else torch.zeros_like(rgb0)
-        losses, _ = K.loss_grads(lcfg, stats if stats_first else None, *largs,
-                                 out=((g_rgb[:Ne], g_rgb0[:Ne]) if use_e else (None, None)) + ((g_rgb[Ne:], g_rgb0[Ne:]) if use_r else (None, None)),
-                                 want_losses=stats_first)
         loss_sum = None
+        if B == 1:
+            target_acc = K.gather_rows(events_accu.view(-1, 1), idx_e).view(-1)
+            largs = ((rgb_map[:Ne], rgb0[:Ne], target_acc) if use_e else (None, None, None)) + \
+                    ((rgb_map[Ne:], rgb0[Ne:], target_rgb) if use_r else (None, None, None))
+            if stats_first:
+                stats = K.loss_stats(lcfg, *largs)
+                dist.allreduce_sum_(stats, self.world, self.pg)
+            losses, _ = K.loss_grads(lcfg, stats if stats_first else None, *largs,
+                                     out=((g_rgb[:Ne], g_rgb0[:Ne]) if use_e else (None, None)) + ((g_rgb[Ne:], g_rgb0[Ne:]) if use_r else (None, None)),
+                                     want_losses=stats_first)
+
+            def late_losses():      # loss values of the mean-squared losses: in the main stream's slack (below)
+                st_ = K.loss_stats(lcfg, *largs)
+                return K.loss_grads(lcfg, st_, *largs, want_grads=False)[0]
+        else:
+            # Dense event bins: bin b is the reference's event term (train.py:204-292) on the rendered colours of poses b (start)
+            # and b + 1 (end) - rows [b Re, (b + 2) Re) of the pose-major event batch, a contiguous view - against bin b's
+            # accumulated polarities; an interior pose collects the gradient of the two bins it bounds.  The blur term once.
+            hw = ce_hw(ce)
+            accu_b = events_accu.view(B, hw)
+            tacc = [K.gather_rows(accu_b[b].reshape(-1, 1), idx_e).view(-1) for b in range(B)] if use_e else []
+            pair = lambda t, b: t[b * Re:(b + 2) * Re]            # noqa: E731
+            none3 = (None, None, None)
+            rargs = (rgb_map[Ne:], rgb0[Ne:], target_rgb)
+            if use_e:
+                g_rgb[:Ne].zero_()
+                g_rgb0[:Ne].zero_()
+            stats_b = None
+            if stats_first:      # ONE exchange for the sums of all bins and of the blur term
+                stats_b = torch.stack([K.loss_stats(lcfg, pair(rgb_map, b), pair(rgb0, b), tacc[b], *none3) for b in range(B)] +
+                                      ([K.loss_stats(lcfg, *none3, *rargs)] if use_r else []))
+                dist.allreduce_sum_(stats_b, self.world, self.pg)
+            tmp, tmp0 = torch.empty_like(rgb_map[:2 * Re]), torch.empty_like(rgb0[:2 * Re])
+            ev_losses = []
+            for b in range(B if use_e else 0):
+                lb, _ = K.loss_grads(lcfg, stats_b[b] if stats_first else None, pair(rgb_map, b), pair(rgb0, b), tacc[b], *none3,
+                                     out=(tmp, tmp0, None, None), want_losses=stats_first)
+                pair(g_rgb, b).add_(tmp)
+                pair(g_rgb0, b).add_(tmp0)
+                ev_losses.append(lb)
+
+            def sum_losses(ev, rg):
+                """[total, event, event fine, event coarse, rgb, rgb fine, rgb coarse, 0] of the step from the per-bin vectors"""
+                out_ = torch.zeros(8, dtype=torch.float32, device=dev)
+                for lb in ev:
+                    out_[1:4] += lb[1:4]
+                if rg is not None:
+                    out_[4:7] = rg[4:7]
+                out_[0] = out_[1] + out_[4]
+                return out_
+            lr_ = None
+            if use_r:
+                lr_, _ = K.loss_grads(lcfg, stats_b[B] if stats_first else None, *none3, *rargs, out=(None, None, g_rgb[Ne:], g_rgb0[Ne:]),
+                                      want_losses=stats_first)
+            losses = sum_losses(ev_losses, lr_) if stats_first else None
+
+            def late_losses():
+                ev = [K.loss_grads(lcfg, K.loss_stats(lcfg, pair(rgb_map, b), pair(rgb0, b), tacc[b], *none3), pair(rgb_map, b),
+                                   pair(rgb0, b), tacc[b], *none3, want_grads=False)[0] for b in range(B if use_e else 0)]
+                rg = K.loss_grads(lcfg, K.loss_stats(lcfg, *none3, *rargs), *none3, *rargs, want_grads=False)[0] if use_r else None
+                return sum_losses(ev, rg)
 
         if crf:   # gradients w.r.t. the tone-mapped colours -> the rendered colours and the tone-mapper parameters
             for p_ in self.crf_params:
@@ -605,7 +699,7 @@ class TrainStep:
         K.ray_grad_reduce(z, d_pts0, d_vp0, d_o, d_d, d_v, 1)
         dp_e = K.rays_bwd(poses_e, idx_e, ce.H, ce.W, ce.fx, ce.fy, ce.cx, ce.cy, cfg.ndc, d_o[:Ne], d_d[:Ne], d_v[:Ne], remap=ce.remap)
         dp_r = K.rays_bwd(poses_r, idx_r, cr.H, cr.W, cr.fx, cr.fy, cr.cx, cr.cy, cfg.ndc, d_o[Ne:], d_d[Ne:], d_v[Ne:], remap=cr.remap)
-        dk_e, dk_r, dt_r = K.spline_poses_bwd_pair(self.knots, self.transform.view(6), evt_ts2, 2, rgb_ts2, P, traj, dp_e, dp_r)
+        dk_e, dk_r, dt_r = K.spline_poses_bwd_pair(self.knots, self.transform.view(6), evt_ts2, Pe, rgb_ts2, P, traj, dp_e, dp_r)
         torch.add(dk_e, dk_r, out=self.g_knots)
         self.g_transform.copy_(dt_r)
 
@@ -615,8 +709,7 @@ class TrainStep:
             self.guard.gate(self.flag, phase=0)
         pending.append(dist.allreduce_sum_async_(self.flat_g[2 * n:], self.world, self.pg))
         if not stats_first:      # loss values of the mean-squared losses: in the main stream's slack, like the caller's overlap work
-            stats = K.loss_stats(lcfg, *largs)
-            losses, _ = K.loss_grads(lcfg, stats, *largs, want_grads=False)
+            losses = late_losses()
             loss_sum = dist.allreduce_sum_async_(losses, self.world, self.pg)
         nxt = overlap() if overlap is not None else None
 
@@ -624,7 +717,7 @@ class TrainStep:
         # The trajectory's part comes first, still in the main stream's slack: its gradients (bucket 3) and the range guard's
         # verdict for this step (summed over the ranks) are final long before the weight-gradient stream is.  [SKIP] makes
         # every Adam launch of the step a no-op.
-        pending[2].wait()
+        self._timed_wait("trajectory", pending[2])
         self.guard.gate(self.flag if self.world > 1 else None, phase=1)
         t = self.global_step + 1
 
@@ -648,8 +741,8 @@ class TrainStep:
                                 "versions": self._param_versions() + tuple(t_._version for t_ in nxt),
                                 "rays": self._ray_setup(nxt[0], nxt[1], self.shard(nxt[2]), self.shard(nxt[3]), dn)}
         with torch.cuda.stream(side):
-            for w in pending[:2]:
-                w.wait()
+            for nm, w in zip(("fine_net", "coarse_net"), pending[:2]):
+                self._timed_wait(nm, w)
         main.wait_stream(side)
         if loss_sum is not None:
             loss_sum.wait()
@@ -663,6 +756,10 @@ class TrainStep:
         self.global_step += 1
         self.last_losses = losses
         return losses
+
+
+def ce_hw(cam):
+    return cam.H * cam.W
 
 
 def psnr(img, gt):

@@ -298,6 +298,9 @@ class RangeGuard:
         # [MAX_CONSECUTIVE]: the longest run of skipped steps since the host last cleared the counters - a run that ended between
         # two posts is seen too
         if max(h[_lib.ST_CONSECUTIVE], h[_lib.ST_MAX_CONSECUTIVE]) >= max_consecutive or h[_lib.ST_ACT] >= lim or h[_lib.ST_GRAD] >= lim:
+            # re-arm: the longest-run word is only cleared by the host; a caller that catches the error and trains on must not be
+            # told about the SAME run at every later post (queued on this stream, behind the step that raised)
+            self.words[_lib.ST_MAX_CONSECUTIVE:_lib.ST_MAX_CONSECUTIVE + 1].zero_()
             self._raise(h)
 
     def check(self, reset=True):
@@ -429,7 +432,7 @@ def mlp_fwd(net, rays_o, rays_d, viewdirs, z, save_acts, precision=None, status=
     raw = _new((n_rays, n_samples, C + 1), z)
     acts = None
     if save_acts:
-        acts = torch.empty(lib.benerf_mlp_act_floats(n_rays * n_samples), dtype=torch.float32, device=z.device)
+        acts = torch.empty(lib.benerf_mlp_act_floats_for(n_rays * n_samples, MLP_PRECISIONS[mode]), dtype=torch.float32, device=z.device)
         acts.benerf_precision = mode
         acts.benerf_pe_weights = net.pe_weights       # the backward of THIS forward uses the same column weights
     s = net.struct()
@@ -468,7 +471,7 @@ def mlp_bwd_dx(net, d_raw, acts, n_rays, n_samples, slot="", status=None, d_raw_
     M = n_rays * n_samples
     dev = d_raw.device
     code = MLP_PRECISIONS[getattr(acts, "benerf_precision", _default_precision)]
-    dacts = scratch("dacts" + slot, lib.benerf_mlp_dact_floats(M), dev)
+    dacts = scratch("dacts" + slot, lib.benerf_mlp_dact_floats_for(M, code), dev)
     d_pts = torch.empty((M, 3), dtype=torch.float32, device=dev)
     d_vd = torch.empty((M, 3), dtype=torch.float32, device=dev)
     pe_w = getattr(acts, "benerf_pe_weights", net.pe_weights)

@@ -204,8 +204,15 @@ class Graph(nn.Module):
 
     def forward(self, iter_step, events, rgb_exp_ts, H, W, K, K_event, args, img_xy_remap, evt_xy_remap):
         """One training iteration's rendering (model/nerf.py:160-234): event-window accumulation,
-        two trajectory queries, two renders.  Same return tuple as the reference."""
+        two trajectory queries, two renders.  Same return tuple as the reference.
+        Extension (BASELINE.json configs[4], "dense event bins"; the reference has one bin): with args.event_bins = B > 1 the
+        selected window is cut into B contiguous equal bins - events_accu becomes [B, H_e, W_e] (bin b: K7 over [t_b, t_b+1]),
+        the event batch is rendered at the B + 1 bin boundaries (get_pose_evt(args, ts, seg_num=B + 1)) and ret_event holds
+        (B + 1) * sampling_event_rays rows, pose-major: bin b's start / end colours are rows [b R, (b + 1) R) / [(b + 1) R, (b + 2) R)."""
         dev = self._device()
+        bins = int(getattr(args, "event_bins", 1))
+        if bins > 1 and not args.event_time_window:
+            raise NotImplementedError("event_bins > 1 cuts a TIME window into bins: needs args.event_time_window")
         ev = self._events_on_device(events, args.dataset == "TUM_VIE")
         He, We = args.event_height, args.event_width
         if args.event_time_window:
@@ -217,7 +224,12 @@ class Graph(nn.Module):
                 low_t = np.random.randint((1 - window_t) // window_t) * window_t
                 upper_t = np.min((low_t + window_t, 1.0))
             lo, up = float(np.asarray(low_t).reshape(-1)[0]), float(np.asarray(upper_t).reshape(-1)[0])
-            accu = K_.event_window_accumulate(ev["x"], ev["y"], ev["p"], ev["ts"], lo, up, He, We)
+            if bins == 1:
+                accu = K_.event_window_accumulate(ev["x"], ev["y"], ev["p"], ev["ts"], lo, up, He, We)
+            else:   # bin boundaries = the float32 linspace the trajectory kernel evaluates the B + 1 event poses at
+                edges = torch.linspace(lo, up, bins + 1, dtype=torch.float32).tolist()
+                accu = torch.stack([K_.event_window_accumulate(ev["x"], ev["y"], ev["p"], ev["ts"], edges[b], edges[b + 1], He, We)
+                                    for b in range(bins)])
             events_ts = np.stack((low_t, upper_t)).reshape(2)
         else:
             num = len(events["pol"])
@@ -232,7 +244,7 @@ class Graph(nn.Module):
             events_ts = ts_np[lo_i:hi_i][np.array([0, int(N_window) - 1])]
         events_accu = accu.double()    # the reference returns float64 (utils/event_utils.py:256-257)
 
-        spline_evt_poses = self.get_pose_evt(args, torch.tensor(events_ts, dtype=torch.float32))
+        spline_evt_poses = self.get_pose_evt(args, torch.tensor(events_ts, dtype=torch.float32), seg_num=None if bins == 1 else bins + 1)
         spline_rgb_poses = self.get_pose_rgb(args, torch.tensor(rgb_exp_ts, dtype=torch.float32))
 
         ray_idx_event = torch.randperm(He * We, device=dev)[:args.sampling_event_rays]

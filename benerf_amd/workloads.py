@@ -48,8 +48,9 @@ def make_args(wl, **over):
 
 
 def rays_per_step(wl):
+    """rays one step renders: (event bins + 1) event poses x Re pixels + n blur poses x Rr pixels (one bin = the reference's step)"""
     w = WORKLOADS[wl] if isinstance(wl, str) else wl
-    return 2 * w["Re"] + w["n"] * w["Rr"]
+    return (w.get("bins", 1) + 1) * w["Re"] + w["n"] * w["Rr"]
 
 
 def mlp_flops_per_point(channels):

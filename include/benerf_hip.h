@@ -148,6 +148,11 @@ size_t benerf_mlp_dact_floats_per_point(void);
 /* floats of the activation-gradient scratch for n_points (valid for either arithmetic mode; >= n_points *
  * benerf_mlp_dact_floats_per_point()) */
 size_t benerf_mlp_dact_floats(int64_t n_points);
+/* The same two buffers sized for ONE arithmetic mode (`precision`: BENERF_MLP_F32 / _SPLIT / _SPLIT_F16BWD below): the 8-bit
+ * residual twins of BENERF_MLP_SPLIT add a third to the saved activations and a half to the gradients, which the other modes
+ * never touch (at C5, 2.1 M points and two networks, several GB).  Returns 0 for an unknown mode. */
+size_t benerf_mlp_act_floats_for(int64_t n_points, int precision);
+size_t benerf_mlp_dact_floats_for(int64_t n_points, int precision);
 /* floats of the weight-gradient partial-sum workspace for n_points */
 size_t benerf_mlp_dw_workspace_floats(int64_t n_points);
 /* One size query for every caller-owned buffer of a render + backward over n_points = n_rays * n_samples sample points

@@ -654,3 +654,39 @@ def step_loss(cfg, p_coarse, p_fine, knots, transform, evt_ts, rgb_ts, idx_evt, 
     if want_extras:
         parts["extras_evt"], parts["extras_rgb"] = ex_e, ex_r
     return loss, parts
+
+
+def event_loss_binned(rgb_evt, rgb0_evt, n_pix, target_acc_bins, channels, dataset, threshold, coeff_syn, coeff_real):
+    """Dense event bins (BASELINE.json configs[4]; an extension - the reference has ONE bin per step): the event batch is
+    rendered at B + 1 poses (pose-major rows [(B + 1) n_pix, C]); bin b contributes the reference's event term
+    (train.py:204-292, `event_loss` above) on the colours of poses b (start) and b + 1 (end) against its own accumulated
+    polarities target_acc_bins[b] [n_pix, 1].  B = 1 is `event_loss`.  Returns (sum, fine sum, coarse sum)."""
+    tot = fine = coarse = 0.0
+    for b in range(len(target_acc_bins)):
+        rows = slice(b * n_pix, (b + 2) * n_pix)
+        t, f, c = event_loss(rgb_evt[rows], rgb0_evt[rows], n_pix, target_acc_bins[b], channels, dataset, threshold, coeff_syn,
+                             coeff_real)
+        tot, fine, coarse = tot + t, fine + f, coarse + c
+    return tot, fine, coarse
+
+
+def step_loss_binned(cfg, p_coarse, p_fine, knots, transform, evt_ts, n_bins, rgb_ts, idx_evt, idx_rgb, target_acc_bins, target_rgb,
+                     draws_evt, draws_rgb, exact_pdf=False, z_forced_evt=None, z_forced_rgb=None):
+    """`step_loss` with dense event bins: the span evt_ts = (t_0, t_B) cut into n_bins contiguous equal bins, ONE event render
+    at the n_bins + 1 boundaries (get_pose_evt(args, ts, seg_num = B + 1): linspace, model/optimize.py:58-82), the event
+    term of every bin, the blur term once.  draws_evt: the draws of the (n_bins + 1) * R event rays, pose-major.  Equals the
+    sum over bins of step_loss's event part on (t_b, t_b+1) with the draws of poses b, b + 1, plus one blur part
+    (tests/test_oracle_golden.py checks exactly that)."""
+    K = cfg.K()
+    poses_e = trajectory_poses(knots, None, evt_ts, n_bins + 1, cfg.traj)
+    poses_r = trajectory_poses(knots, transform, rgb_ts, cfg.n_poses, cfg.traj)
+    ret_e, ex_e = render(p_coarse, p_fine, poses_e, idx_evt, cfg.H, cfg.W, K, cfg.channels, cfg.n_samples, cfg.n_importance,
+                         draws_evt, exact_pdf=exact_pdf, z_forced=z_forced_evt, want_extras=True)
+    ret_r, ex_r = render(p_coarse, p_fine, poses_r, idx_rgb, cfg.H, cfg.W, K, cfg.channels, cfg.n_samples, cfg.n_importance,
+                         draws_rgb, exact_pdf=exact_pdf, z_forced=z_forced_rgb, want_extras=True)
+    le, le_f, le_c = event_loss_binned(ret_e["rgb_map"], ret_e["rgb0"], idx_evt.shape[0], target_acc_bins, cfg.channels, cfg.dataset,
+                                       cfg.threshold, cfg.coeff_syn, cfg.coeff_real)
+    lr_, lr_f, lr_c = blur_loss(ret_r["rgb_map"], ret_r["rgb0"], target_rgb, cfg.n_poses, cfg.rgb_coeff)
+    return le + lr_, {"event": le, "event_fine": le_f, "event_coarse": le_c, "rgb": lr_, "rgb_fine": lr_f, "rgb_coarse": lr_c,
+                      "ret_event": ret_e, "ret_rgb": ret_r, "extras_evt": ex_e, "extras_rgb": ex_r}
+

@@ -96,7 +96,7 @@ def step_grads(cfg, pc, pf, knots, transform, evt_ts, rgb_ts, idx_evt, idx_rgb, 
 
 
 def step_grads_vjp(cfg, pc, pf, knots, transform, evt_ts, rgb_ts, idx_evt, idx_rgb, target_acc, target_rgb, draws_evt, draws_rgb,
-                   dtype=torch.float32, n_chunks=8):
+                   dtype=torch.float32, n_chunks=8, event_bins=1):
     """One training step's loss and gradients in `dtype`, in pixel chunks, for ANY loss - also the L2-normalised event loss
     (train.py:238-292), which is not a sum over pixels and which step_grads therefore refuses to chunk.  Two passes:
       1. without autograd, chunk by chunk: the four rendered colour arrays (rgb_map / rgb0 of the event and of the blur render)
@@ -107,6 +107,7 @@ def step_grads_vjp(cfg, pc, pf, knots, transform, evt_ts, rgb_ts, idx_evt, idx_r
     chunk's rays and the parameters only).  Returns the dict of step_grads."""
     Re, Rr, P, C = idx_evt.shape[0], idx_rgb.shape[0], cfg.n_poses, cfg.channels
     S, F = cfg.n_samples, cfg.n_samples + cfg.n_importance
+    Pe = event_bins + 1
     K = cfg.K()
     with default_dtype(dtype):
         leaf = lambda t: t.detach().to(dtype).clone().requires_grad_(True)   # noqa: E731
@@ -114,15 +115,15 @@ def step_grads_vjp(cfg, pc, pf, knots, transform, evt_ts, rgb_ts, idx_evt, idx_r
         qf = {k: leaf(v) for k, v in pf.items()}
         kn, tr = leaf(knots), leaf(transform)
         z_out = {k: tuple(torch.empty(shape, dtype=torch.float32) for shape in ((n, S), (n, F)))
-                 for k, n in (("evt", 2 * Re), ("rgb", P * Rr))}
-        col = {k: torch.empty((n, C), dtype=dtype) for k, n in (("e1", 2 * Re), ("e0", 2 * Re), ("r1", P * Rr), ("r0", P * Rr))}
+                 for k, n in (("evt", Pe * Re), ("rgb", P * Rr))}
+        col = {k: torch.empty((n, C), dtype=dtype) for k, n in (("e1", Pe * Re), ("e0", Pe * Re), ("r1", P * Rr), ("r0", P * Rr))}
         eb = np.linspace(0, Re, n_chunks + 1).astype(int)
         rb = np.linspace(0, Rr, n_chunks + 1).astype(int)
 
         def renders(c, forced):
             e0, e1, r0, r1 = int(eb[c]), int(eb[c + 1]), int(rb[c]), int(rb[c + 1])
-            rows_e, rows_r = pose_major_rows(2, Re, e0, e1), pose_major_rows(P, Rr, r0, r1)
-            poses_e = O.trajectory_poses(kn, None, evt_ts.to(dtype), 2, cfg.traj)
+            rows_e, rows_r = pose_major_rows(Pe, Re, e0, e1), pose_major_rows(P, Rr, r0, r1)
+            poses_e = O.trajectory_poses(kn, None, evt_ts.to(dtype), Pe, cfg.traj)
             poses_r = O.trajectory_poses(kn, tr, rgb_ts.to(dtype), P, cfg.traj)
             zf_e = zf_r = None
             if forced:
@@ -143,8 +144,12 @@ def step_grads_vjp(cfg, pc, pf, knots, transform, evt_ts, rgb_ts, idx_evt, idx_r
                     z_out[key][0][rows] = ex["z_coarse"].float()
                     z_out[key][1][rows] = ex["z_fine"].float()
         lv = {k: v.clone().requires_grad_(True) for k, v in col.items()}
-        le, _, _ = O.event_loss(lv["e1"], lv["e0"], Re, target_acc.to(torch.float64), C, cfg.dataset, cfg.threshold, cfg.coeff_syn,
-                                cfg.coeff_real)
+        if event_bins == 1:
+            le, _, _ = O.event_loss(lv["e1"], lv["e0"], Re, target_acc.to(torch.float64), C, cfg.dataset, cfg.threshold, cfg.coeff_syn,
+                                    cfg.coeff_real)
+        else:
+            le, _, _ = O.event_loss_binned(lv["e1"], lv["e0"], Re, [t.to(torch.float64) for t in target_acc], C, cfg.dataset,
+                                           cfg.threshold, cfg.coeff_syn, cfg.coeff_real)
         lr_, _, _ = O.blur_loss(lv["r1"], lv["r0"], target_rgb.to(dtype), P, cfg.rgb_coeff)
         loss = le + lr_
         loss.backward()

@@ -19,9 +19,9 @@ def pytest_configure(config):
 
 @pytest.fixture(params=["split", "f32"])
 def mlp_precision(request):
-    """Runs a GPU test under both MFMA arithmetic modes of the fused MLP kernels (include/benerf_hip.h): 'split' (forward: 3 x f16
-    MFMA on hi/lo operands; backward: f16 operands; f32 accumulate; the default) and 'f32' (exact f32 MFMA).  Forward
-    tolerances are identical; a test that gives the split backward a different gradient tolerance says so where it does."""
+    """Runs a GPU test under both MFMA arithmetic modes of the fused MLP kernels (include/benerf_hip.h): 'split' (the default:
+    every GEMM - forward, dX chain, dW - as 3 f16 MFMAs on hi/lo operands, 22 bits in flight, 19-bit saved operands, f32
+    accumulate) and 'f32' (exact f32 MFMA).  Both modes are held to the same tolerances everywhere."""
     from benerf_amd import kernels
     kernels.set_mlp_precision(request.param)
     REPORT.append("---- mlp precision: %s (%s)" % (request.param, request.node.name))

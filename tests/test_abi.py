@@ -42,6 +42,13 @@ def test_size_queries(lib):
         assert lib.benerf_mlp_act_floats(m) == max(f32_act(m), split_act(m))
         mp = (m + 127) // 128 * 128
         assert lib.benerf_mlp_dact_floats(m) == max(m * (8 * 256 + 256 + 128), mp * (9 * 256 + 128) // 2 + 16 + mp * (9 * 256 + 128) // 4)
+        # per-mode sizes (precision codes of include/benerf_hip.h: F32 0, SPLIT 1, AUTO 2, SPLIT_F16BWD 3)
+        assert lib.benerf_mlp_act_floats_for(m, 0) == f32_act(m) and lib.benerf_mlp_act_floats_for(m, 1) == split_act(m)
+        assert lib.benerf_mlp_act_floats_for(m, 3) == split_act(m) - mp * (9 * 256 + 128) // 4
+        assert lib.benerf_mlp_dact_floats_for(m, 0) == m * (8 * 256 + 256 + 128)
+        assert lib.benerf_mlp_dact_floats_for(m, 1) == mp * (9 * 256 + 128) // 2 + 16 + mp * (9 * 256 + 128) // 4
+        assert lib.benerf_mlp_dact_floats_for(m, 3) == mp * (9 * 256 + 128) // 2 + 16
+        assert lib.benerf_mlp_act_floats_for(m, 2) == 0 and lib.benerf_mlp_dact_floats_for(m, 7) == 0
     assert lib.benerf_mlp_dact_floats_per_point() == 8 * 256 + 256 + 128
     assert lib.benerf_mlp_packed_floats() > 2 * 593920 - 200000
     assert lib.benerf_mlp_dw_workspace_floats(1000) > 0

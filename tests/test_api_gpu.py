@@ -198,7 +198,7 @@ def me_mode():
     return K.get_mlp_precision()
 
 
-def _dp_worker(rank, world, port, out_q, mode, base="C5"):
+def _dp_worker(rank, world, port, out_q, mode, base="C5", bins=1, uneven=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -219,26 +219,30 @@ def _dp_worker(rank, world, port, out_q, mode, base="C5"):
     cam = WL.CAMERAS[wl["cam"]]
     _, g = me._graph(args, seed=11 + 100 * rank)      # replicas initialise DIFFERENTLY: TrainStep broadcasts rank 0's parameters
     cam_o = engine.Camera(cam["H"], cam["W"], cam["fx"], cam["fy"], cam["cx"], cam["cy"])
-    step = engine.TrainStep(g, args, cam_o, cam_o, torch.device(DEV), world_size=world, rank=rank, process_group=pg)
+    step = engine.TrainStep(g, args, cam_o, cam_o, torch.device(DEV), world_size=world, rank=rank, process_group=pg, event_bins=bins,
+                            uneven_shards=uneven)
     rng = np.random.default_rng(2)
     HW = cam["H"] * cam["W"]
-    idx_e = torch.from_numpy(rng.permutation(HW)[:32]).to(DEV)
-    idx_r = torch.from_numpy(rng.permutation(HW)[:4]).to(DEV)
-    accu = torch.from_numpy(rng.integers(-3, 4, HW).astype(np.float32)).to(DEV)
+    n_e, n_r = (31, 5) if uneven else (32, 4)      # uneven: a global batch the ranks cannot split evenly (low ranks take one more)
+    idx_e = torch.from_numpy(rng.permutation(HW)[:n_e]).to(DEV)
+    idx_r = torch.from_numpy(rng.permutation(HW)[:n_r]).to(DEV)
+    accu = torch.from_numpy(rng.integers(-3, 4, HW if bins == 1 else (bins, HW)).astype(np.float32)).to(DEV)
     img = torch.from_numpy(rng.random((HW, 3)).astype(np.float32)).to(DEV)
     # explicit draws for the GLOBAL batch; each rank takes the rows of its pixels (pose-major)
     P, S, Ni = 5, 16, 16
-    d_e, d_r = GI.render_draws(rng, 2 * 32, S, Ni), GI.render_draws(rng, P * 4, S, Ni)
+    Pe = bins + 1       # dense event bins: the event batch is rendered at the bins + 1 boundaries
+    d_e, d_r = GI.render_draws(rng, Pe * n_e, S, Ni), GI.render_draws(rng, P * n_r, S, Ni)
 
     def shard(d, n_poses, n_pix):
-        per = n_pix // world
-        sel = torch.cat([torch.arange(p * n_pix + rank * per, p * n_pix + (rank + 1) * per) for p in range(n_poses)])
+        from benerf_amd import dist
+        lo, hi = dist.shard_bounds(n_pix, rank, world, uneven)
+        sel = torch.cat([torch.arange(p * n_pix + lo, p * n_pix + hi) for p in range(n_poses)])
         return engine.Draws(*(d[k][sel].to(DEV) for k in ("t_rand", "noise0", "u", "noise1")))
 
     losses = step.step(torch.tensor([0.2, 0.45], device=DEV), torch.tensor([0.0, 1.0], device=DEV), idx_e, idx_r, accu, img,
-                       shard(d_e, 2, 32), shard(d_r, P, 4))
+                       shard(d_e, Pe, n_e), shard(d_r, P, n_r))
     torch.cuda.synchronize()
-    if world > 1:   # a global batch the ranks cannot split evenly is refused, not silently truncated
+    if world > 1 and not uneven:   # a global batch the ranks cannot split evenly is refused (unless uneven_shards), not silently truncated
         with pytest.raises(ValueError):
             step.step(torch.tensor([0.2, 0.45], device=DEV), torch.tensor([0.0, 1.0], device=DEV), idx_e[:31], idx_r, accu, img)
     result = (losses.cpu().numpy(), step.flat_g.cpu().numpy(), step.flat_p.cpu().numpy())
@@ -250,7 +254,7 @@ def _dp_worker(rank, world, port, out_q, mode, base="C5"):
         if rank == world - 1:
             step.guard.words[_lib.ST_ACT] = 0x7f800000
         step.step(torch.tensor([0.2, 0.45], device=DEV), torch.tensor([0.0, 1.0], device=DEV), idx_e, idx_r, accu, img,
-                  shard(d_e, 2, 32), shard(d_r, P, 4))
+                  shard(d_e, Pe, n_e), shard(d_r, P, n_r))
         torch.cuda.synchronize()
         assert torch.equal(step.flat_p, p_before) and torch.equal(step.flat_m, m_before), "rank %d did not skip the step" % rank
         w = step.guard.words.cpu().tolist()
@@ -266,12 +270,14 @@ def test_sharded_step_equals_single_rank():
     parameters of the sharded step equal the single-rank step on the same global batch; replicas start from rank 0's
     parameters whatever their own initialisation; uneven global batches are rejected."""
     ctx = mp.get_context("spawn")
-    for base, worlds in (("C5", (1, 2, 4)), ("C4", (1, 2))):
+    # third leg: dense event bins (3 bins = 4 event poses, one stacked exchange of all bins' sums for the normalised loss)
+    # fourth leg: uneven shards (31 event / 5 blur pixels over 2 and 4 ranks, TrainStep(uneven_shards=True): nothing dropped)
+    for base, worlds, bins, uneven in (("C5", (1, 2, 4), 1, False), ("C4", (1, 2), 1, False), ("C5", (1, 2), 3, False), ("C5", (1, 2, 4), 1, True)):
         res = {}
         for world in worlds:
             q = ctx.Queue()
-            port = 29650 + world + (os.getpid() % 100) + (10 if base == "C4" else 0)
-            procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q, me_mode(), base)) for r in range(world)]
+            port = 29650 + world + (os.getpid() % 100) + (10 if base == "C4" else 0) + (20 if bins > 1 else 0) + (30 if uneven else 0)
+            procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q, me_mode(), base, bins, uneven)) for r in range(world)]
             for p in procs:
                 p.start()
             res[world] = q.get(timeout=300)
@@ -281,6 +287,7 @@ def test_sharded_step_equals_single_rank():
         l1, g1, p1 = res[1]
         for world in worlds[1:]:
             l2, g2, p2 = res[world]
+            base = base.split("/")[0] + ("" if bins == 1 else "/%d bins" % bins) + ("/uneven" if uneven else "")
             report("DP %s loss (%d ranks vs 1)" % (base, world), l2, l1, atol=1e-6, rtol=1e-5)
             # both modes: only the summation order differs (the split mode's per-rank gradient scales are powers of two)
             report("DP %s flat gradient (%d ranks vs 1)" % (base, world), g2, g1, atol=2e-6 * float(np.abs(g1).max()), rtol=1e-4)

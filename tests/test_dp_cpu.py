@@ -50,7 +50,7 @@ def _local_backward(O, rgb_e, rgb0_e, tgt_acc, rgb_r, rgb0_r, tgt_rgb, C, datase
     torch.autograd.backward(outs, grads)
 
 
-def _worker(rank, world, port, thr, q):
+def _worker(rank, world, port, thr, q, Rr_g=8, uneven=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import benerf_oracle as O
@@ -60,7 +60,7 @@ def _worker(rank, world, port, thr, q):
     torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
     rng = np.random.default_rng(0)           # identical on every rank
-    C, P, Re_g, Rr_g, dataset = 3, 5, 16, 8, "E2NeRF_Real" if thr <= 0 else "BeNeRF_Unreal"
+    C, P, Re_g, dataset = 3, 5, 16, "E2NeRF_Real" if thr <= 0 else "BeNeRF_Unreal"
     W = torch.from_numpy(rng.standard_normal((C, 8)).astype(np.float32)).requires_grad_(True)   # stand-in "network"
     feat_e = torch.from_numpy(rng.standard_normal((2, Re_g, 8)).astype(np.float32))
     feat_r = torch.from_numpy(rng.standard_normal((P, Rr_g, 8)).astype(np.float32))
@@ -70,8 +70,8 @@ def _worker(rank, world, port, thr, q):
     def render(feat):     # [poses, pixels, 8] -> pose-major [poses*pixels, C] in (0,1)
         return torch.sigmoid(feat @ W.t()).reshape(-1, C)
 
-    pix_e = dist.shard_indices(torch.arange(Re_g), rank, world)
-    pix_r = dist.shard_indices(torch.arange(Rr_g), rank, world)
+    pix_e = dist.shard_indices(torch.arange(Re_g), rank, world, uneven)
+    pix_r = dist.shard_indices(torch.arange(Rr_g), rank, world, uneven)
     _local_backward(O, render(feat_e[:, pix_e]), render(feat_e[:, pix_e] * 0.9), acc[pix_e], render(feat_r[:, pix_r]),
                     render(feat_r[:, pix_r] * 1.1), tgt[pix_r], C, dataset, thr, P, Re_g, Rr_g,
                     lambda s: dist.allreduce_sum_(s, world))
@@ -86,6 +86,12 @@ def _worker(rank, world, port, thr, q):
         (le + lr).backward()
         np.testing.assert_allclose(g.numpy(), W2.grad.numpy(), rtol=2e-4, atol=1e-7)
     dist.allreduce_sum_(g, world)
+    # the range guard's verdict rides the trajectory bucket as a float (engine.TrainStep): ranks 2 and 5 of 8 flag a violation,
+    # EVERY rank must see a non-zero sum (= skip the step), and the same count
+    flag = torch.tensor([1.0 if rank in (2, 5) else 0.0])
+    h = dist.allreduce_sum_async_(flag, world)
+    h.wait()
+    assert float(flag) == float(sum(1 for r in range(world) if r in (2, 5))), (rank, float(flag))
     if rank == 0:
         q.put(g.numpy())
     torch.distributed.destroy_process_group()
@@ -93,21 +99,42 @@ def _worker(rank, world, port, thr, q):
 
 @pytest.mark.parametrize("thr", [0.1, -1.0])
 def test_sharded_gradient_equals_single_rank(thr):
-    """world sizes 2 and 4 against the single process (C4 / C5 run on 8 ranks the same way)."""
+    """world sizes 2, 4 and 8 against the single process (C4 / C5 run on 8 ranks; two of the eight ranks flag a
+    range-guard violation and every rank sees the same non-zero verdict)."""
     ctx = mp.get_context("spawn")
     out = {}
-    for world in (1, 2, 4):
+    for world in (1, 2, 4, 8):
         q = ctx.Queue()
         port = 29500 + int(abs(thr) * 10) + world * 7 + (os.getpid() % 200)
         procs = [ctx.Process(target=_worker, args=(r, world, port, thr, q)) for r in range(world)]
         for p in procs:
             p.start()
-        out[world] = q.get(timeout=120)
+        out[world] = q.get(timeout=240)
         for p in procs:
-            p.join(timeout=60)
+            p.join(timeout=120)
             assert p.exitcode == 0
-    np.testing.assert_allclose(out[2], out[1], rtol=2e-5, atol=1e-7)
-    np.testing.assert_allclose(out[4], out[1], rtol=2e-5, atol=1e-7)
+    for world in (2, 4, 8):
+        np.testing.assert_allclose(out[world], out[1], rtol=2e-5, atol=1e-7)
+
+
+def test_uneven_shards_equal_single_rank():
+    """A global batch the ranks cannot split evenly (11 blur pixels, 16 event pixels over 8 and over 3 ranks; C4 strong-scaled:
+    215 blur pixels over 8 GPUs): the left-over pixels go one each to the low ranks (dist.shard_bounds(uneven=True)), the loss
+    means use the global counts, and the summed gradient equals the single process's."""
+    ctx = mp.get_context("spawn")
+    out = {}
+    for world in (1, 3, 8):
+        q = ctx.Queue()
+        port = 29900 + world * 5 + (os.getpid() % 90)
+        procs = [ctx.Process(target=_worker, args=(r, world, port, -1.0, q, 11, True)) for r in range(world)]
+        for p in procs:
+            p.start()
+        out[world] = q.get(timeout=240)
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+    for world in (3, 8):
+        np.testing.assert_allclose(out[world], out[1], rtol=2e-5, atol=1e-7)
 
 
 def test_shard_indices():
@@ -118,6 +145,10 @@ def test_shard_indices():
     assert torch.equal(torch.cat(parts), idx)
     with pytest.raises(ValueError):
         dist.shard_indices(torch.arange(10), 0, 4)
+    # uneven: nothing dropped, nothing twice, the low ranks take the left-over items
+    parts = [dist.shard_indices(torch.arange(215), r, 8, uneven=True) for r in range(8)]
+    assert torch.equal(torch.cat(parts), torch.arange(215)) and [len(p_) for p_ in parts] == [27] * 7 + [26]
+    assert dist.shard_bounds(5, 7, 8, uneven=True) == (5, 5)
 
 
 def test_async_allreduce_and_broadcast_single_process():

@@ -1,5 +1,6 @@
-"""GPU tests against a FLOAT64 evaluation - the arithmetic-neutral yardstick for the default ('split') MFMA mode, whose
-backward GEMMs take f16 operands and are therefore not the reference's fp32 arithmetic.
+"""GPU tests against a FLOAT64 evaluation - the arithmetic-neutral yardstick for the MFMA arithmetic modes.  The default
+('split') mode runs every GEMM - forward, dX chain, dW - as 3 f16 MFMAs on hi/lo operands (22 bits in flight, 19-bit saved
+operands); these tests hold it to the SAME bounds as the exact-f32 mode.
 
 1. test_step_gradients_vs_float64: one training step (train.py:160-340).  For every gradient (knots, transform, every weight
    and bias of both networks) the error of the HIP path against the float64 evaluation of the same step is compared with
@@ -19,8 +20,6 @@ backward GEMMs take f16 operands and are therefore not the reference's fp32 arit
    and backward, against torch float64 evaluating the SAME piecewise-linear branch (the HIP forward's own ReLU masks), at 1 024
    and 130 560 points: what the MFMA arithmetic itself contributes, with the ReLU-flip lottery taken out.
 """
-import os
-
 import numpy as np
 import pytest
 import torch
@@ -191,7 +190,10 @@ def test_full_size_step_vs_oracle():
 # (ReLU-kink flips behind the 2^9 x positional encoding; C5's L2-normalised loss makes every gradient the remainder of cancelling
 # sums).  Neither mode is systematically closer.  What the ARITHMETIC contributes is held to float32's own error by
 # test_mlp_backward_arithmetic_vs_float64, the whole step to the float64 yardstick by test_step_gradients_vs_float64.
-FULL_SIZE_TOL = {"pose": 2e-3, "entries": 2e-3, "norm": 2e-4}
+# Round 5: next to those max-type statistics (which a single flipped ReLU unit of a heavy sample dominates) every gradient is
+# held to SURVEY 8c's UNDOUBLED 1e-3 on a statistic the lottery does not dominate: the whole-tensor relative L2 error
+# ||HIP - oracle||_2 / ||oracle||_2 ("l2").
+FULL_SIZE_TOL = {"pose": 2e-3, "entries": 2e-3, "norm": 2e-4, "l2": 1e-3}
 
 
 def _full_size_vs_oracle(case, x, o32):
@@ -202,14 +204,19 @@ def _full_size_vs_oracle(case, x, o32):
         loss, g = _hip_step(x, mode, {k: (None, v[1]) for k, v in o32["z"].items()})
         if abs(loss - o32["loss"]) > 2e-5 * max(1.0, abs(o32["loss"])):
             bad.append("%s loss %r vs %r" % (mode, loss, o32["loss"]))
-        worst = {"pose": 0.0, "entries": 0.0, "norm": 0.0}
+        worst = {"pose": 0.0, "entries": 0.0, "norm": 0.0, "l2": 0.0}
         for name, ref in o32["grads"].items():
             got = g[name].double().reshape(ref.shape)
+            ref = ref.double()
             mx = float(ref.abs().max())
+            l2 = float((got - ref).norm() / ref.norm())          # whole tensor, relative: SURVEY 8c's 1e-3, not doubled
+            worst["l2"] = max(worst["l2"], l2)
+            if l2 > FULL_SIZE_TOL["l2"]:
+                bad.append("%s %s: relative L2 error %.2e" % (mode, name, l2))
             if name in ("knots", "transform"):
                 e = float((got - ref).abs().max()) / mx
                 worst["pose"] = max(worst["pose"], e)
-                REPORT.append("full-size %s vs oracle, %-5s d%-36s max err %.2e of the largest entry" % (case, mode, name, e))
+                REPORT.append("full-size %s vs oracle, %-5s d%-36s max err %.2e of the largest entry  rel-L2 %.2e" % (case, mode, name, e, l2))
                 if e > FULL_SIZE_TOL["pose"]:
                     bad.append("%s %s: %.2e" % (mode, name, e))
                 continue
@@ -217,17 +224,16 @@ def _full_size_vs_oracle(case, x, o32):
             e = float((got.reshape(-1)[idx] - ref.reshape(-1)[idx]).abs().max()) / mx
             en = abs(float(got.norm() / ref.norm()) - 1.0)
             worst["entries"], worst["norm"] = max(worst["entries"], e), max(worst["norm"], en)
-            REPORT.append("full-size %s vs oracle, %-5s d%-36s sampled entries %.2e  norm %.2e" % (case, mode, name, e, en))
+            REPORT.append("full-size %s vs oracle, %-5s d%-36s sampled entries %.2e  norm %.2e  rel-L2 %.2e" % (case, mode, name, e, en, l2))
             if e > FULL_SIZE_TOL["entries"] or en > FULL_SIZE_TOL["norm"]:
                 bad.append("%s %s: entries %.2e norm %.2e" % (mode, name, e, en))
-        REPORT.append("full-size %s vs oracle, %-5s WORST pose %.2e  sampled entries %.2e  norms %.2e" %
-                      (case, mode, worst["pose"], worst["entries"], worst["norm"]))
+        REPORT.append("full-size %s vs oracle, %-5s WORST pose %.2e  sampled entries %.2e  norms %.2e  rel-L2 %.2e" %
+                      (case, mode, worst["pose"], worst["entries"], worst["norm"], worst["l2"]))
     assert not bad, "%s:\n%s" % (case, "\n".join(bad))
 
 
-# C4 (1.57 M points: ~2.5 minutes of oracle time on the host) runs with BENERF_FULL_TESTS=1; its figures of round 4 are in the table
-# above and in profiles/r04_gpu_parity_report_full_suite.txt (passed, both modes)
-@pytest.mark.parametrize("case", ["C3", "C5"] + (["C4"] if os.environ.get("BENERF_FULL_TESTS") == "1" else []))
+# C4 (1.57 M points: ~2.5 minutes of oracle time on the host) is part of the default suite since round 5
+@pytest.mark.parametrize("case", ["C3", "C4", "C5"])
 def test_full_size_step_vs_oracle_colour_configs(case):
     """The full-size steps of the other BASELINE.json GPU configurations, HIP (both modes) against the float32 oracle on explicit
     draws with the oracle's fine depths forced in: C3 (colour kernels, 0.78 M points), C4 (800 x 800 camera, lin-log brightness,

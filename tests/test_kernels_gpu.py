@@ -569,9 +569,9 @@ def test_mlp_modes_agree_at_full_size(K, C, N, S):
     K.set_mlp_precision("split")
     a, b = out["f32"], out["split"]
     report("K3 full size, split vs f32: raw", b[0], a[0], atol=2e-6 * float(a[0].abs().max()), rtol=1e-5)
-    # Per-point gradients: the split mode's backward chain takes f16 operands (one rounding to 11 bits per layer, random
-    # and unbiased: ~5e-4 of the largest entry after nine layers, the contract's bound is 1e-3).  On top,
-    # gradients are discontinuous where a pre-activation crosses zero: among ~1e9 ReLU units a few hundred sit within
+    # Per-point gradients: the split mode's backward chain carries every operand as an f16 pair (3 MFMAs per block, 22 bits in
+    # flight; on identical masks its error is float32's own: tests/test_f64_truth_gpu.py).  What separates the two modes here is
+    # that gradients are discontinuous where a pre-activation crosses zero: among ~1e9 ReLU units a few hundred sit within
     # the 1e-7 by which the two modes' activations differ, and their masks flip (the oracle shows the same sensitivity to a
     # 1-ulp input change, test_path_gpu.test_fine_pass_gradients_with_forced_samples).  So: every point within 1e-3 of
     # the largest entry except a vanishing fraction, and a small L2 distance.
@@ -583,8 +583,8 @@ def test_mlp_modes_agree_at_full_size(K, C, N, S):
               % (nm, float(bad), y.shape[0], rel_l2))
         assert float(bad) < 2e-4 and rel_l2 < 2e-3, nm
     # weight gradients: sums over all points of noise-like terms (G is random).  The few hundred flipped units move an
-    # entry by ~sqrt(flips) terms out of ~sqrt(N) (1e-3 .. 4e-3 of the largest entry, layer and seed dependent); the f16
-    # operands of the split mode's backward GEMMs add 3e-4 (tools/experiments/f16_dw_error.py); everything else round-off
+    # entry by ~sqrt(flips) terms out of ~sqrt(N) (1e-3 .. 4e-3 of the largest entry, layer and seed dependent); everything else
+    # is round-off (the 19-bit saved operands of the split mode's dW stay inside float32's error band)
     for i, name in enumerate(K.LAYER_NAMES):
         for kind, x, y in (("weight", b[3][i], a[3][i]), ("bias", b[4][i], a[4][i])):
             report("K3 full size, split vs f32: d%s.%s" % (name, kind), x, y, atol=5e-3 * float(y.abs().max()), rtol=1e-3)

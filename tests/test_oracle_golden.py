@@ -177,3 +177,71 @@ def test_g14_barf_c2f(golden):
     for it in (0, 12000, 23000, 60000):
         raw = O.mlp_forward(p, T(g["pts"]), T(g["viewdirs"]), barf=(it, 80000, 0.1, 0.5))
         report("G14 raw it=%d" % it, raw, g["it%d_raw" % it], atol=1e-7)
+
+
+def _binned_case(rng, B, C, dataset, thr, P=5, S=8, Ni=8, Re=6, Rr=3):
+    cam = GI.CAMERAS["e2nerf_real"]
+    pc, pf = O.xavier_params(rng, C), O.xavier_params(rng, C)
+    pc["alpha_linear.bias"] += 1.0
+    pf["alpha_linear.bias"] += 1.0
+    cfg = O.StepConfig(H=cam["H"], W=cam["W"], fx=cam["fx"], fy=cam["fy"], cx=cam["cx"], cy=cam["cy"], channels=C, n_samples=S,
+                       n_importance=Ni, n_poses=P, dataset=dataset, threshold=thr)
+    x = dict(cfg=cfg, pc=pc, pf=pf, knots=GI.knots_init(rng) * 3, tr=GI.transform_small(rng) * 0.1,
+             idx_e=GI.pixel_indices(rng, cam, Re), idx_r=GI.pixel_indices(rng, cam, Rr),
+             d_e=GI.render_draws(rng, (B + 1) * Re, S, Ni), d_r=GI.render_draws(rng, P * Rr, S, Ni),
+             tacc=[T(rng.integers(-3, 4, (Re, 1)).astype(np.float64)) for _ in range(B)],
+             timg=T(rng.random((Rr, C)).astype(np.float32)), evt_ts=torch.tensor([0.2, 0.6]), rgb_ts=torch.tensor([0.0, 1.0]))
+    return x
+
+
+def test_binned_oracle_is_the_sum_of_single_window_steps():
+    """Dense event bins (an extension: the reference has one bin per step): oracle.step_loss_binned must equal the sum
+    over bins of the single-window step_loss's EVENT part (pinned by G8) on that bin's pose pair and draws, plus one blur part;
+    at B = 1 it is step_loss itself."""
+    for si, (C, dataset, thr) in enumerate(((1, "BeNeRF_Unreal", 0.1), (3, "E2NeRF_Real", -1.0))):
+        for B in (1, 3):
+            rng = np.random.default_rng(500 + 10 * si + B)
+            x = _binned_case(rng, B, C, dataset, thr)
+            cfg, Re = x["cfg"], x["idx_e"].shape[0]
+            kn = x["knots"].clone().requires_grad_(True)
+            lb, parts = O.step_loss_binned(cfg, x["pc"], x["pf"], kn, x["tr"], x["evt_ts"], B, x["rgb_ts"], x["idx_e"], x["idx_r"],
+                                           x["tacc"], x["timg"], x["d_e"], x["d_r"])
+            lb.backward()
+            ts = torch.linspace(float(x["evt_ts"][0]), float(x["evt_ts"][1]), B + 1, dtype=torch.float32)
+            kn2 = x["knots"].clone().requires_grad_(True)
+            tot = 0.0
+            for b in range(B):
+                rows = slice(b * Re, (b + 2) * Re)
+                d_b = {k: v[rows] for k, v in x["d_e"].items()}
+                l1, p1 = O.step_loss(cfg, x["pc"], x["pf"], kn2, x["tr"], ts[b:b + 2], x["rgb_ts"], x["idx_e"], x["idx_r"], x["tacc"][b],
+                                     x["timg"], d_b, x["d_r"])
+                tot = tot + p1["event"]
+                if b == 0:
+                    tot = tot + p1["rgb"]
+                    if B == 1:
+                        assert float(l1.detach()) == float(lb.detach()), "B = 1 must be step_loss itself"
+            tot.backward()
+            report("binned oracle loss B=%d %s" % (B, dataset), lb.detach().reshape(1), tot.detach().reshape(1), atol=1e-7, rtol=1e-6)
+            report("binned oracle dknots B=%d %s" % (B, dataset), kn.grad, kn2.grad, atol=1e-6 * float(kn2.grad.abs().max()), rtol=1e-5)
+
+
+def test_binned_vjp_oracle_matches_autograd():
+    """f64_truth.step_grads_vjp(event_bins = B) (the chunked evaluation the full-size GPU tests use) against plain autograd
+    through step_loss_binned, L2-normalised loss included."""
+    import f64_truth as FT
+    rng = np.random.default_rng(77)
+    B = 3
+    x = _binned_case(rng, B, 3, "E2NeRF_Real", -1.0)
+    cfg = x["cfg"]
+    qc = {k: v.clone().requires_grad_(True) for k, v in x["pc"].items()}
+    kn = x["knots"].clone().requires_grad_(True)
+    loss, _ = O.step_loss_binned(cfg, qc, x["pf"], kn, x["tr"], x["evt_ts"], B, x["rgb_ts"], x["idx_e"], x["idx_r"], x["tacc"], x["timg"],
+                                 x["d_e"], x["d_r"])
+    loss.backward()
+    got = FT.step_grads_vjp(cfg, x["pc"], x["pf"], x["knots"], x["tr"], x["evt_ts"], x["rgb_ts"], x["idx_e"], x["idx_r"], x["tacc"],
+                            x["timg"], x["d_e"], x["d_r"], n_chunks=2, event_bins=B)
+    lv = float(loss.detach())
+    assert abs(got["loss"] - lv) <= 1e-6 * max(1.0, abs(lv))
+    report("binned vjp dknots", got["grads"]["knots"].float(), kn.grad, atol=2e-5 * float(kn.grad.abs().max()), rtol=1e-3)
+    w = "pts_linears.3.weight"
+    report("binned vjp d" + w, got["grads"]["nerf." + w].float(), qc[w].grad, atol=2e-5 * float(qc[w].grad.abs().max()), rtol=1e-3)
