@@ -624,6 +624,7 @@ def main():
     # ---- secondary: forward-only (inference) rays/s: (i) the training ray batch without activation saving, (ii) chunks of
     # args.chunk = 4096 rays of ONE pose, as Graph.render_video / render_image_test call it (model/nerf.py:353-390) - SURVEY 8d's
     # secondary metric, with its own HIP-event per-launch durations -> `roofline_inference` ------------------------------------
+    summ_main = K.TIMERS.summary()         # per-launch HIP-event durations of the timed training steps (before any other leg)
     infer = None
     roof_inf = None
     if world == 1 and not a.primary_only:
@@ -676,7 +677,6 @@ def main():
 
     # ---- secondary: the same training step with exact-f32 MFMA products (the strict arithmetic mode), >= 20 timed steps,
     # its own per-kernel HIP-event durations -> `exact_f32` + `roofline_f32` in the JSON line --------------------------------
-    summ_main = K.TIMERS.summary()
     # ---- secondary: board power and shader clock while the step runs (amdsmi, sampled from a thread for ~1.5 s of extra steps):
     # the K3 kernels sit at the board's power cap, the clock the roofline's 2.4 GHz peak assumes is not available to them ------
     power = None

@@ -144,16 +144,26 @@ __device__ __forceinline__ void gemm3_body(const _Float16* __restrict__ Th, cons
     lane = stage_local(lane);
     const WFrag wf(wp, lane);
     const int ctu = __builtin_amdgcn_readfirstlane(ct);
-    int ao[2][4];
+    // The lo plane sits 80 KiB behind the hi plane: past the 16-bit immediate offset of a DS instruction.  Addressed as Tl + offset
+    // the compiler folds plane distance and k-step into ONE constant, finds it too large and emits a v_add per transpose read
+    // (8 per k-step = 0.67 VALU per MFMA of this loop).  A second set of lane offsets with the plane distance folded in, opaque
+    // to the constant folder, leaves the k-step (<= 60 KiB) as the instruction's immediate.
+    int ao[2][4], aol[2][4];
+    const int plane_delta = (int)(Tl - Th);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) ao[j][rt] = frag_off(lane, j, rt);
+        for (int rt = 0; rt < 4; ++rt) {
+            ao[j][rt] = frag_off(lane, j, rt);
+            int v = ao[j][rt] + plane_delta;
+            asm volatile("" : "+v"(v));
+            aol[j][rt] = v;
+        }
     half8 ah[4], al[4];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
         ah[rt] = frag_read(Th, ao[0][rt], ao[1][rt]);
-        al[rt] = frag_read(Tl, ao[0][rt], ao[1][rt]);
+        al[rt] = frag_read(Th, aol[0][rt], aol[1][rt]);
     }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -173,7 +183,7 @@ __device__ __forceinline__ void gemm3_body(const _Float16* __restrict__ Th, cons
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
             acc[rt] = mfma16(al[rt], bh, acc[rt]);
-            if (ks + 1 < KS) al[rt] = frag_read(Tl + (ks + 1) * 16 * PROW, ao[0][rt], ao[1][rt]);
+            if (ks + 1 < KS) al[rt] = frag_read(Th + (ks + 1) * 16 * PROW, aol[0][rt], aol[1][rt]);
         }
         __builtin_amdgcn_sched_barrier(0);          // one k-step per scheduling region: keeps the prefetch distances as written
     }
@@ -194,6 +204,8 @@ __device__ __forceinline__ void gemm_row3(const _Float16* __restrict__ Th, const
                                           int tile, int rt, int lane, f32x16& out) {
     lane = stage_local(lane);
     const int o0 = frag_off(lane, 0, rt), o1 = frag_off(lane, 1, rt);
+    int ol0 = o0 + (int)(Tl - Th), ol1 = o1 + (int)(Tl - Th);      // lo plane through the hi plane's pointer: see gemm3_body
+    asm volatile("" : "+v"(ol0), "+v"(ol1));
     const WFrag wf(wp, lane);
     const int tu = __builtin_amdgcn_readfirstlane(tile);
     u32x4 bq[PF + 1][2];
@@ -204,7 +216,7 @@ __device__ __forceinline__ void gemm_row3(const _Float16* __restrict__ Th, const
             bq[p][1] = wf.load(tu, p, KS, 1);
         }
     half8 ahn = frag_read(Th, o0, o1);
-    half8 aln = frag_read(Tl, o0, o1);
+    half8 aln = frag_read(Th, ol0, ol1);
     // two partial accumulators (even / odd k-steps) halve the dependent chain
     f32x16 o2;
 #pragma unroll
@@ -218,7 +230,7 @@ __device__ __forceinline__ void gemm_row3(const _Float16* __restrict__ Th, const
         }
         if (ks + 1 < KS) {
             ahn = frag_read(Th + (ks + 1) * 16 * PROW, o0, o1);
-            aln = frag_read(Tl + (ks + 1) * 16 * PROW, o0, o1);
+            aln = frag_read(Th + (ks + 1) * 16 * PROW, ol0, ol1);
         }
         const half8 bh = __builtin_bit_cast(half8, bq[ks % (PF + 1)][0]);
         const half8 bl = __builtin_bit_cast(half8, bq[ks % (PF + 1)][1]);
@@ -251,18 +263,28 @@ __device__ __forceinline__ uint32_t bit_mask32(uint32_t w, int k) {
     return m;
 }
 
-// v -> (hi, lo) as packed f16 pairs: hi = rn16(v), lo = rn16(v - hi)
+// v -> (hi, lo) as packed f16 pairs: hi = rn16(v), lo = rn16(v - hi).  The low halves come from v_fma_mixlo_f16 / _mixhi_f16:
+// fma(-hi (read as f16), 1.0, v) evaluated in f32 (v - hi is exact there) and rounded once into the low / high half of the
+// result - two instructions per pair where "convert back, subtract, convert" takes four (round 5: the epilogue is over the
+// issue budget of its K-loop, every instruction counts).  Same values bit for bit.
 __device__ __forceinline__ void split2(float v0, float v1, half2v& hi, half2v& lo) {
     hi = __builtin_convertvector(float2v{v0, v1}, half2v);                          // v_cvt_pk_f16_f32 (RNE)
-    const float2v back = __builtin_convertvector(hi, float2v);
-    lo = __builtin_convertvector(float2v{v0 - back[0], v1 - back[1]}, half2v);
+    uint32_t l;
+    asm("v_fma_mixlo_f16 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, -%1, 1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(l) : "v"(__builtin_bit_cast(uint32_t, hi)), "v"(v0), "v"(v1));
+    lo = __builtin_bit_cast(half2v, l);
+}
+// amax = max(amax, |v0|, |v1|) in ONE instruction (the compiler's IEEE-mode fmaxf chain: v_max_f32 |v0|, |v1| + v_max_f32)
+__device__ __forceinline__ void amax3(float& amax, float v0, float v1) {
+    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(v0), "v"(v1));
 }
 
-// dY = acc masked by the forward pass' ReLU sign bits (bits[h]: this wave's 32 bits of the 64-point forward tile of row tiles
-// 2h, 2h + 1: bit r * 16 + e <-> accumulator element e of row tile 2h + r) -> both planes (hi, lo; tile scale) and, rescaled
-// by gf = s_call / s_tile (a power of two <= 1; exact), the SH gradient arrays `st_hi` / `st_lo` of width 256 (tile part).
+// dY = acc masked by the forward pass' ReLU sign bits (bits[rt]: the 32 points of row tile rt for THIS lane's feature, shifted
+// right by 4 (lane >> 5): bit 8 (e >> 2) + (e & 3) <-> accumulator element e; mlp_split.h: sp_mask_word) -> both planes (hi, lo;
+// tile scale) and, rescaled by gf = s_call / s_tile (a power of two <= 1; exact), the SH gradient arrays `st_hi` / `st_lo` of
+// width 256 (tile part).
 template <bool MASK>
-__device__ __forceinline__ void epilogue3(f32x16 (&acc)[4], const uint32_t (&bits)[2], _Float16* __restrict__ Th, _Float16* __restrict__ Tl,
+__device__ __forceinline__ void epilogue3(f32x16 (&acc)[4], const uint32_t (&bits)[4], _Float16* __restrict__ Th, _Float16* __restrict__ Tl,
                                           int ct, int lane, const _Float16* __restrict__ st_hi, const uint8_t* __restrict__ st_lo, float gf,
                                           float& amax) {
     lane = stage_local(lane);
@@ -294,9 +316,9 @@ __device__ __forceinline__ void epilogue3(f32x16 (&acc)[4], const uint32_t (&bit
                     for (int t = 0; t < 2; ++t) {
                         const int e = (ep * 2 + h) * 4 + jp * 2 + t;
                         v[t] = acc[rt][e];
-                        if (MASK) v[t] = __uint_as_float(__float_as_uint(v[t]) & bit_mask32(bits[rt >> 1], (rt & 1) * 16 + e));
+                        if (MASK) v[t] = __uint_as_float(__float_as_uint(v[t]) & bit_mask32(bits[rt], 8 * (e >> 2) + (e & 3)));
                     }
-                    amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])));   // v_max3_f32
+                    amax3(amax, v[0], v[1]);
                     half2v hv, lv;
                     split2(v[0], v[1], hv, lv);
                     wh[jp] = __builtin_bit_cast(uint32_t, hv);
@@ -349,16 +371,23 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
     const int ct = wave;                                         // this wave's column tile in the 256-wide stages
     const int64_t Mp = m_pad(M);
     uint8_t* st8 = reinterpret_cast<uint8_t*>(dacts + sdact_lo8_base(Mp));      // lo8 region: byte i <-> half i of the SH region
-    // ReLU sign-bit words of the two 64-point forward tiles this workgroup covers: uint64 [layer][tile][4 x 64 threads]; this
-    // wave's column tile ct is the forward thread (ct >> 1) * 64 + lane, 32-bit half ct & 1 (mlp_common.h / mlp_fwd_h.hip)
+    // ReLU sign-bit words.  h0..h7 (round 5, mlp_split.h): uint32 [layer][tile 128][row tile 4][column tile 8][32], written by the
+    // forward's scalar stores; this lane's feature ct * 32 + (lane & 31) is word sp_mask_word(lane & 31) of block (rt, ct), and the
+    // 16 points of its accumulator elements are bits 8 (e >> 2) + 4 (lane >> 5) + (e & 3): shifted down by 4 (lane >> 5) once.
+    // hv (mask layer 8) keeps the uint64 [64-point tile][4 x 64 threads] format of mlp_common.h (P1 below).
     const __amdgpu_buffer_rsrc_t mask_rsrc =
         uniform_rsrc(reinterpret_cast<const uint64_t*>(acts + sact_mask(Mp)) + (int64_t)blockIdx.x * 2 * NTHREADS);
     const int mask_stride_b = (int)((Mp / TM) * NTHREADS * 8);           // bytes between layers (< 2^31 up to 8M points)
-    auto load_bits = [&](int layer, uint32_t (&b)[2]) {
+    auto load_bits = [&](int layer, uint32_t (&b)[4]) {
         const int so = __builtin_amdgcn_readfirstlane(layer * mask_stride_b);
-        const int vo = ((wave >> 1) * 64 + lane) * 8 + (wave & 1) * 4;
-        b[0] = __builtin_amdgcn_raw_buffer_load_b32(mask_rsrc, vo, so, 0);
-        b[1] = __builtin_amdgcn_raw_buffer_load_b32(mask_rsrc, vo + NTHREADS * 8, so, 0);
+        const int vo = (wave * 32 + sp_mask_word(lane & 31)) * 4;
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) b[rt] = __builtin_amdgcn_raw_buffer_load_b32(mask_rsrc, vo + rt * 8 * 32 * 4, so, 0);
+    };
+    auto shift_bits = [&](uint32_t (&b)[4]) {      // at the point of use: the loads are requested a stage ahead
+        const int sh = 4 * (lane >> 5);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) b[rt] >>= sh;
     };
     _Float16* st_dyh = reinterpret_cast<_Float16*>(dacts + sdact_h(Mp, 0));      // layer l: + l * Mp * 256 halfs
     // timing variant (-DBWS_STORE_WINDOW=256): every tile stores into the first WINDOW points - same instructions, bytes stay in L2
@@ -451,7 +480,7 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
     lds_barrier();
 
     f32x16 acc[4];
-    uint32_t bits[2] = {0u, 0u};
+    uint32_t bits[4] = {0u, 0u, 0u, 0u};
 
     // ---- P2: VIEWS^T: dFeat = dYv x Wv[:, :256]; dPE(dir) = dYv x Wv[:, 256:283] --------------------------------
     if (wave < 4) {   // dPE(dir): tile 8 of the block, row tile = wave -> scratch floats [0,27)
@@ -509,10 +538,11 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
     lds_barrier();
     // Loads the next stage needs are requested BEFORE this stage's epilogue stores (in-order retirement): the sign bits of the
     // stage after (from HBM: a whole epilogue + K-loop of cover) and the first weight fragments.
-    uint32_t bits_n[2];
+    uint32_t bits_n[4];
     WRing<BWS_PF> ring;
     load_bits(6, bits_n);
     gemm3_head<16, BWS_PF>(packed_h + pack_offset(PB_L7), ct, lane, ring);
+    shift_bits(bits);
     epilogue3<true>(acc, bits, Th, Tl, ct, lane, st_tile(7), st8_tile(7), gf, amax);
     lds_barrier();
 
@@ -521,8 +551,9 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
         zero4(acc);
         gemm3_body<16, BWS_PF>(Th, Tl, packed_h + bwd_layer_offset(l), ct, lane, ring, acc);
         lds_barrier();
-        bits[0] = bits_n[0];
-        bits[1] = bits_n[1];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) bits[rt] = bits_n[rt];
+        shift_bits(bits);
         if (l >= 2) {
             load_bits(l - 2, bits_n);
             gemm3_head<16, BWS_PF>(packed_h + bwd_layer_offset(l - 1), ct, lane, ring);

@@ -16,6 +16,11 @@
 // four arrays = 24 KiB from HBM, 32 KiB in LDS.  HBM-bound: 14.6 KB per point against 24 MFMAs per wave and chunk.
 // (An LDS-DMA variant of the copy - ring of four slots, no staging registers - measured 5 % faster on f16 pairs in HBM, commit
 // caf2f65; it cannot decode on the way and went with the 4-byte format.)
+// Round 5: the X operand of the big instances (h0..h7, feature) arrives in the forward's SP layout (mlp_split.h: 16-byte units =
+// 8 FEATURES of one point - what the forward's epilogue registers hold; the forward no longer transposes; a 16-point chunk is one
+// contiguous run [slot][point]).  The chunk image keeps those units ([slot][point], XOR-swizzled) and the MFMA B fragments - 8 POINTS of one feature - come out of it with two
+// ds_read_b64_tr_b16 each: the transposition rides on LDS reads this kernel does anyway.  dY stays SH (the dX kernel's
+// accumulators hold 4 points of one feature: its natural layout).
 // The thin instances (X = positional encoding: L0, the PE part of L5, the PE(dir) part of the views layer) stream WITHOUT LDS:
 // see thin_stream below.
 #include "mlp_split.h"
@@ -60,6 +65,31 @@ __device__ __forceinline__ Src inst_src(const DwArgs& a, int inst) {
     }
 }
 
+// buffer descriptor on a wave-uniform base (raw, 2^31 - 1 bytes)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t dw_rsrc(const void* p) {
+    const uint64_t wa = reinterpret_cast<uint64_t>(p);
+    const uint64_t wau = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(wa >> 32)) << 32) |
+                         (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)wa);
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(wau), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ uint2 dw_load_b64(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+    return uint2{v[0], v[1]};
+}
+
+// sum of the 8 + 8 halfs of a unit in f32 (v_dot2_f32_f16 against (1, 1): 8 instructions where convert-and-add takes 32)
+__device__ __forceinline__ float dw_sum_unit(const half8 h, const half8 l, float s) {
+    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    const half2v one = {(_Float16)1.f, (_Float16)1.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        s = __builtin_amdgcn_fdot2(half2v{h[2 * j], h[2 * j + 1]}, one, s, false);
+        s = __builtin_amdgcn_fdot2(half2v{l[2 * j], l[2 * j + 1]}, one, s, false);
+    }
+    return s;
+}
+
 // Output block N x K (the whole instance: K = width of X).  Waves form a WN x (8/WN) grid; each owns TR x TC MFMA tiles: per
 // 16-point chunk acc += Yh^T Xh + Yh^T Xl + Yl^T Xh.  Three chunks are in flight in registers (sets A, B, C) and the LDS image
 // is triple-buffered, so there is one LDS-only barrier per chunk.
@@ -67,9 +97,11 @@ template <int N, int K, int WN, int TR, int TC, bool ALPHA>
 __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int64_t chunk_begin, int64_t chunk_end,
                                         float* __restrict__ part, u32x4* __restrict__ smem) {
     static_assert(WN * TR * 32 == N, "row tiling");
+    static_assert(K == 256 && CHP == 16, "X in SP layout: 32 slots x 16 points = one unit per thread and chunk");
     constexpr int YU = CHB * N, XU = CHB * K;                  // 16-byte units per chunk and plane
     constexpr int NY = (YU + DWT - 1) / DWT, NX = (XU + DWT - 1) / DWT;
-    constexpr bool YFULL = YU % DWT == 0, XFULL = XU % DWT == 0;
+    constexpr bool YFULL = YU % DWT == 0;
+    static_assert(XU == DWT && NX == 1, "X: one SP unit per thread and chunk");
     constexpr int BUF = 2 * YU + 2 * XU + CHP / 4;             // Yh | Yl | Xh | Xl | CHP floats of d_sigma
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 31, lh = lane >> 5;
@@ -97,21 +129,24 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int64_t 
 #else
 #define DWS_CODE_LOAD(expr) (expr)
 #endif
+    // Loads through buffer descriptors: the chunk part of every address is wave-uniform (one SGPR offset), the thread part a
+    // constant (two VGPRs for the whole kernel) - plain pointers cost two 64-bit VGPR addresses per load and, with the SP layout's
+    // index arithmetic on top, nine spilled registers.  Offsets are 32-bit: one array < 2^31 bytes, i.e. < 4 M points per launch
+    // (checked by the launcher).
+    const __amdgpu_buffer_rsrc_t rs_y = dw_rsrc(src.y), rs_y8 = dw_rsrc(src.y8), rs_x = dw_rsrc(src.x), rs_x8 = dw_rsrc(src.x8);
+    // X, SP layout: a chunk is 512 consecutive units [slot tid >> 4][point tid & 15]
 #define DW_PREFETCH(R, CHUNK)                                                                             \
     {                                                                                                     \
-        const int64_t cc = (CHUNK) < chunk_end ? (CHUNK) : chunk_end - 1;                                 \
+        const int cc = (int)((CHUNK) < chunk_end ? (CHUNK) : chunk_end - 1);                              \
         _Pragma("unroll") for (int j = 0; j < NY; ++j)                                                    \
             if (YFULL || tid + j * DWT < YU) {                                                            \
-                R.y[j] = src.y[cc * YU + tid + j * DWT];                                                  \
-                R.y8[j] = DWS_CODE_LOAD(src.y8[cc * YU + tid + j * DWT]);                                 \
+                R.y[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, (tid + j * DWT) * 16, cc * (YU * 16), 0);                       \
+                R.y8[j] = DWS_CODE_LOAD(dw_load_b64(rs_y8, (tid + j * DWT) * 8, cc * (YU * 8)));          \
             }                                                                                             \
-        _Pragma("unroll") for (int j = 0; j < NX; ++j)                                                    \
-            if (XFULL || tid + j * DWT < XU) {                                                            \
-                R.x[j] = src.x[cc * XU + tid + j * DWT];                                                  \
-                R.x8[j] = DWS_CODE_LOAD(src.x8[cc * XU + tid + j * DWT]);                                 \
-            }                                                                                             \
+        R.x[0] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, tid * 16, cc * (XU * 16), 0);                \
+        R.x8[0] = DWS_CODE_LOAD(dw_load_b64(rs_x8, tid * 8, cc * (XU * 8)));                              \
         if (ALPHA) {                                                                                      \
-            const int64_t row = cc * CHP + (tid & (CHP - 1));                                             \
+            const int64_t row = (int64_t)cc * CHP + (tid & (CHP - 1));                                    \
             R.da = a.d_raw[(row < M ? row : M - 1) * (a.C + 1) + a.C];                                    \
             if (row >= M) R.da = 0.f;                                                                     \
         }                                                                                                 \
@@ -133,14 +168,31 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int64_t 
             if (YFULL || u < YU) put_pair(Ys_, Ys_ + YU, u, R.y[j], R.y8[j], valid);
         }
     };
+    // X image: unit (slot s, point p) at s * 16 + (p ^ 4 (s & 3)): the four slots of a column tile start a quarter of the banks
+    // apart, so the transpose reads of a fragment (4 points x 4 slots per half wave) and these 16-byte writes are conflict free
     auto stage_x = [&](const Regs& R, int b, bool valid) {
         u32x4* Xs_ = smem + b * BUF + 2 * YU;
-#pragma unroll
-        for (int j = 0; j < NX; ++j) {
-            const int u = tid + j * DWT;
-            if (XFULL || u < XU) put_pair(Xs_, Xs_ + XU, u, R.x[j], R.x8[j], true);
-        }
+        const int s_ = tid >> 4, p_ = tid & 15;
+        put_pair(Xs_, Xs_ + XU, s_ * 16 + (p_ ^ (4 * (s_ & 3))), R.x[0], R.x8[0], true);
         if (ALPHA && tid < CHP) reinterpret_cast<float*>(Xs_ + 2 * XU)[tid] = valid ? R.da : 0.f;
+    };
+    // B fragment (8 points 8 lh .. + 7 of feature 32 ctile + lr) = two transpose reads (4 points each); byte offsets of this lane
+    // inside the hi image for column tile 0: within a 16-lane group lane t addresses point (t >> 2), features 4 (t & 3) .. + 3 of
+    // the group's 16 and receives feature t (tools/hwprobe/tr_read.hip); + ctile * 1024 per column tile, + XU * 16 for the lo image
+    int xfo[2];
+    {
+        const int t = lane & 15, g1 = (lane >> 4) & 1;
+        const int sl = 2 * g1 + ((t & 3) >> 1);                      // slot inside the column tile = slot & 3
+#pragma unroll
+        for (int h = 0; h < 2; ++h) xfo[h] = ((sl * 16 + ((8 * lh + 4 * h + (t >> 2)) ^ (4 * sl))) * 16) + 8 * (t & 1);
+    }
+    typedef short short4v __attribute__((ext_vector_type(4)));
+    auto xfrag = [&](const u32x4* img, int ctile) -> half8 {
+        const char* base = reinterpret_cast<const char*>(img) + ctile * 1024;
+        const short4v a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3)))*)(reinterpret_cast<const short4v*>(base + xfo[0])));
+        const short4v a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3)))*)(reinterpret_cast<const short4v*>(base + xfo[1])));
+        typedef short short8v __attribute__((ext_vector_type(8)));
+        return __builtin_bit_cast(half8, short8v{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]});
     };
     // one LDS-only barrier per chunk.  The image written before it (chunk j + 1) was last read two barriers earlier (three images)
 #define DW_BARRIER()                                                                                      \
@@ -178,8 +230,8 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int64_t 
                 half8 bxh[CG], bxl[CG];
 #pragma unroll
                 for (int c = 0; c < CG; ++c) {
-                    bxh[c] = __builtin_bit_cast(half8, Xl[lh * K + (wk * TC + c0 + c) * 32 + lr]);
-                    bxl[c] = __builtin_bit_cast(half8, Xl[XU + lh * K + (wk * TC + c0 + c) * 32 + lr]);
+                    bxh[c] = xfrag(Xl, wk * TC + c0 + c);
+                    bxl[c] = xfrag(Xl + XU, wk * TC + c0 + c);
                 }
 #pragma unroll
                 for (int r = 0; r < TR; ++r)
@@ -202,27 +254,28 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int64_t 
             stage_x(Rn, bn, vn);
         }
         if (src.bias && tid < N) {
-            float s = 0.f;
 #pragma unroll
-            for (int mb = 0; mb < CHB; ++mb) {
-                const half8 h = __builtin_bit_cast(half8, Yl[mb * N + tid]);
-                const half8 l = __builtin_bit_cast(half8, Yl[YU + mb * N + tid]);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) s += (float)h[j] + (float)l[j];
-            }
-            bsum += s;
+            for (int mb = 0; mb < CHB; ++mb)
+                bsum = dw_sum_unit(__builtin_bit_cast(half8, Yl[mb * N + tid]), __builtin_bit_cast(half8, Yl[YU + mb * N + tid]), bsum);
         }
         // the alpha head rides on waves 4..7 (column tid - 256): waves 0..3 already carry the bias sums (mlp_dw_h.hip)
         if (ALPHA && tid >= DWT - K) {
-            const int ka = tid - (DWT - K);
+            // column ka = tid - 256 = 64 (wave - 4) + lane of X = h7: the 16 points of the chunk by four transpose reads per image
+            // (lane t of a 16-lane group g: feature 64 w' + 16 g + t, the group's 4 x 16 block = points 4 pg .. + 3)
+            const int t = lane & 15, g = lane >> 4, wq = wave - 4;
+            const int slot = 8 * wq + 2 * g + ((t & 3) >> 1), sl = slot & 3;
             float s = 0.f, sb = 0.f;
 #pragma unroll
-            for (int mb = 0; mb < CHB; ++mb) {
-                const half8 h = __builtin_bit_cast(half8, Xl[mb * K + ka]);
-                const half8 l = __builtin_bit_cast(half8, Xl[XU + mb * K + ka]);
+            for (int pg = 0; pg < 4; ++pg) {
+                const int off = ((slot * 16 + ((4 * pg + (t >> 2)) ^ (4 * sl))) * 16) + 8 * (t & 1);
+                const char* bh = reinterpret_cast<const char*>(Xl) + off;
+                const short4v vh = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3)))*)(reinterpret_cast<const short4v*>(bh)));
+                const short4v vl = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4v __attribute__((address_space(3)))*)(reinterpret_cast<const short4v*>(bh + XU * 16)));
+                typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+                const half4v h = __builtin_bit_cast(half4v, vh), l = __builtin_bit_cast(half4v, vl);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float d = da[mb * 8 + j];
+                for (int j = 0; j < 4; ++j) {
+                    const float d = da[pg * 4 + j];
                     s += d * ((float)h[j] + (float)l[j]);
                     sb += d;
                 }
@@ -583,6 +636,7 @@ int benerf_mlp_dw_split22_launch(int channels, int64_t M, const float* d_raw, co
     a.ws = dw_ws;
     a.M = M;
     a.C = channels;
+    BENERF_REQUIRE(mlp::m_pad(M) * 512 < (1ll << 31), "mlp_bwd(dw, split): at most 4 M points per launch (32-bit buffer offsets)");
     static BenerfLdsAttr attr_big;      // once per device
     if (!benerf_lds_attr(attr_big, (const void*)mlp_dw_split_big_kernel, (int)DWS_SMEM)) {
         benerf_set_error("mlp_bwd(dw, split): cannot reserve LDS");

@@ -11,8 +11,9 @@
 // 16-byte slots (8 halfs) are XOR-swizzled: element (row, col) lives in slot (col>>3) ^ ((row>>1)&7).
 // Range: |x| must stay below 65504 (f16 max) - NeRF activations are O(1..100); every launch folds max|activation|
 // into the caller's status word once it passes 2^15 (mlp_split.h, 'Range guard'), so a violation is never silent.
-// Training mode saves the f16 (hi) halves of the activations as SH arrays (mlp_split.h) + ReLU sign-bit words for the
-// f16 dX / dW kernels.
+// Training mode saves the activations for the backward kernels: BENERF_MLP_SPLIT (SAVE == 2) - f16 hi halves + 8-bit residual codes
+// straight from the epilogue's registers in the SP layout, sign bits through the scalar path (DirectSave below; the narrow hv / PE
+// arrays as SH arrays from the finished planes); BENERF_MLP_SPLIT_F16BWD (SAVE == 1) - the hi halves as SH arrays (mlp_split.h).
 #include "mlp_split.h"
 
 namespace {
@@ -79,11 +80,27 @@ __device__ __forceinline__ void acc_init_bias(f32x16 (&acc1)[NR][NCT], const flo
             }
 }
 
-// combine the two accumulators (+ReLU) -> both LDS planes (hi, scaled lo).
-template <int NCT, bool RELU, int NR>
+// BENERF_MLP_SPLIT training launches (SAVE == 2, round 5): the stage's activations leave for HBM straight from the epilogue's
+// registers - what a lane holds after the lane exchange IS a 16-byte unit of the SP layout (mlp_split.h: 8 features of one
+// point), hi and scaled lo side by side for the residual codes - and the ReLU sign bits go out through the scalar path
+// (v_cmp_gt_f32 -> SGPR pair -> s_store_dwordx2).  No transpose reads of the finished planes, no per-pair address arithmetic.
+struct DirectSave {
+    __amdgpu_buffer_rsrc_t rs, rs8;   // this tile's part of the layer's SP array (hi halves) / of its lo8 twin
+    const uint32_t* mask;             // wave-uniform: sign-bit word ((T * 4 + 0) * 8 + ct) * 32 of the layer, or null (no ReLU)
+};
+
+// combine the two accumulators (+ReLU) -> both LDS planes (hi, scaled lo) [-> HBM: sv].
+// (Tried in round 5 and not kept: requesting the next stage's first weight fragments from inside this epilogue, in front of its
+// stores - vector-memory operations retire in order.  Training launch 1.993 -> 1.975 ms at 522 k points, inside the run-to-run
+// spread, for five spilled registers: profiles/r05_fwd_direct_save_ab.log.)
+template <int NCT, bool RELU, int NR, bool SV = false>
 __device__ __forceinline__ void epilogue_t(f32x16 (&acc1)[NR][NCT], f32x16 (&acc2)[NR][NCT], _Float16* __restrict__ Th,
-                                           _Float16* __restrict__ Tl, int ct0, int lane, float& amax) {
+                                           _Float16* __restrict__ Tl, int ct0, int lane, float& amax, const DirectSave* sv = nullptr) {
+    static_assert(!SV || NCT == 1, "direct save: one column tile per wave");
     const int pl = lane & 31, hf = lane >> 5;
+    // byte offset of this lane's unit (16-point chunk pl >> 4 of the tile, slot 4 ct + hf, point pl & 15) in the tile's part of the SP
+    // array; slot + 2 i is an immediate of the store (i * 512), row tile r two chunks (r * 16 384; the lo8 twin: half of everything)
+    const int vo = SV ? (((pl >> 4) * 32 + ct0 * 4 + hf) * 16 + (pl & 15)) * 16 : 0;
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const int row = r * 32 + pl, sw = hsw(row);
@@ -98,18 +115,37 @@ __device__ __forceinline__ void epilogue_t(f32x16 (&acc1)[NR][NCT], f32x16 (&acc
 #pragma unroll
                 for (int jp = 0; jp < 2; ++jp) {
                     const int e = q * 4 + jp * 2;
-                    float2v v = {acc1[r][c][e] + acc2[r][c][e] * LO_INV, acc1[r][c][e + 1] + acc2[r][c][e + 1] * LO_INV};
-                    if (RELU) {
-                        v[0] = fmaxf(v[0], 0.f);
-                        v[1] = fmaxf(v[1], 0.f);
-                        amax = fmaxf(amax, fmaxf(v[0], v[1]));                              // range guard
-                    } else {
-                        amax = fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1])));
+                    // v = acc1 + acc2 * 2^-11 for the pair as ONE v_pk_fma_f32 (accumulator registers e, e + 1 are an aligned pair)
+                    float2v v;
+                    {
+                        const float2v a1 = {acc1[r][c][e], acc1[r][c][e + 1]}, a2 = {acc2[r][c][e], acc2[r][c][e + 1]};
+                        const float2v sc = {LO_INV, LO_INV};
+                        asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(v) : "v"(a2), "v"(sc), "v"(a1));
+                    }
+                    if (RELU) {     // asm: fmaxf() on an asm result costs a canonicalising v_max_f32 v, v, v in front of the real one
+                        asm("v_max_f32 %0, 0, %0" : "+v"(v[0]));
+                        asm("v_max_f32 %0, 0, %0" : "+v"(v[1]));
+                    }
+                    // range guard: amax = max(amax, |v0|, |v1|) as ONE v_max3_f32 (the compiler's IEEE-mode fmaxf chain is two or three)
+                    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(v[0]), "v"(v[1]));
+                    if (SV && RELU) {     // sign bits of accumulator elements e, e + 1: 64-lane masks, 8 bytes each, through the scalar cache
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            uint64_t m;
+                            asm volatile("v_cmp_gt_f32_e64 %0, %1, 0" : "=s"(m) : "v"(v[t]));
+                            asm volatile("s_store_dwordx2 %0, %1, %2" ::"s"(m), "s"(sv->mask), "n"((r * 8 * 32 + 2 * (e + t)) * 4) : "memory");
+                        }
                     }
                     const half2v hi = __builtin_convertvector(v, half2v);
-                    const float2v res = (v - __builtin_convertvector(hi, float2v)) * LO_SCALE;
+                    // lo = rn16((v - hi) * 2^11) = rn16(fma(-hi, 2^11, v * 2^11)): every step exact in f32 except the final rounding,
+                    // i.e. the same bits as "convert back, subtract, scale, convert" in three instructions per pair instead of five
+                    // (v_pk_mul_f32, v_fma_mixlo_f16, v_fma_mixhi_f16: hi is read as f16 by the mixed-precision FMA)
+                    const float2v vs = v * LO_SCALE;
+                    uint32_t l;
+                    asm("v_fma_mixlo_f16 %0, -%1, %4, %2 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, -%1, %4, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                        : "=&v"(l) : "v"(__builtin_bit_cast(uint32_t, hi)), "v"(vs[0]), "v"(vs[1]), "s"(LO_SCALE));
                     wh[jp] = __builtin_bit_cast(uint32_t, hi);
-                    wl[jp] = __builtin_bit_cast(uint32_t, __builtin_convertvector(res, half2v));
+                    wl[jp] = l;
                 }
                 qh[q] = uint2{wh[0], wh[1]};
                 ql[q] = uint2{wl[0], wl[1]};
@@ -117,8 +153,19 @@ __device__ __forceinline__ void epilogue_t(f32x16 (&acc1)[NR][NCT], f32x16 (&acc
 #pragma unroll
             for (int i = 0; i < 2; ++i) {   // lanes 0-31 end up with slot 2i, lanes 32-63 with slot 2i + 1 of the column tile
                 const int slot = (ct0 + c) * 4 + 2 * i + hf;
-                *reinterpret_cast<uint4*>(rowh + ((slot ^ sw) << 3)) = sh_pair_unit(qh[2 * i], qh[2 * i + 1]);
-                *reinterpret_cast<uint4*>(rowl + ((slot ^ sw) << 3)) = sh_pair_unit(ql[2 * i], ql[2 * i + 1]);
+                const uint4 uh = sh_pair_unit(qh[2 * i], qh[2 * i + 1]), ul = sh_pair_unit(ql[2 * i], ql[2 * i + 1]);
+                *reinterpret_cast<uint4*>(rowh + ((slot ^ sw) << 3)) = uh;
+                *reinterpret_cast<uint4*>(rowl + ((slot ^ sw) << 3)) = ul;
+                if (SV) {
+                    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                    const uint32_t uh4[4] = {uh.x, uh.y, uh.z, uh.w}, ul4[4] = {ul.x, ul.y, ul.z, ul.w};
+                    const uint2 code = h8_encode_unit<11>(uh4, ul4);
+                    // vector offset + immediate, zero scalar offset (mlp_bwd_h.hip: the scalar-offset form of a 16-byte store reads its data late)
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{uh.x, uh.y, uh.z, uh.w}, sv->rs, vo + i * 512 + r * 16384, 0, 0);
+#ifndef FWD_SKIP_LO_STORE    // timing variants only (tools/experiments/build_variant.sh)
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{code.x, code.y}, sv->rs8, vo / 2 + i * 256 + r * 8192, 0, 0);
+#endif
+                }
             }
         }
     }
@@ -254,12 +301,20 @@ static_assert(pack_offset(PF_L1) + 3 * pack_floats(PF_L1) == pack_offset(PF_L4) 
 // One workgroup of 8 waves per 128 points (the whole LDS: two planes [128][320] f16); wave w owns column tile w (32 output
 // features) x all four point tiles: every weight fragment pair (hi, lo: 2 KiB) feeds 12 MFMAs - half the fragment bytes
 // per MFMA of the 64-point / 2 x 2 tiling, and the 8-register ring slot leaves room for a 4-deep prefetch.
-constexpr int FTM = 128, FNT = 512, FPF = 2;
+constexpr int FTM = 128, FNT = 512;
 constexpr size_t FWD_SMEM = (size_t)2 * FTM * LD * sizeof(_Float16);      // 163 840 B
 
 // SAVE: 0 inference, 1 training with the f16 backward (hi halves saved), 2 training with the 22-bit backward (hi + lo)
 template <int C, int SAVE>
 __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
+    // weight-fragment prefetch depth (k-steps).  The SAVE == 2 launch runs its K-loops behind the previous epilogue's 24 activation
+    // stores: three k-steps ahead measured 1.954 -> 1.921 ms at 522 k points (no spill since the direct save freed registers);
+    // the inference launch is indifferent (1.494 / 1.498), the SAVE == 1 variant spills at 3 (profiles/r05_fwd_direct_save_ab.log)
+#ifdef FWD_FPF
+    constexpr int FPF = FWD_FPF;
+#else
+    constexpr int FPF = SAVE == 2 ? 3 : 2;
+#endif
     extern __shared__ __attribute__((aligned(16))) _Float16 Tsm[];   // Th | Tl
     _Float16* Th = Tsm;
     _Float16* Tl = Tsm + FTM * LD;
@@ -298,6 +353,16 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
     if (SAVE && blockIdx.x == 0 && tid == 0) reinterpret_cast<uint32_t*>(acts + sact_info(Mp))[SI_TAG] = SAVE == 2 ? SACT_TAG_SPLIT22 : SACT_TAG_SPLIT;
     // SAVE == 2: byte i of the lo8 region <-> half i of the SH region (mlp_split.h)
     uint8_t* st8_h = SAVE == 2 ? reinterpret_cast<uint8_t*>(acts + sact_lo8_base(Mp)) : nullptr;          // layer l: + l * Mp * 256 bytes
+    // SAVE == 2: the direct save of stage `layer` (0..7: h_layer with its sign bits; 8: feature, no ReLU) - mlp_split.h, SP layout
+    auto direct = [&](int layer, bool relu) {
+        DirectSave d;
+        d.rs = uniform_rsrc(SAVE == 2 ? st_h + ((int64_t)layer * Mp + ms0) * 256 : nullptr);
+        d.rs8 = uniform_rsrc(SAVE == 2 ? st8_h + ((int64_t)layer * Mp + ms0) * 256 : nullptr);
+        d.mask = (SAVE == 2 && relu) ? reinterpret_cast<const uint32_t*>(acts + sact_mask(Mp)) + (int64_t)layer * mask_stride +
+                                           ((int64_t)blockIdx.x * 32 + wave) * 32
+                                     : nullptr;
+        return d;
+    };
     float amax = 0.f;        // running max |activation| of this thread (range guard)
     // f32 scratch in the dead PE columns [288,320) of the lo plane: logical slot 36 + j of this thread's row
     const int psw = hsw(pt);
@@ -379,42 +444,27 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
     zero_acc(acc2);
     gemm_stage<4, 1, FPF, true, 4>(Th, Tl, COL_PE, a.packed + pack_offset(PF_L0), wave, lane, acc1, acc2);
     load_bias<1>(a.bias[1], wave, lane, bq);
-    epilogue_t<1, true, 4>(acc1, acc2, Th, Tl, wave, lane, amax);
+    {
+        const DirectSave d0 = direct(0, true);
+        epilogue_t<1, true, 4, SAVE == 2>(acc1, acc2, Th, Tl, wave, lane, amax, &d0);
+    }
     lds_barrier();
 
     // ---- L1..L7 -------------------------------------------------------------------------------
-    // the previous layer's activations leave for HBM (save_tile: transpose reads of the finished hi plane, 16-byte stores)
-    // right behind this layer's first weight-fragment requests
 #pragma unroll 1
     for (int l = 1; l < 8; ++l) {
-        // The previous layer's activations leave for HBM during this layer's LAST two k-steps (four block pairs each: two
-        // transpose reads of the finished hi plane, the sign bits, one 16-byte store per pair): behind the K-loop's last
-        // weight-fragment request, so that no fragment is queued behind a store (in-order retirement), and in the gaps
-        // between the MFMAs.  The next requests (the following layer's) come an epilogue later.
+        // SAVE == 1 (BENERF_MLP_SPLIT_F16BWD: hi halves only, SH layout): the previous layer's activations leave for HBM during this
+        // layer's LAST two k-steps (four block pairs each: two transpose reads of the finished hi plane, the sign bits, one 16-byte
+        // store per pair): behind the K-loop's last weight-fragment request, so that no fragment is queued behind a store (in-order
+        // retirement), and in the gaps between the MFMAs.  SAVE == 2 (BENERF_MLP_SPLIT) saves from the epilogue's registers instead
+        // (DirectSave; rounds 3-4 spread transpose reads of BOTH planes + the codec over the last eight k-steps here).
         uint64_t pbits = 0;
-        const __amdgpu_buffer_rsrc_t prs = uniform_rsrc(SAVE ? st_h + ((int64_t)(l - 1) * Mp + ms0) * 256 : nullptr);
-        const __amdgpu_buffer_rsrc_t prs8 = uniform_rsrc(SAVE == 2 ? st8_h + ((int64_t)(l - 1) * Mp + ms0) * 256 : nullptr);
-#ifndef FWD_SAVE_KS
-#define FWD_SAVE_KS 8        // k-steps the SAVE == 2 work is spread over (8 block pairs per layer)
-#endif
-        // `last` = the loop's final k-step.  SAVE == 1: the hi halves in its last two k-steps (four block pairs each); SAVE == 2:
-        // hi halves + residual codes together, one block pair in each of the last eight k-steps
-        auto save_at = [&](int ks, int last) {
+        const __amdgpu_buffer_rsrc_t prs = uniform_rsrc(SAVE == 1 ? st_h + ((int64_t)(l - 1) * Mp + ms0) * 256 : nullptr);
+        auto save_at = [&](int ks, int last) {      // `last` = the loop's final k-step
             if (SAVE == 1 && ks >= last - 1) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) save_pair<256, true, 16>(Th, wave, (ks - (last - 1)) * 4 + i, lane, prs, pbits);
                 if (ks == last) store_bits(l - 1, pbits);
-            }
-#ifdef FWD_SAVE_SKEW     /* timing variant: the two waves of a SIMD (w, w + 4) save in different halves of the K-loop */
-            const int first = wave >= 4 ? last - (FWD_SAVE_KS - 1) : 0;
-#else
-            const int first = last - (FWD_SAVE_KS - 1);
-#endif
-            if (SAVE == 2 && ks >= first && ks < first + FWD_SAVE_KS) {
-#pragma unroll
-                for (int i = 0; i < 8 / FWD_SAVE_KS; ++i)
-                    save_pair22<256, true, 16>(Th, Tl, wave, (ks - first) * (8 / FWD_SAVE_KS) + i, lane, prs, prs8, pbits);
-                if (ks == first + FWD_SAVE_KS - 1) store_bits(l - 1, pbits);
             }
         };
         acc_init_bias(acc1, bq);
@@ -425,12 +475,13 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
                                              [&](int ks) { save_at(ks, 15); });
         lds_barrier();
         load_bias<1>(a.bias[l < 7 ? l + 1 : BENERF_L_FEAT], wave, lane, bq);
-        epilogue_t<1, true, 4>(acc1, acc2, Th, Tl, wave, lane, amax);
+        {
+            const DirectSave dl = direct(l, true);
+            epilogue_t<1, true, 4, SAVE == 2>(acc1, acc2, Th, Tl, wave, lane, amax, &dl);
+        }
         lds_barrier();
     }
     if (SAVE == 1) store_bits(7, save_tile<1, 256, true, 16>(Th, wave, lane, st_h + ((int64_t)7 * Mp + ms0) * 256));
-    if (SAVE == 2) store_bits(7, save_tile22<256, true, 16>(Th, Tl, wave, lane, st_h + ((int64_t)7 * Mp + ms0) * 256,
-                                                           st8_h + ((int64_t)7 * Mp + ms0) * 256));
 
     // ---- alpha partials (reads h7) + PE(viewdir) into columns [256,288) ---------------------------
     {
@@ -485,7 +536,10 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
     gemm_stage<16, 1, FPF, true, 4>(Th, Tl, 0, a.packed + pack_offset(PF_FEAT), wave, lane, acc1, acc2);
     lds_barrier();
     load_bias<1>(a.bias[BENERF_L_VIEWS], wave & 3, lane, bq);
-    epilogue_t<1, false, 4>(acc1, acc2, Th, Tl, wave, lane, amax);
+    {
+        const DirectSave df = direct(8, false);
+        epilogue_t<1, false, 4, SAVE == 2>(acc1, acc2, Th, Tl, wave, lane, amax, &df);
+    }
     if (tid < FTM && live) {
         const float4 p = *reinterpret_cast<const float4*>(scratch(0));
         a.raw[m * (C + 1) + C] = ((p.x + p.y) + (p.z + p.w)) + a.b_alpha[0];
@@ -493,8 +547,6 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
     lds_barrier();
     if (SAVE == 1) save_tile<1, 256, false, 16>(Th, wave, lane, reinterpret_cast<_Float16*>(acts + sact_feat(Mp)) + ms0 * 256);
     if (SAVE == 2) {
-        save_tile22<256, false, 16>(Th, Tl, wave, lane, reinterpret_cast<_Float16*>(acts + sact_feat(Mp)) + ms0 * 256,
-                                    st8_h + (int64_t)8 * Mp * 256 + ms0 * 256);
         // PE(dir) (planes' columns [256,288), visible since the barrier behind the FEAT GEMM) as an SH array of width 32 + lo8
         // twin: one block pair per wave
         const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(reinterpret_cast<_Float16*>(acts + sact22_ped_hi(Mp)) + ms0 * ACT_PED_W);
@@ -560,6 +612,7 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
             a.raw[m * (C + 1) + c] = ((p.x + p.y) + (p.z + p.w)) + a.b_rgb[c];
         }
     }
+    if (SAVE == 2) asm volatile("s_dcache_wb" ::: "memory");      // the sign-bit words went through the scalar data cache
 }
 
 }  // namespace

@@ -201,6 +201,28 @@ __host__ __device__ inline int64_t sact22_ped_hi(int64_t Mp) { return sact_ped32
 __host__ __device__ inline int64_t sact22_ped_lo8(int64_t Mp) { return sact_ped32(Mp) + Mp * 16; }
 static_assert(48 + 8 <= ACT_PE_W && 16 + 8 <= ACT_PED_W, "the split22 encodings fit the f32 regions");
 
+// ---- BENERF_MLP_SPLIT, round 5: the 256-wide activation arrays h0..h7 and feature in "SP" (slot-point) layout ------------------
+// The forward's transposed product leaves a lane with ONE point and 8 consecutive features per 16-byte plane slot, the dW
+// contraction wants 8 consecutive POINTS per feature.  Rounds 3-4 transposed in the forward (transpose reads of the finished
+// LDS planes: ~65 VALU + 4 LDS reads per 16 saved values); now the forward stores what its epilogue registers hold and the dW
+// kernel, which stages every chunk through LDS anyway, transposes with the reads it does there (ds_read_b64_tr_b16).  Per
+// 16-point chunk c (= m >> 4: the dW kernel's k-step) and feature slot s (8 features): 16 consecutive 16-byte units, one per
+// point - a chunk of the array is ONE contiguous 8-KiB run for the dW kernel's loads (with whole 128-point tiles per slot the
+// chunk was 32 runs of 256 bytes and the in-step dW launch 3 % slower), a wave's store four 256-byte runs:
+//   hi:     unit ((m >> 4) * W/8 + s) * 16 + (m & 15)  holds features 8 s .. 8 s + 7 of point m   (f16)
+//   codes:  the 8-byte unit of the same index in the lo8 twin
+// Same regions, same sizes as the SH arrays they replace (hv, PE, PE(dir) and every gradient array stay SH).
+__host__ __device__ inline int64_t sp_half_index(int64_t m, int W, int w) {
+    return (((m >> 4) * (W >> 3) + (w >> 3)) * 16 + (m & 15)) * 8 + (w & 7);
+}
+// ReLU sign bits of h0..h7 in BENERF_MLP_SPLIT, round 5: straight out of v_cmp_gt_f32 on the forward's accumulators (one VALU
+// instruction per accumulator register -> a 64-lane mask in an SGPR pair -> s_store_dwordx2; tools/hwprobe/sstore_mask.hip).
+// Accumulator element e of (row tile r, column tile ct) in the transposed product: lanes 0-31 = points 32 r + lane of feature
+// 32 ct + 8 (e >> 2) + (e & 3), lanes 32-63 = the same points of feature + 4.  uint32 word index inside layer l (same region,
+// same stride as before: sact_mask + l * (Mp / 64) * 512 words):   ((T * 4 + r) * 8 + ct) * 32 + 2 e + h,   bit p = point
+// 32 r + p,   h = lane >> 5.  hv (mask layer 8) keeps the uint64 [tile64][256] format of mlp_common.h.
+__host__ __device__ inline int sp_mask_word(int f32) { return 8 * (f32 >> 3) + 2 * (f32 & 3) + ((f32 >> 2) & 1); }   // feature 0..31 of its column tile
+
 // ---- lo8 codec on packed f16 pairs (one 32-bit register = two values) ----------------------------------------------------
 typedef unsigned short h8_ushort2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h8_half2 __attribute__((ext_vector_type(2)));

@@ -669,32 +669,37 @@ class TrainStep:
         d_raw1, _ = K.composite_bwd(raw1, z_fine, rd, nz1[0], nz1[1], nz1[2], nz1[3], g_rgb, d_rays_d=d_d, absmax_out=amax[0:1])
         d_raw0, _ = K.composite_bwd(raw0, z, rd, nz0[0], nz0[1], nz0[2], nz0[3], g_rgb0, d_rays_d=d_d, accumulate=True,
                                     absmax_out=amax[1:2])
-        d_pts1, d_vp1, dacts1 = K.mlp_bwd_dx(self.net_f.packed, d_raw1.view(-1, C + 1), acts1, N, S + Ni, slot="_fine", status=st,
-                                             d_raw_absmax=amax[0:1])
         # At full batch two K3 launches side by side are time slicing (0.91-1.00 of the sum of their times alone,
-        # profiles/r04_overlap_probe.log: each fills the CUs' LDS or registers by itself), so the fine network's weight gradients
+        # profiles/r04_overlap_probe.log: each fills the CUs' LDS or registers by itself), so the first network's weight gradients
         # stay on the main stream and only the LAST weight-gradient launch goes to the side stream, where it hides the trajectory
-        # tail and the loss values.  With the fine launch on the side stream too the C2 step measured 0.3 % shorter (9.07 vs 9.10 ms;
+        # tail and the loss values.  With the first launch on the side stream too the C2 step measured 0.3 % shorter (9.07 vs 9.10 ms;
         # the same in the exact-f32 mode) at the price of HIP-event durations that count the co-running launch (dX read 2.40 instead
         # of 1.51 ms, the f32 dW 0.56 instead of 0.77 of its roof): not worth a roofline nobody can add up.  A small per-rank batch
         # is different - its launches are one or two waves of workgroups, the device is not full for long and the pair does
         # overlap: 1/8 of C2 1.45 vs 1.54 ms, C4 2.51 vs 2.70, C5 3.26 vs 3.38 - so below 2048 fine tiles (8 per CU) both go there.
         fine_on_side = self.dw_stream_mode == "both" or (self.dw_stream_mode == "auto" and N * (S + Ni) < 2048 * 128)
-        side_f = side if fine_on_side else main
-        side_f.wait_stream(main)
-        with torch.cuda.stream(side_f):
-            K.mlp_bwd_dw(self.net_f.packed, d_raw1.view(-1, C + 1), acts1, dacts1, N, S + Ni, self.net_f.gviews_w,
-                         self.net_f.gviews_b, False)
-            # gradient exchange, bucket 1 of 3: the fine network's gradients are final - their all-reduce (RCCL over
-            # xGMI) runs on the communicator's stream while the coarse backward computes
-            pending = [dist.allreduce_sum_async_(self.flat_g[n:2 * n], self.world, self.pg)]
-        d_pts0, d_vp0, dacts0 = K.mlp_bwd_dx(self.net_c.packed, d_raw0.view(-1, C + 1), acts0, N, S, slot="_coarse", status=st,
-                                             d_raw_absmax=amax[1:2])
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            K.mlp_bwd_dw(self.net_c.packed, d_raw0.view(-1, C + 1), acts0, dacts0, N, S, self.net_c.gviews_w,
-                         self.net_c.gviews_b, False)
-            pending.append(dist.allreduce_sum_async_(self.flat_g[:n], self.world, self.pg))      # bucket 2: coarse network
+        # Which chain goes first is a knob, not a gain: with dX on the main stream and dW on the side stream the two chains are a
+        # two-machine flow shop and Johnson's rule says "coarse first" for a small per-rank batch - measured at 1/8 of C2 / C4 / C5:
+        # 1.688 / 2.698 / 3.400 ms against 1.671 / 2.689 / 3.377 ms fine-first (profiles/r05_one_eighth_batch_same_box.log: the
+        # co-running launches slow each other by what the rule would save).  Default: fine first.
+        coarse_first = os.environ.get("BENERF_BWD_ORDER", "fine_first") == "coarse_first"
+        chains = [("fine_net", self.net_f, d_raw1, acts1, S + Ni, "_fine", amax[0:1], slice(n, 2 * n)),
+                  ("coarse_net", self.net_c, d_raw0, acts0, S, "_coarse", amax[1:2], slice(0, n))]
+        if coarse_first:
+            chains.reverse()
+        pending, bucket_names, dxs = [], [], {}
+        for k_, (name_, net_, d_raw_, acts_, ns_, slot_, amax_, sl_) in enumerate(chains):
+            dxs[name_] = K.mlp_bwd_dx(net_.packed, d_raw_.view(-1, C + 1), acts_, N, ns_, slot=slot_, status=st, d_raw_absmax=amax_)
+            stream_ = side if (k_ == 1 or fine_on_side) else main       # the LAST weight-gradient launch always goes to the side stream
+            stream_.wait_stream(main)
+            with torch.cuda.stream(stream_):
+                K.mlp_bwd_dw(net_.packed, d_raw_.view(-1, C + 1), acts_, dxs[name_][2], N, ns_, net_.gviews_w, net_.gviews_b, False)
+                # gradient exchange, buckets 1 and 2 of 3: this network's gradients are final - their all-reduce (RCCL over xGMI)
+                # runs on the communicator's stream while the other network's backward computes
+                pending.append(dist.allreduce_sum_async_(self.flat_g[sl_], self.world, self.pg))
+                bucket_names.append(name_)
+        d_pts1, d_vp1, _ = dxs["fine_net"]
+        d_pts0, d_vp0, _ = dxs["coarse_net"]
         K.ray_grad_reduce(z_fine, d_pts1, d_vp1, d_o, d_d, d_v, 2)       # d_d holds the compositing part; d_o, d_v start here
         K.ray_grad_reduce(z, d_pts0, d_vp0, d_o, d_d, d_v, 1)
         dp_e = K.rays_bwd(poses_e, idx_e, ce.H, ce.W, ce.fx, ce.fy, ce.cx, ce.cy, cfg.ndc, d_o[:Ne], d_d[:Ne], d_v[:Ne], remap=ce.remap)
@@ -741,7 +746,7 @@ class TrainStep:
                                 "versions": self._param_versions() + tuple(t_._version for t_ in nxt),
                                 "rays": self._ray_setup(nxt[0], nxt[1], self.shard(nxt[2]), self.shard(nxt[3]), dn)}
         with torch.cuda.stream(side):
-            for nm, w in zip(("fine_net", "coarse_net"), pending[:2]):
+            for nm, w in zip(bucket_names, pending[:2]):
                 self._timed_wait(nm, w)
         main.wait_stream(side)
         if loss_sum is not None:

@@ -96,13 +96,16 @@ def step_grads(cfg, pc, pf, knots, transform, evt_ts, rgb_ts, idx_evt, idx_rgb, 
 
 
 def step_grads_vjp(cfg, pc, pf, knots, transform, evt_ts, rgb_ts, idx_evt, idx_rgb, target_acc, target_rgb, draws_evt, draws_rgb,
-                   dtype=torch.float32, n_chunks=8, event_bins=1):
+                   dtype=torch.float32, n_chunks=8, event_bins=1, z_forced=None):
     """One training step's loss and gradients in `dtype`, in pixel chunks, for ANY loss - also the L2-normalised event loss
     (train.py:238-292), which is not a sum over pixels and which step_grads therefore refuses to chunk.  Two passes:
       1. without autograd, chunk by chunk: the four rendered colour arrays (rgb_map / rgb0 of the event and of the blur render)
          and the depths of both renders;
       2. the loss on those arrays (tiny graph) gives d loss / d colours; then chunk by chunk WITH autograd the same render (the
          depths of pass 1 forced in, so sample_pdf is not re-drawn) is back-propagated with its slice of those vectors.
+    z_forced: the "z" dict another evaluation returned (e.g. the float32 one for a float64 run): its depths replace this
+    evaluation's own in BOTH passes, so that the two differentiate the same function (sample_pdf turns 1e-7 differences of the
+    coarse weights into different samples).
     By the chain rule the accumulated parameter gradients are the gradients of the whole step (a chunk's colours depend on the
     chunk's rays and the parameters only).  Returns the dict of step_grads."""
     Re, Rr, P, C = idx_evt.shape[0], idx_rgb.shape[0], cfg.n_poses, cfg.channels
@@ -126,9 +129,10 @@ def step_grads_vjp(cfg, pc, pf, knots, transform, evt_ts, rgb_ts, idx_evt, idx_r
             poses_e = O.trajectory_poses(kn, None, evt_ts.to(dtype), Pe, cfg.traj)
             poses_r = O.trajectory_poses(kn, tr, rgb_ts.to(dtype), P, cfg.traj)
             zf_e = zf_r = None
-            if forced:
-                zf_e = tuple(t[rows_e].to(dtype) for t in z_out["evt"])
-                zf_r = tuple(t[rows_r].to(dtype) for t in z_out["rgb"])
+            if forced or z_forced is not None:
+                zsrc = z_out if z_forced is None else z_forced
+                zf_e = tuple(t[rows_e].to(dtype) for t in zsrc["evt"][:2])
+                zf_r = tuple(t[rows_r].to(dtype) for t in zsrc["rgb"][:2])
             ret_e, ex_e = O.render(qc, qf, poses_e, idx_evt[e0:e1], cfg.H, cfg.W, K, C, S, cfg.n_importance,
                                    _chunk_draws(draws_evt, rows_e, dtype), z_forced=zf_e, want_extras=True)
             ret_r, ex_r = O.render(qc, qf, poses_r, idx_rgb[r0:r1], cfg.H, cfg.W, K, C, S, cfg.n_importance,

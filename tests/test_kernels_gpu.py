@@ -332,6 +332,14 @@ def _act_views(acts, M, mode="f32"):
     def sh(off, W):
         return sh1(off, W)
 
+    def sp(off, W=256):   # 'split', round 5 (mlp_split.h, SP layout): [chunk of 16 points][slot of 8 features][point][8 features]
+        h16 = halfs[off * 2: off * 2 + Mp * W]
+        first = (off - Mp * 96) * 2
+        code = lo8[first: first + Mp * W].reshape(Mp // 16, W // 8, 16, 8).astype(np.float32)
+        e5 = np.maximum((h16.view(np.uint16).reshape(Mp // 16, W // 8, 16, 8) >> 10) & 31, 9).astype(np.float32)
+        blk = h16.reshape(Mp // 16, W // 8, 16, 8).astype(np.float32) + (code - 128.0) * np.exp2(e5 - 15.0 - 18.0)
+        return torch.from_numpy(np.ascontiguousarray(blk.transpose(0, 2, 1, 3)).reshape(Mp, W)[:M])
+
     if mode == "split":
         # mlp_split.h, sact22_*: the two f32 regions hold the encodings as SH arrays + lo8 twins (19 bits, like every other saved
         # operand) and the point / view direction as f32 [Mp][8] for the dX kernel, which recomputes sin / cos
@@ -349,9 +357,10 @@ def _act_views(acts, M, mode="f32"):
     else:
         out["pe"] = a[0:Mp * 64].reshape(Mp, 64)[:M]
         out["ped"] = a[Mp * 64:Mp * 96].reshape(Mp, 32)[:M]
+    wide = sp if mode == "split" else sh        # the 256-wide arrays: SP layout in 'split', SH in 'split_f16bwd'
     for l in range(8):
-        out["h%d" % l] = sh(Mp * 96 + l * Mp * 128, 256)
-    out["feat"] = sh(Mp * 96 + 8 * Mp * 128, 256)
+        out["h%d" % l] = wide(Mp * 96 + l * Mp * 128, 256)
+    out["feat"] = wide(Mp * 96 + 8 * Mp * 128, 256)
     out["hv"] = sh(Mp * 96 + 9 * Mp * 128, 128)
     return out
 
