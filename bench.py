@@ -40,10 +40,11 @@ HBM_PEAK_GBS = 8000.0
 # gradient x hi/lo weight), dW 1 (f16 x f16); exact-f32 mode: 1 f32 MFMA chain everywhere
 EXECUTED_PER_PRODUCT = {"split": {"mlp_fwd": 3, "mlp_bwd_dx": 3, "mlp_bwd_dw": 3},
                         "split_f16bwd": {"mlp_fwd": 3, "mlp_bwd_dx": 2, "mlp_bwd_dw": 1}}
-# bytes per sample point the split-mode dW launch streams once (saved activations h0..h7, feature, hv and as many
-# gradients - f16 + 8-bit residual code, 3 bytes per value (split_f16bwd: one f16) -, the PE / PE(dir) operands (split: saved like
-# every other operand, 3 bytes per value; split_f16bwd: f32 rows), one d_raw row)
-DW_BYTES_PER_POINT = {"split": 3 * ((8 * 256 + 256 + 128) + (8 * 256 + 256 + 128)) + 3 * (64 + 32) + 8,
+# bytes per sample point the split-mode dW launch streams once (saved activations h0..h7, hv and as many gradients -
+# f16 + 8-bit residual code, 3 bytes per value; since round 5 neither the linear feature layer's output nor its gradient is saved
+# (split_f16bwd: h0..h7, feature, hv, one f16 per value) -, the PE / PE(dir) operands (split: saved like every other operand, 3
+# bytes per value; split_f16bwd: f32 rows), one d_raw row)
+DW_BYTES_PER_POINT = {"split": 3 * ((8 * 256 + 128) + (8 * 256 + 128)) + 3 * (64 + 32) + 8,
                       "split_f16bwd": 2 * ((8 * 256 + 256 + 128) + (8 * 256 + 256 + 128)) + 4 * (64 + 32) + 8}
 DTYPE_NOTE = {
     "split": "f32 storage; every MLP GEMM (forward, dX, dW) as 3 f16 MFMAs on hi/lo-split operands (22-bit in flight, 19-bit saved "
@@ -87,6 +88,10 @@ def parse():
                          "without wire time")
     ap.add_argument("--batch-fraction", type=int, default=1,
                     help="render 1/F of the workload's pixels per rank (F = 8 on one GPU: the per-rank step of a strong-scaled 8-GPU run)")
+    ap.add_argument("--proxy-rank", type=int, default=0,
+                    help="with --batch-fraction F: WHICH rank's share of the F-way split this one GPU renders.  0 (default) holds the largest "
+                         "share when the batch does not split evenly (107 blur pixels over 8 ranks: 14, against 13 on rank 7) - the rank "
+                         "the step of a strong-scaled job waits for")
     ap.add_argument("--event-bins", type=int, default=1,
                     help="dense event bins (BASELINE.json configs[4]; an extension, the reference has one bin per step): the event "
                          "window is cut into B contiguous equal bins, the event pixels are rendered at the B + 1 bin boundaries, every "
@@ -498,7 +503,7 @@ def main():
     # the ranks cannot split evenly (C4: 215 blur pixels over 8 ranks) go one each to the low ranks (dist.shard_bounds), nothing is
     # dropped.  --batch-fraction F (one-GPU proxy of a strong-scaled rank): the share of rank 0 of F, i.e. the LARGEST share.
     def share(n, parts):
-        lo, hi = D.shard_bounds(n, 0, parts, uneven=True)
+        lo, hi = D.shard_bounds(n, min(a.proxy_rank, parts - 1), parts, uneven=True)
         return max(hi - lo, 1)
     Re_n, Rr_n = share(wl["Re"], a.batch_fraction), share(wl["Rr"], a.batch_fraction)
     if a.scaling == "strong":

@@ -64,7 +64,7 @@ _SIGNATURES = {
     "benerf_mlp_h8_roundtrip": (c_int, [P, c_int64, c_int, P, P, P, P]),
     "benerf_step_gate": (c_int, [P, P, c_int, P]),
     "benerf_mlp_bwd_dx": (c_int, [POINTER(MlpParams), P, c_int, c_int, c_int, P, P, P, P, P, c_int, P, P, P]),
-    "benerf_mlp_bwd_dw": (c_int, [c_int, c_int, c_int, P, P, P, P, c_size_t, POINTER(MlpGrads), c_int, c_int, P, P]),
+    "benerf_mlp_bwd_dw": (c_int, [POINTER(MlpParams), c_int, c_int, c_int, P, P, P, P, c_size_t, POINTER(MlpGrads), c_int, c_int, P, P]),
     "benerf_composite_fwd": (c_int, [P, P, P, P, c_float, c_uint64, c_uint64, c_int, c_int, c_int, P, P, P, P, P, P, P]),
     "benerf_composite_bwd": (c_int, [P, P, P, P, c_float, c_uint64, c_uint64, c_int, c_int, c_int, P, P, P, P, P, P,
                                      c_int, P, P]),

@@ -339,8 +339,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_bwd_kernel(BwdArgs a) {
 }  // namespace
 
 // part 2 (mlp_dw.hip)
-int benerf_mlp_dw_launch(int precision, int channels, int64_t M, const float* d_raw, const float* acts, const float* dacts,
-                         float* dw_ws, const BenerfMlpGrads* grads, int accumulate, const float* pe_weights, hipStream_t stream);
+int benerf_mlp_dw_launch(const BenerfMlpParams* params, int precision, int channels, int64_t M, const float* d_raw, const float* acts,
+                         const float* dacts, float* dw_ws, const BenerfMlpGrads* grads, int accumulate, const float* pe_weights,
+                         hipStream_t stream);
 
 // f16 variant (mlp_bwd_h.hip)
 int benerf_mlp_dx_split_launch(const BenerfMlpParams* params, const float* packed, int channels, int64_t M, const float* d_raw,
@@ -400,10 +401,12 @@ extern "C" int benerf_mlp_bwd_dx(const BenerfMlpParams* params, const float* pac
     return launch_dx(params, packed, channels, M, d_raw, acts, dacts, d_pts, d_vdir_pts, as_stream(stream));
 }
 
-extern "C" int benerf_mlp_bwd_dw(int channels, int n_rays, int n_samples, const float* d_raw, const float* acts,
-                                 const float* dacts, float* dw_ws, size_t dw_ws_floats, const BenerfMlpGrads* grads,
+extern "C" int benerf_mlp_bwd_dw(const BenerfMlpParams* params, int channels, int n_rays, int n_samples, const float* d_raw,
+                                 const float* acts, const float* dacts, float* dw_ws, size_t dw_ws_floats, const BenerfMlpGrads* grads,
                                  int accumulate, int precision, const float* pe_weights, benerf_stream_t stream) {
     BENERF_REQUIRE(d_raw && acts && dacts && dw_ws && grads, "mlp_bwd_dw: null pointer");
+    BENERF_REQUIRE(precision != BENERF_MLP_SPLIT || (params && params->w[BENERF_L_VIEWS] && params->w[BENERF_L_FEAT] && params->b[BENERF_L_FEAT]),
+                   "mlp_bwd_dw: BENERF_MLP_SPLIT needs the network's parameters (views / feature weights, feature bias)");
     BENERF_REQUIRE(channels == 1 || channels == 3, "mlp_bwd_dw: channels must be 1 or 3");
     BENERF_REQUIRE(n_rays > 0 && n_samples > 0, "mlp_bwd_dw: bad sizes");
     BENERF_REQUIRE(precision == BENERF_MLP_F32 || precision == BENERF_MLP_SPLIT || precision == BENERF_MLP_SPLIT_F16BWD,
@@ -413,6 +416,6 @@ extern "C" int benerf_mlp_bwd_dw(int channels, int n_rays, int n_samples, const 
         return BENERF_EWORKSPACE;
     }
     for (int l = 0; l < BENERF_NLAYERS; ++l) BENERF_REQUIRE(grads->w[l] && grads->b[l], "mlp_bwd_dw: null grad %d", l);
-    return benerf_mlp_dw_launch(precision, channels, (int64_t)n_rays * n_samples, d_raw, acts, dacts, dw_ws, grads, accumulate,
+    return benerf_mlp_dw_launch(params, precision, channels, (int64_t)n_rays * n_samples, d_raw, acts, dacts, dw_ws, grads, accumulate,
                                 pe_weights, as_stream(stream));
 }

@@ -283,7 +283,8 @@ __device__ __forceinline__ void amax3(float& amax, float v0, float v1) {
 // right by 4 (lane >> 5): bit 8 (e >> 2) + (e & 3) <-> accumulator element e; mlp_split.h: sp_mask_word) -> both planes (hi, lo;
 // tile scale) and, rescaled by gf = s_call / s_tile (a power of two <= 1; exact), the SH gradient arrays `st_hi` / `st_lo` of
 // width 256 (tile part).
-template <bool MASK>
+// STORE = false: planes only (d feature: the dW kernels do not need it, mlp_common.h: DWS_*)
+template <bool MASK, bool STORE = true>
 __device__ __forceinline__ void epilogue3(f32x16 (&acc)[4], const uint32_t (&bits)[4], _Float16* __restrict__ Th, _Float16* __restrict__ Tl,
                                           int ct, int lane, const _Float16* __restrict__ st_hi, const uint8_t* __restrict__ st_lo, float gf,
                                           float& amax) {
@@ -334,6 +335,7 @@ __device__ __forceinline__ void epilogue3(f32x16 (&acc)[4], const uint32_t (&bit
                 qh[h] = uint2{wh[0], wh[1]};
                 ql[h] = uint2{wl[0], wl[1]};
             }
+            if (!STORE) continue;
             // lanes exchange halves, then the exact rescale (v_pk_mul_f16 by a power of two) and the residual codes
             const uint4 uh = sh_pair_unit(qh[0], qh[1]);
             const uint4 ul = sh_pair_unit(ql[0], ql[1]);
@@ -498,10 +500,9 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
     zero4(acc);
     gemm3<8>(Th, Tl, packed_h + pack_offset(PB_VIEWS), ct, lane, acc);
     lds_barrier();   // dYv fully consumed; dPE(dir) visible
-    {
-        _Float16* stf = reinterpret_cast<_Float16*>(dacts + sdact_feat(Mp)) + ms0 * 256;
-        epilogue3<false>(acc, bits, Th, Tl, ct, lane, stf, st8 + 2 * sdact_feat(Mp) + ms0 * 256, gf, amax);
-    }
+    // d feature stays in the planes: neither feature nor its gradient goes to HBM (the feature layer is linear into the views
+    // layer; its weight gradient is composed from dhv^T h7 in the dW reduce, mlp_common.h: DWS_*)
+    epilogue3<false, false>(acc, bits, Th, Tl, ct, lane, nullptr, nullptr, gf, amax);
     if (tid < TMB && m0 + tid < M) {   // d viewdirs (per point) through PE(dir): sin / cos recomputed from the saved direction
         const int64_t m = m0 + tid;
         const float4 vd4 = reinterpret_cast<const float4*>(acts + sact22_pts(Mp))[m * 2 + 1];

@@ -204,7 +204,46 @@ __host__ __device__ constexpr int64_t dwh_inst_offset(int inst) {
 }
 static_assert(dwh_inst_offset(DW_COUNT) <= DW_WS_FLOATS, "split-mode partials fit the f32-mode workspace");
 static_assert(DWH_BIG_BLOCKS == 256, "one workgroup per CU");
+#ifndef DWH_ALLOW_ANY   /* timing variants with other thin split counts (tools/experiments/build_variant.sh) */
 static_assert(DWH_SMALL_BLOCKS == 512, "two light workgroups per CU");
+#endif
+
+// BENERF_MLP_SPLIT, round 5 (mlp_dw_s.hip).  The feature layer feeds the views layer WITHOUT a ReLU in between (model/nerf.py:
+// 100-106: feature = W_f h7 + b_f; hv = relu(W_v [feature, PE(dir)] + b_v)), so with G = dhv^T h7 (128 x 256, one contraction over
+// the points) both weight gradients that involve `feature` follow by two tiny GEMMs in the reduce stage:
+//     d feature = dhv W_vf              =>  dW_f  = d feature^T h7 = W_vf^T G,        db_f = W_vf^T (sum dhv)
+//     dW_v[:, :256] = dhv^T feature     =   G W_f^T + (sum dhv) b_f^T
+// Neither `feature` nor its gradient is saved any more (768 bytes per point less out of the forward, 768 less out of dX, 1 536
+// less into dW), the 256 x 256 FEAT instance of the big kernel is gone and the views block reads h7 instead of feature (and
+// carries the alpha head, which wants h7 too): 7 plain instances x DWS_LS point-splits + DWS_GS for G = 256 workgroups, balanced
+// by measured time (round 4: the views block cost 0.79 of a plain instance per point, the alpha head 0.36: G = 1.15 -> 31 / 39).  The alpha partials keep their place in the FEAT instance's part
+// of the workspace (its first split's block doubles as the buffer of the reduced G + sum dhv).
+#ifndef DWS_LS
+#define DWS_LS 31
+#endif
+#ifndef DWS_GS
+#define DWS_GS 39
+#endif
+__host__ __device__ constexpr int dws_splits(int inst) {
+    switch (inst) {
+        case DW_FEAT: case DW_VIEWSF: return DWS_GS;
+        case DW_L0: case DW_L5P: return DWH_T0;
+        case DW_VIEWSP: return DWH_T1;
+        case DW_RGB: return DWH_T2;
+        default: return DWS_LS;
+    }
+}
+constexpr int DWS_BIG_BLOCKS = 7 * DWS_LS + DWS_GS;
+__host__ __device__ constexpr int dws_big_inst(int b) { return b < 7 * DWS_LS ? b / DWS_LS : DW_VIEWSF; }
+__host__ __device__ constexpr int dws_big_split(int b) { return b < 7 * DWS_LS ? b % DWS_LS : b - 7 * DWS_LS; }
+__host__ __device__ constexpr int64_t dws_inst_offset(int inst) {
+    int64_t o = 0;
+    for (int i = 0; i < inst; ++i) o += dw_inst_floats(i) * dws_splits(i);
+    return o;
+}
+static_assert(dws_inst_offset(DW_COUNT) <= DW_WS_FLOATS, "BENERF_MLP_SPLIT partials fit the f32-mode workspace");
+static_assert(DWS_BIG_BLOCKS == 256, "one workgroup per CU");
+static_assert(128 * 256 + 128 <= 256 * 256 + 256, "reduced G + sum dhv fit in front of the alpha partials of the FEAT block");
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding global load and
 // STORE (s_waitcnt vmcnt(0)) - with ~10 KB of activations stored per point that is one HBM write latency per stage.

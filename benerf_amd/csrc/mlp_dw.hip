@@ -287,17 +287,22 @@ struct ReduceArgs {
     float* gb[BENERF_NLAYERS];
     int C;
     int accumulate;
-    int split_mode;          // partials written by mlp_dw_h.hip: other split table; dY-derived sums carry the factor s_s
+    int split_mode;          // 1: partials written by mlp_dw_h.hip / 2: by mlp_dw_s.hip (their split tables); dY-derived sums carry the factor s_s
+    // split_mode 2 (BENERF_MLP_SPLIT): the feature / views weight gradients are composed from G = dhv^T h7 (mlp_common.h)
+    const float* w_views;    // [128][283]
+    const float* w_feat;     // [256][256]
+    const float* b_feat;     // [256]
+    float* gbuf;             // reduced G [128][256] + sum dhv [128] (unscaled), written by dw_reduce_g_kernel
     const float* grad_info;  // split mode: info words of the dY arrays ([SD_DRAW] = max |d_raw|, s_s derives from it)
     const float* pe_w;       // BARF c2f: the saved encodings are unweighted, so the PE columns of layers 0 / 5 / views are
                              // scaled here (dW[:, col] = w[col] * sum dY * PE[col]); null = no weighting
 };
 
-template <bool SPLIT>
+template <int SPLIT>     // 0: f32 kernels' split table, 1: mlp_dw_h.hip's, 2: mlp_dw_s.hip's
 __device__ __forceinline__ float sum_splits_t(const float* ws, int inst, int64_t elem) {
-    const float* p = ws + (SPLIT ? dwh_inst_offset(inst) : dw_inst_offset(inst)) + elem;
+    const float* p = ws + (SPLIT == 2 ? dws_inst_offset(inst) : SPLIT ? dwh_inst_offset(inst) : dw_inst_offset(inst)) + elem;
     const int64_t stride = dw_inst_floats(inst);
-    const int n = SPLIT ? dwh_splits(inst) : dw_splits(inst);
+    const int n = SPLIT == 2 ? dws_splits(inst) : SPLIT ? dwh_splits(inst) : dw_splits(inst);
     // fixed summation order (run-to-run reproducible); eight loads in flight per step - the partial sums were just
     // written and sit in L2 / MALL, so this kernel is bound by the length of its dependent load chains
     float s = 0.f;
@@ -314,7 +319,7 @@ __device__ __forceinline__ float sum_splits_t(const float* ws, int inst, int64_t
 }
 // split mode: weight blocks and bias sums carry the gradient scale s_s of the call (mlp_split.h, pow2_scale6); the
 // alpha / rgb heads are computed from the unscaled d_raw
-template <bool SPLIT>
+template <int SPLIT>
 __device__ __forceinline__ float unscale_of(const float* grad_info, int inst) {
     if (!SPLIT || inst == DW_RGB) return 1.f;
     float s_s, inv_s_s;
@@ -339,7 +344,75 @@ __device__ __forceinline__ int layer_inst(int l) {   // instance holding the bia
     }
 }
 
-template <bool SPLIT>
+// BENERF_MLP_SPLIT: G = dhv^T h7 and sum dhv, reduced over the splits in fixed order and unscaled -> gbuf (32 896 floats)
+__global__ void dw_reduce_g_kernel(ReduceArgs a) {
+    constexpr int SPLIT = 2;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < 128 * 256 + 128) a.gbuf[e] = sum_splits(a.ws, DW_VIEWSF, e);
+}
+
+// BENERF_MLP_SPLIT: the two small GEMMs that turn G = dhv^T h7 into weight gradients (mlp_common.h: DWS_*), 32 x 32 output tiles
+// through LDS, fixed summation order (k ascending), f32 FMAs:
+//   blocks [0, 64):   dW_f[n][j]      = sum_i W_v[i][n] G[i][j]                          (256 x 256, K = 128)
+//   blocks [64, 96):  dW_v[n][j<256]  = sum_k G[n][k] W_f[j][k] + (sum dhv)[n] b_f[j]    (128 x 256, K = 256)
+//   block 96:         db_f[n] = sum_i W_v[i][n] (sum dhv)[i];   db_v[n] = (sum dhv)[n]
+__global__ __launch_bounds__(256) void dw_compose_kernel(ReduceArgs a) {
+    __shared__ float As[32][33], Bs[32][33];
+    const float* G = a.gbuf;
+    const float* bs = a.gbuf + 128 * 256;
+    const int t = threadIdx.x, tx = t & 31, ty = t >> 5;
+    const int b = blockIdx.x;
+    if (b == 96) {
+        float acc = 0.f;
+        for (int i = 0; i < 128; ++i) acc = fmaf(a.w_views[i * 283 + t], bs[i], acc);      // t = n: coalesced rows of W_v
+        float* d = a.gb[BENERF_L_FEAT] + t;
+        *d = a.accumulate ? *d + acc : acc;
+        if (t < 128) {
+            float* dv = a.gb[BENERF_L_VIEWS] + t;
+            *dv = a.accumulate ? *dv + bs[t] : bs[t];
+        }
+        return;
+    }
+    const bool feat = b < 64;
+    const int bb = feat ? b : b - 64;
+    const int m0 = (bb >> 3) * 32, n0 = (bb & 7) * 32, K = feat ? 128 : 256;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < K; k0 += 32) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = ty + 8 * r;
+            if (feat) {     // A[m][k] = W_v[k][m] (m contiguous), B[k][n] = G[k][n] (n contiguous)
+                As[tx][q] = a.w_views[(k0 + q) * 283 + m0 + tx];
+                Bs[q][tx] = G[(k0 + q) * 256 + n0 + tx];
+            } else {        // A[m][k] = G[m][k] (k contiguous), B[k][n] = W_f[n][k] (k contiguous)
+                As[q][tx] = G[(m0 + q) * 256 + k0 + tx];
+                Bs[tx][q] = a.w_feat[(n0 + q) * 256 + k0 + tx];
+            }
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) {
+            const float bv = Bs[k][tx];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = fmaf(As[ty + 8 * r][k], bv, acc[r]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = m0 + ty + 8 * r, n = n0 + tx;
+        float v = acc[r];
+        float* d;
+        if (feat) d = a.gw[BENERF_L_FEAT] + m * 256 + n;
+        else {
+            v = fmaf(bs[m], a.b_feat[n], v);
+            d = a.gw[BENERF_L_VIEWS] + m * 283 + n;
+        }
+        *d = a.accumulate ? *d + v : v;
+    }
+}
+
+template <int SPLIT>
 __global__ void dw_reduce_kernel(ReduceArgs a) {
     const int l = blockIdx.y;
     const int C = a.C;
@@ -348,6 +421,18 @@ __global__ void dw_reduce_kernel(ReduceArgs a) {
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nw + out; e += (int64_t)gridDim.x * blockDim.x) {
         float v;
         float* dst;
+        if (SPLIT == 2 && (l == BENERF_L_FEAT || l == BENERF_L_VIEWS)) {
+            // the feature layer and the first 256 columns + bias of the views layer are composed from G by dw_compose_kernel;
+            // what is left here: the PE(dir) columns of the views layer
+            if (l == BENERF_L_FEAT || e >= nw) continue;
+            const int n = (int)(e / in), j = (int)(e % in);
+            if (j < 256) continue;
+            v = sum_splits(a.ws, DW_VIEWSP, (int64_t)n * 32 + (j - 256));
+            if (a.pe_w) v *= a.pe_w[64 + (j - 256)];
+            dst = a.gw[l] + e;
+            *dst = a.accumulate ? *dst + v : v;
+            continue;
+        }
         if (e < nw) {
             const int n = (int)(e / in), j = (int)(e % in);
             dst = a.gw[l] + e;
@@ -381,9 +466,18 @@ __global__ void dw_reduce_kernel(ReduceArgs a) {
 }  // namespace
 
 int benerf_mlp_dw_reduce_launch(const float* ws, const BenerfMlpGrads* grads, int channels, int accumulate, int split_mode,
-                                const float* grad_info, const float* pe_weights, hipStream_t stream) {
+                                const float* grad_info, const float* pe_weights, hipStream_t stream, const BenerfMlpParams* params) {
     ReduceArgs r;
     r.ws = ws;
+    r.w_views = r.w_feat = r.b_feat = nullptr;
+    r.gbuf = nullptr;
+    if (split_mode == 2) {
+        r.w_views = params->w[BENERF_L_VIEWS];
+        r.w_feat = params->w[BENERF_L_FEAT];
+        r.b_feat = params->b[BENERF_L_FEAT];
+        // nothing of the FEAT instance's first split block but its alpha tail (floats [65 792, 66 049)) is written by the kernels
+        r.gbuf = const_cast<float*>(ws) + dws_inst_offset(DW_FEAT);
+    }
     for (int l = 0; l < BENERF_NLAYERS; ++l) {
         r.gw[l] = grads->w[l];
         r.gb[l] = grads->b[l];
@@ -393,8 +487,12 @@ int benerf_mlp_dw_reduce_launch(const float* ws, const BenerfMlpGrads* grads, in
     r.split_mode = split_mode;
     r.grad_info = grad_info;
     r.pe_w = pe_weights;
-    if (split_mode) hipLaunchKernelGGL(dw_reduce_kernel<true>, dim3(128, BENERF_NLAYERS), dim3(256), 0, stream, r);
-    else hipLaunchKernelGGL(dw_reduce_kernel<false>, dim3(128, BENERF_NLAYERS), dim3(256), 0, stream, r);
+    if (split_mode == 2) {
+        hipLaunchKernelGGL(dw_reduce_g_kernel, dim3((128 * 256 + 128 + 255) / 256), dim3(256), 0, stream, r);
+        hipLaunchKernelGGL(dw_compose_kernel, dim3(97), dim3(256), 0, stream, r);
+        hipLaunchKernelGGL(dw_reduce_kernel<2>, dim3(128, BENERF_NLAYERS), dim3(256), 0, stream, r);
+    } else if (split_mode) hipLaunchKernelGGL(dw_reduce_kernel<1>, dim3(128, BENERF_NLAYERS), dim3(256), 0, stream, r);
+    else hipLaunchKernelGGL(dw_reduce_kernel<0>, dim3(128, BENERF_NLAYERS), dim3(256), 0, stream, r);
     BENERF_LAUNCH_CHECK("mlp_bwd(reduce)");
     return BENERF_OK;
 }
@@ -404,14 +502,15 @@ int benerf_mlp_dw_split_launch(int channels, int64_t M, const float* d_raw, cons
                                const BenerfMlpGrads* grads, int accumulate, const float* pe_weights, hipStream_t stream);
 
 // 22-bit variant (mlp_dw_s.hip)
-int benerf_mlp_dw_split22_launch(int channels, int64_t M, const float* d_raw, const float* acts, const float* dacts, float* dw_ws,
-                                 const BenerfMlpGrads* grads, int accumulate, const float* pe_weights, hipStream_t stream);
+int benerf_mlp_dw_split22_launch(const BenerfMlpParams* params, int channels, int64_t M, const float* d_raw, const float* acts,
+                                 const float* dacts, float* dw_ws, const BenerfMlpGrads* grads, int accumulate, const float* pe_weights,
+                                 hipStream_t stream);
 
-int benerf_mlp_dw_launch(int precision, int channels, int64_t M, const float* d_raw, const float* acts,
+int benerf_mlp_dw_launch(const BenerfMlpParams* params, int precision, int channels, int64_t M, const float* d_raw, const float* acts,
                          const float* dacts, float* dw_ws, const BenerfMlpGrads* grads, int accumulate,
                          const float* pe_weights, hipStream_t stream) {
     if (precision == BENERF_MLP_SPLIT)
-        return benerf_mlp_dw_split22_launch(channels, M, d_raw, acts, dacts, dw_ws, grads, accumulate, pe_weights, stream);
+        return benerf_mlp_dw_split22_launch(params, channels, M, d_raw, acts, dacts, dw_ws, grads, accumulate, pe_weights, stream);
     if (precision == BENERF_MLP_SPLIT_F16BWD)
         return benerf_mlp_dw_split_launch(channels, M, d_raw, acts, dacts, dw_ws, grads, accumulate, pe_weights, stream);
     DwArgs a;
@@ -428,5 +527,5 @@ int benerf_mlp_dw_launch(int precision, int channels, int64_t M, const float* d_
     }
     hipLaunchKernelGGL(mlp_dw_kernel, dim3(mlp::DW_TOTAL_BLOCKS), dim3(DWT), DW_SMEM, stream, a);
     BENERF_LAUNCH_CHECK("mlp_bwd(dw)");
-    return benerf_mlp_dw_reduce_launch(dw_ws, grads, channels, accumulate, 0, nullptr, pe_weights, stream);
+    return benerf_mlp_dw_reduce_launch(dw_ws, grads, channels, accumulate, 0, nullptr, pe_weights, stream, nullptr);
 }

@@ -372,7 +372,7 @@ __global__ __launch_bounds__(DWT, 4) void mlp_dw_f16_small_kernel(DwArgs a) {
 }  // namespace
 
 int benerf_mlp_dw_reduce_launch(const float* ws, const BenerfMlpGrads* grads, int channels, int accumulate, int split_mode,
-                                const float* grad_info, const float* pe_weights, hipStream_t stream);
+                                const float* grad_info, const float* pe_weights, hipStream_t stream, const BenerfMlpParams* params);
 
 int benerf_mlp_dw_split_launch(int channels, int64_t M, const float* d_raw, const float* acts, const float* dacts, float* dw_ws,
                                const BenerfMlpGrads* grads, int accumulate, const float* pe_weights, hipStream_t stream) {
@@ -394,5 +394,5 @@ int benerf_mlp_dw_split_launch(int channels, int64_t M, const float* d_raw, cons
     BENERF_LAUNCH_CHECK("mlp_bwd(dw small, f16)");
     hipLaunchKernelGGL(mlp_dw_f16_big_kernel, dim3(mlp::DWH_BIG_BLOCKS), dim3(DWT), DWH_SMEM, stream, a);
     BENERF_LAUNCH_CHECK("mlp_bwd(dw, f16)");
-    return benerf_mlp_dw_reduce_launch(dw_ws, grads, channels, accumulate, 1, dacts + mlp::sdact_info(mlp::m_pad(M)), pe_weights, stream);
+    return benerf_mlp_dw_reduce_launch(dw_ws, grads, channels, accumulate, 1, dacts + mlp::sdact_info(mlp::m_pad(M)), pe_weights, stream, nullptr);
 }

@@ -59,8 +59,9 @@ __device__ __forceinline__ Src inst_src(const DwArgs& a, int inst) {
                    reinterpret_cast<const u32x4*>(A + xoff), reinterpret_cast<const uint2*>(sact_lo8(A, Mp, xoff)), true};
     };
     switch (inst) {     // the big kernel's instances
-        case DW_FEAT: return Y(sdact_feat(Mp), sact_h(Mp, 7));
-        case DW_VIEWSF: return Y(sdact_hv(Mp), sact_feat(Mp));
+        // G = dhv^T h7 (mlp_common.h, round 5): the views block reads h7, not `feature` - neither feature nor its gradient is saved;
+        // the feature layer's and the views layer's weight gradients are composed from G in the reduce stage
+        case DW_VIEWSF: return Y(sdact_hv(Mp), sact_h(Mp, 7));
         default: return Y(sdact_h(Mp, 1 + (inst - DW_L1)), sact_h(Mp, inst - DW_L1));     // DW_L1 .. DW_L7 (DW_L5H: the h4 part of layer 5)
     }
 }
@@ -93,9 +94,10 @@ __device__ __forceinline__ float dw_sum_unit(const half8 h, const half8 l, float
 // Output block N x K (the whole instance: K = width of X).  Waves form a WN x (8/WN) grid; each owns TR x TC MFMA tiles: per
 // 16-point chunk acc += Yh^T Xh + Yh^T Xl + Yl^T Xh.  Three chunks are in flight in registers (sets A, B, C) and the LDS image
 // is triple-buffered, so there is one LDS-only barrier per chunk.
+// ALPHA: the alpha head (dW_alpha = d_sigma^T X, X = h7) rides on waves 4..7; its partial row [256] + bias go to `apart`
 template <int N, int K, int WN, int TR, int TC, bool ALPHA>
 __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int64_t chunk_begin, int64_t chunk_end,
-                                        float* __restrict__ part, u32x4* __restrict__ smem) {
+                                        float* __restrict__ part, u32x4* __restrict__ smem, float* __restrict__ apart = nullptr) {
     static_assert(WN * TR * 32 == N, "row tiling");
     static_assert(K == 256 && CHP == 16, "X in SP layout: 32 slots x 16 points = one unit per thread and chunk");
     constexpr int YU = CHB * N, XU = CHB * K;                  // 16-byte units per chunk and plane
@@ -329,8 +331,8 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int64_t 
     }
     if (tid < N) part[(int64_t)N * K + tid] = src.bias ? bsum : 0.f;
     if (ALPHA && tid >= DWT - K) {
-        part[(int64_t)N * K + N + tid - (DWT - K)] = asum;
-        if (tid == DWT - K) part[(int64_t)N * K + N + 256] = absum;
+        apart[tid - (DWT - K)] = asum;
+        if (tid == DWT - K) apart[256] = absum;
     }
 }
 
@@ -424,7 +426,7 @@ __device__ __forceinline__ void dw_rgb(const DwArgs& a, int64_t blk_begin, int64
 constexpr size_t DWS_SMEM = 3 * (size_t)(2 * CHB * 256 + 2 * CHB * 256 + CHP / 4) * 16;       // three chunk images of the 256 x 256 block: 98 496 B
 __device__ __forceinline__ void chunk_range(const DwArgs& a, int inst, int split, int64_t& cb, int64_t& ce) {
     const int64_t nchunks = m_pad(a.M) / CHP;
-    const int64_t per = (nchunks + dwh_splits(inst) - 1) / dwh_splits(inst);
+    const int64_t per = (nchunks + dws_splits(inst) - 1) / dws_splits(inst);
     cb = (int64_t)split * per;
     ce = cb + per;
     if (cb > nchunks) cb = nchunks;
@@ -434,23 +436,25 @@ __device__ __forceinline__ void chunk_range(const DwArgs& a, int inst, int split
 // -DBENERF_TRACE_DW: thread 0 of every workgroup stamps the 100 MHz wall clock at its start and end behind the partial sums in
 // the workspace (u64 [kernel: 0 small, 1 big][512 workgroups][2]) - tools/experiments/trace_dw.py prints per-instance finish times.
 #ifdef BENERF_TRACE_DW
-#define DW_TRACE(kern, which) do { if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(a.ws + ((dwh_inst_offset(DW_COUNT) + 63) & ~63LL))[((kern) * 512 + blockIdx.x) * 2 + (which)] = wall_clock64(); } while (0)
+#define DW_TRACE(kern, which) do { if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(a.ws + ((dws_inst_offset(DW_COUNT) + 63) & ~63LL))[((kern) * 512 + blockIdx.x) * 2 + (which)] = wall_clock64(); } while (0)
 #else
 #define DW_TRACE(kern, which) do { } while (0)
 #endif
 
-// the eight 256x256 instances + the 128x256 views block: one workgroup per CU, every operand byte read once
+// the seven 256x256 instances L1 .. L7 + the 128x256 block G = dhv^T h7 (with the alpha head): one workgroup per CU, every operand
+// byte read once
 __global__ __launch_bounds__(DWT, 2) void mlp_dw_split_big_kernel(DwArgs a) {
     extern __shared__ __attribute__((aligned(16))) u32x4 smem_u[];
     DW_TRACE(1, 0);
-    const int inst = dwh_big_inst(blockIdx.x), split = dwh_big_split(blockIdx.x);
+    const int inst = dws_big_inst(blockIdx.x), split = dws_big_split(blockIdx.x);
     int64_t cb, ce;
     chunk_range(a, inst, split, cb, ce);
-    float* part = a.ws + dwh_inst_offset(inst) + (int64_t)split * dw_inst_floats(inst);
+    float* part = a.ws + dws_inst_offset(inst) + (int64_t)split * dw_inst_floats(inst);
     const Src src = inst_src(a, inst);
-    if (inst == DW_FEAT) dw_gemm<256, 256, 4, 2, 4, true>(a, src, cb, ce, part, smem_u);
-    else if (inst <= DW_L7) dw_gemm<256, 256, 4, 2, 4, false>(a, src, cb, ce, part, smem_u);
-    else dw_gemm<128, 256, 2, 2, 2, false>(a, src, cb, ce, part, smem_u);
+    if (inst <= DW_L7) dw_gemm<256, 256, 4, 2, 4, false>(a, src, cb, ce, part, smem_u);
+    else     // alpha partials: the tail of this split's block in the (otherwise unused) FEAT instance part of the workspace
+        dw_gemm<128, 256, 2, 2, 2, true>(a, src, cb, ce, part, smem_u,
+                                         a.ws + dws_inst_offset(DW_FEAT) + (int64_t)split * dw_inst_floats(DW_FEAT) + 256 * 256 + 256);
     DW_TRACE(1, 1);
 }
 
@@ -586,7 +590,7 @@ __device__ __forceinline__ void thin_stream(const u32x4* const (&yh)[NYA], const
 // Workgroups [0, DWH_T0): split b of L0 + L5P, wave w = row tile w; [DWH_T0, + DWH_T1 / 2): VIEWSP, two splits per workgroup (waves
 // 0-3 / 4-7, row tile w & 3); then DWH_T2 workgroups of the rgb head.
 constexpr int DWS_SMALL_BLOCKS = DWH_T0 + DWH_T1 / 2 + DWH_T2;
-static_assert(DWH_T1 % 2 == 0 && dwh_splits(DW_L0) == dwh_splits(DW_L5P), "thin split tables");
+static_assert(DWH_T1 % 2 == 0 && dws_splits(DW_L0) == dws_splits(DW_L5P), "thin split tables");
 __global__ __launch_bounds__(DWT, 2) void mlp_dw_split_small_kernel(DwArgs a) {
     __shared__ __attribute__((aligned(16))) float rgb_smem[32 * 8 * 4 + 18 * 128];
     DW_TRACE(0, 0);
@@ -602,8 +606,8 @@ __global__ __launch_bounds__(DWT, 2) void mlp_dw_split_small_kernel(DwArgs a) {
         chunk_range(a, DW_L0, b, cb, ce);
         const u32x4* const yh[2] = {dy(sdact_h(Mp, 0)), dy(sdact_h(Mp, 5))};
         const uint2* const y8[2] = {dy8(sdact_h(Mp, 0)), dy8(sdact_h(Mp, 5))};
-        float* const part[2] = {a.ws + dwh_inst_offset(DW_L0) + (int64_t)b * dw_inst_floats(DW_L0),
-                                a.ws + dwh_inst_offset(DW_L5P) + (int64_t)b * dw_inst_floats(DW_L5P)};
+        float* const part[2] = {a.ws + dws_inst_offset(DW_L0) + (int64_t)b * dw_inst_floats(DW_L0),
+                                a.ws + dws_inst_offset(DW_L5P) + (int64_t)b * dw_inst_floats(DW_L5P)};
         thin_stream<2, 256, 2, true>(yh, y8, reinterpret_cast<const u32x4*>(A + sact22_pe_hi(Mp)),
                                      reinterpret_cast<const uint2*>(A + sact22_pe_lo8(Mp)), wave, cb, ce, lane, part);
     } else if (b < DWH_T0 + DWH_T1 / 2) {
@@ -611,13 +615,13 @@ __global__ __launch_bounds__(DWT, 2) void mlp_dw_split_small_kernel(DwArgs a) {
         chunk_range(a, DW_VIEWSP, split, cb, ce);
         const u32x4* const yh[1] = {dy(sdact_hv(Mp))};
         const uint2* const y8[1] = {dy8(sdact_hv(Mp))};
-        float* const part[1] = {a.ws + dwh_inst_offset(DW_VIEWSP) + (int64_t)split * dw_inst_floats(DW_VIEWSP)};
+        float* const part[1] = {a.ws + dws_inst_offset(DW_VIEWSP) + (int64_t)split * dw_inst_floats(DW_VIEWSP)};
         thin_stream<1, 128, 1, false>(yh, y8, reinterpret_cast<const u32x4*>(A + sact22_ped_hi(Mp)),
                                       reinterpret_cast<const uint2*>(A + sact22_ped_lo8(Mp)), wave & 3, cb, ce, lane, part);
     } else {
         const int split = b - (DWH_T0 + DWH_T1 / 2);
         chunk_range(a, DW_RGB, split, cb, ce);
-        dw_rgb(a, cb * CHB, ce * CHB, a.ws + dwh_inst_offset(DW_RGB) + (int64_t)split * dw_inst_floats(DW_RGB), rgb_smem);
+        dw_rgb(a, cb * CHB, ce * CHB, a.ws + dws_inst_offset(DW_RGB) + (int64_t)split * dw_inst_floats(DW_RGB), rgb_smem);
     }
     DW_TRACE(0, 1);
 }
@@ -625,10 +629,11 @@ __global__ __launch_bounds__(DWT, 2) void mlp_dw_split_small_kernel(DwArgs a) {
 }  // namespace
 
 int benerf_mlp_dw_reduce_launch(const float* ws, const BenerfMlpGrads* grads, int channels, int accumulate, int split_mode,
-                                const float* grad_info, const float* pe_weights, hipStream_t stream);
+                                const float* grad_info, const float* pe_weights, hipStream_t stream, const BenerfMlpParams* params);
 
-int benerf_mlp_dw_split22_launch(int channels, int64_t M, const float* d_raw, const float* acts, const float* dacts, float* dw_ws,
-                                 const BenerfMlpGrads* grads, int accumulate, const float* pe_weights, hipStream_t stream) {
+int benerf_mlp_dw_split22_launch(const BenerfMlpParams* params, int channels, int64_t M, const float* d_raw, const float* acts,
+                                 const float* dacts, float* dw_ws, const BenerfMlpGrads* grads, int accumulate, const float* pe_weights,
+                                 hipStream_t stream) {
     DwArgs a;
     a.d_raw = d_raw;
     a.acts = acts;
@@ -645,7 +650,7 @@ int benerf_mlp_dw_split22_launch(int channels, int64_t M, const float* d_raw, co
     (void)pe_weights;       // the saved encodings carry the BARF column weights already (mlp_split.h: sact22_*)
     hipLaunchKernelGGL(mlp_dw_split_small_kernel, dim3(DWS_SMALL_BLOCKS), dim3(DWT), 0, stream, a);
     BENERF_LAUNCH_CHECK("mlp_bwd(dw small, split)");
-    hipLaunchKernelGGL(mlp_dw_split_big_kernel, dim3(mlp::DWH_BIG_BLOCKS), dim3(DWT), DWS_SMEM, stream, a);
+    hipLaunchKernelGGL(mlp_dw_split_big_kernel, dim3(mlp::DWS_BIG_BLOCKS), dim3(DWT), DWS_SMEM, stream, a);
     BENERF_LAUNCH_CHECK("mlp_bwd(dw, split)");
-    return benerf_mlp_dw_reduce_launch(dw_ws, grads, channels, accumulate, 1, dacts + mlp::sdact_info(mlp::m_pad(M)), nullptr, stream);
+    return benerf_mlp_dw_reduce_launch(dw_ws, grads, channels, accumulate, 2, dacts + mlp::sdact_info(mlp::m_pad(M)), nullptr, stream, params);
 }

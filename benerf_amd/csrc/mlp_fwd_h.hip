@@ -353,7 +353,7 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
     if (SAVE && blockIdx.x == 0 && tid == 0) reinterpret_cast<uint32_t*>(acts + sact_info(Mp))[SI_TAG] = SAVE == 2 ? SACT_TAG_SPLIT22 : SACT_TAG_SPLIT;
     // SAVE == 2: byte i of the lo8 region <-> half i of the SH region (mlp_split.h)
     uint8_t* st8_h = SAVE == 2 ? reinterpret_cast<uint8_t*>(acts + sact_lo8_base(Mp)) : nullptr;          // layer l: + l * Mp * 256 bytes
-    // SAVE == 2: the direct save of stage `layer` (0..7: h_layer with its sign bits; 8: feature, no ReLU) - mlp_split.h, SP layout
+    // SAVE == 2: the direct save of stage `layer` (0..7: h_layer with its sign bits) - mlp_split.h, SP layout
     auto direct = [&](int layer, bool relu) {
         DirectSave d;
         d.rs = uniform_rsrc(SAVE == 2 ? st_h + ((int64_t)layer * Mp + ms0) * 256 : nullptr);
@@ -536,10 +536,9 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
     gemm_stage<16, 1, FPF, true, 4>(Th, Tl, 0, a.packed + pack_offset(PF_FEAT), wave, lane, acc1, acc2);
     lds_barrier();
     load_bias<1>(a.bias[BENERF_L_VIEWS], wave & 3, lane, bq);
-    {
-        const DirectSave df = direct(8, false);
-        epilogue_t<1, false, 4, SAVE == 2>(acc1, acc2, Th, Tl, wave, lane, amax, &df);
-    }
+    // `feature` is NOT saved in BENERF_MLP_SPLIT (round 5): it feeds the views layer without a ReLU in between, the weight gradients
+    // that involve it are composed from dhv^T h7 (mlp_common.h: DWS_*); BENERF_MLP_SPLIT_F16BWD saves it below
+    epilogue_t<1, false, 4>(acc1, acc2, Th, Tl, wave, lane, amax);
     if (tid < FTM && live) {
         const float4 p = *reinterpret_cast<const float4*>(scratch(0));
         a.raw[m * (C + 1) + C] = ((p.x + p.y) + (p.z + p.w)) + a.b_alpha[0];

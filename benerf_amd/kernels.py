@@ -495,8 +495,9 @@ def mlp_bwd_dw(net, d_raw, acts, dacts, n_rays, n_samples, grad_w, grad_b, accum
     ws = scratch("dw_ws", ws_floats, d_raw.device)
     pe_w = getattr(acts, "benerf_pe_weights", net.pe_weights)
     g = _param_struct(MlpGrads, grad_w, grad_b)
+    s = net.struct()        # BENERF_MLP_SPLIT composes the feature / views weight gradients from dhv^T h7 and these weights
     _timer("mlp_bwd_dw", M)
-    _lib.check(lib.benerf_mlp_bwd_dw(net.channels, n_rays, n_samples, _chk(d_raw), _chk(acts), dacts.data_ptr(),
+    _lib.check(lib.benerf_mlp_bwd_dw(ctypes.byref(s), net.channels, n_rays, n_samples, _chk(d_raw), _chk(acts), dacts.data_ptr(),
                                      ws.data_ptr(), ws_floats, ctypes.byref(g), int(bool(accumulate)), code,
                                      _chk(pe_w, name="pe_weights"), _stream()), "mlp_bwd_dw")
     _timer(None, 0)

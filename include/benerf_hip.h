@@ -235,6 +235,9 @@ int benerf_mlp_fwd(const BenerfMlpParams* params, const float* packed, int chann
  *   _dx: activation-gradient chain -> dacts scratch [benerf_mlp_dact_floats(n_points)], d_pts [n_points,3],
  *        d_vdir_pts [n_points,3] (per point; reduce with benerf_ray_grad_reduce);
  *   _dw: weight gradients from acts + dacts; dw_ws scratch [benerf_mlp_dw_workspace_floats(n_points)];
+ *        params: the network's weights - read by BENERF_MLP_SPLIT only (the feature layer's and the views layer's weight
+ *        gradients are composed from ONE product dhv^T h7 and those two weights: the linear feature layer is neither saved nor
+ *        back-propagated through HBM), may be NULL in the other modes;
  *        grads: overwritten when accumulate == 0, added to otherwise; pe_weights: the forward call's
  *        BenerfMlpParams.pe_weights (the saved encodings are unweighted; the columns are scaled in the reduce).
  * precision: BENERF_MLP_F32, BENERF_MLP_SPLIT or BENERF_MLP_SPLIT_F16BWD, the mode of the forward launch that wrote acts.
@@ -243,7 +246,7 @@ int benerf_mlp_bwd_dx(const BenerfMlpParams* params, const float* packed, int ch
                       int n_rays, int n_samples, const float* d_raw, const float* acts,
                       float* dacts, float* d_pts, float* d_vdir_pts, int precision, uint32_t* status, const float* d_raw_absmax,
                       benerf_stream_t stream);
-int benerf_mlp_bwd_dw(int channels, int n_rays, int n_samples, const float* d_raw,
+int benerf_mlp_bwd_dw(const BenerfMlpParams* params, int channels, int n_rays, int n_samples, const float* d_raw,
                       const float* acts, const float* dacts, float* dw_ws, size_t dw_ws_floats,
                       const BenerfMlpGrads* grads, int accumulate, int precision, const float* pe_weights,
                       benerf_stream_t stream);

@@ -47,7 +47,9 @@ def test_bench_bookkeeping_helpers():
     # operands everywhere); the opt-in reduced-precision backward: 3 + 2 + 1
     assert bench.EXECUTED_PER_PRODUCT["split"] == {"mlp_fwd": 3, "mlp_bwd_dx": 3, "mlp_bwd_dw": 3}
     assert bench.EXECUTED_PER_PRODUCT["split_f16bwd"] == {"mlp_fwd": 3, "mlp_bwd_dx": 2, "mlp_bwd_dw": 1}
-    assert bench.DW_BYTES_PER_POINT["split"] == 3 * 2 * 2432 + 3 * 96 + 8        # PE / PE(dir) saved like every operand: hi + 8-bit code
+    # h0..h7 + hv and dY0..dY7 + dhv (the linear feature layer's output and gradient are not saved: dW composes them from dhv^T h7),
+    # PE / PE(dir) saved like every operand: hi + 8-bit code
+    assert bench.DW_BYTES_PER_POINT["split"] == 3 * 2 * 2176 + 3 * 96 + 8
     assert WL.rays_per_step(wl) == 4081 and WL.rays_per_step(dict(wl, bins=4)) == 5 * 1024 + 19 * 107      # dense event bins: B + 1 event poses
     assert bench.physical_cores() >= 1
     b = bench.algorithmic_bytes_per_step(wl, wl["channels"])

@@ -130,8 +130,13 @@ def _hip_step(x, mode, z_forced):
         K.set_mlp_precision(prev)
 
 
-def _assert_no_worse(tab, label, case):
-    """tab: f64_truth.error_table rows {name: {label: (max, norm, L2)}} with the float32 oracle under 'o32'."""
+def _assert_no_worse(tab, label, case, lottery_factor=None):
+    """tab: f64_truth.error_table rows {name: {label: (max, norm, L2)}} with the float32 oracle under 'o32'.
+    lottery_factor: replaces FACTOR for the statistics a single flipped ReLU unit dominates - the largest entry error ("max") of
+    every gradient and, for the 24 + 6 pose numbers, all of them (their whole-tensor L2 is no average) - on batches too small to
+    average the flips out (round 5: the exact-f32 mode itself, bit-exact f32 products on another summation order, sits at 2.1 x
+    the float32 oracle's error on the pose gradients of a binned C5 step and at 2.6 x on one weight entry of an 0.17 M-point
+    batch).  The whole-tensor L2 error of the weight gradients keeps FACTOR everywhere."""
     bad, worst = [], {"L2": (0.0, ""), "max": (0.0, ""), "norm": (0.0, "")}
     for name, row in tab.items():
         n_entries = 24 if name == "knots" else 6 if name == "transform" else 1 << 20
@@ -139,12 +144,13 @@ def _assert_no_worse(tab, label, case):
             if stat == "norm" and (n_entries < 256 or name.endswith(".bias") and "rgb_linear" in name):
                 continue      # the norm of a handful of numbers is one more draw of the L2 error, which is bounded above
             e, ref = row[label][j], row["o32"][j]
-            bound = FACTOR[stat] * ref + FLOOR[stat]
+            factor = lottery_factor if (lottery_factor is not None and (stat == "max" or n_entries < 256)) else FACTOR[stat]
+            bound = factor * ref + FLOOR[stat]
             ratio = e / bound
             if ratio > worst[stat][0]:
                 worst[stat] = (ratio, "%s %.2e vs oracle %.2e" % (name, e, ref))
             if e > bound:
-                bad.append("%s %s: %.3e > %.1f x %.3e + %.0e" % (name, stat, e, FACTOR[stat], ref, FLOOR[stat]))
+                bad.append("%s %s: %.3e > %.1f x %.3e + %.0e" % (name, stat, e, factor, ref, FLOOR[stat]))
     for stat, (ratio, what) in worst.items():
         REPORT.append("f64 truth %-10s %-5s %-4s closest to its bound: %.2f of it (%s)" % (case, label, stat, ratio, what))
     assert not bad, "%s, mode %s - gradients further from float64 than the float32 oracle allows:\n%s" % (case, label, "\n".join(bad))
@@ -166,7 +172,8 @@ def test_step_gradients_vs_float64(case):
         assert abs(loss - o64["loss"]) <= 2e-5 * max(1.0, abs(o64["loss"])), (mode, loss, o64["loss"])
     tab = T.error_table(o64["grads"], cands)
     for mode in ("f32", "split"):
-        _assert_no_worse(tab, mode, case)
+        # G8-sized batches (~4 k points): one flipped unit of a heavy sample IS the largest entry error - the lottery factor there
+        _assert_no_worse(tab, mode, case, lottery_factor=3.0 if case.startswith("g8_") else None)
 
 
 def test_full_size_step_vs_oracle():
@@ -304,7 +311,10 @@ def test_mlp_backward_arithmetic_vs_float64(n_rays):
             net.pack()
             raw, acts = K.mlp_fwd(net, dv(ro), dv(rd), dv(vd), dv(z), True)
             av = _act_views(acts, M, mode)
-            masks = {k: (av[k] > 0).to(torch.float64) for k in ["h%d" % i for i in range(8)] + ["hv"]}
+            # the branch the HIP forward took: its own sign-bit words where the mode stores them apart from the values ('split':
+            # v_cmp on the f32 value - a positive value below f16's subnormal grid has hi = 0 and IS active), else value > 0
+            masks = {k: (av["mask" + k[1:]] if ("mask" + k[1:]) in av else av[k] > 0).to(torch.float64)
+                     for k in ["h%d" % i for i in range(8)] + ["hv"]}
             g64, raw64 = truth(masks)
             e_raw = float((raw.cpu().double().reshape(raw64.shape) - raw64).abs().max() / raw64.abs().max())
             REPORT.append("MLP arithmetic vs f64 (own masks), %d points, %-5s raw: %.2e of the largest" % (M, mode, e_raw))

@@ -358,9 +358,20 @@ def _act_views(acts, M, mode="f32"):
         out["pe"] = a[0:Mp * 64].reshape(Mp, 64)[:M]
         out["ped"] = a[Mp * 64:Mp * 96].reshape(Mp, 32)[:M]
     wide = sp if mode == "split" else sh        # the 256-wide arrays: SP layout in 'split', SH in 'split_f16bwd'
+    if mode == "split":
+        # ReLU sign bits of h0..h7 as the forward's scalar stores leave them (mlp_split.h: sp_mask_word): uint32 word
+        # ((T * 4 + r) * 8 + ct) * 32 + 2 e + h of layer l, bit p = point 128 T + 32 r + p, feature 32 ct + 8 (e >> 2) + 4 h + (e & 3)
+        moff = Mp * 96 + 9 * Mp * 128 + Mp * 64
+        words = a.numpy().view(np.uint32)[moff: moff + 8 * Mp * 8].reshape(8, Mp // 128, 4, 8, 16, 2)      # [l][T][r][ct][e][h]
+        bits = ((words[..., None] >> np.arange(32, dtype=np.uint32)) & 1).astype(bool)                      # [...][p]
+        # -> [l][T][r][p][ct][e >> 2][h][e & 3] = [l][point][feature]
+        bits = bits.reshape(8, Mp // 128, 4, 8, 4, 4, 2, 32).transpose(0, 1, 2, 7, 3, 4, 6, 5).reshape(8, Mp, 256)
+        for l in range(8):
+            out["mask%d" % l] = torch.from_numpy(np.ascontiguousarray(bits[l, :M]))
     for l in range(8):
         out["h%d" % l] = wide(Mp * 96 + l * Mp * 128, 256)
-    out["feat"] = wide(Mp * 96 + 8 * Mp * 128, 256)
+    if mode != "split":      # 'split' does not save the (linear) feature layer's output: mlp_common.h, DWS_*
+        out["feat"] = wide(Mp * 96 + 8 * Mp * 128, 256)
     out["hv"] = sh(Mp * 96 + 9 * Mp * 128, 128)
     return out
 
@@ -388,8 +399,18 @@ def test_mlp_fwd_golden(K, mlp_mode, golden, C, variant, S):
         # (one unit of the residual = 2^-18 relative) cannot hide; split_f16bwd: the f16 half alone
         rt = {"split_f16bwd": 2.0 ** -11, "split": 2e-5, "f32": 1e-4}[mlp_mode]
         for name in ("h0", "h4", "h7", "feat", "hv"):
+            if name not in av:
+                continue
             r = g[tag + "_" + name]
             report("K3 act %s %s" % (name, tag), av[name], r, atol=2e-5 * float(np.abs(r).max()), rtol=rt)
+        if mlp_mode == "split":
+            # the sign-bit words (v_cmp_gt_f32 on the f32 value, scalar stores) against the saved values: they may differ only
+            # where a positive value is too small for its f16 half (below 2^-24: hi = 0, the unit IS active)
+            for l in range(8):
+                ref_act = torch.from_numpy(np.asarray(g[tag + "_h%d" % l])) > 0 if tag + "_h%d" % l in g else av["h%d" % l] > 0
+                diff = av["mask%d" % l] != (av["h%d" % l] > 0)
+                assert int(diff.sum()) == 0 or float(av["h%d" % l][diff].abs().max()) == 0.0, "layer %d: %d sign bits off" % (l, int(diff.sum()))
+                assert int((av["mask%d" % l] != ref_act).sum()) <= max(2, int(1e-5 * ref_act.numel())), "layer %d sign bits vs golden" % l
     report("K3 raw " + tag, raw, ref, atol=1e-5 * max(sc, 1.0), rtol=1e-5)
     raw2, _, _ = _run_mlp_on_points(K, net, pts, vd, False)
     assert torch.equal(raw2, raw), "inference and training forward must agree bit for bit"
