@@ -482,14 +482,17 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
     lds_barrier();
 
     f32x16 acc[4];
-    uint32_t bits[4] = {0u, 0u, 0u, 0u};
+    uint32_t bits[4];
 
-    // ---- P2: VIEWS^T: dFeat = dYv x Wv[:, :256]; dPE(dir) = dYv x Wv[:, 256:283] --------------------------------
+    // ---- P2: VIEWS^T and FEAT^T in ONE stage (round 5): dh7 = dYv x W_c + d_sigma w_alpha, W_c = W_v[:, :256] W_f (mlp_common.h:
+    // PB_VIEWSC - the feature layer feeds the views layer without a ReLU, so its gradient never has to exist); dPE(dir) = dYv x
+    // W_v[:, 256:283]; mask h7 -> dY7 ----------------------------------------------------------------------------------------
+    load_bits(7, bits);
     if (wave < 4) {   // dPE(dir): tile 8 of the block, row tile = wave -> scratch floats [0,27)
         f32x16 ap;
 #pragma unroll
         for (int e = 0; e < 16; ++e) ap[e] = 0.f;
-        gemm_row3<8>(Th, Tl, packed_h + pack_offset(PB_VIEWS), 8, wave, lane, ap);
+        gemm_row3<8>(Th, Tl, packed_h + pack_offset(PB_VIEWSC), 8, wave, lane, ap);
         const int ln = stage_local(lane);
         if ((ln & 31) < 27) {
 #pragma unroll
@@ -498,11 +501,16 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
         __builtin_amdgcn_sched_barrier(0);
     }
     zero4(acc);
-    gemm3<8>(Th, Tl, packed_h + pack_offset(PB_VIEWS), ct, lane, acc);
+    gemm3<8>(Th, Tl, packed_h + pack_offset(PB_VIEWSC), ct, lane, acc);
+    {
+        const float wa = a.w_alpha[ct * 32 + (lane & 31)];
+        const int r4 = 4 * (lane >> 5);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[rt][e] += *fscr1(Th, rt * 32 + (e & 3) + 8 * (e >> 2) + r4, 28 + C) * wa;
+    }
     lds_barrier();   // dYv fully consumed; dPE(dir) visible
-    // d feature stays in the planes: neither feature nor its gradient goes to HBM (the feature layer is linear into the views
-    // layer; its weight gradient is composed from dhv^T h7 in the dW reduce, mlp_common.h: DWS_*)
-    epilogue3<false, false>(acc, bits, Th, Tl, ct, lane, nullptr, nullptr, gf, amax);
     if (tid < TMB && m0 + tid < M) {   // d viewdirs (per point) through PE(dir): sin / cos recomputed from the saved direction
         const int64_t m = m0 + tid;
         const float4 vd4 = reinterpret_cast<const float4*>(acts + sact22_pts(Mp))[m * 2 + 1];
@@ -522,21 +530,6 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
             a.d_vdir[m * 3 + d] = sv * inv_s;
         }
     }
-    load_bits(7, bits);
-    lds_barrier();
-
-    // ---- P3: FEAT^T (+ alpha head), mask h7 -> dY7 ----------------------------------------------------
-    zero4(acc);
-    gemm3<16>(Th, Tl, packed_h + pack_offset(PB_FEAT), ct, lane, acc);
-    {
-        const float wa = a.w_alpha[ct * 32 + (lane & 31)];
-        const int r4 = 4 * (lane >> 5);
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[rt][e] += *fscr1(Th, rt * 32 + (e & 3) + 8 * (e >> 2) + r4, 28 + C) * wa;
-    }
-    lds_barrier();
     // Loads the next stage needs are requested BEFORE this stage's epilogue stores (in-order retirement): the sign bits of the
     // stage after (from HBM: a whole epilogue + K-loop of cover) and the first weight fragments.
     uint32_t bits_n[4];

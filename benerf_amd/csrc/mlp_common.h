@@ -59,15 +59,23 @@ enum PackId {
     PF_L0 = 0, PF_L1, PF_L2, PF_L3, PF_L4, PF_L5, PF_L6, PF_L7, PF_FEAT, PF_VIEWS,   // forward: col = output feature
     PB_VIEWS, PB_FEAT, PB_L7, PB_L6, PB_L5, PB_L4, PB_L3, PB_L2, PB_L1, PB_L0,       // backward: col = input feature
     PB_VIEWSPE,   // PE(dir) slice of the views weights as [4 thread groups][128 n][8]: (g, n, q) = Wv[n][256 + g + 4q]
+    // Round 5, split-f16 kernels: the feature layer (model/nerf.py:100-106: feature = W_f h7 + b_f, fed to the views layer WITHOUT a
+    // ReLU) folded into the views layer - W_c = W_v[:, :256] W_f, b_c = W_v[:, :256] b_f + b_v, computed in float64 at every
+    // re-pack (fuse_views_kernel) - so the split forward runs VIEWS straight on h7 and the split dX chain goes from dhv to dh7 in
+    // one stage: a whole 256 x 256 GEMM stage less in each.  Same shapes as PF_VIEWS / PB_VIEWS, source [W_c | W_v[:, 256:283]].
+    PF_VIEWSC, PB_VIEWSC,
     PACK_COUNT
 };
+__host__ __device__ constexpr bool pack_is_forward(int id) { return id <= PF_VIEWS || id == PF_VIEWSC; }
+// fused matrix [128][283] + fused bias [128] (f32), behind the two packed sections of a network's buffer
+constexpr int64_t FUSED_W_FLOATS = 128 * 283, FUSED_FLOATS = (FUSED_W_FLOATS + 128 + 63) / 64 * 64;
 struct PackShape { int tiles, kblocks; };
 __host__ __device__ constexpr PackShape pack_shape(int id) {
     switch (id) {
         case PF_L0: return {8, 8};        // K 63 -> 64
         case PF_L5: return {8, 40};       // K [h4 256 | PE 63 -> 64]
-        case PF_VIEWS: return {4, 36};    // N 128, K [feature 256 | PE_dir 27 -> 32]
-        case PB_VIEWS: return {10, 16};   // out 256 feature cols + tile 8 = the 27 PE(dir) cols (tile 9: zero pad), contraction n = 128
+        case PF_VIEWS: case PF_VIEWSC: return {4, 36};    // N 128, K [feature (fused: h7) 256 | PE_dir 27 -> 32]
+        case PB_VIEWS: case PB_VIEWSC: return {10, 16};   // out 256 feature (fused: h7) cols + tile 8 = the 27 PE(dir) cols (tile 9: zero pad), contraction n = 128
         case PB_L5: return {10, 32};      // out [h4 256 | PE 64]
         case PB_L0: return {2, 32};       // out PE 64
         case PB_VIEWSPE: return {1, 16};  // 4 * 128 * 8 floats, own layout
@@ -88,7 +96,7 @@ constexpr int64_t PACKED_FLOATS = pack_offset(PACK_COUNT);
 __host__ __device__ constexpr int pack_layer(int id) {
     switch (id) {
         case PF_FEAT: case PB_FEAT: return BENERF_L_FEAT;
-        case PF_VIEWS: case PB_VIEWS: case PB_VIEWSPE: return BENERF_L_VIEWS;
+        case PF_VIEWS: case PB_VIEWS: case PB_VIEWSPE: case PF_VIEWSC: case PB_VIEWSC: return BENERF_L_VIEWS;
         case PB_L7: return 7; case PB_L6: return 6; case PB_L5: return 5; case PB_L4: return 4;
         case PB_L3: return 3; case PB_L2: return 2; case PB_L1: return 1; case PB_L0: return 0;
         default: return id;   // PF_L0..PF_L7

@@ -361,7 +361,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void mlp_fwd_kernel(FwdArgs a) {
 // split-f16 variant (mlp_fwd_h.hip)
 int benerf_mlp_fwd_split_launch(const BenerfMlpParams* params, const float* packed, int channels, int n_rays, int n_samples,
                                 const float* rays_o, const float* rays_d, const float* viewdirs, const float* z, float* raw,
-                                float* acts, int save_lo, uint32_t* status, hipStream_t stream);
+                                float* acts, int save_lo, int fuse, uint32_t* status, hipStream_t stream);
 
 extern "C" int benerf_mlp_fwd(const BenerfMlpParams* params, const float* packed, int channels, int n_rays,
                               int n_samples, const float* rays_o, const float* rays_d, const float* viewdirs,
@@ -384,8 +384,10 @@ extern "C" int benerf_mlp_fwd(const BenerfMlpParams* params, const float* packed
             }
             gate = status + 3;
         }
+        // BENERF_MLP_SPLIT_F16BWD (training and inference alike) runs the unfused layer sequence: its backward wants `feature`
         const int rc = benerf_mlp_fwd_split_launch(params, packed, channels, n_rays, n_samples, rays_o, rays_d, viewdirs, z, raw, acts,
-                                                   precision == BENERF_MLP_SPLIT, status, as_stream(stream));
+                                                   precision == BENERF_MLP_SPLIT, precision != BENERF_MLP_SPLIT_F16BWD, status,
+                                                   as_stream(stream));
         if (rc != BENERF_OK || precision != BENERF_MLP_AUTO) return rc;
     }
     FwdArgs a;

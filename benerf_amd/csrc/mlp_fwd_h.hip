@@ -30,6 +30,7 @@ struct FwdArgs {
     const float* b_alpha;
     const float* w_rgb;
     const float* b_rgb;
+    const float* bias_c;     // fused feature -> views bias b_c [128] (mlp_common.h: PF_VIEWSC)
     const float* pe_w;       // BARF c2f column weights (include/benerf_hip.h) or null
     float* raw;
     float* acts;
@@ -305,7 +306,9 @@ constexpr int FTM = 128, FNT = 512;
 constexpr size_t FWD_SMEM = (size_t)2 * FTM * LD * sizeof(_Float16);      // 163 840 B
 
 // SAVE: 0 inference, 1 training with the f16 backward (hi halves saved), 2 training with the 22-bit backward (hi + lo)
-template <int C, int SAVE>
+// FUSE: the feature layer folded into the views layer (mlp_common.h: PF_VIEWSC) - no FEAT stage; BENERF_MLP_SPLIT_F16BWD, whose
+// backward kernels want `feature` saved, runs the unfused sequence (training AND inference, so that they agree bit for bit)
+template <int C, int SAVE, bool FUSE = (SAVE != 1)>
 __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
     // weight-fragment prefetch depth (k-steps).  The SAVE == 2 launch runs its K-loops behind the previous epilogue's 24 activation
     // stores: three k-steps ahead measured 1.954 -> 1.921 ms at 522 k points (no spill since the direct save freed registers);
@@ -530,20 +533,24 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
         }
     }
 
-    // ---- FEAT (linear) ----------------------------------------------------------------------------
-    acc_init_bias(acc1, bq);
-    zero_acc(acc2);
-    gemm_stage<16, 1, FPF, true, 4>(Th, Tl, 0, a.packed + pack_offset(PF_FEAT), wave, lane, acc1, acc2);
-    lds_barrier();
-    load_bias<1>(a.bias[BENERF_L_VIEWS], wave & 3, lane, bq);
-    // `feature` is NOT saved in BENERF_MLP_SPLIT (round 5): it feeds the views layer without a ReLU in between, the weight gradients
-    // that involve it are composed from dhv^T h7 (mlp_common.h: DWS_*); BENERF_MLP_SPLIT_F16BWD saves it below
-    epilogue_t<1, false, 4>(acc1, acc2, Th, Tl, wave, lane, amax);
+    if (!FUSE) {
+        // ---- FEAT (linear) ------------------------------------------------------------------------
+        acc_init_bias(acc1, bq);
+        zero_acc(acc2);
+        gemm_stage<16, 1, FPF, true, 4>(Th, Tl, 0, a.packed + pack_offset(PF_FEAT), wave, lane, acc1, acc2);
+        lds_barrier();
+        load_bias<1>(a.bias[BENERF_L_VIEWS], wave & 3, lane, bq);
+        epilogue_t<1, false, 4>(acc1, acc2, Th, Tl, wave, lane, amax);
+    } else {
+        // no FEAT stage: VIEWS runs on [h7 | PE(dir)] with W_c = W_v[:, :256] W_f, bias b_c = W_v[:, :256] b_f + b_v
+        lds_barrier();      // the alpha partials and the PE(dir) columns are visible
+        load_bias<1>(a.bias_c, wave & 3, lane, bq);
+    }
     if (tid < FTM && live) {
         const float4 p = *reinterpret_cast<const float4*>(scratch(0));
         a.raw[m * (C + 1) + C] = ((p.x + p.y) + (p.z + p.w)) + a.b_alpha[0];
     }
-    lds_barrier();
+    if (!FUSE) lds_barrier();       // feature is in the planes
     if (SAVE == 1) save_tile<1, 256, false, 16>(Th, wave, lane, reinterpret_cast<_Float16*>(acts + sact_feat(Mp)) + ms0 * 256);
     if (SAVE == 2) {
         // PE(dir) (planes' columns [256,288), visible since the barrier behind the FEAT GEMM) as an SH array of width 32 + lo8
@@ -554,7 +561,7 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
         save_pair22<ACT_PED_W, false, 16, COL_PE>(Th, Tl, 0, wave, lane, rs, rs8, nobits);
     }
 
-    // ---- VIEWS: [feature | PE(dir)] (288) -> 128: wave w computes column tile w & 3 for the point half w >> 2 -------------
+    // ---- VIEWS: [feature (FUSE: h7) | PE(dir)] (288) -> 128: wave w computes column tile w & 3 for the point half w >> 2 ----
     {
         const int vct = wave & 3, vrh = wave >> 2;
         _Float16* Thh = Th + vrh * 64 * LD;          // rows + 64: same swizzle
@@ -562,7 +569,7 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
         f32x16 av1[2][1], av2[2][1];
         acc_init_bias(av1, bq);
         zero_acc(av2);
-        gemm_stage<18, 1, FPF, true, 2>(Thh, Tlh, 0, a.packed + pack_offset(PF_VIEWS), vct, lane, av1, av2);
+        gemm_stage<18, 1, FPF, true, 2>(Thh, Tlh, 0, a.packed + pack_offset(FUSE ? PF_VIEWSC : PF_VIEWS), vct, lane, av1, av2);
         lds_barrier();
         epilogue_t<1, true, 2>(av1, av2, Thh, Tlh, vct, lane, amax);
         lds_barrier();
@@ -616,16 +623,18 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
 
 }  // namespace
 
-// save_lo: training launches (acts != NULL) also save the low halves (BENERF_MLP_SPLIT: the 22-bit backward reads them)
+// save_lo: training launches (acts != NULL) also save the low halves (BENERF_MLP_SPLIT); fuse: the feature layer folded into the views
+// layer (everything but BENERF_MLP_SPLIT_F16BWD, whose backward wants `feature`)
 int benerf_mlp_fwd_split_launch(const BenerfMlpParams* params, const float* packed, int channels, int n_rays, int n_samples,
                                 const float* rays_o, const float* rays_d, const float* viewdirs, const float* z, float* raw,
-                                float* acts, int save_lo, uint32_t* status, hipStream_t stream) {
+                                float* acts, int save_lo, int fuse, uint32_t* status, hipStream_t stream) {
     FwdArgs a;
     a.rays_o = rays_o;
     a.rays_d = rays_d;
     a.viewdirs = viewdirs;
     a.z = z;
     a.packed = packed + mlp::PACKED_FLOATS;
+    a.bias_c = packed + 2 * mlp::PACKED_FLOATS + mlp::FUSED_W_FLOATS;
     for (int l = 0; l < 8; ++l) a.bias[l] = params->b[l];
     a.bias[BENERF_L_VIEWS] = params->b[BENERF_L_VIEWS];
     a.bias[BENERF_L_FEAT] = params->b[BENERF_L_FEAT];
@@ -645,23 +654,26 @@ int benerf_mlp_fwd_split_launch(const BenerfMlpParams* params, const float* pack
     BENERF_REQUIRE(tiles < (1ll << 31) && a.M < (1ll << 31), "mlp_fwd(split): too many points");
     dim3 grid((unsigned)tiles), block(FNT);
     const int smem = (int)FWD_SMEM;
-#define BENERF_FWD_LAUNCH(CH, SV)                                                                                        \
+    BENERF_REQUIRE(!acts || (save_lo ? fuse : !fuse), "mlp_fwd(split): BENERF_MLP_SPLIT training launches are fused, BENERF_MLP_SPLIT_F16BWD ones are not");
+#define BENERF_FWD_LAUNCH(CH, SV, FU)                                                                                    \
     do {                                                                                                                 \
         static BenerfLdsAttr attr_;                                                                                      \
-        if (!benerf_lds_attr(attr_, (const void*)mlp_fwd_split_kernel<CH, SV>, smem)) {                                  \
+        if (!benerf_lds_attr(attr_, (const void*)mlp_fwd_split_kernel<CH, SV, FU>, smem)) {                              \
             benerf_set_error("mlp_fwd(split): cannot reserve %d bytes of LDS", smem);                                    \
             return BENERF_EHIP;                                                                                          \
         }                                                                                                                \
-        hipLaunchKernelGGL((mlp_fwd_split_kernel<CH, SV>), grid, block, smem, stream, a);                                \
+        hipLaunchKernelGGL((mlp_fwd_split_kernel<CH, SV, FU>), grid, block, smem, stream, a);                            \
     } while (0)
     if (channels == 1) {
-        if (acts && save_lo) BENERF_FWD_LAUNCH(1, 2);
-        else if (acts) BENERF_FWD_LAUNCH(1, 1);
-        else BENERF_FWD_LAUNCH(1, 0);
+        if (acts && save_lo) BENERF_FWD_LAUNCH(1, 2, true);
+        else if (acts) BENERF_FWD_LAUNCH(1, 1, false);
+        else if (fuse) BENERF_FWD_LAUNCH(1, 0, true);
+        else BENERF_FWD_LAUNCH(1, 0, false);
     } else {
-        if (acts && save_lo) BENERF_FWD_LAUNCH(3, 2);
-        else if (acts) BENERF_FWD_LAUNCH(3, 1);
-        else BENERF_FWD_LAUNCH(3, 0);
+        if (acts && save_lo) BENERF_FWD_LAUNCH(3, 2, true);
+        else if (acts) BENERF_FWD_LAUNCH(3, 1, false);
+        else if (fuse) BENERF_FWD_LAUNCH(3, 0, true);
+        else BENERF_FWD_LAUNCH(3, 0, false);
     }
 #undef BENERF_FWD_LAUNCH
     BENERF_LAUNCH_CHECK("mlp_fwd(split)");

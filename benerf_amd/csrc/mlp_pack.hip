@@ -8,16 +8,57 @@ using namespace mlp;
 
 struct PackArgs {
     const float* w[BENERF_NLAYERS];
+    const float* b_feat;     // fuse_views_kernel
+    const float* b_views;
     float* packed;
 };
+
+// W_c = W_v[:, :256] W_f and b_c = W_v[:, :256] b_f + b_v in float64 (mlp_common.h: PF_VIEWSC) -> f32 [128][283] (the PE(dir)
+// columns copied) + [128] behind the packed sections.  32 x 32 output tiles through LDS; blocks [0, 32): W_c, block 32: the rest.
+__device__ __forceinline__ void fuse_body(const PackArgs& a) {
+    __shared__ double As[32][33], Bs[32][33];
+    const float* Wv = a.w[BENERF_L_VIEWS];
+    const float* Wf = a.w[BENERF_L_FEAT];
+    float* out = a.packed + 2 * PACKED_FLOATS;
+    const int t = threadIdx.x, tx = t & 31, ty = t >> 5, b = blockIdx.x;
+    if (b == 32) {
+        for (int e = t; e < 128 * 27; e += 256) out[(e / 27) * 283 + 256 + e % 27] = Wv[(e / 27) * 283 + 256 + e % 27];
+        if (t < 128) {
+            double acc = (double)a.b_views[t];
+            for (int j = 0; j < 256; ++j) acc += (double)Wv[t * 283 + j] * (double)a.b_feat[j];
+            out[FUSED_W_FLOATS + t] = (float)acc;
+        }
+        return;
+    }
+    const int m0 = (b >> 3) * 32, n0 = (b & 7) * 32;      // W_c[m][n] = sum_k W_v[m][k] W_f[k][n]
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int k0 = 0; k0 < 256; k0 += 32) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = ty + 8 * r;
+            As[q][tx] = (double)Wv[(m0 + q) * 283 + k0 + tx];
+            Bs[q][tx] = (double)Wf[(k0 + q) * 256 + n0 + tx];
+        }
+        __syncthreads();
+        for (int k = 0; k < 32; ++k) {
+            const double bv = Bs[k][tx];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] += As[ty + 8 * r][k] * bv;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[(m0 + ty + 8 * r) * 283 + n0 + tx] = (float)acc[r];
+}
 
 // source element for packed block `id`, column index `col` (tile*32 + lane&31) and
 // contraction index `kk` (kblock*8 + 4*(lane>>5) + i); returns 0 for padding.
 __device__ __forceinline__ float pack_source(const PackArgs& a, int id, int col, int kk) {
     const int layer = pack_layer(id);
-    const float* W = a.w[layer];
+    // the fused blocks read [W_c | W_v[:, 256:283]] as fuse_views_kernel left it behind the packed sections
+    const float* W = (id == PF_VIEWSC || id == PB_VIEWSC) ? a.packed + 2 * PACKED_FLOATS : a.w[layer];
     const int in = layer_in(layer);
-    if (id <= PF_VIEWS) {
+    if (pack_is_forward(id)) {
         // forward: col = output feature n, kk = packed input index
         const int n = col;
         int k;
@@ -28,7 +69,7 @@ __device__ __forceinline__ float pack_source(const PackArgs& a, int id, int col,
             if (kk < 256) k = 63 + kk;
             else if (kk < 319) k = kk - 256;
             else return 0.f;
-        } else if (id == PF_VIEWS) {       // [feature (256) | PE_dir (27)] = nn.Linear order
+        } else if (id == PF_VIEWS || id == PF_VIEWSC) {       // [feature (256) | PE_dir (27)] = nn.Linear order
             if (kk >= 283) return 0.f;
             k = kk;
         } else {
@@ -47,7 +88,7 @@ __device__ __forceinline__ float pack_source(const PackArgs& a, int id, int col,
         if (col >= 63) return 0.f;
         k = col;
     } else {
-        if (id == PB_VIEWS && col >= 283) return 0.f;   // PB_VIEWS: 256 feature columns, then the 27 PE(dir) columns, then padding
+        if ((id == PB_VIEWS || id == PB_VIEWSC) && col >= 283) return 0.f;   // 256 feature columns, then the 27 PE(dir) columns, then padding
         k = col;
     }
     return W[(int64_t)n * in + k];
@@ -60,6 +101,8 @@ __device__ __forceinline__ void pack_body(const PackArgs& a);
 __global__ void pack_kernel(PackArgs a) { pack_body(a); }
 // both networks of a training step in one launch (blockIdx.z)
 __global__ void pack_pair_kernel(PackArgs2 a) { pack_body(a.net[blockIdx.z]); }
+__global__ __launch_bounds__(256) void fuse_views_kernel(PackArgs a) { fuse_body(a); }
+__global__ __launch_bounds__(256) void fuse_views_pair_kernel(PackArgs2 a) { fuse_body(a.net[blockIdx.z]); }
 
 __device__ __forceinline__ void pack_body(const PackArgs& a) {
     const int id = blockIdx.y;
@@ -112,7 +155,7 @@ __device__ __forceinline__ void pack_body(const PackArgs& a) {
         for (int j = 0; j < 8; ++j) {
             const float w = pack_source(a, id, col, k0 + j);
             hi[j] = (_Float16)w;
-            lo[j] = (_Float16)((w - (float)hi[j]) * (id <= PF_VIEWS ? 2048.f : 1.f));
+            lo[j] = (_Float16)((w - (float)hi[j]) * (pack_is_forward(id) ? 2048.f : 1.f));
         }
         const int64_t frag = (((int64_t)(tile >> 1) * ksteps + ks) * 2 + (tile & 1)) * 2;   // 1 KiB fragments
         dsth[frag * 64 + lane] = hi;
@@ -163,7 +206,8 @@ extern "C" int benerf_mlp_h8_roundtrip(const float* x, int64_t n, int residual_l
     return BENERF_OK;
 }
 
-extern "C" size_t benerf_mlp_packed_floats(void) { return (size_t)(2 * mlp::PACKED_FLOATS); }   // f32 blocks | split-f16 blocks
+// f32 blocks | split-f16 blocks | fused feature -> views matrix and bias (f32)
+extern "C" size_t benerf_mlp_packed_floats(void) { return (size_t)(2 * mlp::PACKED_FLOATS + mlp::FUSED_FLOATS); }
 // buffers are sized for either arithmetic mode (the split mode pads the point count to whole 128-point tiles)
 extern "C" size_t benerf_mlp_act_floats(int64_t n_points) {
     const int64_t a = mlp::act_total_floats(n_points), b = mlp::sact22_total_floats(n_points);   // sact22 >= sact
@@ -210,7 +254,11 @@ extern "C" int benerf_mlp_pack_weights(const BenerfMlpParams* params, int channe
         BENERF_REQUIRE(params->w[l], "mlp_pack_weights: null weight %d", l);
         a.w[l] = params->w[l];
     }
+    BENERF_REQUIRE(params->b[BENERF_L_FEAT] && params->b[BENERF_L_VIEWS], "mlp_pack_weights: null feature / views bias");
+    a.b_feat = params->b[BENERF_L_FEAT];
+    a.b_views = params->b[BENERF_L_VIEWS];
     a.packed = packed;
+    hipLaunchKernelGGL(fuse_views_kernel, dim3(33), dim3(256), 0, as_stream(stream), a);
     hipLaunchKernelGGL(pack_kernel, dim3(40, mlp::PACK_COUNT), dim3(256), 0, as_stream(stream), a);
     BENERF_LAUNCH_CHECK("mlp_pack_weights");
     return BENERF_OK;
@@ -226,8 +274,15 @@ extern "C" int benerf_mlp_pack_weights_pair(const BenerfMlpParams* params_a, flo
         a.net[0].w[l] = params_a->w[l];
         a.net[1].w[l] = params_b->w[l];
     }
+    BENERF_REQUIRE(params_a->b[BENERF_L_FEAT] && params_a->b[BENERF_L_VIEWS] && params_b->b[BENERF_L_FEAT] && params_b->b[BENERF_L_VIEWS],
+                   "mlp_pack_weights_pair: null feature / views bias");
+    a.net[0].b_feat = params_a->b[BENERF_L_FEAT];
+    a.net[0].b_views = params_a->b[BENERF_L_VIEWS];
+    a.net[1].b_feat = params_b->b[BENERF_L_FEAT];
+    a.net[1].b_views = params_b->b[BENERF_L_VIEWS];
     a.net[0].packed = packed_a;
     a.net[1].packed = packed_b;
+    hipLaunchKernelGGL(fuse_views_pair_kernel, dim3(33, 1, 2), dim3(256), 0, as_stream(stream), a);
     hipLaunchKernelGGL(pack_pair_kernel, dim3(40, mlp::PACK_COUNT, 2), dim3(256), 0, as_stream(stream), a);
     BENERF_LAUNCH_CHECK("mlp_pack_weights_pair");
     return BENERF_OK;

@@ -437,9 +437,12 @@ def mlp_fwd(net, rays_o, rays_d, viewdirs, z, save_acts, precision=None, status=
         acts.benerf_pe_weights = net.pe_weights       # the backward of THIS forward uses the same column weights
     s = net.struct()
     code = MLP_PRECISIONS[mode]
-    if code != 0 and not save_acts:
+    if mode == "split" and not save_acts:
         code = _MLP_AUTO
         status = _auto_status(z.device)
+    # 'split_f16bwd' inference launches keep their own code: that mode's forward runs the UNFUSED layer sequence (its backward
+    # wants the feature layer's output), training and inference alike, so that the two agree bit for bit - without the exact-f32
+    # fallback launch of BENERF_MLP_AUTO (the range guard still records a violation)
     if status is None:
         status = mlp_status(z.device)
     _timer("mlp_fwd", n_rays * n_samples)
