@@ -59,8 +59,15 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 // row is XORed with feature & 3, the 16-byte slot (8 points) inside it with (feature >> 2) & 3 - the four feature rows of a
 // transpose read land in four different bank quarters, eight consecutive features of a quad write in eight different slots.
 constexpr int PROW = 128;                                               // halfs per feature row
+// Round 5: the two 8-byte halves of a slot are swapped for features with bit 4 set - the epilogue's quad writes of lanes n and
+// n + 16 (same segment, same slot, same half before) no longer collide (57-61 M SQ_LDS_BANK_CONFLICT cycles per 522 k-point launch);
+// a k-step's 16 feature rows share bit 4, so the transpose reads see the same relative pattern as before.
 __device__ __forceinline__ int fidx(int f, int p) {
+#ifdef BWS_OLD_SWIZZLE
     return f * PROW + ((((p >> 5) ^ (f & 3)) << 5) | ((((p >> 3) & 3) ^ ((f >> 2) & 3)) << 3) | (p & 7));
+#else
+    return f * PROW + ((((p >> 5) ^ (f & 3)) << 5) | ((((p >> 3) & 3) ^ ((f >> 2) & 3)) << 3) | ((p & 7) ^ (((f >> 4) & 1) << 2)));
+#endif
 }
 // f32 scratch float i (0..31) of point `row`: the feature rows [256,320) of the hi plane (never a GEMM operand here) as 4096
 // floats, 32 per point, groups of four floats XOR-swizzled by the point
@@ -148,22 +155,31 @@ __device__ __forceinline__ void gemm3_body(const _Float16* __restrict__ Th, cons
     // the compiler folds plane distance and k-step into ONE constant, finds it too large and emits a v_add per transpose read
     // (8 per k-step = 0.67 VALU per MFMA of this loop).  A second set of lane offsets with the plane distance folded in, opaque
     // to the constant folder, leaves the k-step (<= 60 KiB) as the instruction's immediate.
-    int ao[2][4], aol[2][4];
+    // [parity of the k-step]: fidx swaps the two 8-byte halves of a slot for features with bit 4 set = every odd k-step
+    int ao[2][2][4], aol[2][2][4];
     const int plane_delta = (int)(Tl - Th);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
-            ao[j][rt] = frag_off(lane, j, rt);
-            int v = ao[j][rt] + plane_delta;
-            asm volatile("" : "+v"(v));
-            aol[j][rt] = v;
+            ao[0][j][rt] = frag_off(lane, j, rt);
+#ifdef BWS_OLD_SWIZZLE
+            ao[1][j][rt] = ao[0][j][rt];
+#else
+            ao[1][j][rt] = ao[0][j][rt] ^ 4;
+#endif
+#pragma unroll
+            for (int par = 0; par < 2; ++par) {
+                int v = ao[par][j][rt] + plane_delta;
+                asm volatile("" : "+v"(v));
+                aol[par][j][rt] = v;
+            }
         }
     half8 ah[4], al[4];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
-        ah[rt] = frag_read(Th, ao[0][rt], ao[1][rt]);
-        al[rt] = frag_read(Th, aol[0][rt], aol[1][rt]);
+        ah[rt] = frag_read(Th, ao[0][0][rt], ao[0][1][rt]);
+        al[rt] = frag_read(Th, aol[0][0][rt], aol[0][1][rt]);
     }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -178,12 +194,12 @@ __device__ __forceinline__ void gemm3_body(const _Float16* __restrict__ Th, cons
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
             acc[rt] = mfma16(ah[rt], bl, acc[rt]);
-            if (ks + 1 < KS) ah[rt] = frag_read(Th + (ks + 1) * 16 * PROW, ao[0][rt], ao[1][rt]);
+            if (ks + 1 < KS) ah[rt] = frag_read(Th + (ks + 1) * 16 * PROW, ao[(ks + 1) & 1][0][rt], ao[(ks + 1) & 1][1][rt]);
         }
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
             acc[rt] = mfma16(al[rt], bh, acc[rt]);
-            if (ks + 1 < KS) al[rt] = frag_read(Th + (ks + 1) * 16 * PROW, aol[0][rt], aol[1][rt]);
+            if (ks + 1 < KS) al[rt] = frag_read(Th + (ks + 1) * 16 * PROW, aol[(ks + 1) & 1][0][rt], aol[(ks + 1) & 1][1][rt]);
         }
         __builtin_amdgcn_sched_barrier(0);          // one k-step per scheduling region: keeps the prefetch distances as written
     }
@@ -206,6 +222,11 @@ __device__ __forceinline__ void gemm_row3(const _Float16* __restrict__ Th, const
     const int o0 = frag_off(lane, 0, rt), o1 = frag_off(lane, 1, rt);
     int ol0 = o0 + (int)(Tl - Th), ol1 = o1 + (int)(Tl - Th);      // lo plane through the hi plane's pointer: see gemm3_body
     asm volatile("" : "+v"(ol0), "+v"(ol1));
+#ifdef BWS_OLD_SWIZZLE
+    constexpr int ODD = 0;
+#else
+    constexpr int ODD = 4;      // fidx: odd k-steps (features with bit 4 set) have the halves of a slot swapped
+#endif
     const WFrag wf(wp, lane);
     const int tu = __builtin_amdgcn_readfirstlane(tile);
     u32x4 bq[PF + 1][2];
@@ -229,8 +250,9 @@ __device__ __forceinline__ void gemm_row3(const _Float16* __restrict__ Th, const
             bq[(ks + PF) % (PF + 1)][1] = wf.load(tu, ks + PF, KS, 1);
         }
         if (ks + 1 < KS) {
-            ahn = frag_read(Th + (ks + 1) * 16 * PROW, o0, o1);
-            aln = frag_read(Th + (ks + 1) * 16 * PROW, ol0, ol1);
+            const int x = ((ks + 1) & 1) ? ODD : 0;
+            ahn = frag_read(Th + (ks + 1) * 16 * PROW, o0 ^ x, o1 ^ x);
+            aln = frag_read(Th + (ks + 1) * 16 * PROW, ol0 ^ x, ol1 ^ x);
         }
         const half8 bh = __builtin_bit_cast(half8, bq[ks % (PF + 1)][0]);
         const half8 bl = __builtin_bit_cast(half8, bq[ks % (PF + 1)][1]);
@@ -299,7 +321,11 @@ __device__ __forceinline__ void epilogue3(f32x16 (&acc)[4], const uint32_t (&bit
     const int n = ct * 32 + lr;
     // plane offset of this lane's quad (4 points r4 .. r4 + 3 of an 8-point block) in row tile 0, block 0; row tile rt and block q
     // enter through the swizzle: + (((rt ^ (n & 3)) << 5) | ((q ^ ((n >> 2) & 3)) << 3))
+#ifdef BWS_OLD_SWIZZLE
     const int tq = n * PROW + r4;
+#else
+    const int tq = n * PROW + (r4 ^ (((n >> 4) & 1) << 2));      // fidx: the slot's halves swapped for features with bit 4 set
+#endif
     const int sw_seg = n & 3, sw_slot = (n >> 2) & 3;
     const int st_lane = (((lane >> 5) * 256 + n) * 8) * 2;   // byte offset of unit (block, n); lanes 32-63: the odd block of a pair
 #pragma unroll

@@ -14,6 +14,7 @@
 // Training mode saves the activations for the backward kernels: BENERF_MLP_SPLIT (SAVE == 2) - f16 hi halves + 8-bit residual codes
 // straight from the epilogue's registers in the SP layout, sign bits through the scalar path (DirectSave below; the narrow hv / PE
 // arrays as SH arrays from the finished planes); BENERF_MLP_SPLIT_F16BWD (SAVE == 1) - the hi halves as SH arrays (mlp_split.h).
+#define BENERF_HSW_V2      // this kernel's planes use the round-5 slot swizzle (mlp_split.h: hsw)
 #include "mlp_split.h"
 
 namespace {

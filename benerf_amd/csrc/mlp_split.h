@@ -13,7 +13,18 @@ namespace mlp {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 constexpr float LO_SCALE = 2048.f, LO_INV = 1.f / 2048.f;
 
+#if !defined(BENERF_HSW_V2) || defined(FWD_OLD_SWIZZLE)
+// the translation units that do not ask for the round-5 swizzle (BENERF_MLP_SPLIT_F16BWD's dX kernel, mlp_bwd_h.hip, is written against this one)
 __device__ __forceinline__ int hsw(int row) { return (row >> 1) & 7; }
+#else
+// Round 5.  (row >> 1) & 7 served the K-loop's 16-byte reads (16 rows per LDS cycle over 64 banks: a row's 640 bytes put odd rows
+// half a bank sweep behind even ones, so the slot only has to separate rows of equal parity) and left the epilogue's 16-byte
+// WRITES two-way conflicted (8 rows per cycle over 32 banks: eight consecutive rows shared four slots; 49-70 M
+// SQ_LDS_BANK_CONFLICT cycles per 522 k-point launch).  (row & 7) ^ ((row >> 3) & 1) is a bijection on eight consecutive rows
+// (writes) AND on the eight rows of equal parity among sixteen (reads): rows 0, 2, .., 14 -> 0, 2, 4, 6, 1, 3, 5, 7.  Rows r and
+// r + 32 / r + 64 still share their swizzle (gemm_stage, the VIEWS half tiles).
+__device__ __forceinline__ int hsw(int row) { return (row & 7) ^ ((row >> 3) & 1); }
+#endif
 // half index of element (row, col) inside a plane
 __device__ __forceinline__ int hidx(int row, int col) { return row * LD + ((((col >> 3) ^ hsw(row)) << 3) | (col & 7)); }
 

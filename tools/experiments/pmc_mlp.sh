@@ -11,8 +11,8 @@ acc=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/pmc_dx/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k=r["Kernel_Name"]
-        name = ("dx" if ("mlp_bwd_split" in k or "mlp_bwd_f16" in k) else "fwd (training launch)" if ("mlp_fwd_split_kernel<1, 2>" in k or "mlp_fwd_split_kernel<1, 1>" in k)
-                else "fwd (inference launch)" if "mlp_fwd_split_kernel<1, 0>" in k else "dw_big" if ("dw_split_big" in k or "dw_f16_big" in k)
+        name = ("dx" if ("mlp_bwd_split" in k or "mlp_bwd_f16" in k) else "fwd (training launch)" if ("mlp_fwd_split_kernel<1, 2" in k or "mlp_fwd_split_kernel<1, 1" in k)
+                else "fwd (inference launch)" if "mlp_fwd_split_kernel<1, 0" in k else "dw_big" if ("dw_split_big" in k or "dw_f16_big" in k)
                 else "dw_small" if ("dw_split_small" in k or "dw_f16_small" in k) else None)
         if name: acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for name,d in sorted(acc.items()):

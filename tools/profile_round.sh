@@ -1,7 +1,7 @@
 # Runs on the GPU box (gpurun): bench lines of every workload + rocprofv3 passes of the C2 bench command.
 #   ROUND=r02 bash tools/profile_round.sh ; python tools/summarize_profile.py gpurun_out/prof_r02_split profiles r02_split ...
 set -x
-R=${ROUND:-r04}
+R=${ROUND:-r05}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/bench_$R
 timeout 900 python bench.py 2>/dev/null | tail -1 > gpurun_out/bench_$R/bench_C2.json
