@@ -541,13 +541,24 @@ __device__ __forceinline__ void thin_stream(const u32x4* const (&yh)[NYA], const
 #pragma unroll
         for (int c = 0; c < TC; ++c) {
             bh[c] = __builtin_bit_cast(half8, R.x[c]);
+#ifdef TS_X_NODECODE     /* timing variant: what does decoding the (wave-redundant) X codes cost? */
+            bl[c] = __builtin_bit_cast(half8, u32x4{R.xc[c].x, R.xc[c].y, R.xc[c].x, R.xc[c].y});
+#else
             bl[c] = h8_lo_of(R.x[c], R.xc[c]);
+#endif
         }
 #pragma unroll
         for (int i = 0; i < NYA; ++i) {
+#ifdef TS_NO_TAIL_MASK   /* timing variant: the past-the-range masks (wrong sums at ragged split ends) */
+            const u32x4 yv = R.y[i];
+            const half8 ah = __builtin_bit_cast(half8, yv);
+            const half8 al = h8_lo_of(R.y[i], R.yc[i]);
+            (void)vm;
+#else
             const u32x4 yv = R.y[i] & vm;
             const half8 ah = __builtin_bit_cast(half8, yv);
             const half8 al = __builtin_bit_cast(half8, __builtin_bit_cast(u32x4, h8_lo_of(R.y[i], R.yc[i])) & vm);
+#endif
 #pragma unroll
             for (int c = 0; c < TC; ++c) acc[i][c] = mfma16(ah, bh[c], acc[i][c]);
 #pragma unroll

@@ -136,7 +136,11 @@ def _assert_no_worse(tab, label, case, lottery_factor=None):
     every gradient and, for the 24 + 6 pose numbers, all of them (their whole-tensor L2 is no average) - on batches too small to
     average the flips out (round 5: the exact-f32 mode itself, bit-exact f32 products on another summation order, sits at 2.1 x
     the float32 oracle's error on the pose gradients of a binned C5 step and at 2.6 x on one weight entry of an 0.17 M-point
-    batch).  The whole-tensor L2 error of the weight gradients keeps FACTOR everywhere."""
+    batch), and the norm error of every gradient: |norm(g) - norm(g64)| / norm(g64) is ONE signed number per tensor (the projection
+    of the error vector onto the gradient), so "HIP's draw <= 1.5 x the oracle's draw" fails by chance for two implementations of
+    identical quality whenever the oracle's own draw happens to be small (round 5, 4 bins at C5 shape: the exact-f32 control sits at
+    1.83 x the float32 oracle's norm error on nerf.pts_linears.0.bias - 4.32e-4 against 2.36e-4 - the split mode at 2.16 x).  The
+    whole-tensor L2 error of the weight gradients, which bounds the norm error from above, keeps FACTOR everywhere."""
     bad, worst = [], {"L2": (0.0, ""), "max": (0.0, ""), "norm": (0.0, "")}
     for name, row in tab.items():
         n_entries = 24 if name == "knots" else 6 if name == "transform" else 1 << 20
@@ -144,7 +148,7 @@ def _assert_no_worse(tab, label, case, lottery_factor=None):
             if stat == "norm" and (n_entries < 256 or name.endswith(".bias") and "rgb_linear" in name):
                 continue      # the norm of a handful of numbers is one more draw of the L2 error, which is bounded above
             e, ref = row[label][j], row["o32"][j]
-            factor = lottery_factor if (lottery_factor is not None and (stat == "max" or n_entries < 256)) else FACTOR[stat]
+            factor = lottery_factor if (lottery_factor is not None and (stat in ("max", "norm") or n_entries < 256)) else FACTOR[stat]
             bound = factor * ref + FLOOR[stat]
             ratio = e / bound
             if ratio > worst[stat][0]:
