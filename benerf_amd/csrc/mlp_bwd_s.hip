@@ -23,6 +23,13 @@
 // point, the tile's maximum at [26] of points 0 / 1 during P0, scaled d_raw at [28,32)), later the layer-5 skip's dPE block as hi + lo.
 #include "mlp_split.h"
 
+// -DBENERF_TRACE_DX: thread 0 of the first 2048 workgroups stamps the 100 MHz wall clock at the phase boundaries into the d_viewdirs
+// output (which is then not written) - tools/experiments/trace_phases.py prints the per-phase durations behind DESIGN.md 4.
+#ifdef BENERF_TRACE_DX
+#define TR(i) do { if (tid == 0 && blockIdx.x < 2048) reinterpret_cast<unsigned long long*>(a.d_vdir)[blockIdx.x * 64 + (i)] = wall_clock64(); } while (0)
+#else
+#define TR(i) do { } while (0)
+#endif
 namespace {
 using namespace mlp;
 
@@ -433,6 +440,10 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
     if (a.status && blockIdx.x == 0 && tid == 0 && reinterpret_cast<const uint32_t*>(acts + sact_info(Mp))[SI_TAG] != SACT_TAG_SPLIT22)
         a.status[2] = 1u;
     float amax = 0.f;          // max |tile-scaled gradient| of this thread before its f16 split (range guard)
+    TR(0);
+#ifdef BENERF_TRACE_DX
+    if (tid == 0 && blockIdx.x < 2048) { unsigned hw, xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); reinterpret_cast<unsigned long long*>(a.d_vdir)[blockIdx.x * 64 + 63] = ((unsigned long long)xcc << 32) | hw; }
+#endif
 
     // ---- P0: d_raw tile, its power-of-two scale, scaled values -> scratch floats [28, 28+C] of each row ------
     float dr0[C + 1];
@@ -456,6 +467,7 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
     }
     lds_barrier();
     const float gf = s_g * inv_s;   // tile scale -> scale of the stored dY (power of two <= 1)
+    TR(1);
 
     // ---- P1: rgb layer backward + ReLU mask of the views layer -> dYv in planes[:, 0:128) ----
     // wave w: column tile w & 3, point half w >> 2 (row tiles 2 (w >> 2), + 1) - the split forward's VIEWS mapping, so the hv sign
@@ -506,6 +518,7 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
             }
     }
     lds_barrier();
+    TR(2);
 
     f32x16 acc[4];
     uint32_t bits[4];
@@ -537,6 +550,7 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
             for (int e = 0; e < 16; ++e) acc[rt][e] += *fscr1(Th, rt * 32 + (e & 3) + 8 * (e >> 2) + r4, 28 + C) * wa;
     }
     lds_barrier();   // dYv fully consumed; dPE(dir) visible
+    TR(3);
     if (tid < TMB && m0 + tid < M) {   // d viewdirs (per point) through PE(dir): sin / cos recomputed from the saved direction
         const int64_t m = m0 + tid;
         const float4 vd4 = reinterpret_cast<const float4*>(acts + sact22_pts(Mp))[m * 2 + 1];
@@ -553,7 +567,9 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
                 const float ws = a.pe_w ? a.pe_w[64 + es] : 1.f, wc = a.pe_w ? a.pe_w[64 + ec] : 1.f;
                 sv += (float)(1 << f) * (cs * (ws * *fscr1(Th, tid, es)) - sn * (wc * *fscr1(Th, tid, ec)));
             }
+#ifndef BENERF_TRACE_DX
             a.d_vdir[m * 3 + d] = sv * inv_s;
+#endif
         }
     }
     // Loads the next stage needs are requested BEFORE this stage's epilogue stores (in-order retirement): the sign bits of the
@@ -565,12 +581,14 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
     shift_bits(bits);
     epilogue3<true>(acc, bits, Th, Tl, ct, lane, st_tile(7), st8_tile(7), gf, amax);
     lds_barrier();
+    TR(4);
 
     // ---- P4: L7 .. L1: dY_l x W_l, mask h_{l-1} -> dY_{l-1} ----------------------------------------------
     auto layer = [&](int l) __attribute__((always_inline)) {
         zero4(acc);
         gemm3_body<16, BWS_PF>(Th, Tl, packed_h + bwd_layer_offset(l), ct, lane, ring, acc);
         lds_barrier();
+        TR(5 + 2 * (7 - l));
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) bits[rt] = bits_n[rt];
         shift_bits(bits);
@@ -580,6 +598,7 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
         }
         epilogue3<true>(acc, bits, Th, Tl, ct, lane, st_tile(l - 1), st8_tile(l - 1), gf, amax);
         lds_barrier();
+        TR(6 + 2 * (7 - l));
     };
 #pragma unroll 1
     for (int l = 7; l >= 6; --l) layer(l);
@@ -623,6 +642,7 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
             dpe[e] = (float)Th[o] + (float)Tl[o];
         }
     }
+    TR(19);
     gemm_row3<16>(Th, Tl, packed_h + pack_offset(PB_L0), pct, prt, lane, dpe);
     lds_barrier();      // every wave is done reading dY0: the planes become f32 scratch, 77 floats per point:
     // [0,64) dPE, [64,73) the partial sums of the other three frequency groups.  The odd row stride keeps P6's per-point walks
@@ -636,6 +656,7 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
         for (int e = 0; e < 16; ++e) F[(prt * 32 + acc_row(e, ln)) * FLD + pct * 32 + (ln & 31)] = dpe[e];
     }
     lds_barrier();
+    TR(20);
 
     // ---- P6: dPE -> d_pts; sin / cos recomputed from the point; four threads per point (frequencies g, g + 4, g + 8) ------------
     {
@@ -670,6 +691,7 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
             }
         }
     }
+    TR(21);
 }
 
 // max |d_raw| -> dacts info word (zeroed by the launcher; non-negative floats order like their bit patterns)

@@ -292,7 +292,7 @@ struct ReduceArgs {
     const float* w_views;    // [128][283]
     const float* w_feat;     // [256][256]
     const float* b_feat;     // [256]
-    float* gbuf;             // reduced G [128][256] + sum dhv [128] (unscaled), written by dw_reduce_g_kernel
+    float* gbuf;             // reduced G [128][256] + sum dhv [128] (unscaled), written by dw_reduce_kernel<2> (the feature layer's blocks)
     const float* grad_info;  // split mode: info words of the dY arrays ([SD_DRAW] = max |d_raw|, s_s derives from it)
     const float* pe_w;       // BARF c2f: the saved encodings are unweighted, so the PE columns of layers 0 / 5 / views are
                              // scaled here (dW[:, col] = w[col] * sum dY * PE[col]); null = no weighting
@@ -342,13 +342,6 @@ __device__ __forceinline__ int layer_inst(int l) {   // instance holding the bia
         case BENERF_L_RGB: return DW_RGB;
         default: return DW_L1 + (l - 1);
     }
-}
-
-// BENERF_MLP_SPLIT: G = dhv^T h7 and sum dhv, reduced over the splits in fixed order and unscaled -> gbuf (32 896 floats)
-__global__ void dw_reduce_g_kernel(ReduceArgs a) {
-    constexpr int SPLIT = 2;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < 128 * 256 + 128) a.gbuf[e] = sum_splits(a.ws, DW_VIEWSF, e);
 }
 
 // BENERF_MLP_SPLIT: the two small GEMMs that turn G = dhv^T h7 into weight gradients (mlp_common.h: DWS_*), 32 x 32 output tiles
@@ -423,8 +416,14 @@ __global__ void dw_reduce_kernel(ReduceArgs a) {
         float* dst;
         if (SPLIT == 2 && (l == BENERF_L_FEAT || l == BENERF_L_VIEWS)) {
             // the feature layer and the first 256 columns + bias of the views layer are composed from G by dw_compose_kernel;
-            // what is left here: the PE(dir) columns of the views layer
-            if (l == BENERF_L_FEAT || e >= nw) continue;
+            // what is left here: the PE(dir) columns of the views layer - and, on the feature layer's otherwise idle blocks, the
+            // reduction of G = dhv^T h7 + sum dhv over its splits -> gbuf (32 896 floats, fixed order, unscaled; round 5: this was
+            // a launch of its own in front of this one)
+            if (l == BENERF_L_FEAT) {
+                if (e < 128 * 256 + 128) a.gbuf[e] = sum_splits(a.ws, DW_VIEWSF, e);
+                continue;
+            }
+            if (e >= nw) continue;
             const int n = (int)(e / in), j = (int)(e % in);
             if (j < 256) continue;
             v = sum_splits(a.ws, DW_VIEWSP, (int64_t)n * 32 + (j - 256));
@@ -488,9 +487,8 @@ int benerf_mlp_dw_reduce_launch(const float* ws, const BenerfMlpGrads* grads, in
     r.grad_info = grad_info;
     r.pe_w = pe_weights;
     if (split_mode == 2) {
-        hipLaunchKernelGGL(dw_reduce_g_kernel, dim3((128 * 256 + 128 + 255) / 256), dim3(256), 0, stream, r);
+        hipLaunchKernelGGL(dw_reduce_kernel<2>, dim3(128, BENERF_NLAYERS), dim3(256), 0, stream, r);      // incl. G -> gbuf
         hipLaunchKernelGGL(dw_compose_kernel, dim3(97), dim3(256), 0, stream, r);
-        hipLaunchKernelGGL(dw_reduce_kernel<2>, dim3(128, BENERF_NLAYERS), dim3(256), 0, stream, r);
     } else if (split_mode) hipLaunchKernelGGL(dw_reduce_kernel<1>, dim3(128, BENERF_NLAYERS), dim3(256), 0, stream, r);
     else hipLaunchKernelGGL(dw_reduce_kernel<0>, dim3(128, BENERF_NLAYERS), dim3(256), 0, stream, r);
     BENERF_LAUNCH_CHECK("mlp_bwd(reduce)");

@@ -17,6 +17,13 @@
 #define BENERF_HSW_V2      // this kernel's planes use the round-5 slot swizzle (mlp_split.h: hsw)
 #include "mlp_split.h"
 
+// -DBENERF_TRACE_FWD: thread 0 of the first 2048 workgroups stamps the 100 MHz wall clock at the phase boundaries into the `raw`
+// output (which is then not written) - tools/experiments/trace_phases.py prints the per-phase durations behind DESIGN.md 4.
+#ifdef BENERF_TRACE_FWD
+#define TRF(i) do { if (tid == 0 && blockIdx.x < 2048) reinterpret_cast<unsigned long long*>(a.raw)[blockIdx.x * 32 + (i)] = wall_clock64(); } while (0)
+#else
+#define TRF(i) do { } while (0)
+#endif
 namespace {
 using namespace mlp;
 
@@ -94,7 +101,9 @@ struct DirectSave {
 // combine the two accumulators (+ReLU) -> both LDS planes (hi, scaled lo) [-> HBM: sv].
 // (Tried in round 5 and not kept: requesting the next stage's first weight fragments from inside this epilogue, in front of its
 // stores - vector-memory operations retire in order.  Training launch 1.993 -> 1.975 ms at 522 k points, inside the run-to-run
-// spread, for five spilled registers: profiles/r05_fwd_direct_save_ab.log.)
+// spread, for five spilled registers: profiles/r05_fwd_direct_save_ab.log.  The other way round - the finished units wait in
+// registers and are stored at the head of the next K-loop, behind its first fragment requests - measured 1.655-1.672 -> 1.677-1.681 ms
+// with the last row tile's units deferred (all that fits without spills inside the loop): profiles/r05_fwd_deferred_stores_ab.log.)
 template <int NCT, bool RELU, int NR, bool SV = false>
 __device__ __forceinline__ void epilogue_t(f32x16 (&acc1)[NR][NCT], f32x16 (&acc2)[NR][NCT], _Float16* __restrict__ Th,
                                            _Float16* __restrict__ Tl, int ct0, int lane, float& amax, const DirectSave* sv = nullptr) {
@@ -372,6 +381,10 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
     const int psw = hsw(pt);
     auto scratch = [&](int j) { return reinterpret_cast<float*>(Tl + pt * LD + (((36 + j) ^ psw) << 3)); };
 
+    TRF(0);
+#ifdef BENERF_TRACE_FWD
+    if (tid == 0 && blockIdx.x < 2048) { unsigned hw, xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); reinterpret_cast<unsigned long long*>(a.raw)[blockIdx.x * 32 + 31] = ((unsigned long long)xcc << 32) | hw; }
+#endif
     // ---- prologue: pts = o + d*z (separately rounded like torch), PE(pts) -> planes (+ acts) ------------
     {
         const float zz = a.z[mc];
@@ -410,6 +423,7 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
         }
     }
     lds_barrier();
+    TRF(1);
     if (SAVE == 2) {
         // the 22-bit backward: the encoding leaves as an SH array + lo8 twin straight from the planes' PE columns (the thin dW
         // instances load MFMA fragments from it like from every other saved operand), and the point itself (+ its view
@@ -453,6 +467,7 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
         epilogue_t<1, true, 4, SAVE == 2>(acc1, acc2, Th, Tl, wave, lane, amax, &d0);
     }
     lds_barrier();
+    TRF(2);
 
     // ---- L1..L7 -------------------------------------------------------------------------------
 #pragma unroll 1
@@ -478,12 +493,14 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
         else gemm_stage<16, 1, FPF, true, 4>(Th, Tl, 0, a.packed + fwd_layer_offset(l), wave, lane, acc1, acc2, NoAfterHead(),
                                              [&](int ks) { save_at(ks, 15); });
         lds_barrier();
+        TRF(3 + 2 * (l - 1));
         load_bias<1>(a.bias[l < 7 ? l + 1 : BENERF_L_FEAT], wave, lane, bq);
         {
             const DirectSave dl = direct(l, true);
             epilogue_t<1, true, 4, SAVE == 2>(acc1, acc2, Th, Tl, wave, lane, amax, &dl);
         }
         lds_barrier();
+        TRF(4 + 2 * (l - 1));
     }
     if (SAVE == 1) store_bits(7, save_tile<1, 256, true, 16>(Th, wave, lane, st_h + ((int64_t)7 * Mp + ms0) * 256));
 
@@ -545,11 +562,14 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
     } else {
         // no FEAT stage: VIEWS runs on [h7 | PE(dir)] with W_c = W_v[:, :256] W_f, bias b_c = W_v[:, :256] b_f + b_v
         lds_barrier();      // the alpha partials and the PE(dir) columns are visible
+        TRF(17);
         load_bias<1>(a.bias_c, wave & 3, lane, bq);
     }
     if (tid < FTM && live) {
         const float4 p = *reinterpret_cast<const float4*>(scratch(0));
+#ifndef BENERF_TRACE_FWD
         a.raw[m * (C + 1) + C] = ((p.x + p.y) + (p.z + p.w)) + a.b_alpha[0];
+#endif
     }
     if (!FUSE) lds_barrier();       // feature is in the planes
     if (SAVE == 1) save_tile<1, 256, false, 16>(Th, wave, lane, reinterpret_cast<_Float16*>(acts + sact_feat(Mp)) + ms0 * 256);
@@ -572,8 +592,10 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
         zero_acc(av2);
         gemm_stage<18, 1, FPF, true, 2>(Thh, Tlh, 0, a.packed + pack_offset(FUSE ? PF_VIEWSC : PF_VIEWS), vct, lane, av1, av2);
         lds_barrier();
+        TRF(18);
         epilogue_t<1, true, 2>(av1, av2, Thh, Tlh, vct, lane, amax);
         lds_barrier();
+        TRF(19);
         if (SAVE) {  // sign bits of hv: bit b*4 + j = point 8b + 4 (lane >> 5) + j of this half, column tile = wave & 3
             _Float16* sthv = reinterpret_cast<_Float16*>(acts + sact_hv(Mp)) + (ms0 + vrh * 64) * ACT_HV_W;
             const uint64_t bits = SAVE == 2 ? save_tile22<ACT_HV_W, true, 8>(Thh, Tlh, vct, lane, sthv, st8_h + (int64_t)9 * Mp * 256 + (ms0 + vrh * 64) * ACT_HV_W)
@@ -616,9 +638,12 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             const float4 p = *reinterpret_cast<const float4*>(scratch(1 + c));
+#ifndef BENERF_TRACE_FWD
             a.raw[m * (C + 1) + c] = ((p.x + p.y) + (p.z + p.w)) + a.b_rgb[c];
+#endif
         }
     }
+    TRF(20);
     if (SAVE == 2) asm volatile("s_dcache_wb" ::: "memory");      // the sign-bit words went through the scalar data cache
 }
 

@@ -102,9 +102,11 @@ def test_four_bins_gradients_vs_float64(case):
     3.7e-3 from the float32 oracle at C5 shape, the weights 6e-4).  Cases: an eighth of C2 (gray, safelog, mean-squared event
     loss: 128 event pixels x 5 poses + 19 x 13 blur rays = 887 rays, 0.17 M points) and a sixteenth of the C5 batch (colour,
     lin-log, 31 blur poses, 64 + 192 samples, the L2-NORMALISED loss of every bin: 128 event pixels x 5 poses + 31 x 8 blur
-    rays = 888 rays, 0.23 M points).  The statistics one flipped ReLU unit dominates - the largest entry error, and everything
-    about the 24 + 6 pose numbers - get the lottery factor of tests/test_f64_truth_gpu.py (3 instead of 1.5: measured with the
-    EXACT-f32 mode, profiles/r05_gpu_parity_report.txt); the whole-tensor L2 error of every weight gradient is held to 1.5."""
+    rays = 888 rays, 0.23 M points).  The statistics one flipped ReLU unit dominates - the largest entry error, the norm error (one
+    signed number per tensor) and everything about the 24 + 6 pose numbers - get the lottery factor of tests/test_f64_truth_gpu.py
+    (3 instead of 1.5: measured with the EXACT-f32 mode, profiles/r05_gpu_parity_report.txt - it sits at 1.83 x the float32 oracle's
+    norm error on the coarse network's layer-0 bias at C5 shape); the whole-tensor L2 error of every weight gradient, which bounds
+    its norm error from above, is held to 1.5."""
     from benerf_amd import workloads as WL
     from test_f64_truth_gpu import _assert_no_worse
     B = 4
