@@ -20,7 +20,7 @@
 // operand): an accumulator lane holds 4 consecutive points of one feature, so the lane pair (l, l + 32) forms whole 16-byte SH
 // units in registers (v_permlane32_swap) and the ReLU sign-bit words the forward pass saved line up with the accumulators.
 // The planes' PE feature rows [256,320) are never a GEMM operand here: f32 scratch (hi plane: dPE(dir) at floats [0,27) of a
-// point, the tile's maximum at [26] of points 0 / 1 during P0, scaled d_raw at [28,32)), later the layer-5 skip's dPE block as hi + lo.
+// point, the tile's maximum at [26] of points 0 / 1 during P0; lo plane: the scaled d_raw, channel-major - draw_cm), later the layer-5 skip's dPE block as hi + lo.
 #include "mlp_split.h"
 
 // -DBENERF_TRACE_DX: thread 0 of the first 2048 workgroups stamps the 100 MHz wall clock at the phase boundaries into the d_viewdirs
@@ -81,6 +81,10 @@ __device__ __forceinline__ int fidx(int f, int p) {
 __device__ __forceinline__ float* fscr1(_Float16* T, int row, int i) {
     return reinterpret_cast<float*>(T + 256 * PROW) + row * 32 + (i ^ ((row & 7) << 2));
 }
+// The tile's scaled d_raw, CHANNEL-major: float [C + 1][128 points] at the head of the LO plane's feature rows [256,320) (free until the
+// layer-5 skip's dPE block): a lane of P1 / P2 wants the 4 consecutive points of an accumulator quad - one 16-byte read per channel
+// where the point-major scratch rows took four (round 5: P1 was 4.4 us of a 105 us tile on 2-byte plane writes and per-element reads).
+__device__ __forceinline__ float* draw_cm(_Float16* Tl, int c) { return reinterpret_cast<float*>(Tl + 256 * PROW) + c * 128; }
 // A fragment pieces of this lane: half offsets at k-step 0 for piece j (features 8 (lane >> 5) + 4 j + ((lane & 15) >> 2)) and row
 // tile rt (points rt * 32 + 16 ((lane >> 4) & 1) + 4 (lane & 3)); a k-step further is 16 feature rows = 16 * PROW halfs
 __device__ __forceinline__ int frag_off(int lane, int j, int rt) {
@@ -313,10 +317,12 @@ __device__ __forceinline__ void amax3(float& amax, float v0, float v1) {
 // tile scale) and, rescaled by gf = s_call / s_tile (a power of two <= 1; exact), the SH gradient arrays `st_hi` / `st_lo` of
 // width 256 (tile part).
 // STORE = false: planes only (d feature: the dW kernels do not need it, mlp_common.h: DWS_*)
-template <bool MASK, bool STORE = true>
-__device__ __forceinline__ void epilogue3(f32x16 (&acc)[4], const uint32_t (&bits)[4], _Float16* __restrict__ Th, _Float16* __restrict__ Tl,
+// NRT row tiles starting at row tile rt0 (wave-uniform; P1: the views layer's 128-wide stage runs as column tile w & 3 x point half
+// w >> 2), W: width of the SH arrays `st_hi` / `st_lo` (their tile part: block 0 = the tile's first 8 points).
+template <bool MASK, bool STORE = true, int NRT = 4, int W = 256>
+__device__ __forceinline__ void epilogue3(f32x16 (&acc)[NRT], const uint32_t (&bits)[NRT], _Float16* __restrict__ Th, _Float16* __restrict__ Tl,
                                           int ct, int lane, const _Float16* __restrict__ st_hi, const uint8_t* __restrict__ st_lo, float gf,
-                                          float& amax) {
+                                          float& amax, int rt0 = 0) {
     lane = stage_local(lane);
     const int lr = lane & 31, r4 = 4 * (lane >> 5);
     const __amdgpu_buffer_rsrc_t rs_hi = uniform_rsrc(st_hi);         // this tile's 16 blocks of the SH arrays (64 KiB each)
@@ -334,9 +340,9 @@ __device__ __forceinline__ void epilogue3(f32x16 (&acc)[4], const uint32_t (&bit
     const int tq = n * PROW + (r4 ^ (((n >> 4) & 1) << 2));      // fidx: the slot's halves swapped for features with bit 4 set
 #endif
     const int sw_seg = n & 3, sw_slot = (n >> 2) & 3;
-    const int st_lane = (((lane >> 5) * 256 + n) * 8) * 2;   // byte offset of unit (block, n); lanes 32-63: the odd block of a pair
+    const int st_lane = ((((lane >> 5) + rt0 * 4) * W + n) * 8) * 2;   // byte offset of unit (block, n); lanes 32-63: the odd block of a pair
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
+    for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
         for (int ep = 0; ep < 2; ++ep) {
             uint2 qh[2], ql[2];
@@ -359,7 +365,7 @@ __device__ __forceinline__ void epilogue3(f32x16 (&acc)[4], const uint32_t (&bit
                     wl[jp] = __builtin_bit_cast(uint32_t, lv);
                 }
                 {   // this quad (block q = 2 ep + h of row tile rt) -> both planes, 8 bytes each
-                    const int o = tq + (((rt ^ sw_seg) << 5) | ((((ep * 2 + h) ^ sw_slot)) << 3));
+                    const int o = tq + ((((NRT == 4 ? rt : rt0 + rt) ^ sw_seg) << 5) | ((((ep * 2 + h) ^ sw_slot)) << 3));
                     *reinterpret_cast<uint2*>(Th + o) = uint2{wh[0], wh[1]};
 #ifndef BWS_SKIP_PLANE_LO
                     *reinterpret_cast<uint2*>(Tl + o) = uint2{wl[0], wl[1]};
@@ -383,8 +389,8 @@ __device__ __forceinline__ void epilogue3(f32x16 (&acc)[4], const uint32_t (&bit
             // vector offset + zero scalar offset (mlp_bwd_h.hip: the scalar-offset form of a 16-byte store reads its data late)
 #ifndef BWS_SKIP_STORE      // timing variants only (tools/experiments/build_variant.sh)
             typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{oh[0], oh[1], oh[2], oh[3]}, rs_hi, st_lane + (rt * 4 + ep * 2) * 256 * 8 * 2, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b64(u32x2{code.x, code.y}, rs_lo, st_lane / 2 + (rt * 4 + ep * 2) * 256 * 8, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{oh[0], oh[1], oh[2], oh[3]}, rs_hi, st_lane + (rt * 4 + ep * 2) * W * 8 * 2, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{code.x, code.y}, rs_lo, st_lane / 2 + (rt * 4 + ep * 2) * W * 8, 0, 0);
 #endif
         }
 }
@@ -463,7 +469,7 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
     pow2_scale6(fmaxf(*fscr1(Th, 0, 26), *fscr1(Th, 1, 26)), s, inv_s);     // 2^(6 - exponent(max)), exact inverse
     if (tid < TMB) {
 #pragma unroll
-        for (int c = 0; c <= C; ++c) *fscr1(Th, tid, 28 + c) = dr0[c] * s;
+        for (int c = 0; c <= C; ++c) draw_cm(Tl, c)[tid] = dr0[c] * s;
     }
     lds_barrier();
     const float gf = s_g * inv_s;   // tile scale -> scale of the stored dY (power of two <= 1)
@@ -477,45 +483,41 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
         typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
         const u32x2 hvw = __builtin_amdgcn_raw_buffer_load_b64(mask_rsrc, (vct * 64 + lane) * 8 + vrh * NTHREADS * 8,
                                                                __builtin_amdgcn_readfirstlane(8 * mask_stride_b), 0);
-        const uint32_t hvbits = hvw[0];
         const int col = vct * 32 + (lane & 31), r4 = 4 * (lane >> 5);
         float wr[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) wr[c] = a.w_rgb[c * 128 + col];
-        _Float16* st_lane = reinterpret_cast<_Float16*>(dacts + sdact_hv(Mp)) + (((m0 >> 3) + (lane >> 5)) * ACT_HV_W + col) * 8;
-        uint8_t* st8_lane = st8 + 2 * sdact_hv(Mp) + (((m0 >> 3) + (lane >> 5)) * ACT_HV_W + col) * 8;
+        // g = d_rgb . w_rgb[:, col] for this lane's 2 x 16 points, in accumulator order (element e of row tile rt = point
+        // rt * 32 + 8 (e >> 2) + r4 + (e & 3): a quad = 4 consecutive points = one 16-byte read per channel)
+        f32x16 g2[2];
 #pragma unroll
         for (int rtl = 0; rtl < 2; ++rtl)
 #pragma unroll
-            for (int ep = 0; ep < 2; ++ep) {
-                const int rt = vrh * 2 + rtl;
-                Quad16 qh[2], ql[2];
+            for (int q = 0; q < 4; ++q) {
+                const int p0 = (vrh * 2 + rtl) * 32 + 8 * q + r4;
+                float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int h = 0; h < 2; ++h)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int e = (ep * 2 + h) * 4 + j;
-                        const int p = rt * 32 + (e & 3) + 8 * (e >> 2) + r4;
-                        const float4 dr = *reinterpret_cast<const float4*>(fscr1(Th, p, 28));
-                        const float drv[4] = {dr.x, dr.y, dr.z, dr.w};
-                        float g = 0.f;
-#pragma unroll
-                        for (int c = 0; c < C; ++c) g += drv[c] * wr[c];
-                        const float v = ((hvbits >> (rtl * 16 + e)) & 1u) ? g : 0.f;
-                        const _Float16 vh = (_Float16)v;
-                        Th[fidx(col, p)] = vh;
-                        Tl[fidx(col, p)] = (_Float16)(v - (float)vh);
-                        const float sv = v * gf;
-                        amax = fmaxf(amax, fabsf(v));
-                        qh[h].v[j] = (_Float16)sv;
-                        ql[h].v[j] = (_Float16)((sv - (float)qh[h].v[j]) * 4096.f);       // encoder input: residual * 2^12
-                    }
-                const uint4 uh = sh_pair_unit(qh[0], qh[1]);
-                const uint4 ul = sh_pair_unit(ql[0], ql[1]);
-                const uint32_t uhw[4] = {uh.x, uh.y, uh.z, uh.w}, ulw[4] = {ul.x, ul.y, ul.z, ul.w};
-                *reinterpret_cast<uint4*>(st_lane + (int64_t)(rt * 4 + ep * 2) * ACT_HV_W * 8) = uh;
-                *reinterpret_cast<uint2*>(st8_lane + (int64_t)(rt * 4 + ep * 2) * ACT_HV_W * 8) = h8_encode_unit<12>(uhw, ulw);
+                for (int c = 0; c < C; ++c) {
+                    const float4 d = *reinterpret_cast<const float4*>(draw_cm(Tl, c) + p0);
+                    g.x += d.x * wr[c];
+                    g.y += d.y * wr[c];
+                    g.z += d.z * wr[c];
+                    g.w += d.w * wr[c];
+                }
+                g2[rtl][q * 4 + 0] = g.x;
+                g2[rtl][q * 4 + 1] = g.y;
+                g2[rtl][q * 4 + 2] = g.z;
+                g2[rtl][q * 4 + 3] = g.w;
             }
+        // the forward's hv sign bits (bit 16 rtl + e of this thread's word) in epilogue3's order (bit 8 (e >> 2) + (e & 3))
+        uint32_t hb[2];
+#pragma unroll
+        for (int rtl = 0; rtl < 2; ++rtl) {
+            const uint32_t x = hvw[0] >> (16 * rtl);
+            hb[rtl] = (x & 0xFu) | ((x & 0xF0u) << 4) | ((x & 0xF00u) << 8) | ((x & 0xF000u) << 12);
+        }
+        epilogue3<true, true, 2, ACT_HV_W>(g2, hb, Th, Tl, vct, lane, reinterpret_cast<_Float16*>(dacts + sdact_hv(Mp)) + ms0 * ACT_HV_W,
+                                           st8 + 2 * sdact_hv(Mp) + ms0 * ACT_HV_W, gf, amax, vrh * 2);
     }
     lds_barrier();
     TR(2);
@@ -547,7 +549,13 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[rt][e] += *fscr1(Th, rt * 32 + (e & 3) + 8 * (e >> 2) + r4, 28 + C) * wa;
+            for (int q = 0; q < 4; ++q) {
+                const float4 ds = *reinterpret_cast<const float4*>(draw_cm(Tl, C) + rt * 32 + 8 * q + r4);
+                acc[rt][q * 4 + 0] += ds.x * wa;
+                acc[rt][q * 4 + 1] += ds.y * wa;
+                acc[rt][q * 4 + 2] += ds.z * wa;
+                acc[rt][q * 4 + 3] += ds.w * wa;
+            }
     }
     lds_barrier();   // dYv fully consumed; dPE(dir) visible
     TR(3);
