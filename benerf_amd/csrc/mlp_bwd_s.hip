@@ -129,9 +129,22 @@ static_assert(pack_offset(PB_L7) + 1 * pack_floats(PB_L7) == pack_offset(PB_L6) 
 
 // lane-derived addresses stay local to a stage (hoisted out of the layer loop they overflow the register file: mlp_bwd_h.hip)
 __device__ __forceinline__ int stage_local(int lane) {
+#ifndef BWS_HOIST     /* experiment: let the compiler hoist the lane-derived addresses out of the layer loop */
     asm volatile("" : "+v"(lane));
+#endif
     return lane;
 }
+
+// The lane-derived LDS offsets the 256-wide stages share, computed ONCE per tile (16 registers carried across the layer loop):
+//   ao0[j][rt]  piece j of the A fragment of row tile rt at k-step 0, hi plane (frag_off)
+//   ta[rt], b[q] plane offset of the epilogue's quad (row tile rt, block q) = ta[rt] + b[q]  (feature ct * 32 + (lane & 31))
+// Recomputed per stage (stage_local: nothing carried) they were ~190 of a layer's 704 VALU instructions - 130 of them in front of the
+// K-loop's first MFMA; carried ALL (the compiler's own hoisting: 32 fragment offsets + 16 quad offsets) they spill 33 registers.  What a
+// stage derives from these 16 per layer: the odd k-steps' offsets (^ 4), the lo plane's (+ plane distance), the 16 quad sums.
+struct LaneAddr {
+    int ao0[2][4];
+    int ta[4], b[4];
+};
 
 #ifndef BWS_PF
 #define BWS_PF 3
@@ -158,7 +171,7 @@ __device__ __forceinline__ void gemm3_head(const float* __restrict__ wp, int ct,
 // fragments PF k-steps ahead, ONE set of activation fragments, each reloaded right behind its last MFMA of the k-step.
 template <int KS, int PF>
 __device__ __forceinline__ void gemm3_body(const _Float16* __restrict__ Th, const _Float16* __restrict__ Tl, const float* __restrict__ wp,
-                                           int ct, int lane, WRing<PF>& r, f32x16 (&acc)[4]) {
+                                           int ct, int lane, WRing<PF>& r, f32x16 (&acc)[4], const LaneAddr& la) {
     lane = stage_local(lane);
     const WFrag wf(wp, lane);
     const int ctu = __builtin_amdgcn_readfirstlane(ct);
@@ -173,7 +186,11 @@ __device__ __forceinline__ void gemm3_body(const _Float16* __restrict__ Th, cons
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
-            ao[0][j][rt] = frag_off(lane, j, rt);
+            {   // a per-stage copy of the carried offset: what is derived from it below stays inside the stage (not hoisted, not spilled)
+                int v = la.ao0[j][rt];
+                asm volatile("" : "+v"(v));
+                ao[0][j][rt] = v;
+            }
 #ifdef BWS_OLD_SWIZZLE
             ao[1][j][rt] = ao[0][j][rt];
 #else
@@ -218,10 +235,10 @@ __device__ __forceinline__ void gemm3_body(const _Float16* __restrict__ Th, cons
 
 template <int KS, int PF = BWS_PF>
 __device__ __forceinline__ void gemm3(const _Float16* __restrict__ Th, const _Float16* __restrict__ Tl, const float* __restrict__ wp, int ct,
-                                      int lane, f32x16 (&acc)[4]) {
+                                      int lane, f32x16 (&acc)[4], const LaneAddr& la) {
     WRing<PF> r;
     gemm3_head<KS, PF>(wp, ct, lane, r);
-    gemm3_body<KS, PF>(Th, Tl, wp, ct, lane, r, acc);
+    gemm3_body<KS, PF>(Th, Tl, wp, ct, lane, r, acc, la);
 }
 
 // One row tile x one column tile: out += (Th + Tl)[rt*32.., 0 .. KS*16) x W(tile).  Three MFMAs per k-step on ONE accumulator
@@ -319,10 +336,10 @@ __device__ __forceinline__ void amax3(float& amax, float v0, float v1) {
 // STORE = false: planes only (d feature: the dW kernels do not need it, mlp_common.h: DWS_*)
 // NRT row tiles starting at row tile rt0 (wave-uniform; P1: the views layer's 128-wide stage runs as column tile w & 3 x point half
 // w >> 2), W: width of the SH arrays `st_hi` / `st_lo` (their tile part: block 0 = the tile's first 8 points).
-template <bool MASK, bool STORE = true, int NRT = 4, int W = 256>
+template <bool MASK, bool STORE = true, int NRT = 4, int W = 256, bool USE_LA = false>
 __device__ __forceinline__ void epilogue3(f32x16 (&acc)[NRT], const uint32_t (&bits)[NRT], _Float16* __restrict__ Th, _Float16* __restrict__ Tl,
                                           int ct, int lane, const _Float16* __restrict__ st_hi, const uint8_t* __restrict__ st_lo, float gf,
-                                          float& amax, int rt0 = 0) {
+                                          float& amax, int rt0, const LaneAddr& la) {
     lane = stage_local(lane);
     const int lr = lane & 31, r4 = 4 * (lane >> 5);
     const __amdgpu_buffer_rsrc_t rs_hi = uniform_rsrc(st_hi);         // this tile's 16 blocks of the SH arrays (64 KiB each)
@@ -341,6 +358,16 @@ __device__ __forceinline__ void epilogue3(f32x16 (&acc)[NRT], const uint32_t (&b
 #endif
     const int sw_seg = n & 3, sw_slot = (n >> 2) & 3;
     const int st_lane = ((((lane >> 5) + rt0 * 4) * W + n) * 8) * 2;   // byte offset of unit (block, n); lanes 32-63: the odd block of a pair
+    // the 256-wide stages: quad offsets from the carried pieces (LaneAddr), through per-stage copies so that the 16 sums are not hoisted
+    int qb[4] = {0, 0, 0, 0};
+    if (USE_LA) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int v = la.b[q];
+            asm volatile("" : "+v"(v));
+            qb[q] = v;
+        }
+    }
 #pragma unroll
     for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
@@ -365,7 +392,8 @@ __device__ __forceinline__ void epilogue3(f32x16 (&acc)[NRT], const uint32_t (&b
                     wl[jp] = __builtin_bit_cast(uint32_t, lv);
                 }
                 {   // this quad (block q = 2 ep + h of row tile rt) -> both planes, 8 bytes each
-                    const int o = tq + ((((NRT == 4 ? rt : rt0 + rt) ^ sw_seg) << 5) | ((((ep * 2 + h) ^ sw_slot)) << 3));
+                    const int o = USE_LA ? la.ta[rt] + qb[ep * 2 + h]
+                                         : tq + ((((NRT == 4 ? rt : rt0 + rt) ^ sw_seg) << 5) | ((((ep * 2 + h) ^ sw_slot)) << 3));
                     *reinterpret_cast<uint2*>(Th + o) = uint2{wh[0], wh[1]};
 #ifndef BWS_SKIP_PLANE_LO
                     *reinterpret_cast<uint2*>(Tl + o) = uint2{wl[0], wl[1]};
@@ -517,13 +545,32 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
             hb[rtl] = (x & 0xFu) | ((x & 0xF0u) << 4) | ((x & 0xF00u) << 8) | ((x & 0xF000u) << 12);
         }
         epilogue3<true, true, 2, ACT_HV_W>(g2, hb, Th, Tl, vct, lane, reinterpret_cast<_Float16*>(dacts + sdact_hv(Mp)) + ms0 * ACT_HV_W,
-                                           st8 + 2 * sdact_hv(Mp) + ms0 * ACT_HV_W, gf, amax, vrh * 2);
+                                           st8 + 2 * sdact_hv(Mp) + ms0 * ACT_HV_W, gf, amax, vrh * 2, LaneAddr());
     }
     lds_barrier();
     TR(2);
 
     f32x16 acc[4];
     uint32_t bits[4];
+    LaneAddr la;
+    {
+        const int ln = stage_local(lane);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) la.ao0[j][rt] = frag_off(ln, j, rt);
+        const int n = ct * 32 + (ln & 31), r4 = 4 * (ln >> 5);
+#ifdef BWS_OLD_SWIZZLE
+        const int tq = n * PROW + r4;
+#else
+        const int tq = n * PROW + (r4 ^ (((n >> 4) & 1) << 2));
+#endif
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            la.ta[k] = tq + ((k ^ (n & 3)) << 5);
+            la.b[k] = (k ^ ((n >> 2) & 3)) << 3;
+        }
+    }
 
     // ---- P2: VIEWS^T and FEAT^T in ONE stage (round 5): dh7 = dYv x W_c + d_sigma w_alpha, W_c = W_v[:, :256] W_f (mlp_common.h:
     // PB_VIEWSC - the feature layer feeds the views layer without a ReLU, so its gradient never has to exist); dPE(dir) = dYv x
@@ -542,7 +589,7 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
         __builtin_amdgcn_sched_barrier(0);
     }
     zero4(acc);
-    gemm3<8>(Th, Tl, packed_h + pack_offset(PB_VIEWSC), ct, lane, acc);
+    gemm3<8>(Th, Tl, packed_h + pack_offset(PB_VIEWSC), ct, lane, acc, la);
     {
         const float wa = a.w_alpha[ct * 32 + (lane & 31)];
         const int r4 = 4 * (lane >> 5);
@@ -587,14 +634,14 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
     load_bits(6, bits_n);
     gemm3_head<16, BWS_PF>(packed_h + pack_offset(PB_L7), ct, lane, ring);
     shift_bits(bits);
-    epilogue3<true>(acc, bits, Th, Tl, ct, lane, st_tile(7), st8_tile(7), gf, amax);
+    epilogue3<true, true, 4, 256, true>(acc, bits, Th, Tl, ct, lane, st_tile(7), st8_tile(7), gf, amax, 0, la);
     lds_barrier();
     TR(4);
 
     // ---- P4: L7 .. L1: dY_l x W_l, mask h_{l-1} -> dY_{l-1} ----------------------------------------------
     auto layer = [&](int l) __attribute__((always_inline)) {
         zero4(acc);
-        gemm3_body<16, BWS_PF>(Th, Tl, packed_h + bwd_layer_offset(l), ct, lane, ring, acc);
+        gemm3_body<16, BWS_PF>(Th, Tl, packed_h + bwd_layer_offset(l), ct, lane, ring, acc, la);
         lds_barrier();
         TR(5 + 2 * (7 - l));
 #pragma unroll
@@ -604,7 +651,7 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
             load_bits(l - 2, bits_n);
             gemm3_head<16, BWS_PF>(packed_h + bwd_layer_offset(l - 1), ct, lane, ring);
         }
-        epilogue3<true>(acc, bits, Th, Tl, ct, lane, st_tile(l - 1), st8_tile(l - 1), gf, amax);
+        epilogue3<true, true, 4, 256, true>(acc, bits, Th, Tl, ct, lane, st_tile(l - 1), st8_tile(l - 1), gf, amax, 0, la);
         lds_barrier();
         TR(6 + 2 * (7 - l));
     };
