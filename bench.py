@@ -88,10 +88,12 @@ def parse():
                          "without wire time")
     ap.add_argument("--batch-fraction", type=int, default=1,
                     help="render 1/F of the workload's pixels per rank (F = 8 on one GPU: the per-rank step of a strong-scaled 8-GPU run)")
-    ap.add_argument("--proxy-rank", type=int, default=0,
-                    help="with --batch-fraction F: WHICH rank's share of the F-way split this one GPU renders.  0 (default) holds the largest "
-                         "share when the batch does not split evenly (107 blur pixels over 8 ranks: 14, against 13 on rank 7) - the rank "
-                         "the step of a strong-scaled job waits for")
+    ap.add_argument("--proxy-rank", type=int, default=-1,
+                    help="with --batch-fraction F: WHICH rank's share of the F-way ray-balanced split (dist.balanced_shard_bounds) this one "
+                         "GPU renders.  -1 (default): the rank with the most rays - the one the step of a strong-scaled job waits for")
+    ap.add_argument("--pixel-shards", action="store_true",
+                    help="with --batch-fraction F: the round-4 split instead (event and blur pixels each dealt evenly, left-overs to the low "
+                         "ranks; rank 0's share) - for the A/B in profiles/r05_one_eighth_batch_same_box.log")
     ap.add_argument("--event-bins", type=int, default=1,
                     help="dense event bins (BASELINE.json configs[4]; an extension, the reference has one bin per step): the event "
                          "window is cut into B contiguous equal bins, the event pixels are rendered at the B + 1 bin boundaries, every "
@@ -501,15 +503,21 @@ def main():
     # Pixel counts.  weak: the workload's batch per rank (global = world x that); strong: the workload's batch IS the global batch
     # (C4 / C5 are 8192 rays in total) and every rank renders its contiguous share - the left-over pixels of a batch
     # the ranks cannot split evenly (C4: 215 blur pixels over 8 ranks) go one each to the low ranks (dist.shard_bounds), nothing is
-    # dropped.  --batch-fraction F (one-GPU proxy of a strong-scaled rank): the share of rank 0 of F, i.e. the LARGEST share.
-    def share(n, parts):
-        lo, hi = D.shard_bounds(n, min(a.proxy_rank, parts - 1), parts, uneven=True)
-        return max(hi - lo, 1)
-    Re_n, Rr_n = share(wl["Re"], a.batch_fraction), share(wl["Rr"], a.batch_fraction)
+    # dropped; the event pixels are dealt so that every rank renders the same number of rays +- a pixel's worth
+    # (dist.balanced_shard_bounds).  --batch-fraction F (one-GPU proxy of a strong-scaled rank): the share of the rank with the
+    # MOST rays of an F-way split (or of --proxy-rank).
+    pe_rays, pn_rays = a.event_bins + 1, wl["n"]
+    def shares(ne, nr, parts):
+        return [(e1 - e0, r1 - r0) for (e0, e1), (r0, r1) in D.balanced_shard_bounds(ne, nr, pe_rays, pn_rays, parts)]
+    if a.pixel_shards:
+        Re_n, Rr_n = (max(D.shard_bounds(n, 0, a.batch_fraction, uneven=True)[1], 1) for n in (wl["Re"], wl["Rr"]))
+    else:
+        sh = shares(wl["Re"], wl["Rr"], a.batch_fraction)
+        k = a.proxy_rank if a.proxy_rank >= 0 else max(range(len(sh)), key=lambda i: (pe_rays * sh[i][0] + pn_rays * sh[i][1], -i))
+        Re_n, Rr_n = (max(v, 1) for v in sh[min(k, len(sh) - 1)])
     if a.scaling == "strong":
         Re_g, Rr_g = Re_n, Rr_n
-        (e0, e1), (r0, r1) = D.shard_bounds(Re_g, rank, world, uneven=True), D.shard_bounds(Rr_g, rank, world, uneven=True)
-        wl["Re"], wl["Rr"] = e1 - e0, r1 - r0
+        wl["Re"], wl["Rr"] = shares(Re_g, Rr_g, world)[rank]
         if min(wl["Re"], wl["Rr"]) < 1:
             sys.exit("bench.py: rank %d would render no pixels (%d event / %d blur pixels over %d ranks)" % (rank, Re_g, Rr_g, world))
     else:

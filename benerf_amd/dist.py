@@ -31,6 +31,32 @@ def shard_bounds(n, rank, world, uneven=False):
     return lo, lo + per + (1 if rank < rem else 0)
 
 
+def balanced_shard_bounds(n_evt, n_rgb, rays_per_evt, rays_per_rgb, world):
+    """Ray-balanced contiguous slices of an uneven strong-scaled batch: [((e_lo, e_hi), (r_lo, r_hi))] * world.
+    The blur pixels are split as shard_bounds(uneven=True) does (left-over pixels one each to the low ranks); a blur pixel is
+    rays_per_rgb rays (the n virtual poses), so ranks with one blur pixel more get FEWER event pixels (rays_per_evt rays each: 2
+    poses, or bins + 1), such that every rank renders as close to total / world rays as whole pixels allow (largest-remainder
+    rounding, ties to the low rank - every rank computes the same table).  Why it matters beyond balance: the fused MLP kernels
+    work in 128-point tiles, one per CU and round - at 1/8 of C2 a rank with 14 instead of 13 blur pixels renders 522 rays =
+    261 coarse tiles = TWO rounds of the 256 CUs instead of one (and three instead of two in the fine network): +0.18 ms on a
+    1.35 ms step, while 510 +- 1 rays on every rank fit one round (profiles/r05_one_eighth_batch_same_box.log)."""
+    rb = [shard_bounds(n_rgb, k, world, uneven=True) for k in range(world)]
+    target = (rays_per_evt * n_evt + rays_per_rgb * n_rgb) / world
+    ideal = [max((target - rays_per_rgb * (hi - lo)) / rays_per_evt, 0.0) for lo, hi in rb]
+    e = [int(x) for x in ideal]
+    left = n_evt - sum(e)
+    if left < 0:        # cannot happen with ideal >= 0 summing to n_evt, guard against float round-off
+        raise ValueError("balanced_shard_bounds: internal rounding error")
+    order = sorted(range(world), key=lambda k: (-(ideal[k] - e[k]), k))
+    for i in range(left):
+        e[order[i % world]] += 1
+    out, lo = [], 0
+    for k in range(world):
+        out.append(((lo, lo + e[k]), rb[k]))
+        lo += e[k]
+    return out
+
+
 def shard_indices(idx, rank, world, uneven=False):
     """Contiguous slice of a global index vector for this rank (shard_bounds)."""
     lo, hi = shard_bounds(idx.shape[0], rank, world, uneven)

@@ -268,8 +268,9 @@ class TrainStep:
         # is rendered ONCE at the event_bins + 1 bin boundaries (get_pose_evt(args, ts, seg_num=B + 1), model/optimize.py:58-82)
         # and every bin contributes the reference's event-loss term (train.py:204-292) on its pose pair and its own accumulated
         # polarity image; event_bins = 1 is the reference's step.
-        # uneven_shards: a global batch the ranks cannot split evenly is rendered whole - the left-over pixels go one each to the
-        # low ranks (dist.shard_bounds) - instead of being refused; the loss means use the true global counts either way
+        # uneven_shards: a global batch the ranks cannot split evenly is rendered whole instead of being refused - the left-over
+        # blur pixels go one each to the low ranks and the event pixels are dealt so that every rank renders the same number of
+        # RAYS +- one pixel's worth (dist.balanced_shard_bounds); the loss means use the true global counts either way
         self.uneven_shards = bool(uneven_shards)
         # wait_events: when a list, every wait of the main / side stream for a gradient bucket is bracketed by HIP events
         # (bucket name, before, after) - bench.py reports how long a step actually stalls on each exchange
@@ -447,9 +448,13 @@ class TrainStep:
         (those steps were skipped on every rank: parameters and Adam moments untouched)."""
         self.guard.check(reset)
 
-    def shard(self, idx):
-        """Contiguous slice of a global pixel-index vector for this rank."""
-        return dist.shard_indices(idx, self.rank, self.world, self.uneven_shards)
+    def shard(self, idx_evt, idx_rgb):
+        """This rank's contiguous slices of the global event / blur pixel-index vectors."""
+        if not self.uneven_shards or self.world == 1:
+            return dist.shard_indices(idx_evt, self.rank, self.world), dist.shard_indices(idx_rgb, self.rank, self.world)
+        (e0, e1), (r0, r1) = dist.balanced_shard_bounds(idx_evt.shape[0], idx_rgb.shape[0], self.event_bins + 1,
+                                                        self.cfg.num_interpolated_pose, self.world)[self.rank]
+        return idx_evt[e0:e1].contiguous(), idx_rgb[r0:r1].contiguous()
 
     def _ray_setup(self, evt_ts2, rgb_ts2, idx_e, idx_r, d):
         """Poses of both trajectories (K1), rays of both batches (K2), stratified coarse depths: everything in front of the
@@ -517,7 +522,7 @@ class TrainStep:
         st = self.guard.words
         P = cfg.num_interpolated_pose
         S, Ni = cfg.N_samples, cfg.N_importance
-        idx_e, idx_r = self.shard(idx_evt_global), self.shard(idx_rgb_global)
+        idx_e, idx_r = self.shard(idx_evt_global, idx_rgb_global)
         Re, Rr = idx_e.shape[0], idx_r.shape[0]
         B = self.event_bins
         Pe = B + 1
@@ -744,7 +749,7 @@ class TrainStep:
             # call bump these version counters - the set-up is then recomputed (the fused Adam writes through raw pointers)
             self._prefetched = {"inputs": nxt, "step_id": step_id + 1,
                                 "versions": self._param_versions() + tuple(t_._version for t_ in nxt),
-                                "rays": self._ray_setup(nxt[0], nxt[1], self.shard(nxt[2]), self.shard(nxt[3]), dn)}
+                                "rays": self._ray_setup(nxt[0], nxt[1], *self.shard(nxt[2], nxt[3]), dn)}
         with torch.cuda.stream(side):
             for nm, w in zip(bucket_names, pending[:2]):
                 self._timed_wait(nm, w)

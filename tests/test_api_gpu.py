@@ -233,14 +233,17 @@ def _dp_worker(rank, world, port, out_q, mode, base="C5", bins=1, uneven=False):
     Pe = bins + 1       # dense event bins: the event batch is rendered at the bins + 1 boundaries
     d_e, d_r = GI.render_draws(rng, Pe * n_e, S, Ni), GI.render_draws(rng, P * n_r, S, Ni)
 
-    def shard(d, n_poses, n_pix):
+    def shard(d, n_poses, n_pix, which):
         from benerf_amd import dist
-        lo, hi = dist.shard_bounds(n_pix, rank, world, uneven)
+        if uneven and world > 1:     # TrainStep(uneven_shards=True): the ray-balanced table (event pixels compensate the blur pixels' left-overs)
+            lo, hi = dist.balanced_shard_bounds(n_e, n_r, Pe, P, world)[rank][which]
+        else:
+            lo, hi = dist.shard_bounds(n_pix, rank, world, uneven)
         sel = torch.cat([torch.arange(p * n_pix + lo, p * n_pix + hi) for p in range(n_poses)])
         return engine.Draws(*(d[k][sel].to(DEV) for k in ("t_rand", "noise0", "u", "noise1")))
 
     losses = step.step(torch.tensor([0.2, 0.45], device=DEV), torch.tensor([0.0, 1.0], device=DEV), idx_e, idx_r, accu, img,
-                       shard(d_e, Pe, n_e), shard(d_r, P, n_r))
+                       shard(d_e, Pe, n_e, 0), shard(d_r, P, n_r, 1))
     torch.cuda.synchronize()
     if world > 1 and not uneven:   # a global batch the ranks cannot split evenly is refused (unless uneven_shards), not silently truncated
         with pytest.raises(ValueError):
@@ -254,7 +257,7 @@ def _dp_worker(rank, world, port, out_q, mode, base="C5", bins=1, uneven=False):
         if rank == world - 1:
             step.guard.words[_lib.ST_ACT] = 0x7f800000
         step.step(torch.tensor([0.2, 0.45], device=DEV), torch.tensor([0.0, 1.0], device=DEV), idx_e, idx_r, accu, img,
-                  shard(d_e, Pe, n_e), shard(d_r, P, n_r))
+                  shard(d_e, Pe, n_e, 0), shard(d_r, P, n_r, 1))
         torch.cuda.synchronize()
         assert torch.equal(step.flat_p, p_before) and torch.equal(step.flat_m, m_before), "rank %d did not skip the step" % rank
         w = step.guard.words.cpu().tolist()
@@ -778,10 +781,11 @@ def test_bench_two_ranks_end_to_end():
 
     two = run(["--gpus", "2", "--oversubscribe"])
     assert two["n_gpus"] == 2 and two["rccl_ranks_seen"] == 2 and two["scaling"] == "strong" and two["allreduce_ms"] > 0
-    # 215 blur pixels do not split over two ranks: rank 0 renders 108, rank 1 107 - nothing is dropped (round 5: uneven shards)
-    assert two["config"]["parallelism"] == "dp2" and two["config"]["rays_per_step_per_gpu"] == 2 * 1024 + 19 * 108
+    # 215 blur pixels do not split over two ranks: rank 0 renders 108, rank 1 107 - nothing is dropped - and the 2048 event pixels are
+    # dealt 1019 / 1029 so that both ranks render the same number of rays +- 1 (round 5: dist.balanced_shard_bounds)
+    assert two["config"]["parallelism"] == "dp2" and two["config"]["rays_per_step_per_gpu"] == 2 * 1019 + 19 * 108
     assert two["config"]["rays_global"] == 2 * 2048 + 19 * 215 == 8181
-    assert two["per_rank"]["rays_per_step_by_rank"] == [2 * 1024 + 19 * 108, 2 * 1024 + 19 * 107]
+    assert two["per_rank"]["rays_per_step_by_rank"] == [2 * 1019 + 19 * 108, 2 * 1029 + 19 * 107]
     assert two["per_rank"]["ms_per_step_max"] >= two["per_rank"]["ms_per_step_min"] > 0
     assert set(two["bucket_wait"]) >= {"fine_net", "coarse_net", "trajectory"}
     assert abs(two["value"] - 8181 / (two["ms_per_step"] * 1e-3)) / two["value"] < 2e-3

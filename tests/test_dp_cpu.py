@@ -50,7 +50,7 @@ def _local_backward(O, rgb_e, rgb0_e, tgt_acc, rgb_r, rgb0_r, tgt_rgb, C, datase
     torch.autograd.backward(outs, grads)
 
 
-def _worker(rank, world, port, thr, q, Rr_g=8, uneven=False):
+def _worker(rank, world, port, thr, q, Rr_g=8, uneven=False, balanced=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import benerf_oracle as O
@@ -70,8 +70,12 @@ def _worker(rank, world, port, thr, q, Rr_g=8, uneven=False):
     def render(feat):     # [poses, pixels, 8] -> pose-major [poses*pixels, C] in (0,1)
         return torch.sigmoid(feat @ W.t()).reshape(-1, C)
 
-    pix_e = dist.shard_indices(torch.arange(Re_g), rank, world, uneven)
-    pix_r = dist.shard_indices(torch.arange(Rr_g), rank, world, uneven)
+    if balanced:      # TrainStep(uneven_shards=True): blur left-overs to the low ranks, event pixels dealt to equalise the RAY counts
+        (e0, e1), (r0, r1) = dist.balanced_shard_bounds(Re_g, Rr_g, 2, P, world)[rank]
+        pix_e, pix_r = torch.arange(e0, e1), torch.arange(r0, r1)
+    else:
+        pix_e = dist.shard_indices(torch.arange(Re_g), rank, world, uneven)
+        pix_r = dist.shard_indices(torch.arange(Rr_g), rank, world, uneven)
     _local_backward(O, render(feat_e[:, pix_e]), render(feat_e[:, pix_e] * 0.9), acc[pix_e], render(feat_r[:, pix_r]),
                     render(feat_r[:, pix_r] * 1.1), tgt[pix_r], C, dataset, thr, P, Re_g, Rr_g,
                     lambda s: dist.allreduce_sum_(s, world))
@@ -120,13 +124,15 @@ def test_sharded_gradient_equals_single_rank(thr):
 def test_uneven_shards_equal_single_rank():
     """A global batch the ranks cannot split evenly (11 blur pixels, 16 event pixels over 8 and over 3 ranks; C4 strong-scaled:
     215 blur pixels over 8 GPUs): the left-over pixels go one each to the low ranks (dist.shard_bounds(uneven=True)), the loss
-    means use the global counts, and the summed gradient equals the single process's."""
+    means use the global counts, and the summed gradient equals the single process's.  World 8 runs the ray-balanced table of
+    TrainStep(uneven_shards=True) (dist.balanced_shard_bounds: ranks with a blur pixel more take fewer event pixels), world 3 the
+    plain per-vector split."""
     ctx = mp.get_context("spawn")
     out = {}
     for world in (1, 3, 8):
         q = ctx.Queue()
         port = 29900 + world * 5 + (os.getpid() % 90)
-        procs = [ctx.Process(target=_worker, args=(r, world, port, -1.0, q, 11, True)) for r in range(world)]
+        procs = [ctx.Process(target=_worker, args=(r, world, port, -1.0, q, 11, True, world == 8)) for r in range(world)]
         for p in procs:
             p.start()
         out[world] = q.get(timeout=240)
@@ -149,6 +155,19 @@ def test_shard_indices():
     parts = [dist.shard_indices(torch.arange(215), r, 8, uneven=True) for r in range(8)]
     assert torch.equal(torch.cat(parts), torch.arange(215)) and [len(p_) for p_ in parts] == [27] * 7 + [26]
     assert dist.shard_bounds(5, 7, 8, uneven=True) == (5, 5)
+    # ray-balanced table (TrainStep(uneven_shards=True)): contiguous, complete, blur pixels as above, every rank within one event
+    # pixel's rays of the mean - C2 / C4 / C5 over 8 ranks stay inside whole rounds of 128-point tiles (<= 512 / 1024 rays)
+    for ne, nr, pe, pn, cap in ((1024, 107, 2, 19, 512), (2048, 215, 2, 19, 1024), (2048, 132, 2, 31, 1024), (16, 11, 2, 5, None), (31, 5, 2, 5, None)):
+        for world in (2, 3, 8):
+            tab = dist.balanced_shard_bounds(ne, nr, pe, pn, world)
+            assert tab[0][0][0] == 0 and tab[0][1][0] == 0 and tab[-1][0][1] == ne and tab[-1][1][1] == nr
+            assert all(tab[k][0][1] == tab[k + 1][0][0] and tab[k][1][1] == tab[k + 1][1][0] for k in range(world - 1))
+            assert [r1 - r0 for _, (r0, r1) in tab] == [dist.shard_bounds(nr, k, world, uneven=True)[1] - dist.shard_bounds(nr, k, world, uneven=True)[0]
+                                                        for k in range(world)]
+            rays = [pe * (e1 - e0) + pn * (r1 - r0) for (e0, e1), (r0, r1) in tab]
+            assert max(rays) - min(rays) <= pe + 1 or min(e1 - e0 for (e0, e1), _ in tab) == 0, (ne, nr, world, rays)
+            if cap is not None and world == 8:
+                assert max(rays) <= cap, rays
 
 
 def test_async_allreduce_and_broadcast_single_process():

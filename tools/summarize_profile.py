@@ -28,6 +28,7 @@ PARTS = [
     ("mlp_dw_f16_small_kernel", "mlp_bwd_dw", "small"),
     ("mlp_dw_kernel", "mlp_bwd_dw", "dw"),
     ("dw_reduce_kernel", "mlp_bwd_dw", "reduce"),
+    ("dw_compose_kernel", "mlp_bwd_dw", "compose"),      # round 5: feature / views weight gradients composed from G = dhv^T h7
 ]
 
 
