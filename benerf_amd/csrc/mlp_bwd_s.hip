@@ -169,9 +169,11 @@ __device__ __forceinline__ void gemm3_head(const float* __restrict__ wp, int ct,
 // acc[rt] += (Th + Tl)[rt*32.., 0 .. KS*16) x (W_hi + W_lo)(tile ct) without the lo x lo term, rt = 0..3.  Per k-step: the four
 // hi x hi MFMAs, the four hi x lo, the four lo x hi - the three MFMAs on one accumulator are four issue slots apart.  Weight
 // fragments PF k-steps ahead, ONE set of activation fragments, each reloaded right behind its last MFMA of the k-step.
-template <int KS, int PF>
+struct NoKstepHook { __device__ __forceinline__ void operator()(int) const {} };
+// hook(ks): caller's work placed in k-step ks's scheduling region, behind its MFMAs' operands (the previous stage's deferred units)
+template <int KS, int PF, class HK = NoKstepHook>
 __device__ __forceinline__ void gemm3_body(const _Float16* __restrict__ Th, const _Float16* __restrict__ Tl, const float* __restrict__ wp,
-                                           int ct, int lane, WRing<PF>& r, f32x16 (&acc)[4], const LaneAddr& la) {
+                                           int ct, int lane, WRing<PF>& r, f32x16 (&acc)[4], const LaneAddr& la, HK hook = HK()) {
     lane = stage_local(lane);
     const WFrag wf(wp, lane);
     const int ctu = __builtin_amdgcn_readfirstlane(ct);
@@ -217,6 +219,7 @@ __device__ __forceinline__ void gemm3_body(const _Float16* __restrict__ Th, cons
         }
         const half8 bh = __builtin_bit_cast(half8, r.q[ks % (PF + 1)][0]);
         const half8 bl = __builtin_bit_cast(half8, r.q[ks % (PF + 1)][1]);
+        hook(ks);
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) acc[rt] = mfma16(ah[rt], bh, acc[rt]);
 #pragma unroll
@@ -329,6 +332,59 @@ __device__ __forceinline__ void amax3(float& amax, float v0, float v1) {
     asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(amax) : "v"(v0), "v"(v1));
 }
 
+// The STORE half of an epilogue - lane exchange, rescale, residual codes, two stores per unit: ~34 of a unit's instructions, 40 % of the
+// epilogue's VALU work - needs nothing but the packed (hi, lo) quads.  For the row tiles an epilogue finishes LAST (2 and 3) those quads
+// wait in registers (32: the dX kernel has them to spare, the forward does not) and the units are formed in the NEXT stage's K-loop, one
+// per k-step behind its last weight-fragment request, in the shadow of its MFMAs (the VALU is idle there; BWS_DEFER).
+struct DeferUnits {
+    uint2 qh[2][2][2], ql[2][2][2];     // [row tile - 2][ep][h]
+};
+#ifndef BWS_DEFER
+#define BWS_DEFER 1
+#endif
+__device__ __forceinline__ void store_unit(u32x4 hi, uint2 code, __amdgpu_buffer_rsrc_t rs_hi, __amdgpu_buffer_rsrc_t rs_lo, int st_lane, int rt, int ep) {
+#ifndef BWS_SKIP_STORE      // timing variants only (tools/experiments/build_variant.sh)
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    __builtin_amdgcn_raw_buffer_store_b128(hi, rs_hi, st_lane + (rt * 4 + ep * 2) * 256 * 8 * 2, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2{code.x, code.y}, rs_lo, st_lane / 2 + (rt * 4 + ep * 2) * 256 * 8, 0, 0);
+#endif
+}
+// the VALU half of a deferred unit: quads -> rescaled hi halves + residual codes
+__device__ __forceinline__ void form_unit(const uint2 (&qh)[2], const uint2 (&ql)[2], float gf, u32x4& hi, uint2& code) {
+    const _Float16 gh = (_Float16)gf, gl = (_Float16)(gf * 4096.f);
+    const half2v g2 = {gh, gh}, g2l = {gl, gl};
+    const uint4 uh = sh_pair_unit(qh[0], qh[1]);
+    const uint4 ul = sh_pair_unit(ql[0], ql[1]);
+    const uint32_t uhw[4] = {uh.x, uh.y, uh.z, uh.w}, ulw[4] = {ul.x, ul.y, ul.z, ul.w};
+    uint32_t oh[4], ol[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        oh[i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2v, uhw[i]) * g2);
+        ol[i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2v, ulw[i]) * g2l);
+    }
+    code = h8_encode_unit<12>(oh, ol);
+    hi = u32x4{oh[0], oh[1], oh[2], oh[3]};
+}
+// one unit (row tile rt, block pair ep) of a 256-wide SH gradient array from its two quads: see epilogue3
+__device__ __forceinline__ void finish_unit(const uint2 (&qh)[2], const uint2 (&ql)[2], __amdgpu_buffer_rsrc_t rs_hi, __amdgpu_buffer_rsrc_t rs_lo,
+                                            int st_lane, int rt, int ep, float gf) {
+    const _Float16 gh = (_Float16)gf, gl = (_Float16)(gf * 4096.f);
+    const half2v g2 = {gh, gh}, g2l = {gl, gl};
+    const uint4 uh = sh_pair_unit(qh[0], qh[1]);
+    const uint4 ul = sh_pair_unit(ql[0], ql[1]);
+    const uint32_t uhw[4] = {uh.x, uh.y, uh.z, uh.w}, ulw[4] = {ul.x, ul.y, ul.z, ul.w};
+    uint32_t oh[4], ol[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        oh[i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2v, uhw[i]) * g2);
+        ol[i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(half2v, ulw[i]) * g2l);
+    }
+    const uint2 code = h8_encode_unit<12>(oh, ol);
+    store_unit(u32x4{oh[0], oh[1], oh[2], oh[3]}, code, rs_hi, rs_lo, st_lane, rt, ep);
+}
+// byte offset of this lane's unit (block lane >> 5 of a pair, feature n) in the tile's part of a 256-wide SH array
+__device__ __forceinline__ int unit_lane_offset(int ct, int lane) { return (((lane >> 5) * 256 + ct * 32 + (lane & 31)) * 8) * 2; }
+
 // dY = acc masked by the forward pass' ReLU sign bits (bits[rt]: the 32 points of row tile rt for THIS lane's feature, shifted
 // right by 4 (lane >> 5): bit 8 (e >> 2) + (e & 3) <-> accumulator element e; mlp_split.h: sp_mask_word) -> both planes (hi, lo;
 // tile scale) and, rescaled by gf = s_call / s_tile (a power of two <= 1; exact), the SH gradient arrays `st_hi` / `st_lo` of
@@ -336,10 +392,11 @@ __device__ __forceinline__ void amax3(float& amax, float v0, float v1) {
 // STORE = false: planes only (d feature: the dW kernels do not need it, mlp_common.h: DWS_*)
 // NRT row tiles starting at row tile rt0 (wave-uniform; P1: the views layer's 128-wide stage runs as column tile w & 3 x point half
 // w >> 2), W: width of the SH arrays `st_hi` / `st_lo` (their tile part: block 0 = the tile's first 8 points).
-template <bool MASK, bool STORE = true, int NRT = 4, int W = 256, bool USE_LA = false>
+template <bool MASK, bool STORE = true, int NRT = 4, int W = 256, bool USE_LA = false, bool DEFER = false>
 __device__ __forceinline__ void epilogue3(f32x16 (&acc)[NRT], const uint32_t (&bits)[NRT], _Float16* __restrict__ Th, _Float16* __restrict__ Tl,
                                           int ct, int lane, const _Float16* __restrict__ st_hi, const uint8_t* __restrict__ st_lo, float gf,
-                                          float& amax, int rt0, const LaneAddr& la) {
+                                          float& amax, int rt0, const LaneAddr& la, DeferUnits* du = nullptr) {
+    static_assert(!DEFER || (NRT == 4 && W == 256 && STORE), "deferred units: the 256-wide stages");
     lane = stage_local(lane);
     const int lr = lane & 31, r4 = 4 * (lane >> 5);
     const __amdgpu_buffer_rsrc_t rs_hi = uniform_rsrc(st_hi);         // this tile's 16 blocks of the SH arrays (64 KiB each)
@@ -403,6 +460,14 @@ __device__ __forceinline__ void epilogue3(f32x16 (&acc)[NRT], const uint32_t (&b
                 ql[h] = uint2{wl[0], wl[1]};
             }
             if (!STORE) continue;
+            if (DEFER && rt >= 2) {     // the quads wait for the next K-loop (DeferUnits)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    du->qh[rt - 2][ep][h] = qh[h];
+                    du->ql[rt - 2][ep][h] = ql[h];
+                }
+                continue;
+            }
             // lanes exchange halves, then the exact rescale (v_pk_mul_f16 by a power of two) and the residual codes
             const uint4 uh = sh_pair_unit(qh[0], qh[1]);
             const uint4 ul = sh_pair_unit(ql[0], ql[1]);
@@ -634,14 +699,38 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
     load_bits(6, bits_n);
     gemm3_head<16, BWS_PF>(packed_h + pack_offset(PB_L7), ct, lane, ring);
     shift_bits(bits);
-    epilogue3<true, true, 4, 256, true>(acc, bits, Th, Tl, ct, lane, st_tile(7), st8_tile(7), gf, amax, 0, la);
+    DeferUnits du;
+    epilogue3<true, true, 4, 256, true, BWS_DEFER != 0>(acc, bits, Th, Tl, ct, lane, st_tile(7), st8_tile(7), gf, amax, 0, la, &du);
     lds_barrier();
     TR(4);
 
     // ---- P4: L7 .. L1: dY_l x W_l, mask h_{l-1} -> dY_{l-1} ----------------------------------------------
     auto layer = [&](int l) __attribute__((always_inline)) {
         zero4(acc);
-        gemm3_body<16, BWS_PF>(Th, Tl, packed_h + bwd_layer_offset(l), ct, lane, ring, acc, la);
+        // dY_l's deferred units (row tiles 2, 3) are formed and stored in k-steps 12..15 of this K-loop: behind its last fragment
+        // request (k-step 12 = 16 - 1 - PF), so that no fragment waits for a store (vector-memory operations retire in order)
+        const __amdgpu_buffer_rsrc_t drs_hi = uniform_rsrc(st_tile(l)), drs_lo = uniform_rsrc(st8_tile(l));
+#if BWS_DEFER == 2      // VALU half early (k-steps 2, 5, 8, 11), stores in k-steps 12..15
+        u32x4 ph[4];
+        uint2 pc[4];
+        gemm3_body<16, BWS_PF>(Th, Tl, packed_h + bwd_layer_offset(l), ct, lane, ring, acc, la, [&](int ks) {
+            if (ks < 12 && ks % 3 == 2) {
+                const int u = ks / 3;
+                form_unit(du.qh[u >> 1][u & 1], du.ql[u >> 1][u & 1], gf, ph[u], pc[u]);
+            }
+            if (ks >= 12) {
+                const int u = ks - 12;
+                store_unit(ph[u], pc[u], drs_hi, drs_lo, unit_lane_offset(ct, stage_local(lane)), 2 + (u >> 1), u & 1);
+            }
+        });
+#else
+        gemm3_body<16, BWS_PF>(Th, Tl, packed_h + bwd_layer_offset(l), ct, lane, ring, acc, la, [&](int ks) {
+            if (BWS_DEFER && ks >= 12) {
+                const int u = ks - 12;
+                finish_unit(du.qh[u >> 1][u & 1], du.ql[u >> 1][u & 1], drs_hi, drs_lo, unit_lane_offset(ct, stage_local(lane)), 2 + (u >> 1), u & 1, gf);
+            }
+        });
+#endif
         lds_barrier();
         TR(5 + 2 * (7 - l));
 #pragma unroll
@@ -651,7 +740,7 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
             load_bits(l - 2, bits_n);
             gemm3_head<16, BWS_PF>(packed_h + bwd_layer_offset(l - 1), ct, lane, ring);
         }
-        epilogue3<true, true, 4, 256, true>(acc, bits, Th, Tl, ct, lane, st_tile(l - 1), st8_tile(l - 1), gf, amax, 0, la);
+        epilogue3<true, true, 4, 256, true, BWS_DEFER != 0>(acc, bits, Th, Tl, ct, lane, st_tile(l - 1), st8_tile(l - 1), gf, amax, 0, la, &du);
         lds_barrier();
         TR(6 + 2 * (7 - l));
     };
@@ -678,6 +767,12 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
     }
 #pragma unroll 1
     for (int l = 5; l >= 1; --l) layer(l);
+    if (BWS_DEFER) {     // dY0's deferred units: no K-loop of this shape follows
+        const __amdgpu_buffer_rsrc_t drs_hi = uniform_rsrc(st_tile(0)), drs_lo = uniform_rsrc(st8_tile(0));
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            finish_unit(du.qh[u >> 1][u & 1], du.ql[u >> 1][u & 1], drs_hi, drs_lo, unit_lane_offset(ct, stage_local(lane)), 2 + (u >> 1), u & 1, gf);
+    }
 
     if (a.status) {   // range guard of the f16 gradient halves: one atomic per wave, only near f16's maximum
         const float wmax = wave_max_nonneg(amax);
