@@ -350,7 +350,11 @@ __device__ __forceinline__ int layer_inst(int l) {   // instance holding the bia
 //   blocks [64, 96):  dW_v[n][j<256]  = sum_k G[n][k] W_f[j][k] + (sum dhv)[n] b_f[j]    (128 x 256, K = 256)
 //   block 96:         db_f[n] = sum_i W_v[i][n] (sum dhv)[i];   db_v[n] = (sum dhv)[n]
 __global__ __launch_bounds__(256) void dw_compose_kernel(ReduceArgs a) {
-    __shared__ float As[32][33], Bs[32][33];
+    // Round 5 (end): the whole contraction range of a tile goes into LDS in ONE load phase (every global load of the block in flight
+    // at once) instead of 4 / 8 chunks of 32 with two barriers each - the kernel was a chain of global-load latencies (26 us for
+    // 25 MFLOP).  Same products, same summation order (k ascending): bit-identical results.  Tiles [32][K] / [K][32] f32, K <= 256:
+    // 64 KiB; the operand stored transposed (lanes along k) is XOR-swizzled by k & 31 inside its 32-wide rows.
+    __shared__ float As[32 * 256], Bs[256 * 32];
     const float* G = a.gbuf;
     const float* bs = a.gbuf + 128 * 256;
     const int t = threadIdx.x, tx = t & 31, ty = t >> 5;
@@ -369,27 +373,39 @@ __global__ __launch_bounds__(256) void dw_compose_kernel(ReduceArgs a) {
     const bool feat = b < 64;
     const int bb = feat ? b : b - 64;
     const int m0 = (bb >> 3) * 32, n0 = (bb & 7) * 32, K = feat ? 128 : 256;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    // A tile as [m][k] (row stride K), B tile as [k][n] (row stride 32)
     for (int k0 = 0; k0 < K; k0 += 32) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int q = ty + 8 * r;
-            if (feat) {     // A[m][k] = W_v[k][m] (m contiguous), B[k][n] = G[k][n] (n contiguous)
-                As[tx][q] = a.w_views[(k0 + q) * 283 + m0 + tx];
-                Bs[q][tx] = G[(k0 + q) * 256 + n0 + tx];
-            } else {        // A[m][k] = G[m][k] (k contiguous), B[k][n] = W_f[n][k] (k contiguous)
-                As[q][tx] = G[(m0 + q) * 256 + k0 + tx];
-                Bs[tx][q] = a.w_feat[(n0 + q) * 256 + k0 + tx];
+            if (feat) {     // A[m][k] = W_v[k][m] (lanes along m: transposed store, swizzled by m = tx), B[k][n] = G[k][n]
+                As[tx * K + ((k0 + q) ^ tx)] = a.w_views[(k0 + q) * 283 + m0 + tx];
+                Bs[(k0 + q) * 32 + tx] = G[(k0 + q) * 256 + n0 + tx];
+            } else {        // A[m][k] = G[m][k], B[k][n] = W_f[n][k] (lanes along k: transposed store, swizzled by k & 31 = tx)
+                As[q * K + k0 + tx] = G[(m0 + q) * 256 + k0 + tx];
+                Bs[(k0 + tx) * 32 + (q ^ tx)] = a.w_feat[(n0 + q) * 256 + k0 + tx];
             }
         }
-        __syncthreads();
+    }
+    __syncthreads();
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (feat) {
 #pragma unroll 8
-        for (int k = 0; k < 32; ++k) {
-            const float bv = Bs[k][tx];
+        for (int k = 0; k < 128; ++k) {
+            const float bv = Bs[k * 32 + tx];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] = fmaf(As[ty + 8 * r][k], bv, acc[r]);
+            for (int r = 0; r < 4; ++r) {
+                const int m = ty + 8 * r;
+                acc[r] = fmaf(As[m * 128 + (k ^ m)], bv, acc[r]);
+            }
         }
-        __syncthreads();
+    } else {
+#pragma unroll 8
+        for (int k = 0; k < 256; ++k) {
+            const float bv = Bs[k * 32 + (tx ^ (k & 31))];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = fmaf(As[(ty + 8 * r) * 256 + k], bv, acc[r]);
+        }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {

@@ -16,7 +16,11 @@ struct PackArgs {
 // W_c = W_v[:, :256] W_f and b_c = W_v[:, :256] b_f + b_v in float64 (mlp_common.h: PF_VIEWSC) -> f32 [128][283] (the PE(dir)
 // columns copied) + [128] behind the packed sections.  32 x 32 output tiles through LDS; blocks [0, 32): W_c, block 32: the rest.
 __device__ __forceinline__ void fuse_body(const PackArgs& a) {
-    __shared__ double As[32][33], Bs[32][33];
+    // One load phase for the whole contraction range (every global load of the block in flight at once; the operands are f32, so
+    // the tiles [32][256] / [256][32] are 64 KiB of LDS as floats) instead of 8 chunks with two barriers each: the kernel was a chain
+    // of global-load latencies on the step's critical path (between Adam and the re-pack).  Same float64 products, same summation
+    // order (k ascending): bit-identical W_c.
+    __shared__ float As[32 * 256], Bs[256 * 32];
     const float* Wv = a.w[BENERF_L_VIEWS];
     const float* Wf = a.w[BENERF_L_FEAT];
     float* out = a.packed + 2 * PACKED_FLOATS;
@@ -31,21 +35,21 @@ __device__ __forceinline__ void fuse_body(const PackArgs& a) {
         return;
     }
     const int m0 = (b >> 3) * 32, n0 = (b & 7) * 32;      // W_c[m][n] = sum_k W_v[m][k] W_f[k][n]
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
     for (int k0 = 0; k0 < 256; k0 += 32) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int q = ty + 8 * r;
-            As[q][tx] = (double)Wv[(m0 + q) * 283 + k0 + tx];
-            Bs[q][tx] = (double)Wf[(k0 + q) * 256 + n0 + tx];
+            As[q * 256 + k0 + tx] = Wv[(m0 + q) * 283 + k0 + tx];
+            Bs[(k0 + q) * 32 + tx] = Wf[(k0 + q) * 256 + n0 + tx];
         }
-        __syncthreads();
-        for (int k = 0; k < 32; ++k) {
-            const double bv = Bs[k][tx];
+    }
+    __syncthreads();
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 8
+    for (int k = 0; k < 256; ++k) {
+        const double bv = (double)Bs[k * 32 + tx];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] += As[ty + 8 * r][k] * bv;
-        }
-        __syncthreads();
+        for (int r = 0; r < 4; ++r) acc[r] += (double)As[(ty + 8 * r) * 256 + k] * bv;
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) out[(m0 + ty + 8 * r) * 283 + n0 + tx] = (float)acc[r];
