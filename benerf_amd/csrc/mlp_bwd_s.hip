@@ -66,14 +66,24 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 // row is XORed with feature & 3, the 16-byte slot (8 points) inside it with (feature >> 2) & 3 - the four feature rows of a
 // transpose read land in four different bank quarters, eight consecutive features of a quad write in eight different slots.
 constexpr int PROW = 128;                                               // halfs per feature row
-// Round 5: the two 8-byte halves of a slot are swapped for features with bit 4 set - the epilogue's quad writes of lanes n and
-// n + 16 (same segment, same slot, same half before) no longer collide (57-61 M SQ_LDS_BANK_CONFLICT cycles per 522 k-point launch);
-// a k-step's 16 feature rows share bit 4, so the transpose reads see the same relative pattern as before.
+// Round 5: the two 8-byte halves of a slot are swapped for features with bit BWS_HALF_BIT set (below); the transpose reads of a
+// 16-lane group fetch whole 32-byte runs of four feature rows in four different 64-byte segments, so they do not care which half is which.
+// Which feature bit swaps the two 8-byte halves of a slot.  Bit 4 (round 5's first version) separated lanes n and n + 16 of an epilogue
+// quad write: 57 M -> 41-43 M conflict cycles per 522 k-point launch.  What the counter then still showed was attributed with
+// early-return builds (-DBWS_STOP_AFTER): 31 of the 41 M sit in the seven layer stages = the epilogue's 256 ds_write_b64 per layer and tile,
+// each two-way conflicted.  An 8-byte write of a wave goes out 16 lanes per cycle over 128 bytes of banks; a feature row is 256 bytes, so
+// its 64-byte segments s and s ^ 2 share banks, and among lanes 0..15 the segment (rt ^ (n & 3)) takes both - unless the half follows
+// bit 1 of the feature: then (segment & 1, half) is a bijection on n & 3 and the sixteen lanes cover sixteen different 8-byte bank pairs.
+// Bit 1: 41.0 M -> 5.5 M conflict cycles per launch (profiles/r05_dx_lds_conflicts.log); time-neutral (LDS conflicts were never what
+// bounds the epilogue), and the A-fragment offsets no longer depend on the k-step's parity.
+#ifndef BWS_HALF_BIT
+#define BWS_HALF_BIT 1
+#endif
 __device__ __forceinline__ int fidx(int f, int p) {
 #ifdef BWS_OLD_SWIZZLE
     return f * PROW + ((((p >> 5) ^ (f & 3)) << 5) | ((((p >> 3) & 3) ^ ((f >> 2) & 3)) << 3) | (p & 7));
 #else
-    return f * PROW + ((((p >> 5) ^ (f & 3)) << 5) | ((((p >> 3) & 3) ^ ((f >> 2) & 3)) << 3) | ((p & 7) ^ (((f >> 4) & 1) << 2)));
+    return f * PROW + ((((p >> 5) ^ (f & 3)) << 5) | ((((p >> 3) & 3) ^ ((f >> 2) & 3)) << 3) | ((p & 7) ^ (((f >> BWS_HALF_BIT) & 1) << 2)));
 #endif
 }
 // f32 scratch float i (0..31) of point `row`: the feature rows [256,320) of the hi plane (never a GEMM operand here) as 4096
@@ -196,7 +206,7 @@ __device__ __forceinline__ void gemm3_body(const _Float16* __restrict__ Th, cons
 #ifdef BWS_OLD_SWIZZLE
             ao[1][j][rt] = ao[0][j][rt];
 #else
-            ao[1][j][rt] = ao[0][j][rt] ^ 4;
+            ao[1][j][rt] = BWS_HALF_BIT == 4 ? ao[0][j][rt] ^ 4 : ao[0][j][rt];      // bit 4 = the k-step's parity; lower bits do not change with the k-step
 #endif
 #pragma unroll
             for (int par = 0; par < 2; ++par) {
@@ -256,7 +266,7 @@ __device__ __forceinline__ void gemm_row3(const _Float16* __restrict__ Th, const
 #ifdef BWS_OLD_SWIZZLE
     constexpr int ODD = 0;
 #else
-    constexpr int ODD = 4;      // fidx: odd k-steps (features with bit 4 set) have the halves of a slot swapped
+    constexpr int ODD = BWS_HALF_BIT == 4 ? 4 : 0;      // fidx: odd k-steps (features with bit 4 set) have the halves of a slot swapped
 #endif
     const WFrag wf(wp, lane);
     const int tu = __builtin_amdgcn_readfirstlane(tile);
@@ -411,7 +421,7 @@ __device__ __forceinline__ void epilogue3(f32x16 (&acc)[NRT], const uint32_t (&b
 #ifdef BWS_OLD_SWIZZLE
     const int tq = n * PROW + r4;
 #else
-    const int tq = n * PROW + (r4 ^ (((n >> 4) & 1) << 2));      // fidx: the slot's halves swapped for features with bit 4 set
+    const int tq = n * PROW + (r4 ^ (((n >> BWS_HALF_BIT) & 1) << 2));      // fidx: the slot's halves swapped for features with that bit set
 #endif
     const int sw_seg = n & 3, sw_slot = (n >> 2) & 3;
     const int st_lane = ((((lane >> 5) + rt0 * 4) * W + n) * 8) * 2;   // byte offset of unit (block, n); lanes 32-63: the odd block of a pair
@@ -628,7 +638,7 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
 #ifdef BWS_OLD_SWIZZLE
         const int tq = n * PROW + r4;
 #else
-        const int tq = n * PROW + (r4 ^ (((n >> 4) & 1) << 2));
+        const int tq = n * PROW + (r4 ^ (((n >> BWS_HALF_BIT) & 1) << 2));
 #endif
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -703,6 +713,9 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
     epilogue3<true, true, 4, 256, true, BWS_DEFER != 0>(acc, bits, Th, Tl, ct, lane, st_tile(7), st8_tile(7), gf, amax, 0, la, &du);
     lds_barrier();
     TR(4);
+#if defined(BWS_STOP_AFTER) && BWS_STOP_AFTER == 2     /* attribution of counters to phases (wrong results): stop behind P2 */
+    return;
+#endif
 
     // ---- P4: L7 .. L1: dY_l x W_l, mask h_{l-1} -> dY_{l-1} ----------------------------------------------
     auto layer = [&](int l) __attribute__((always_inline)) {
@@ -767,6 +780,9 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
     }
 #pragma unroll 1
     for (int l = 5; l >= 1; --l) layer(l);
+#if defined(BWS_STOP_AFTER) && BWS_STOP_AFTER == 4     /* ... behind the layer loops */
+    return;
+#endif
     if (BWS_DEFER) {     // dY0's deferred units: no K-loop of this shape follows
         const __amdgpu_buffer_rsrc_t drs_hi = uniform_rsrc(st_tile(0)), drs_lo = uniform_rsrc(st8_tile(0));
 #pragma unroll
