@@ -22,6 +22,12 @@
 // The planes' PE feature rows [256,320) are never a GEMM operand here: f32 scratch (hi plane: dPE(dir) at floats [0,27) of a
 // point, the tile's maximum at [26] of points 0 / 1 during P0; lo plane: the scaled d_raw, channel-major - draw_cm), later the layer-5 skip's dPE block as hi + lo.
 #include "mlp_split.h"
+// Cache policy of the dY stores (aux of raw_buffer_store: 0 default, 2 = nt): written once, read by the dW launch after this one - nt keeps
+// them from evicting the weight fragments out of L2 (mlp_fwd_h.hip: FWD_ST_AUX; profiles/r05_cache_policy_ab.log).  The forward's sign-bit
+// words are read once, too: nt loads.
+#ifndef BWS_ST_AUX
+#define BWS_ST_AUX 2
+#endif
 
 // -DBENERF_TRACE_DX: thread 0 of the first 2048 workgroups stamps the 100 MHz wall clock at the phase boundaries into the d_viewdirs
 // output (which is then not written) - tools/experiments/trace_phases.py prints the per-phase durations behind DESIGN.md 4.
@@ -355,8 +361,8 @@ struct DeferUnits {
 __device__ __forceinline__ void store_unit(u32x4 hi, uint2 code, __amdgpu_buffer_rsrc_t rs_hi, __amdgpu_buffer_rsrc_t rs_lo, int st_lane, int rt, int ep) {
 #ifndef BWS_SKIP_STORE      // timing variants only (tools/experiments/build_variant.sh)
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-    __builtin_amdgcn_raw_buffer_store_b128(hi, rs_hi, st_lane + (rt * 4 + ep * 2) * 256 * 8 * 2, 0, 0);
-    __builtin_amdgcn_raw_buffer_store_b64(u32x2{code.x, code.y}, rs_lo, st_lane / 2 + (rt * 4 + ep * 2) * 256 * 8, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(hi, rs_hi, st_lane + (rt * 4 + ep * 2) * 256 * 8 * 2, 0, BWS_ST_AUX);
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2{code.x, code.y}, rs_lo, st_lane / 2 + (rt * 4 + ep * 2) * 256 * 8, 0, BWS_ST_AUX);
 #endif
 }
 // the VALU half of a deferred unit: quads -> rescaled hi halves + residual codes
@@ -492,8 +498,8 @@ __device__ __forceinline__ void epilogue3(f32x16 (&acc)[NRT], const uint32_t (&b
             // vector offset + zero scalar offset (mlp_bwd_h.hip: the scalar-offset form of a 16-byte store reads its data late)
 #ifndef BWS_SKIP_STORE      // timing variants only (tools/experiments/build_variant.sh)
             typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{oh[0], oh[1], oh[2], oh[3]}, rs_hi, st_lane + (rt * 4 + ep * 2) * W * 8 * 2, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b64(u32x2{code.x, code.y}, rs_lo, st_lane / 2 + (rt * 4 + ep * 2) * W * 8, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{oh[0], oh[1], oh[2], oh[3]}, rs_hi, st_lane + (rt * 4 + ep * 2) * W * 8 * 2, 0, BWS_ST_AUX);
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{code.x, code.y}, rs_lo, st_lane / 2 + (rt * 4 + ep * 2) * W * 8, 0, BWS_ST_AUX);
 #endif
         }
 }
@@ -526,7 +532,7 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
         const int so = __builtin_amdgcn_readfirstlane(layer * mask_stride_b);
         const int vo = (wave * 32 + sp_mask_word(lane & 31)) * 4;
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) b[rt] = __builtin_amdgcn_raw_buffer_load_b32(mask_rsrc, vo + rt * 8 * 32 * 4, so, 0);
+        for (int rt = 0; rt < 4; ++rt) b[rt] = __builtin_amdgcn_raw_buffer_load_b32(mask_rsrc, vo + rt * 8 * 32 * 4, so, BWS_ST_AUX);
     };
     auto shift_bits = [&](uint32_t (&b)[4]) {      // at the point of use: the loads are requested a stage ahead
         const int sh = 4 * (lane >> 5);

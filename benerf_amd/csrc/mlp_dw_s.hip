@@ -73,9 +73,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t dw_rsrc(const void* p) {
                          (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)wa);
     return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(wau), 0, 0x7fffffff, 0x00020000);
 }
+// cache policy of the operand loads: every byte of the saved activations / gradients is read by exactly ONE workgroup, once (aux 2 = nt on
+// gfx950; measured: see DWS_NT in profiles/r05_dw_nt_loads_ab.log)
+#ifndef DWS_NT
+#define DWS_NT 2
+#endif
 __device__ __forceinline__ uint2 dw_load_b64(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, DWS_NT);
     return uint2{v[0], v[1]};
 }
 
@@ -142,10 +147,10 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int64_t 
         const int cc = (int)((CHUNK) < chunk_end ? (CHUNK) : chunk_end - 1);                              \
         _Pragma("unroll") for (int j = 0; j < NY; ++j)                                                    \
             if (YFULL || tid + j * DWT < YU) {                                                            \
-                R.y[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, (tid + j * DWT) * 16, cc * (YU * 16), 0);                       \
+                R.y[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, (tid + j * DWT) * 16, cc * (YU * 16), DWS_NT);                  \
                 R.y8[j] = DWS_CODE_LOAD(dw_load_b64(rs_y8, (tid + j * DWT) * 8, cc * (YU * 8)));          \
             }                                                                                             \
-        R.x[0] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, tid * 16, cc * (XU * 16), 0);                \
+        R.x[0] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, tid * 16, cc * (XU * 16), DWS_NT);           \
         R.x8[0] = DWS_CODE_LOAD(dw_load_b64(rs_x8, tid * 8, cc * (XU * 8)));                              \
         if (ALPHA) {                                                                                      \
             const int64_t row = (int64_t)cc * CHP + (tid & (CHP - 1));                                    \
@@ -372,8 +377,17 @@ __device__ __forceinline__ void dw_rgb(const DwArgs& a, int64_t blk_begin, int64
             hh[i] = u32x4{0u, 0u, 0u, 0u};
             h8c[i] = uint2{0x80808080u, 0x80808080u};
             if (mb < blk_end) {
+#if DWS_NT
+                hh[i] = __builtin_nontemporal_load(&hv[mb * ACT_HV_W + j]);     // 8 points of column j
+                {
+                    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                    const u32x2 c2 = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(&hv8[mb * ACT_HV_W + j]));
+                    h8c[i] = uint2{c2[0], c2[1]};
+                }
+#else
                 hh[i] = hv[mb * ACT_HV_W + j];     // 8 points of column j
                 h8c[i] = hv8[mb * ACT_HV_W + j];
+#endif
             }
         }
 #pragma unroll
@@ -525,8 +539,17 @@ __device__ __forceinline__ void thin_stream(const u32x4* const (&yh)[NYA], const
         const int64_t kk = k < ke ? k : ke - 1;
 #pragma unroll
         for (int i = 0; i < NYA; ++i) {
+#if DWS_NT
+            R.y[i] = __builtin_nontemporal_load(&yh[i][kk * (2 * YW) + yo]);
+            {
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                const u32x2 c2 = __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(&y8[i][kk * (2 * YW) + yo]));
+                R.yc[i] = uint2{c2[0], c2[1]};
+            }
+#else
             R.y[i] = yh[i][kk * (2 * YW) + yo];
             R.yc[i] = y8[i][kk * (2 * YW) + yo];
+#endif
         }
 #pragma unroll
         for (int c = 0; c < TC; ++c) {

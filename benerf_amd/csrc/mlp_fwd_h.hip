@@ -16,6 +16,13 @@
 // arrays as SH arrays from the finished planes); BENERF_MLP_SPLIT_F16BWD (SAVE == 1) - the hi halves as SH arrays (mlp_split.h).
 #define BENERF_HSW_V2      // this kernel's planes use the round-5 slot swizzle (mlp_split.h: hsw)
 #include "mlp_split.h"
+// Cache policy of the saved-operand stores (aux of raw_buffer_store on gfx950: 0 default, 1 = sc0, 2 = nt, 16 = sc1).  The activations are
+// written once and read ~2 ms later by another kernel - 2.8 GB per 522 k-point launch streaming through the 4 MiB L2 of an XCD, where the
+// weight fragments every K-loop re-reads (2.3 MB per network) live.  nt: C2 step 7.96-7.99 -> 7.66-7.72 ms with the dX kernel's stores
+// and the dW kernels' loads (forward 1.28 -> 1.22 ms in the step; sc0 7.88, sc1 8.00, sc1 + nt = nt: profiles/r05_cache_policy_ab.log).
+#ifndef FWD_ST_AUX
+#define FWD_ST_AUX 2
+#endif
 
 // -DBENERF_TRACE_FWD: thread 0 of the first 2048 workgroups stamps the 100 MHz wall clock at the phase boundaries into the `raw`
 // output (which is then not written) - tools/experiments/trace_phases.py prints the per-phase durations behind DESIGN.md 4.
@@ -172,9 +179,9 @@ __device__ __forceinline__ void epilogue_t(f32x16 (&acc1)[NR][NCT], f32x16 (&acc
                     const uint32_t uh4[4] = {uh.x, uh.y, uh.z, uh.w}, ul4[4] = {ul.x, ul.y, ul.z, ul.w};
                     const uint2 code = h8_encode_unit<11>(uh4, ul4);
                     // vector offset + immediate, zero scalar offset (mlp_bwd_h.hip: the scalar-offset form of a 16-byte store reads its data late)
-                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{uh.x, uh.y, uh.z, uh.w}, sv->rs, vo + i * 512 + r * 16384, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{uh.x, uh.y, uh.z, uh.w}, sv->rs, vo + i * 512 + r * 16384, 0, FWD_ST_AUX);
 #ifndef FWD_SKIP_LO_STORE    // timing variants only (tools/experiments/build_variant.sh)
-                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{code.x, code.y}, sv->rs8, vo / 2 + i * 256 + r * 8192, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(u32x2{code.x, code.y}, sv->rs8, vo / 2 + i * 256 + r * 8192, 0, FWD_ST_AUX);
 #endif
                 }
             }
@@ -219,7 +226,7 @@ __device__ __forceinline__ void save_pair(const _Float16* __restrict__ Th, int c
         if (MASK) bits |= (uint64_t)nonzero4(q[k]) << (b * 4);        // post-ReLU: > 0 <=> != 0
     }
     const uint4 u = sh_pair_unit(q[0], q[1]);
-    __builtin_amdgcn_raw_buffer_store_b128(u32x4{u.x, u.y, u.z, u.w}, rs, (((2 * bp + hf) * W + n) * 8) * 2, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{u.x, u.y, u.z, u.w}, rs, (((2 * bp + hf) * W + n) * 8) * 2, 0, FWD_ST_AUX);
 }
 
 template <int NCT, int W, bool MASK, int NBLK>
@@ -247,7 +254,7 @@ __device__ __forceinline__ uint64_t save_tile(const _Float16* __restrict__ Th, i
             }
             const uint4 u = sh_pair_unit(q[0], q[1]);           // lanes 0-31: block 2bp, lanes 32-63: block 2bp + 1
             // vector offset, zero scalar offset (mlp_bwd_h.hip: the scalar-offset form reads its data late)
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4{u.x, u.y, u.z, u.w}, rs, (((2 * bp + hf) * W + n) * 8) * 2, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{u.x, u.y, u.z, u.w}, rs, (((2 * bp + hf) * W + n) * 8) * 2, 0, FWD_ST_AUX);
         }
     }
     return bits;
@@ -283,10 +290,10 @@ __device__ __forceinline__ void save_pair22(const _Float16* __restrict__ Th, con
     const uint32_t uh4[4] = {u.x, u.y, u.z, u.w}, ul4[4] = {ul.x, ul.y, ul.z, ul.w};
     const uint2 code = h8_encode_unit<11>(uh4, ul4);
     const int unit = (2 * bp + hf) * W + n;
-    __builtin_amdgcn_raw_buffer_store_b128(u32x4{u.x, u.y, u.z, u.w}, rs, unit * 16, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{u.x, u.y, u.z, u.w}, rs, unit * 16, 0, FWD_ST_AUX);
 #ifndef FWD_SKIP_LO_STORE    // timing variants only (tools/experiments/build_variant.sh)
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-    __builtin_amdgcn_raw_buffer_store_b64(u32x2{code.x, code.y}, rs8, unit * 8, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2{code.x, code.y}, rs8, unit * 8, 0, FWD_ST_AUX);
 #endif
 }
 // a whole tile part (column tile ct, NBLK blocks): hi array at `st_tile` (halfs), codes at `st8_tile` (bytes)
