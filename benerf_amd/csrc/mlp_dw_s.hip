@@ -240,6 +240,13 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int64_t 
                     bxh[c] = xfrag(Xl, wk * TC + c0 + c);
                     bxl[c] = xfrag(Xl + XU, wk * TC + c0 + c);
                 }
+#ifdef DWS_ONE_MFMA      /* timing variant (wrong results): one MFMA per block instead of three - how far from its byte bound is the kernel? */
+#pragma unroll
+                for (int r = 0; r < TR; ++r)
+#pragma unroll
+                    for (int c = 0; c < CG; ++c) acc[r][c0 + c] = mfma16(ayh[r], bxh[c], acc[r][c0 + c]);
+                asm volatile("" :: "v"(bxl[0]), "v"(ayl[0]));
+#else
 #pragma unroll
                 for (int r = 0; r < TR; ++r)
 #pragma unroll
@@ -252,6 +259,7 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int64_t 
                 for (int r = 0; r < TR; ++r)
 #pragma unroll
                     for (int c = 0; c < CG; ++c) acc[r][c0 + c] = mfma16(ayl[r], bxh[c], acc[r][c0 + c]);
+#endif
                 if (ALLMMA && c0 == 0) stage_y(Rn, bn, vn);
                 if (ALLMMA && c0 + CG >= TC) stage_x(Rn, bn, vn);
             }
