@@ -446,6 +446,9 @@ __device__ __forceinline__ void dw_rgb(const DwArgs& a, int64_t blk_begin, int64
 }
 
 constexpr size_t DWS_SMEM = 3 * (size_t)(2 * CHB * 256 + 2 * CHB * 256 + CHP / 4) * 16;       // three chunk images of the 256 x 256 block: 98 496 B
+__device__ __forceinline__ int64_t chunks_per_split(const DwArgs& a, int inst) {
+    return (m_pad(a.M) / CHP + dws_splits(inst) - 1) / dws_splits(inst);
+}
 __device__ __forceinline__ void chunk_range(const DwArgs& a, int inst, int split, int64_t& cb, int64_t& ce) {
     const int64_t nchunks = m_pad(a.M) / CHP;
     const int64_t per = (nchunks + dws_splits(inst) - 1) / dws_splits(inst);
@@ -523,9 +526,17 @@ __device__ __forceinline__ float h8_sum_unit(const half8 h, const half8 l) {
 
 // NYA dY arrays of width YW (row tile rt of each) x the X array of width 32 TC, k-steps [kb, ke).  part[i]: this split's partial
 // block of dY array i ([YW][32 TC] then bias [YW]); bias sums for array 0 only when BIAS0.
+// klen: the loop's length in k-steps, the SAME for every wave of the workgroup (>= ke - kb; the k-steps past ke are loaded clamped and
+// multiplied by zero): the waves meet at a workgroup barrier every TS_LOCKSTEP ring cycles.  Nothing is exchanged there - the barrier
+// keeps the eight streams of a workgroup within a few k-steps of each other, so that together they read contiguous 8-KiB runs of an
+// array at the same time; drifting apart they are eight 512-byte-strided streams to the DRAM pages (round 5, end: thin kernel
+// 290 -> 272 us at 522 k points with the barrier in the L0 + L5P workgroups alone: profiles/r05_thin_lockstep_ab.log).
+#ifndef TS_LOCKSTEP
+#define TS_LOCKSTEP 1
+#endif
 template <int NYA, int YW, int TC, bool BIAS0>
 __device__ __forceinline__ void thin_stream(const u32x4* const (&yh)[NYA], const uint2* const (&y8)[NYA], const u32x4* __restrict__ xh,
-                                            const uint2* __restrict__ x8, int rt, int64_t kb, int64_t ke, int lane,
+                                            const uint2* __restrict__ x8, int rt, int64_t kb, int64_t ke, int64_t klen, int lane,
                                             float* const (&part)[NYA]) {
     constexpr int XW = 32 * TC;
     const int lr = lane & 31, lh = lane >> 5;
@@ -544,7 +555,7 @@ __device__ __forceinline__ void thin_stream(const u32x4* const (&yh)[NYA], const
     // unconditional loads (a k-step past the range is clamped to the last one and not multiplied): loads under branches make
     // the compiler's waitcnt bookkeeping fall back to vmcnt(0) (mlp_dw_h.hip)
     auto load = [&](Regs& R, int64_t k) {
-        const int64_t kk = k < ke ? k : ke - 1;
+        const int64_t kk = k < ke ? k : (ke > 0 ? ke - 1 : 0);
 #pragma unroll
         for (int i = 0; i < NYA; ++i) {
 #if DWS_NT
@@ -599,7 +610,7 @@ __device__ __forceinline__ void thin_stream(const u32x4* const (&yh)[NYA], const
             if (BIAS0 && i == 0) bsum += h8_sum_unit(ah, al);
         }
     };
-    if (kb < ke) {
+    {
 #pragma unroll
         for (int d = 0; d < TS_DEPTH; ++d) {
             load(r[d], kb + d);
@@ -607,9 +618,14 @@ __device__ __forceinline__ void thin_stream(const u32x4* const (&yh)[NYA], const
             // this block and the loop's own back edge) degrade to vmcnt(0) - no prefetch distance left
             __builtin_amdgcn_sched_barrier(0);
         }
-        for (int64_t k = kb; k < ke; k += TS_DEPTH) {
+        int cyc = 0;
+        for (int64_t k = kb; k < kb + klen; k += TS_DEPTH, ++cyc) {
+            if (TS_LOCKSTEP > 0 && cyc % (TS_LOCKSTEP > 0 ? TS_LOCKSTEP : 1) == 0) __builtin_amdgcn_s_barrier();      // no data exchanged: see above
 #pragma unroll
             for (int d = 0; d < TS_DEPTH; ++d) {
+#ifdef TS_LOCKSTEP_K     /* experiment: a barrier in front of every TS_LOCKSTEP_K-th k-step instead of every ring cycle */
+                if (d % TS_LOCKSTEP_K == 0 && d > 0) __builtin_amdgcn_s_barrier();
+#endif
                 compute(r[d], k + d < ke ? 0xffffffffu : 0u);
                 load(r[d], k + d + TS_DEPTH);
                 __builtin_amdgcn_sched_barrier(0);      // keep the ring as written: stage d's loads stay behind its own MFMAs
@@ -651,7 +667,7 @@ __global__ __launch_bounds__(DWT, 2) void mlp_dw_split_small_kernel(DwArgs a) {
         float* const part[2] = {a.ws + dws_inst_offset(DW_L0) + (int64_t)b * dw_inst_floats(DW_L0),
                                 a.ws + dws_inst_offset(DW_L5P) + (int64_t)b * dw_inst_floats(DW_L5P)};
         thin_stream<2, 256, 2, true>(yh, y8, reinterpret_cast<const u32x4*>(A + sact22_pe_hi(Mp)),
-                                     reinterpret_cast<const uint2*>(A + sact22_pe_lo8(Mp)), wave, cb, ce, lane, part);
+                                     reinterpret_cast<const uint2*>(A + sact22_pe_lo8(Mp)), wave, cb, ce, chunks_per_split(a, DW_L0), lane, part);
     } else if (b < DWH_T0 + DWH_T1 / 2) {
         const int split = 2 * (b - DWH_T0) + (wave >> 2);
         chunk_range(a, DW_VIEWSP, split, cb, ce);
@@ -659,7 +675,7 @@ __global__ __launch_bounds__(DWT, 2) void mlp_dw_split_small_kernel(DwArgs a) {
         const uint2* const y8[1] = {dy8(sdact_hv(Mp))};
         float* const part[1] = {a.ws + dws_inst_offset(DW_VIEWSP) + (int64_t)split * dw_inst_floats(DW_VIEWSP)};
         thin_stream<1, 128, 1, false>(yh, y8, reinterpret_cast<const u32x4*>(A + sact22_ped_hi(Mp)),
-                                      reinterpret_cast<const uint2*>(A + sact22_ped_lo8(Mp)), wave & 3, cb, ce, lane, part);
+                                      reinterpret_cast<const uint2*>(A + sact22_ped_lo8(Mp)), wave & 3, cb, ce, chunks_per_split(a, DW_VIEWSP), lane, part);
     } else {
         const int split = b - (DWH_T0 + DWH_T1 / 2);
         chunk_range(a, DW_RGB, split, cb, ce);
