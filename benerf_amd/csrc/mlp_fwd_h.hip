@@ -151,7 +151,9 @@ __device__ __forceinline__ void epilogue_t(f32x16 (&acc1)[NR][NCT], f32x16 (&acc
                         for (int t = 0; t < 2; ++t) {
                             uint64_t m;
                             asm volatile("v_cmp_gt_f32_e64 %0, %1, 0" : "=s"(m) : "v"(v[t]));
+#ifndef FWD_NO_MASK_STORE     /* timing variant (dX then reads stale masks): what do the scalar stores cost? */
                             asm volatile("s_store_dwordx2 %0, %1, %2" ::"s"(m), "s"(sv->mask), "n"((r * 8 * 32 + 2 * (e + t)) * 4) : "memory");
+#endif
                         }
                     }
                     const half2v hi = __builtin_convertvector(v, half2v);
