@@ -43,13 +43,22 @@ def balanced_shard_bounds(n_evt, n_rgb, rays_per_evt, rays_per_rgb, world):
     rb = [shard_bounds(n_rgb, k, world, uneven=True) for k in range(world)]
     target = (rays_per_evt * n_evt + rays_per_rgb * n_rgb) / world
     ideal = [max((target - rays_per_rgb * (hi - lo)) / rays_per_evt, 0.0) for lo, hi in rb]
-    e = [int(x) for x in ideal]
+    # the ideal shares sum to n_evt unless one was clipped at zero (a rank whose blur pixels alone exceed the mean: tiny batches) -
+    # then the event pixels are dealt in proportion to what is left of the ideal shares
+    tot = sum(ideal)
+    ideal = [x * n_evt / tot for x in ideal] if tot > 0 else [n_evt / world] * world
+    e = [min(int(x + 1e-9), n_evt) for x in ideal]
     left = n_evt - sum(e)
-    if left < 0:        # cannot happen with ideal >= 0 summing to n_evt, guard against float round-off
-        raise ValueError("balanced_shard_bounds: internal rounding error")
     order = sorted(range(world), key=lambda k: (-(ideal[k] - e[k]), k))
-    for i in range(left):
+    i = 0
+    while left > 0:
         e[order[i % world]] += 1
+        left -= 1
+        i += 1
+    while left < 0:     # float round-off only
+        k = max(range(world), key=lambda j: (e[j], -j))
+        e[k] -= 1
+        left += 1
     out, lo = [], 0
     for k in range(world):
         out.append(((lo, lo + e[k]), rb[k]))

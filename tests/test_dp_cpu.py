@@ -168,6 +168,12 @@ def test_shard_indices():
             assert max(rays) - min(rays) <= pe + 1 or min(e1 - e0 for (e0, e1), _ in tab) == 0, (ne, nr, world, rays)
             if cap is not None and world == 8:
                 assert max(rays) <= cap, rays
+    # degenerate batches (a rank whose blur pixels alone exceed the mean share of rays; no event or no blur pixels): still a partition
+    for ne, nr, pe, pn, world in ((1, 5, 2, 19, 4), (2, 20, 2, 19, 4), (0, 7, 2, 19, 3), (5, 0, 2, 19, 3)):
+        tab = dist.balanced_shard_bounds(ne, nr, pe, pn, world)
+        assert tab[0][0][0] == 0 and tab[-1][0][1] == ne and tab[-1][1][1] == nr
+        assert all(tab[k][0][1] == tab[k + 1][0][0] and tab[k][1][1] == tab[k + 1][1][0] for k in range(world - 1))
+        assert all(e1 >= e0 and r1 >= r0 for (e0, e1), (r0, r1) in tab)
 
 
 def test_async_allreduce_and_broadcast_single_process():
