@@ -163,7 +163,7 @@ struct LaneAddr {
 };
 
 #ifndef BWS_PF
-#define BWS_PF 3
+#define BWS_PF 2        /* k-steps of weight-fragment prefetch: see BWS_DEFER_RT */
 #endif
 template <int PF>
 struct WRing { u32x4 q[PF + 1][2]; };
@@ -197,8 +197,14 @@ __device__ __forceinline__ void gemm3_body(const _Float16* __restrict__ Th, cons
     // the compiler folds plane distance and k-step into ONE constant, finds it too large and emits a v_add per transpose read
     // (8 per k-step = 0.67 VALU per MFMA of this loop).  A second set of lane offsets with the plane distance folded in, opaque
     // to the constant folder, leaves the k-step (<= 60 KiB) as the instruction's immediate.
-    // [parity of the k-step]: fidx swaps the two 8-byte halves of a slot for features with bit 4 set = every odd k-step
-    int ao[2][2][4], aol[2][2][4];
+    // [parity of the k-step]: with the half-swap on feature bit 4 the two 8-byte halves of a slot are swapped in every odd k-step (NPAR = 2 sets
+    // of offsets); on a lower bit (the shipped bit 1) the k-step does not enter
+#ifdef BWS_OLD_SWIZZLE
+    constexpr int NPAR = 1;
+#else
+    constexpr int NPAR = BWS_HALF_BIT == 4 ? 2 : 1;
+#endif
+    int ao[NPAR][2][4], aol[NPAR][2][4];
     const int plane_delta = (int)(Tl - Th);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -209,13 +215,9 @@ __device__ __forceinline__ void gemm3_body(const _Float16* __restrict__ Th, cons
                 asm volatile("" : "+v"(v));
                 ao[0][j][rt] = v;
             }
-#ifdef BWS_OLD_SWIZZLE
-            ao[1][j][rt] = ao[0][j][rt];
-#else
-            ao[1][j][rt] = BWS_HALF_BIT == 4 ? ao[0][j][rt] ^ 4 : ao[0][j][rt];      // bit 4 = the k-step's parity; lower bits do not change with the k-step
-#endif
+            if (NPAR == 2) ao[NPAR - 1][j][rt] = ao[0][j][rt] ^ 4;
 #pragma unroll
-            for (int par = 0; par < 2; ++par) {
+            for (int par = 0; par < NPAR; ++par) {
                 int v = ao[par][j][rt] + plane_delta;
                 asm volatile("" : "+v"(v));
                 aol[par][j][rt] = v;
@@ -241,12 +243,12 @@ __device__ __forceinline__ void gemm3_body(const _Float16* __restrict__ Th, cons
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
             acc[rt] = mfma16(ah[rt], bl, acc[rt]);
-            if (ks + 1 < KS) ah[rt] = frag_read(Th + (ks + 1) * 16 * PROW, ao[(ks + 1) & 1][0][rt], ao[(ks + 1) & 1][1][rt]);
+            if (ks + 1 < KS) ah[rt] = frag_read(Th + (ks + 1) * 16 * PROW, ao[(ks + 1) & (NPAR - 1)][0][rt], ao[(ks + 1) & (NPAR - 1)][1][rt]);
         }
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
             acc[rt] = mfma16(al[rt], bh, acc[rt]);
-            if (ks + 1 < KS) al[rt] = frag_read(Th + (ks + 1) * 16 * PROW, aol[(ks + 1) & 1][0][rt], aol[(ks + 1) & 1][1][rt]);
+            if (ks + 1 < KS) al[rt] = frag_read(Th + (ks + 1) * 16 * PROW, aol[(ks + 1) & (NPAR - 1)][0][rt], aol[(ks + 1) & (NPAR - 1)][1][rt]);
         }
         __builtin_amdgcn_sched_barrier(0);          // one k-step per scheduling region: keeps the prefetch distances as written
     }
@@ -350,10 +352,19 @@ __device__ __forceinline__ void amax3(float& amax, float v0, float v1) {
 
 // The STORE half of an epilogue - lane exchange, rescale, residual codes, two stores per unit: ~34 of a unit's instructions, 40 % of the
 // epilogue's VALU work - needs nothing but the packed (hi, lo) quads.  For the row tiles an epilogue finishes LAST (2 and 3) those quads
-// wait in registers (32: the dX kernel has them to spare, the forward does not) and the units are formed in the NEXT stage's K-loop, one
-// per k-step behind its last weight-fragment request, in the shadow of its MFMAs (the VALU is idle there; BWS_DEFER).
+// wait in registers (the dX kernel has them to spare, the forward does not) and the units are formed in the NEXT stage's K-loop, one
+// per k-step in its last k-steps, in the shadow of its MFMAs (the VALU is idle there; BWS_DEFER, BWS_DEFER_RT).
+// First deferred row tile: the units of row tiles BWS_DEFER_RT .. 3 wait (16 registers per row tile).  2 (the first version: 32 registers, four
+// units in k-steps 12..15): -1.7 % of the kernel; 1: +-0 on top of it; 0 - ALL eight units, k-steps 8..15, the epilogue stores nothing itself -
+// another -1.8 % alone and -4 % inside the step (C2 7.38 -> 7.31 ms; profiles/r05_dx_deferred_units_ab.log).  64 registers of quads next to the
+// accumulators fit only with the weight-fragment ring two k-steps deep (BWS_PF = 2: 253 VGPRs, no scratch; three deep: two values spilled across
+// the layer loops) - the depth itself measures +-0.
+#ifndef BWS_DEFER_RT
+#define BWS_DEFER_RT 0
+#endif
+constexpr int NDEFER = 2 * (4 - BWS_DEFER_RT);     // deferred units per stage, one per k-step in the next K-loop's last NDEFER k-steps
 struct DeferUnits {
-    uint2 qh[2][2][2], ql[2][2][2];     // [row tile - 2][ep][h]
+    uint2 qh[4 - BWS_DEFER_RT][2][2], ql[4 - BWS_DEFER_RT][2][2];     // [row tile - BWS_DEFER_RT][ep][h]
 };
 #ifndef BWS_DEFER
 #define BWS_DEFER 1
@@ -476,11 +487,11 @@ __device__ __forceinline__ void epilogue3(f32x16 (&acc)[NRT], const uint32_t (&b
                 ql[h] = uint2{wl[0], wl[1]};
             }
             if (!STORE) continue;
-            if (DEFER && rt >= 2) {     // the quads wait for the next K-loop (DeferUnits)
+            if (DEFER && rt >= BWS_DEFER_RT) {     // the quads wait for the next K-loop (DeferUnits)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    du->qh[rt - 2][ep][h] = qh[h];
-                    du->ql[rt - 2][ep][h] = ql[h];
+                    du->qh[rt - BWS_DEFER_RT][ep][h] = qh[h];
+                    du->ql[rt - BWS_DEFER_RT][ep][h] = ql[h];
                 }
                 continue;
             }
@@ -726,10 +737,11 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
     // ---- P4: L7 .. L1: dY_l x W_l, mask h_{l-1} -> dY_{l-1} ----------------------------------------------
     auto layer = [&](int l) __attribute__((always_inline)) {
         zero4(acc);
-        // dY_l's deferred units (row tiles 2, 3) are formed and stored in k-steps 12..15 of this K-loop: behind its last fragment
-        // request (k-step 12 = 16 - 1 - PF), so that no fragment waits for a store (vector-memory operations retire in order)
+        // dY_l's deferred units (row tiles BWS_DEFER_RT .. 3: all eight) are formed and stored in the last NDEFER k-steps of this K-loop, one
+        // per k-step (the first of them in front of the K-loop's last fragment requests: measured, they do not hold the fragments up)
         const __amdgpu_buffer_rsrc_t drs_hi = uniform_rsrc(st_tile(l)), drs_lo = uniform_rsrc(st8_tile(l));
-#if BWS_DEFER == 2      // VALU half early (k-steps 2, 5, 8, 11), stores in k-steps 12..15
+#if BWS_DEFER == 2      // VALU half early (k-steps 2, 5, 8, 11), stores in k-steps 12..15 (BWS_DEFER_RT == 2 only)
+        static_assert(BWS_DEFER_RT == 2, "the early-VALU variant is written for four deferred units");
         u32x4 ph[4];
         uint2 pc[4];
         gemm3_body<16, BWS_PF>(Th, Tl, packed_h + bwd_layer_offset(l), ct, lane, ring, acc, la, [&](int ks) {
@@ -744,9 +756,9 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
         });
 #else
         gemm3_body<16, BWS_PF>(Th, Tl, packed_h + bwd_layer_offset(l), ct, lane, ring, acc, la, [&](int ks) {
-            if (BWS_DEFER && ks >= 12) {
-                const int u = ks - 12;
-                finish_unit(du.qh[u >> 1][u & 1], du.ql[u >> 1][u & 1], drs_hi, drs_lo, unit_lane_offset(ct, stage_local(lane)), 2 + (u >> 1), u & 1, gf);
+            if (BWS_DEFER && ks >= 16 - NDEFER) {
+                const int u = ks - (16 - NDEFER);
+                finish_unit(du.qh[u >> 1][u & 1], du.ql[u >> 1][u & 1], drs_hi, drs_lo, unit_lane_offset(ct, stage_local(lane)), BWS_DEFER_RT + (u >> 1), u & 1, gf);
             }
         });
 #endif
@@ -792,8 +804,8 @@ __global__ __launch_bounds__(BNT, 2) void mlp_bwd_split_kernel(BwdArgs a) {
     if (BWS_DEFER) {     // dY0's deferred units: no K-loop of this shape follows
         const __amdgpu_buffer_rsrc_t drs_hi = uniform_rsrc(st_tile(0)), drs_lo = uniform_rsrc(st8_tile(0));
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            finish_unit(du.qh[u >> 1][u & 1], du.ql[u >> 1][u & 1], drs_hi, drs_lo, unit_lane_offset(ct, stage_local(lane)), 2 + (u >> 1), u & 1, gf);
+        for (int u = 0; u < NDEFER; ++u)
+            finish_unit(du.qh[u >> 1][u & 1], du.ql[u >> 1][u & 1], drs_hi, drs_lo, unit_lane_offset(ct, stage_local(lane)), BWS_DEFER_RT + (u >> 1), u & 1, gf);
     }
 
     if (a.status) {   // range guard of the f16 gradient halves: one atomic per wave, only near f16's maximum
