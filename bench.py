@@ -260,6 +260,58 @@ def hbm_traffic_leg(a, timeout_s=120):
     return res, time.perf_counter() - t0
 
 
+def dropin_leg(a, timeout_s=240):
+    """The path an UNCHANGED train.py runs: tools/dropin_driver.py - train.py:153-394 restated with the reference's names (graph.forward,
+    the loss lines on torch tensors, every logger.write(.item()), loss.backward(), the optimizer_*.step() calls, the five learning-rate
+    updates) on the modules `benerf_amd.dropin.install()` registers - at the same workload and arithmetic mode, in a child process (the
+    driver switches torch's default tensor type to cuda like train.py:472 and aliases top-level module names): >= 20 timed
+    iterations after warm-up, wall clock around them, HIP-event durations of the K3 launches.  A second child under
+    `rocprofv3 --kernel-trace` (6 iterations) gives launches per iteration and where the device idles (tools/dropin_timeline.py)."""
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    drv = os.path.join(ROOT, "tools", "dropin_driver.py")
+    cmd = [sys.executable, drv, "--workload", a.workload, "--mlp-precision", a.mlp_precision, "--timers"]
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        r = subprocess.run(cmd + ["--steps", str(max(20, a.steps)), "--warmup", str(max(5, a.warmup))], env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, text=True, timeout=timeout_s)
+        if r.returncode != 0:
+            return {"error": "tools/dropin_driver.py failed (rc %d): %s" % (r.returncode, r.stderr.strip()[-300:])}
+        leg = json.loads(r.stdout.strip().splitlines()[-1])
+    except (subprocess.TimeoutExpired, OSError, ValueError, IndexError) as e:
+        return {"error": "dropin leg: %r" % (e,)}
+    out = {"value": leg["rays_per_s"], "unit": "rays/s", "ms_per_step": leg["ms_per_step"], "median_ms_per_step": leg["median_ms_per_step"],
+           "steps": leg["steps"], "warmup": leg["warmup"], "rays_per_step": leg["rays_per_step"], "final_loss": leg["final_loss"],
+           "host_syncs_per_step": leg["host_syncs_per_step"], "per_kernel": leg.get("per_kernel"),
+           "what": "train.py:153-394 as the reference writes it (tools/dropin_driver.py) on the drop-in modules: Graph.forward -> torch loss "
+                   "lines + logger .item() reads -> loss.backward() -> optimizer_*.step() -> learning-rate updates; same workload, same "
+                   "arithmetic mode as `value`"}
+    rp = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    under_profiler = any(k.startswith(("ROCPROF", "ROCPROFILER", "ROCP_")) for k in os.environ)
+    if rp is not None and not under_profiler and not os.environ.get("BENERF_BENCH_NO_PMC"):
+        tmp = tempfile.mkdtemp(prefix="benerf_dropin_", dir="/tmp")
+        try:
+            r = subprocess.run([rp, "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "t", "--"] + cmd[:-1] + ["--steps", "6", "--warmup", "3"],
+                               cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            hits = glob.glob(os.path.join(tmp, "**", "t_kernel_trace.csv"), recursive=True)
+            if r.returncode == 0 and hits:
+                t = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dropin_timeline.py"), hits[0], "--json"], stdout=subprocess.PIPE,
+                                   text=True, timeout=60)
+                tl = json.loads(t.stdout)
+                out["launches_per_step"] = tl["launches_per_step"]
+                out["timeline_profiled"] = {"span_ms": tl["span_ms"], "sections": tl["sections"],
+                                            "note": "one iteration under rocprofv3 --kernel-trace (slower than un-profiled by ~4 us per launch); "
+                                                    "`loss` = train.py's own loss lines + their autograd backward, between the render's last "
+                                                    "forward and first backward launch: device idle there is host time of the reference's code"}
+        except (subprocess.TimeoutExpired, OSError, ValueError, KeyError) as e:
+            out["timeline_profiled"] = {"error": repr(e)[:200]}
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
 def split_mode(a):
     return a.mlp_precision != "f32"
 
@@ -933,6 +985,14 @@ def main():
                     out["torch_gpu_baseline"]["speedup_vs_it"] = round(out["value"] / out["torch_gpu_baseline"]["value"], 2)
             except Exception as e:   # informational leg only: never fail the bench line on it
                 out["torch_gpu_baseline"] = {"error": repr(e)[:200]}
+            if a.event_bins == 1 and a.batch_fraction == 1 and not a.rccl_loopback:
+                # the path train.py drops onto, unchanged: timed in a child process once this one is done with the device
+                torch.cuda.synchronize()
+                out["dropin"] = dropin_leg(a)
+                base = out.get("torch_gpu_baseline", {}).get("value")
+                if base and "value" in out["dropin"]:
+                    out["dropin"]["speedup_vs_torch_gpu"] = round(out["dropin"]["value"] / base, 2)
+                    out["dropin"]["fraction_of_train_step"] = round(out["dropin"]["value"] / out["value"], 3)
         else:
             out["cpu_baseline"] = None
         if a.rccl_loopback:

@@ -21,6 +21,7 @@ import torch
 from . import _lib
 from . import dist
 from . import kernels as K
+from . import optim
 
 NOISE_STD_DEFAULT = 1.0   # NeRF.raw2output default, never overridden by the reference (model/nerf.py:118)
 
@@ -48,11 +49,13 @@ class Draws:
         self.seed, self.offset, self.noise_std = int(seed), int(offset), float(noise_std)
         self.near, self.far = float(near), float(far)      # depth range of the stratified samples (model/nerf.py:297-299)
 
-    def noise_args(self, which):
+    def noise_args(self, which, part=0):
+        """part: a render node that composites its batches in separate launches (RenderPair) draws each one's Philox noise from
+        a stream of its own (the kernel keys the counter by the row inside the launch)."""
         t = self.noise0 if which == 0 else self.noise1
         if t is not None:
             return t, 0.0, 0, 0
-        return None, self.noise_std, self.seed, self.offset * 4 + (1 if which == 0 else 3)
+        return None, self.noise_std, self.seed, (self.offset + part * (1 << 20)) * 4 + (1 if which == 0 else 3)
 
     def jitter_args(self):
         return self.t_rand, self.seed, self.offset * 4 + 0
@@ -84,6 +87,28 @@ class SplinePoses(torch.autograd.Function):
         if d_tr is not None:
             d_tr = d_tr.reshape(tr_shape)
         return d_knots, d_tr, None, None, None, None
+
+
+class SplinePosesPair(torch.autograd.Function):
+    """Both trajectory queries of one training iteration in one launch each way (K1): (knots [4,6], transform [1,6], ts_a [2],
+    ts_b [2]) -> (poses_a [n_a,3,4] on the knots - get_pose_evt, model/optimize.py:58-82 -, poses_b [n_b,3,4] on knots +
+    transform - get_pose_rgb, model/optimize.py:84-111)."""
+
+    @staticmethod
+    def forward(ctx, knots, transform, ts_a, ts_b, n_a, n_b, traj):
+        knots_c, tr_c = knots.detach().contiguous(), transform.detach().reshape(6).contiguous()
+        ta, tb = ts_a.detach().contiguous(), ts_b.detach().contiguous()
+        ctx.save_for_backward(knots_c, tr_c, ta, tb)
+        ctx.cfg = (n_a, n_b, traj, transform.shape)
+        return K.spline_poses_fwd_pair(knots_c, tr_c, ta, n_a, tb, n_b, traj)
+
+    @staticmethod
+    def backward(ctx, d_a, d_b):
+        knots, tr, ta, tb = ctx.saved_tensors
+        n_a, n_b, traj, tr_shape = ctx.cfg
+        z = lambda d, n: torch.zeros((n, 3, 4), dtype=torch.float32, device=knots.device) if d is None else d.contiguous()   # noqa: E731
+        dk_a, dk_b, dt_b = K.spline_poses_bwd_pair(knots, tr, ta, n_a, tb, n_b, traj, z(d_a, n_a), z(d_b, n_b))
+        return dk_a.add_(dk_b), dt_b.reshape(tr_shape), None, None, None, None, None
 
 
 def _render_forward(cam, ndc, n_samples, n_importance, draws, poses, ray_idx, net_c, net_f, save):
@@ -123,6 +148,7 @@ def _render_backward(cam, ndc, draws, poses, ray_idx, net_c, net_f, saved, g, gr
     d_d = torch.empty((n_rays, 3), dtype=torch.float32, device=dev)   # first written by composite_bwd
     d_v = torch.zeros((n_rays, 3), dtype=torch.float32, device=dev)
     fine = "raw1" in saved
+    acc_c, acc_f = accumulate if isinstance(accumulate, tuple) else (accumulate, accumulate)
 
     def zeros_like_rgb(t):
         return torch.zeros_like(t)
@@ -136,7 +162,7 @@ def _render_backward(cam, ndc, draws, poses, ray_idx, net_c, net_f, saved, g, gr
         d_raw1, _ = K.composite_bwd(saved["raw1"], saved["z_fine"], rd, nz1[0], nz1[1], nz1[2], nz1[3], g_rgb,
                                     g.get("acc_map"), None, g.get("disp_map"), d_rays_d=d_d, accumulate=False)
         d_pts, d_vp = K.mlp_bwd(net_f, d_raw1.reshape(-1, d_raw1.shape[-1]), saved["acts1"], n_rays,
-                                saved["z_fine"].shape[1], grads_f[0], grads_f[1], accumulate)
+                                saved["z_fine"].shape[1], grads_f[0], grads_f[1], acc_f)
         # d_d already holds the ||rays_d|| term of the fine compositing: accumulate on top of it
         K.ray_grad_reduce(saved["z_fine"], d_pts, d_vp, d_o, d_d, d_v, True)
         first = False
@@ -149,9 +175,48 @@ def _render_backward(cam, ndc, draws, poses, ray_idx, net_c, net_f, saved, g, gr
     d_raw0, _ = K.composite_bwd(saved["raw0"], z, rd, nz0[0], nz0[1], nz0[2], nz0[3], g_rgb0, g_acc0, None, g_disp0,
                                 d_rays_d=d_d, accumulate=not first)
     d_pts, d_vp = K.mlp_bwd(net_c, d_raw0.reshape(-1, d_raw0.shape[-1]), saved["acts0"], n_rays, z.shape[1],
-                            grads_c[0], grads_c[1], accumulate)
+                            grads_c[0], grads_c[1], acc_c)
     K.ray_grad_reduce(z, d_pts, d_vp, d_o, d_d, d_v, True)
     return K.rays_bwd(poses, ray_idx, cam.H, cam.W, cam.fx, cam.fy, cam.cx, cam.cy, ndc, d_o, d_d, d_v, remap=cam.remap)
+
+
+def _pass_id():
+    """Id of the running backward pass (autograd graph task), -1 outside one / on a torch without the query."""
+    try:
+        return torch._C._current_graph_task_id()
+    except AttributeError:      # pragma: no cover
+        return -1
+
+
+def _grad_targets(net):
+    """Where the 24 weight / bias gradients of one network go in a render node's backward.
+    Returns (grad_w, grad_b, accumulate, returned): the tensors K3's dW launch writes (or adds into, `accumulate`), and what the
+    node hands autograd for the 24 parameter inputs.
+
+    Parameters that live in an optimiser's arena (optim.FlatAdam): the launch writes the arena's gradient buffer and autograd
+    gets fresh VIEWS of it, which AccumulateGrad adopts as `.grad` without a copy when the gradient is None (after the
+    reference's zero_grad(), train.py:196-200).  When the slots already hold live data - `.grad` is a window on them (a caller
+    accumulating over several backward passes), or another render node of THIS pass wrote them (two `graph.render` calls in one
+    loss) - the launch adds on top and autograd is handed nothing (None = no contribution).
+    Anything else (no arena, mixed states, a torch without graph-task ids): fresh buffers, autograd accumulates them."""
+    params = list(net.weights) + list(net.biases)
+    n_w = len(net.weights)
+    hit = optim.arena_of(params)
+    pid = _pass_id()
+    if hit is not None and pid != -1:
+        arena, idx = hit
+        n = len(params)
+        windows = [arena.grad_is_window(i) for i in idx]
+        same_pass = arena.pass_ids.get(idx[0]) == pid
+        views = [arena.grad_view(i) for i in idx]
+        if same_pass or all(windows):
+            arena.pass_ids[idx[0]] = pid
+            return views[:n_w], views[n_w:], True, [None] * n
+        if not any(windows):
+            arena.pass_ids[idx[0]] = pid
+            return views[:n_w], views[n_w:], False, views
+    gw, gb = [torch.empty_like(w) for w in net.weights], [torch.empty_like(b) for b in net.biases]
+    return gw, gb, False, gw + gb
 
 
 class RenderRays(torch.autograd.Function):
@@ -192,19 +257,147 @@ class RenderRays(torch.autograd.Function):
         else:
             g = {"rgb_map": c(gs[0]), "disp_map": c(gs[1]), "acc_map": c(gs[2])}
         net_c, net_f = ctx.net_c, ctx.net_f
-        gc = ([torch.empty_like(w) for w in net_c.weights], [torch.empty_like(b) for b in net_c.biases])
-        gf = (None, None)
-        if net_f is not None:
-            gf = ([torch.empty_like(w) for w in net_f.weights], [torch.empty_like(b) for b in net_f.biases])
+        tc = _grad_targets(net_c)
+        tf = _grad_targets(net_f) if net_f is not None else (None, None, False, [])
         d_poses = _render_backward(ctx.cam, ctx.ndc, ctx.draws, ctx.poses, ctx.ray_idx, net_c, net_f, ctx.saved_k, g,
-                                   gc, gf, False)
+                                   (tc[0], tc[1]), (tf[0], tf[1]), (tc[2], tf[2]))
         if K.is_split():
             K.range_guard(d_poses.device).post()
         ctx.saved_k = None
-        grads = list(gc[0]) + list(gc[1])
-        if net_f is not None:
-            grads += list(gf[0]) + list(gf[1])
-        return (d_poses, None, None, None, None, None, None, None, None) + tuple(grads)
+        return (d_poses, None, None, None, None, None, None, None, None) + tuple(tc[3]) + tuple(tf[3])
+
+
+class RenderPair(torch.autograd.Function):
+    """The two renders of one training iteration - event batch (cam_e, poses_e) and blur batch (cam_r, poses_r) of
+    Graph.forward (model/nerf.py:160-234) - as ONE autograd node over ONE batched launch sequence: rays of both batches in one
+    buffer, one coarse and one fine K3 launch, compositing per batch (separate, non-view outputs: the reference's loop may
+    scale what it gets in place), one dX / dW launch per network in the backward.  Same kernels and order as TrainStep.
+
+    inputs: poses_e [Pe,3,4], poses_r [Pr,3,4], then the 24 coarse and 24 fine parameter tensors.
+    outputs: (rgb_map, disp_map, acc_map, rgb0, disp0, acc0, sigma) of the event batch, then the same seven of the blur batch
+    (sigma is not differentiable here - it is never used in a loss); then, with pose_chunks, the per-pose row blocks of the four
+    colour maps as outputs of their own (event rgb_map, event rgb0, blur rgb_map, blur rgb0: Pe + Pe + Pr + Pr views of the maps
+    above).  The reference's loop takes exactly these blocks out of the maps - `ret_event["rgb_map"][:pixels_num]`, the
+    num_interpolated_pose slices of the blur loop (train.py:166-175, 307-315) - and autograd answers every such slice of a
+    differentiable tensor with three launches in the backward pass (zero-fill of a full-size gradient, copy of the slice, add
+    into the running sum): ~126 launches per iteration, 1 ms of host time with the device idle.  model/nerf.py's PoseMajorRows
+    hands out these outputs for those very slices instead: the block gradients arrive here directly and are joined by one
+    concatenation per map."""
+
+    @staticmethod
+    def forward(ctx, poses_e, poses_r, idx_e, idx_r, cam_e, cam_r, ndc, n_samples, n_importance, draws, net_c, net_f, pose_chunks, *params):
+        pe, pr = poses_e.detach().contiguous(), poses_r.detach().contiguous()
+        dev = pe.device
+        need_grad = any(ctx.needs_input_grad)
+        if need_grad and K.is_split():
+            K.range_guard(dev).poll()          # what the previous backward posted (see RenderRays.forward)
+        if net_c._key() != net_c.version or net_f._key() != net_f.version:
+            K.PackedMlp.pack_pair(net_c, net_f)        # one re-pack launch per optimiser step for both networks
+        S, Ni = n_samples, n_importance
+        Ne, Nr = pe.shape[0] * idx_e.shape[0], pr.shape[0] * idx_r.shape[0]
+        N = Ne + Nr
+        ro = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        rd, vd = torch.empty_like(ro), torch.empty_like(ro)
+        K.rays_fwd(pe, idx_e, cam_e.H, cam_e.W, cam_e.fx, cam_e.fy, cam_e.cx, cam_e.cy, ndc, out=(ro[:Ne], rd[:Ne], vd[:Ne]), remap=cam_e.remap)
+        K.rays_fwd(pr, idx_r, cam_r.H, cam_r.W, cam_r.fx, cam_r.fy, cam_r.cx, cam_r.cy, ndc, out=(ro[Ne:], rd[Ne:], vd[Ne:]), remap=cam_r.remap)
+        t_rand, seed, off = draws.jitter_args()
+        z = K.stratified_z(N, S, dev, t_rand, seed, off, draws.near, draws.far)
+        parts = ((0, Ne), (Ne, N))
+
+        def composite(raw, zz, which, weights=None):
+            """compositing per batch: separate outputs; the sampling weights of both land in one [N, S] buffer"""
+            outs = []
+            for k, (a, b) in enumerate(parts):
+                nz = draws.noise_args(which, k)
+                o_ = {"weights": weights[a:b]} if weights is not None else None
+                want = ("rgb_map", "disp", "acc") + (("weights",) if weights is not None else ("sigma",))
+                outs.append(K.composite_fwd(raw[a:b], zz[a:b], rd[a:b], None if nz[0] is None else nz[0][a:b], nz[1], nz[2], nz[3],
+                                            want=want, out=o_))
+            return outs
+
+        raw0, acts0 = K.mlp_fwd(net_c, ro, rd, vd, z, need_grad)
+        w0 = torch.empty((N, S), dtype=torch.float32, device=dev)
+        c0 = composite(raw0, z, 0, w0)
+        u, useed, uoff = draws.u_args()
+        z_fine = K.sample_pdf_merge(z, w0, Ni, u, useed, uoff)
+        raw1, acts1 = K.mlp_fwd(net_f, ro, rd, vd, z_fine, need_grad)
+        c1 = composite(raw1, z_fine, 1)
+        ctx.cfg = (cam_e, cam_r, ndc, draws, net_c, net_f, pe, pr, idx_e, idx_r, Ne, N)
+        ctx.saved_k = (ro, rd, vd, z, z_fine, raw0, raw1, acts0, acts1) if need_grad else None
+        outs = []
+        for k in range(2):
+            outs += [c1[k]["rgb_map"], c1[k]["disp"], c1[k]["acc"], c0[k]["rgb_map"], c0[k]["disp"], c0[k]["acc"], c1[k]["sigma"]]
+        ctx.mark_non_differentiable(outs[6], outs[13])
+        ctx.chunks = None
+        if pose_chunks:
+            Pe, Pr, Re, Rr = pe.shape[0], pr.shape[0], idx_e.shape[0], idx_r.shape[0]
+            ctx.chunks = (Pe, Pr)
+            for k, (P, R) in enumerate(((Pe, Re), (Pr, Rr))):
+                for m in (outs[7 * k], outs[7 * k + 3]):            # rgb_map, rgb0 of batch k
+                    outs += [m[j * R:(j + 1) * R] for j in range(P)]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        cam_e, cam_r, ndc, draws, net_c, net_f, pe, pr, idx_e, idx_r, Ne, N = ctx.cfg
+        ro, rd, vd, z, z_fine, raw0, raw1, acts0, acts1 = ctx.saved_k
+        ctx.saved_k = None
+        dev = ro.device
+        S, Sf = z.shape[1], z_fine.shape[1]
+        C1 = raw0.shape[-1]
+        parts = [[0, Ne, list(gs[0:7])], [Ne, N, list(gs[7:14])]]
+        if ctx.chunks is not None:
+            # gradients of the per-pose row blocks: joined (one concatenation per map) and added to the whole map's gradient, if any
+            o = 14
+            for k, P in enumerate(ctx.chunks):
+                rows = (parts[k][1] - parts[k][0]) // P
+                for slot in (0, 3):
+                    blk = gs[o:o + P]
+                    o += P
+                    if all(b is None for b in blk):
+                        continue
+                    ref = next(b for b in blk if b is not None)
+                    joined = torch.cat([b if b is not None else ref.new_zeros((rows,) + tuple(ref.shape[1:])) for b in blk])
+                    parts[k][2][slot] = joined if parts[k][2][slot] is None else parts[k][2][slot] + joined
+
+        def c(t):
+            return None if t is None else t.contiguous()
+
+        d_d = torch.empty_like(ro)
+        amax = torch.zeros(2, dtype=torch.float32, device=dev)
+
+        def composite_bwd(raw, zz, which, slot, first):
+            """d_raw of both batches in one [N, S, C+1] buffer; the ||rays_d|| term starts (first) or extends d_d"""
+            d_raw = torch.empty_like(raw)
+            for k, (a, b, g) in enumerate(parts):
+                nz = draws.noise_args(which, k)
+                g_rgb, g_disp, g_acc = (g[0], g[1], g[2]) if slot == 1 else (g[3], g[4], g[5])
+                if g_rgb is None:
+                    g_rgb = torch.zeros((b - a, C1 - 1), dtype=torch.float32, device=dev)
+                K.composite_bwd(raw[a:b], zz[a:b], rd[a:b], None if nz[0] is None else nz[0][a:b], nz[1], nz[2], nz[3], c(g_rgb), c(g_acc),
+                                None, c(g_disp), d_rays_d=d_d[a:b], accumulate=not first, absmax_out=amax[slot:slot + 1], d_raw_out=d_raw[a:b])
+            return d_raw
+
+        # the device idles while autograd walks the caller's loss lines: the first large launch (the fine network's dX chain) goes out
+        # with as little host work in front of it as possible, everything else is prepared while it runs
+        d_raw1 = composite_bwd(raw1, z_fine, 1, 1, True)
+        dx1 = K.mlp_bwd_dx(net_f, d_raw1.view(-1, C1), acts1, N, Sf, slot="_fine", d_raw_absmax=amax[1:2])
+        d_raw0 = composite_bwd(raw0, z, 0, 0, False)
+        d_o, d_v = torch.empty_like(ro), torch.empty_like(ro)
+        grads = {}
+        for net, d_raw, acts, zz, ns, slot, dx in ((net_f, d_raw1, acts1, z_fine, Sf, 1, dx1), (net_c, d_raw0, acts0, z, S, 0, None)):
+            gw, gb, acc, ret = _grad_targets(net)
+            if dx is None:
+                dx = K.mlp_bwd_dx(net, d_raw.view(-1, C1), acts, N, ns, slot="_coarse", d_raw_absmax=amax[slot:slot + 1])
+            d_pts, d_vp, dacts = dx
+            K.mlp_bwd_dw(net, d_raw.view(-1, C1), acts, dacts, N, ns, gw, gb, acc)
+            K.ray_grad_reduce(zz, d_pts, d_vp, d_o, d_d, d_v, 2 if slot == 1 else 1)   # d_d holds the compositing part; d_o, d_v start with the fine pass
+            grads[slot] = ret
+        dp_e = K.rays_bwd(pe, idx_e, cam_e.H, cam_e.W, cam_e.fx, cam_e.fy, cam_e.cx, cam_e.cy, ndc, d_o[:Ne], d_d[:Ne], d_v[:Ne], remap=cam_e.remap)
+        dp_r = K.rays_bwd(pr, idx_r, cam_r.H, cam_r.W, cam_r.fx, cam_r.fy, cam_r.cx, cam_r.cy, ndc, d_o[Ne:], d_d[Ne:], d_v[Ne:], remap=cam_r.remap)
+        if K.is_split():
+            K.range_guard(dev).post()
+        return (dp_e, dp_r) + (None,) * 11 + tuple(grads[0]) + tuple(grads[1])
 
 
 # ------------------------------------------------------------------------------------------

@@ -515,15 +515,20 @@ def mlp_bwd(net, d_raw, acts, n_rays, n_samples, grad_w, grad_b, accumulate):
 
 # ----------------------------------------------------------------------------- K4 compositing
 def composite_fwd(raw, z, rays_d, noise=None, noise_std=0.0, seed=0, offset=0, want=("rgb_map", "disp", "acc", "weights",
-                                                                                    "depth", "sigma")):
+                                                                                    "depth", "sigma"), out=None):
+    """out: optional dict of caller-owned tensors for some of the outputs (e.g. a row range of a batch buffer); the others in
+    `want` are allocated.  Philox noise (noise None, noise_std > 0) is keyed by the ray's row INSIDE this call."""
     lib = _lib.load()
     n_rays, n_samples, c1 = raw.shape
     C = c1 - 1
-    out = {}
+    out = dict(out) if out else {}
     shapes = {"rgb_map": (n_rays, C), "disp": (n_rays,), "acc": (n_rays,), "weights": (n_rays, n_samples),
               "depth": (n_rays,), "sigma": (n_rays, n_samples)}
     for k in want:
-        out[k] = _new(shapes[k], raw)
+        if k not in out:
+            out[k] = _new(shapes[k], raw)
+        else:
+            _chk(out[k], name=k)
     p = lambda k: out[k].data_ptr() if k in out else None  # noqa: E731
     _lib.check(lib.benerf_composite_fwd(_chk(raw), _chk(z), _chk(rays_d), _chk(noise), noise_std, seed, offset, C, n_rays,
                                         n_samples, p("rgb_map"), p("disp"), p("acc"), p("weights"), p("depth"),
@@ -532,11 +537,14 @@ def composite_fwd(raw, z, rays_d, noise=None, noise_std=0.0, seed=0, offset=0, w
 
 
 def composite_bwd(raw, z, rays_d, noise, noise_std, seed, offset, d_rgb_map, d_acc=None, d_depth=None, d_disp=None,
-                  d_rays_d=None, accumulate=False, absmax_out=None):
-    """absmax_out: None, or a zeroed 1-element device float that receives max |d_raw| (hand it to mlp_bwd_dx)."""
+                  d_rays_d=None, accumulate=False, absmax_out=None, d_raw_out=None):
+    """absmax_out: None, or a zeroed 1-element device float that receives max |d_raw| (hand it to mlp_bwd_dx; an atomic
+    maximum: several calls may fold into one word).  d_raw_out: caller-owned [n_rays, n_samples, C + 1] (a row range of a batch buffer)."""
     lib = _lib.load()
     n_rays, n_samples, c1 = raw.shape
-    d_raw = torch.empty_like(raw)
+    d_raw = torch.empty_like(raw) if d_raw_out is None else d_raw_out
+    _chk(d_raw, name="d_raw_out")
+    assert d_raw.shape == raw.shape
     if d_rays_d is None:
         d_rays_d = _new((n_rays, 3), raw)
         accumulate = False
@@ -698,7 +706,7 @@ def posenc(x, n_freqs, include_input=True):
 
 def mse_fwd(a, b):
     lib = _lib.load()
-    out = _new((1,), a)
+    out = _new((), a)       # 0-dim: the reference scales the loss IN PLACE (train.py:222 `event_loss_fine *= ...`) - a view out of an autograd Function forbids that
     _lib.check(lib.benerf_mse_fwd(_chk(a), _chk(b), a.numel(), out.data_ptr(), _stream()), "mse_fwd")
     return out
 

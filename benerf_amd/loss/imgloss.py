@@ -11,7 +11,7 @@ class _Mse(torch.autograd.Function):
         ac, bc = a.detach().float().contiguous(), b.detach().float().contiguous()
         ctx.save_for_backward(ac, bc)
         ctx.shapes = (a.shape, b.shape, a.dtype, b.dtype)
-        return K.mse_fwd(ac.view(-1), bc.view(-1)).reshape(())
+        return K.mse_fwd(ac.view(-1), bc.view(-1))
 
     @staticmethod
     def backward(ctx, g):

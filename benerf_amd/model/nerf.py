@@ -34,12 +34,81 @@ class Model:
         print(f"Successfully finished model on {datetime.now()}")
 
 
-def _draw(fn, shape, device, scale=None):
-    """One draw from the global torch generator, reference order/shape."""
+def _draw(fn, shape, device, scale=None, out=None):
+    """One draw from the global torch generator, reference order/shape.  out: a contiguous float32 tensor of that
+    shape to draw into (a row range of a batch buffer) - the same values as a fresh tensor gets."""
+    if out is not None:
+        t = fn(shape, out=out)
+        if scale is not None and scale != 1.0:
+            t.mul_(scale)
+        return t
     t = fn(shape, device=device)
-    if scale is not None:
+    if scale is not None and scale != 1.0:
         t = t * scale
     return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+class PoseMajorRows(torch.Tensor):
+    """A rendered colour map [P * R, C] (pose-major: R pixels for each of P poses) that answers the slices the reference's loop
+    takes out of it - whole per-pose row blocks `[j * R:(j + 1) * R]` - with the render node's own per-block outputs
+    (engine.RenderPair) instead of a generic autograd slice.  Same values, same gradients (tests/test_dropin_gpu.py); what changes
+    is the backward cost: no zero-fill + copy + accumulate launches per slice.  Every other operation - any other index, any torch
+    function - sees a plain tensor and returns plain tensors."""
+    __torch_function__ = torch._C._disabled_torch_function_impl
+
+    def __getitem__(self, idx):
+        blocks = getattr(self, "_pose_blocks", None)
+        if blocks is not None and type(idx) is slice and idx.step in (None, 1):
+            R = blocks[0].shape[0]
+            a = 0 if idx.start is None else idx.start
+            b = self.shape[0] if idx.stop is None else idx.stop
+            if type(a) is int and type(b) is int and a >= 0 and b - a == R and a % R == 0 and a // R < len(blocks) and torch.is_grad_enabled():
+                return blocks[a // R]
+        return super().__getitem__(idx)
+
+
+def _pose_major(t, blocks):
+    rows = t.as_subclass(PoseMajorRows)
+    rows._pose_blocks = tuple(blocks)
+    return rows
+
+
+class _FrontStream:
+    """A second HIP stream for the parameter-independent head of Graph.forward (see there).  Tensors made inside are registered
+    with keep(): close() tells the caching allocator that the main stream uses them too (record_stream) and makes the main
+    stream wait for the front's work."""
+
+    def __init__(self, graph, dev):
+        self.on = dev.type == "cuda" and os.environ.get("BENERF_FRONT_STREAM", "1") != "0"
+        self.open = False
+        self.made = []
+        if self.on:
+            side = getattr(graph, "_front_stream", None)
+            if side is None or side.device != dev:
+                side = graph._front_stream = torch.cuda.Stream(device=dev)
+            self.side = side
+            self.main = torch.cuda.current_stream(dev)
+
+    def __enter__(self):
+        if self.on:
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+            self.open = True
+        return self
+
+    def keep(self, t):
+        if self.open and t is not None:
+            self.made.append(t)
+        return t
+
+    def close(self):
+        if self.open:
+            self.open = False
+            self.ctx.__exit__(None, None, None)
+            for t in self.made:
+                t.record_stream(self.main)
+            self.made = []
+            self.main.wait_stream(self.side)
 
 
 class _MlpPoints(torch.autograd.Function):
@@ -215,6 +284,21 @@ class Graph(nn.Module):
             raise NotImplementedError("event_bins > 1 cuts a TIME window into bins: needs args.event_time_window")
         ev = self._events_on_device(events, args.dataset == "TUM_VIE")
         He, We = args.event_height, args.event_width
+        # Everything of an iteration that depends on no parameter - the event-window accumulation (K7), the pixel draws (torch's
+        # randperm: ~18 sort launches each, 0.2 ms of device time), the eight sampling draws - runs on a second stream: when the host
+        # gets here the device is still busy with the PREVIOUS iteration's backward on the main stream (loss.backward() and the
+        # optimiser steps only queue work), so these ~80 small launches execute beside it instead of in front of the first MLP launch.
+        # Random values are fixed by the host-side call order, not by the stream.  BENERF_FRONT_STREAM=0 keeps them on the main stream.
+        front = _FrontStream(self, dev)
+        front.__enter__()
+        try:
+            out = self._forward_body(front, iter_step, ev, events, rgb_exp_ts, H, W, K, K_event, args, img_xy_remap, evt_xy_remap, bins, He, We)
+        finally:
+            front.close()
+        return out
+
+    def _forward_body(self, front, iter_step, ev, events, rgb_exp_ts, H, W, K, K_event, args, img_xy_remap, evt_xy_remap, bins, He, We):
+        dev = self._device()
         if args.event_time_window:
             window_t = args.accumulate_time_length
             if args.random_sampling_window:
@@ -242,22 +326,98 @@ class Graph(nn.Module):
             accu = K_.event_accumulate(ev["x"][lo_i:hi_i], ev["y"][lo_i:hi_i], ev["p"][lo_i:hi_i], He, We)
             ts_np = np.asarray(events["ts"])
             events_ts = ts_np[lo_i:hi_i][np.array([0, int(N_window) - 1])]
-        events_accu = accu.double()    # the reference returns float64 (utils/event_utils.py:256-257)
+        events_accu = front.keep(accu.double())    # the reference returns float64 (utils/event_utils.py:256-257)
 
-        spline_evt_poses = self.get_pose_evt(args, torch.tensor(events_ts, dtype=torch.float32), seg_num=None if bins == 1 else bins + 1)
-        spline_rgb_poses = self.get_pose_rgb(args, torch.tensor(rgb_exp_ts, dtype=torch.float32))
-
-        ray_idx_event = torch.randperm(He * We, device=dev)[:args.sampling_event_rays]
-        ret_event = self.render(iter_step, spline_evt_poses, ray_idx_event.reshape(-1, 1).squeeze(), He, We,
-                                torch.Tensor(K_event), args, enable_crf=True, sensor_type="event",
-                                remap=self._device_lut(evt_xy_remap, He, We) if args.dataset == "TUM_VIE" else torch.tensor(evt_xy_remap),
-                                training=True)
-        ray_idx_rgb = torch.randperm(H * W, device=dev)[:args.sampling_rgb_rays // args.num_interpolated_pose]
-        ret_rgb = self.render(iter_step, spline_rgb_poses, ray_idx_rgb.reshape(-1, 1).squeeze(), H, W, torch.Tensor(K),
-                              args, enable_crf=True, sensor_type="rgb",
-                              remap=self._device_lut(img_xy_remap, H, W) if args.dataset == "TUM_VIE" else torch.tensor(img_xy_remap),
-                              training=True)
+        # The reference queries the two trajectories and renders the two batches one after the other (model/nerf.py:209-232); here
+        # both trajectory evaluations are one launch (K1) and both renders one batched launch sequence behind ONE autograd node
+        # (engine.RenderPair).  Nothing in front of it synchronises the host: the window times go to the device by value, the
+        # camera matrices are read on the host (the reference's torch.Tensor(K_event) would be a device tensor under its cuda
+        # default tensor type, each K[i][j] read a round trip).  Random draws: the reference's order and shapes from the global
+        # torch generator - randperm (event pixels), four draws of the event render, randperm (blur pixels), four draws of the
+        # blur render.
+        ts_e = front.keep(self._ts_on_device(events_ts, dev))
+        ts_r = front.keep(self._ts_on_device(rgb_exp_ts, dev))
+        Pe, Pr = (2 if bins == 1 else bins + 1), args.num_interpolated_pose
+        if not self._stock_queries() or not hasattr(self, "transform") or getattr(self, "nerf_fine", None) is None or not args.use_viewdirs:
+            # a graph whose get_pose_* / render were overridden (subclass or instance), one without the optimize.py members or
+            # without a fine network: the reference's own sequence of four calls
+            front.close()
+            spline_evt_poses = self.get_pose_evt(args, ts_e, seg_num=None if bins == 1 else bins + 1)
+            spline_rgb_poses = self.get_pose_rgb(args, ts_r)
+            ray_idx_event = torch.randperm(He * We, device=dev)[:args.sampling_event_rays]
+            ret_event = self.render(iter_step, spline_evt_poses, ray_idx_event, He, We, K_event, args, enable_crf=True, sensor_type="event",
+                                    remap=evt_xy_remap, training=True)
+            ray_idx_rgb = torch.randperm(H * W, device=dev)[:args.sampling_rgb_rays // args.num_interpolated_pose]
+            ret_rgb = self.render(iter_step, spline_rgb_poses, ray_idx_rgb, H, W, K, args, enable_crf=True, sensor_type="rgb",
+                                  remap=img_xy_remap, training=True)
+            return ret_event, ret_rgb, ray_idx_event, ray_idx_rgb, events_accu
+        tum = args.dataset == "TUM_VIE"
+        cam_e = Camera.from_K(He, We, K_event, self._device_lut(evt_xy_remap, He, We) if tum else None)
+        cam_r = Camera.from_K(H, W, K, self._device_lut(img_xy_remap, H, W) if tum else None)
+        S, Ni = args.N_samples, args.N_importance
+        std = float(getattr(args, "benerf_raw_noise_std", engine.NOISE_STD_DEFAULT))
+        n_rgb_pix = args.sampling_rgb_rays // args.num_interpolated_pose
+        Ne, Nr = Pe * args.sampling_event_rays, Pr * n_rgb_pix
+        N = Ne + Nr
+        philox = getattr(args, "benerf_rng", "torch") == "philox"
+        ray_idx_event = front.keep(torch.randperm(He * We, device=dev))[:args.sampling_event_rays]
+        if philox:
+            ray_idx_rgb = front.keep(torch.randperm(H * W, device=dev))[:n_rgb_pix]
+            self._philox_calls = getattr(self, "_philox_calls", 0) + 2
+            draws = Draws(seed=int(getattr(args, "benerf_seed", 0)), offset=self._philox_calls, noise_std=std)
+        else:
+            f32 = dict(dtype=torch.float32, device=dev)
+            t_rand, u = front.keep(torch.empty((N, S), **f32)), front.keep(torch.empty((N, Ni), **f32))
+            noise0 = front.keep(torch.empty((N, S), **f32)) if std > 0 else None
+            noise1 = front.keep(torch.empty((N, S + Ni), **f32)) if std > 0 else None
+            for a, b in ((0, Ne), (Ne, N)):
+                if a:
+                    ray_idx_rgb = front.keep(torch.randperm(H * W, device=dev))[:n_rgb_pix]
+                _draw(torch.rand, (b - a, S), dev, out=t_rand[a:b])
+                if std > 0:
+                    _draw(torch.randn, (b - a, S), dev, std, out=noise0[a:b])
+                _draw(torch.rand, [b - a, Ni], dev, out=u[a:b])
+                if std > 0:
+                    _draw(torch.randn, (b - a, S + Ni), dev, std, out=noise1[a:b])
+            draws = Draws(t_rand, noise0, u, noise1, noise_std=0.0 if std <= 0 else std)
+        ray_idx_event, ray_idx_rgb = front.keep(ray_idx_event.contiguous()), front.keep(ray_idx_rgb.contiguous())
+        front.close()          # back on the main stream, which now waits for the front
+        traj = {"spline": 0, "linear": 1}[args.traj]
+        spline_evt_poses, spline_rgb_poses = engine.SplinePosesPair.apply(self.evt_knot_pose_se3.params.weight, self.transform.params.weight,
+                                                                        ts_e, ts_r, Pe, Pr, traj)
+        net_c, net_f = self.nerf.packed(), self.nerf_fine.packed()
+        net_c.pe_weights = net_f.pe_weights = barf_weights(iter_step, args, dev)
+        chunks = os.environ.get("BENERF_POSE_BLOCKS", "1") != "0" and torch.is_grad_enabled()
+        outs = engine.RenderPair.apply(spline_evt_poses, spline_rgb_poses, ray_idx_event, ray_idx_rgb, cam_e, cam_r,
+                                       bool(args.ndc), S, Ni, draws, net_c, net_f, chunks, *net_c.weights, *net_c.biases, *net_f.weights, *net_f.biases)
+        keys = ("rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "sigma")
+        ret_event, ret_rgb = dict(zip(keys, outs[:7])), dict(zip(keys, outs[7:14]))
+        if chunks and len(outs) > 14:
+            o = 14
+            for ret, P in ((ret_event, Pe), (ret_rgb, Pr)):
+                for key in ("rgb_map", "rgb0"):
+                    ret[key] = _pose_major(ret[key], outs[o:o + P])
+                    o += P
         return ret_event, ret_rgb, ray_idx_event, ray_idx_rgb, events_accu
+
+    def _stock_queries(self):
+        """True if get_pose_evt / get_pose_rgb / render are the stock implementations (model/optimize.py's Graph, this class):
+        only then may Graph.forward replace the four calls by the fused pair of nodes."""
+        stock = getattr(type(self), "_stock_pose_queries", None)
+        if stock is None or any(n in self.__dict__ for n in ("get_pose_evt", "get_pose_rgb", "render")):
+            return False
+        return all(getattr(type(self), n, None) is f for n, f in stock.items()) and type(self).render is Graph.render
+
+    def _ts_on_device(self, ts, dev):
+        """[t0, t1] as a float32 device tensor WITHOUT a host-to-device copy (which, from pageable memory, waits for everything
+        queued on the stream - i.e. for the previous iteration's backward): two fills by value."""
+        if torch.is_tensor(ts) and ts.is_cuda:
+            return ts.reshape(-1)[:2].to(torch.float32)
+        v = np.asarray(ts.detach().cpu() if torch.is_tensor(ts) else ts, dtype=np.float64).reshape(-1)
+        out = torch.empty(2, dtype=torch.float32, device=dev)
+        out[0:1].fill_(float(np.float32(v[0])))
+        out[1:2].fill_(float(np.float32(v[1])))
+        return out
 
     # ---- render -------------------------------------------------------------------------------------------
     def render(self, iter_step, poses, ray_idx, H, W, K, args, enable_crf: bool, sensor_type: str,

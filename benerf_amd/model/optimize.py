@@ -7,6 +7,7 @@ from .. import engine
 from . import nerf
 from .component import ColorToneMapper, LuminanceToneMapper
 from .component import ControlKnotLieAlgebra, TransformationLieAlgebra
+from ..optim import FlatAdam
 
 
 class Model(nerf.Model):
@@ -34,17 +35,18 @@ class Model(nerf.Model):
         return g
 
     def setup_optimizer(self, args):
-        """Five Adam optimisers with torch defaults (model/optimize.py:36-55)."""
+        """Five Adam optimisers with torch defaults (model/optimize.py:36-55).  They ARE torch.optim.Adam objects (param_groups,
+        state, state_dict format, zero_grad) whose step() is one fused launch over a flat parameter arena: benerf_amd/optim.py."""
         g = self.graph
+        # the reference's parameter order: a checkpoint's optimizer state_dict maps state to parameters BY POSITION (train.py:443-455)
         grad_vars = list(g.nerf.parameters())
         if args.N_importance > 0:
             grad_vars += list(g.nerf_fine.parameters())
-        self.optim_nerf = torch.optim.Adam(params=grad_vars, lr=args.lrate)
-        self.optim_pose = torch.optim.Adam(params=list(g.evt_knot_pose_se3.parameters()), lr=args.pose_lrate)
-        self.optim_transform = torch.optim.Adam(params=list(g.transform.parameters()), lr=args.transform_lrate)
-        self.optim_event_crf = torch.optim.Adam(params=list(g.event_crf.mlp_luminance.parameters()),
-                                                lr=args.event_crf_lrate)
-        self.optim_rgb_crf = torch.optim.Adam(params=list(g.rgb_crf.mlp_gray.parameters()), lr=args.rgb_crf_lrate)
+        self.optim_nerf = FlatAdam(params=grad_vars, lr=args.lrate)
+        self.optim_pose = FlatAdam(params=list(g.evt_knot_pose_se3.parameters()), lr=args.pose_lrate)
+        self.optim_transform = FlatAdam(params=list(g.transform.parameters()), lr=args.transform_lrate)
+        self.optim_event_crf = FlatAdam(params=list(g.event_crf.mlp_luminance.parameters()), lr=args.event_crf_lrate)
+        self.optim_rgb_crf = FlatAdam(params=list(g.rgb_crf.mlp_gray.parameters()), lr=args.rgb_crf_lrate)
         return self.optim_nerf, self.optim_pose, self.optim_transform, self.optim_rgb_crf, self.optim_event_crf
 
 
@@ -67,3 +69,5 @@ class Graph(nerf.Graph):
         """RGB-camera poses: knots + transform in se(3), linspace over the exposure
         (model/optimize.py:84-111)."""
         return self._poses(args, exposure_ts, args.num_interpolated_pose if seg_num is None else seg_num, True)
+
+    _stock_pose_queries = {"get_pose_evt": get_pose_evt, "get_pose_rgb": get_pose_rgb}

@@ -43,8 +43,8 @@ class Recorder:
             self.perms.append(out.detach().cpu())
             return out
 
-        def draw(fn, shape, device, scale=None):
-            out = orig_draw(fn, shape, device, scale)
+        def draw(fn, shape, device, scale=None, **kw):
+            out = orig_draw(fn, shape, device, scale, **kw)
             self.draws.append(out.detach().cpu())
             return out
 
@@ -142,10 +142,12 @@ def test_train_py_shaped_loop(installed, monkeypatch):
             target_s *= torch.tensor(args.event_threshold)
             fine_bright2 = rgb2brightlog(ret_gray2["rgb_map"], args.dataset)
             fine_bright1 = rgb2brightlog(ret_gray1["rgb_map"], args.dataset)
-            event_loss_fine = mse_loss((fine_bright2 - fine_bright1), target_s) * args.event_coeff_syn
+            event_loss_fine = mse_loss((fine_bright2 - fine_bright1), target_s)
+            event_loss_fine *= args.event_coeff_syn           # in place, as train.py:222 does it
             coarse_bright2 = rgb2brightlog(ret_gray2["rgb0"], args.dataset)
             coarse_bright1 = rgb2brightlog(ret_gray1["rgb0"], args.dataset)
-            event_loss_coarse = mse_loss((coarse_bright2 - coarse_bright1), target_s) * args.event_coeff_syn
+            event_loss_coarse = mse_loss((coarse_bright2 - coarse_bright1), target_s)
+            event_loss_coarse *= args.event_coeff_syn
             loss += event_loss_coarse + event_loss_fine
             image = torch.Tensor(img[0])
             target_rgb = image.reshape(-1, H * W, args.channels)[:, ray_idx_rgb].reshape(-1, args.channels)
@@ -155,7 +157,11 @@ def test_train_py_shaped_loop(installed, monkeypatch):
                 blur += ret_rgb["rgb_map"][j * interval:(j + 1) * interval]
                 blur0 += ret_rgb["rgb0"][j * interval:(j + 1) * interval]
             blur, blur0 = blur / args.num_interpolated_pose, blur0 / args.num_interpolated_pose
-            loss += (mse_loss(blur, target_rgb) + mse_loss(blur0, target_rgb)) * args.rgb_coeff
+            rgb_loss_fine = mse_loss(blur, target_rgb)
+            rgb_loss_fine *= args.rgb_coeff                   # train.py:321
+            rgb_loss_coarse = mse_loss(blur0, target_rgb)
+            rgb_loss_coarse *= args.rgb_coeff
+            loss += rgb_loss_fine + rgb_loss_coarse
             loss.backward()
             hip_knot_grad = graph.evt_knot_pose_se3.params.weight.grad.detach().cpu().clone()
             hip_w_grad = graph.nerf_fine.pts_linears[7].weight.grad.detach().cpu().clone()
