@@ -229,6 +229,7 @@ class RenderRays(torch.autograd.Function):
     @staticmethod
     def forward(ctx, poses, ray_idx, cam, ndc, n_samples, n_importance, draws, net_c, net_f, *params):
         poses_c = poses.detach().contiguous()
+        ctx.set_materialize_grads(False)
         need_grad = any(ctx.needs_input_grad)
         if need_grad and K.is_split():
             # range guard of the autograd path: the previous backward posted the device's status words to pinned host memory;
@@ -288,6 +289,7 @@ class RenderPair(torch.autograd.Function):
     def forward(ctx, poses_e, poses_r, idx_e, idx_r, cam_e, cam_r, ndc, n_samples, n_importance, draws, net_c, net_f, pose_chunks, *params):
         pe, pr = poses_e.detach().contiguous(), poses_r.detach().contiguous()
         dev = pe.device
+        ctx.set_materialize_grads(False)       # outputs no loss uses (disp, acc, unused blocks) arrive as None, not as zero-filled tensors
         need_grad = any(ctx.needs_input_grad)
         if need_grad and K.is_split():
             K.range_guard(dev).poll()          # what the previous backward posted (see RenderRays.forward)
@@ -558,6 +560,10 @@ class TrainStep:
             self.crf_groups.append((first, oc - first, lr0, dr, slot))
         self.off_crf = o + 31
         self.global_step = 0
+        # keep_maps: parity runs set it - the step then also composites acc / disp and leaves the per-ray outputs of its two
+        # compositing passes in last_maps (rows: event batch pose-major, then blur batch pose-major)
+        self.keep_maps = False
+        self.last_maps = None
         self._prefetched = None     # next step's ray set-up, computed in this step's slack (step(overlap=...))
         # replicas start from rank 0's parameters (and its - zero - Adam state), whatever their local initialisation was
         for buf in (self.flat_p, self.flat_m, self.flat_v):
@@ -746,13 +752,17 @@ class TrainStep:
         self.net_c.packed.pe_weights = self.net_f.packed.pe_weights = pw
         raw0, acts0 = K.mlp_fwd(self.net_c.packed, ro, rd, vd, z, True, status=st)
         nz0 = d.noise_args(0)
-        c0 = K.composite_fwd(raw0, z, rd, nz0[0], nz0[1], nz0[2], nz0[3], want=("rgb_map", "weights"))
+        extra = ("disp", "acc") if self.keep_maps else ()
+        c0 = K.composite_fwd(raw0, z, rd, nz0[0], nz0[1], nz0[2], nz0[3], want=("rgb_map", "weights") + extra)
         u, usd, uoff = d.u_args()
         z_fine = K.sample_pdf_merge(z, c0["weights"], Ni, u, usd, uoff) if z_fine_forced is None else z_fine_forced.contiguous()
         raw1, acts1 = K.mlp_fwd(self.net_f.packed, ro, rd, vd, z_fine, True, status=st)
         nz1 = d.noise_args(1)
-        c1 = K.composite_fwd(raw1, z_fine, rd, nz1[0], nz1[1], nz1[2], nz1[3], want=("rgb_map",))
+        c1 = K.composite_fwd(raw1, z_fine, rd, nz1[0], nz1[1], nz1[2], nz1[3], want=("rgb_map",) + extra)
         rgb_map, rgb0 = c1["rgb_map"], c0["rgb_map"]
+        if self.keep_maps:
+            self.last_maps = {"rgb_map": rgb_map, "rgb0": rgb0, "acc_map": c1["acc"], "acc0": c0["acc"], "disp_map": c1["disp"],
+                              "disp0": c0["disp"], "n_event_rays": Ne}
 
         # ---- loss + gradient w.r.t. rendered colours (K6) ------------------------------------------
         target_rgb = K.gather_rows(image, idx_r)

@@ -64,6 +64,7 @@ def step_grads(cfg, pc, pf, knots, transform, evt_ts, rgb_ts, idx_evt, idx_rgb, 
         z_out = {k: tuple(torch.empty(shape, dtype=torch.float32) for shape in ((n, S), (n, F), (n, S, 3), (n, F, 3), (n, 3)))
                  for k, n in (("evt", 2 * Re), ("rgb", P * Rr))}
         total = 0.0
+        maps = {k: {} for k in ("evt", "rgb")}       # per-ray outputs of both renders (float32): rgb_map, rgb0, acc_map, acc0, disp_map, disp0
         eb = np.linspace(0, Re, n_chunks + 1).astype(int)
         rb = np.linspace(0, Rr, n_chunks + 1).astype(int)
         for c in range(n_chunks):
@@ -87,12 +88,26 @@ def step_grads(cfg, pc, pf, knots, transform, evt_ts, rgb_ts, idx_evt, idx_rgb, 
             for key, rows, ex in (("evt", rows_e, parts["extras_evt"]), ("rgb", rows_r, parts["extras_rgb"])):
                 for j, name in enumerate(("z_coarse", "z_fine", "pts_coarse", "pts_fine", "viewdirs")):
                     z_out[key][j][rows] = ex[name].detach().float()
+            _store_maps(maps["evt"], parts["ret_event"], rows_e, 2 * Re)
+            _store_maps(maps["rgb"], parts["ret_rgb"], rows_r, P * Rr)
             del loss, parts, part
         grads = {"knots": kn.grad.double(), "transform": tr.grad.double()}
         for tag, q in (("nerf", qc), ("nerf_fine", qf)):
             for k, v in q.items():
                 grads[tag + "." + k] = v.grad.double()
-    return {"loss": total, "grads": grads, "z": z_out}
+    return {"loss": total, "grads": grads, "z": z_out, "maps": maps}
+
+
+MAP_KEYS = ("rgb_map", "rgb0", "acc_map", "acc0", "disp_map", "disp0")
+
+
+def _store_maps(dst, ret, rows, n_total):
+    """rows of the per-ray outputs of one render chunk -> float32 arrays over the whole batch"""
+    for k in MAP_KEYS:
+        v = ret[k].detach().float()
+        if k not in dst:
+            dst[k] = torch.empty((n_total,) + tuple(v.shape[1:]), dtype=torch.float32)
+        dst[k][rows] = v
 
 
 def step_grads_vjp(cfg, pc, pf, knots, transform, evt_ts, rgb_ts, idx_evt, idx_rgb, target_acc, target_rgb, draws_evt, draws_rgb,
@@ -139,11 +154,14 @@ def step_grads_vjp(cfg, pc, pf, knots, transform, evt_ts, rgb_ts, idx_evt, idx_r
                                    _chunk_draws(draws_rgb, rows_r, dtype), z_forced=zf_r, want_extras=True)
             return rows_e, rows_r, ret_e, ret_r, ex_e, ex_r
 
+        maps = {k: {} for k in ("evt", "rgb")}
         with torch.no_grad():
             for c in range(n_chunks):
                 rows_e, rows_r, ret_e, ret_r, ex_e, ex_r = renders(c, False)
                 col["e1"][rows_e], col["e0"][rows_e] = ret_e["rgb_map"], ret_e["rgb0"]
                 col["r1"][rows_r], col["r0"][rows_r] = ret_r["rgb_map"], ret_r["rgb0"]
+                _store_maps(maps["evt"], ret_e, rows_e, Pe * Re)
+                _store_maps(maps["rgb"], ret_r, rows_r, P * Rr)
                 for key, rows, ex in (("evt", rows_e, ex_e), ("rgb", rows_r, ex_r)):
                     z_out[key][0][rows] = ex["z_coarse"].float()
                     z_out[key][1][rows] = ex["z_fine"].float()
@@ -165,7 +183,7 @@ def step_grads_vjp(cfg, pc, pf, knots, transform, evt_ts, rgb_ts, idx_evt, idx_r
         for tag, q in (("nerf", qc), ("nerf_fine", qf)):
             for k, v in q.items():
                 grads[tag + "." + k] = v.grad.double()
-    return {"loss": float(loss.detach()), "grads": grads, "z": z_out}
+    return {"loss": float(loss.detach()), "grads": grads, "z": z_out, "maps": maps}
 
 
 def error_table(truth, candidates):

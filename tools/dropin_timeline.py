@@ -2,17 +2,17 @@
 """Per-launch timeline of ONE iteration of the reference-shaped training loop (tools/dropin_driver.py) out of a rocprofv3 kernel
 trace, cut into the sections a reader of train.py knows:
 
-    front      graph.forward up to the first MLP launch (event window, pixel draws, sampling draws, trajectory, rays)
     render     first MLP forward launch .. last compositing launch of graph.forward
     loss       train.py:163-337 - the loss lines on torch tensors, their `.item()` reads, and the autograd backward of those lines
                (everything between the render's last forward launch and its first backward launch)
     backward   first compositing-backward launch .. the last launch of loss.backward()
-    optimise   the optimiser steps + whatever else precedes the next iteration's first launch
+    optimise+front   the optimiser steps, then the NEXT iteration's graph.forward up to its first MLP launch (event window, pixel
+               draws, sampling draws - on a second stream, started while the backward launches above still run -, trajectory, rays)
 
     rocprofv3 --kernel-trace --output-format csv -d OUT -o t -- python tools/dropin_driver.py --steps 6 --warmup 3
     python tools/dropin_timeline.py OUT/**/t_kernel_trace.csv [--json] [--step-from-end 2]
 
-A step starts at its event-window accumulation launch (K7: the first launch of Graph.forward).  `busy` = union of the launch
+A step is cut at its first MLP forward launch.  `busy` = union of the launch
 intervals, `idle` = span - busy: device time with nothing to run, i.e. the host (python / autograd) deciding what to launch next.
 """
 import collections
@@ -52,14 +52,18 @@ def union(iv):
 K3 = ("mlp_fwd", "mlp_bwd", "mlp_dw", "dw_reduce", "dw_compose")
 
 
-def sections(seg):
-    """indices into seg: (first mlp fwd, last composite_fwd, first composite_bwd, last backward-side launch)"""
-    names = [short(r[0]) for r in seg]
-    i_fwd = next(i for i, n in enumerate(names) if n.startswith("mlp_fwd"))
-    i_cf = max(i for i, n in enumerate(names) if n.startswith("composite_fwd"))
-    i_cb = next(i for i, n in enumerate(names) if n.startswith("composite_bwd"))
-    i_bw = max(i for i, n in enumerate(names) if n.startswith(("spline_bwd", "rays_bwd", "dw_compose", "dw_reduce")))
-    return i_fwd, i_cf, i_cb, i_bw
+def first_fwd_of_steps(rows):
+    """index of the first MLP forward launch of every iteration (the coarse one: the forward launch that follows a launch of the
+    backward side or the start of the trace)"""
+    out, seen_bwd = [], True
+    for i, r in enumerate(rows):
+        n = short(r[0])
+        if n.startswith("mlp_fwd") and seen_bwd:
+            out.append(i)
+            seen_bwd = False
+        elif n.startswith(("mlp_bwd", "mlp_dw")):
+            seen_bwd = True
+    return out
 
 
 def main():
@@ -69,15 +73,18 @@ def main():
     if "--step-from-end" in sys.argv:
         back = int(sys.argv[sys.argv.index("--step-from-end") + 1])
     rows = load(path)
-    starts = [i for i, r in enumerate(rows) if "event_window_accumulate" in r[0] or "event_accumulate" in r[0]]
+    starts = first_fwd_of_steps(rows)
     if len(starts) < back + 1:
         sys.exit("not enough steps in the trace")
     per_step = [starts[k + 1] - starts[k] for k in range(len(starts) - 1)]
     seg = rows[starts[-back - 1]:starts[-back]]
     t0 = seg[0][1]
     t_end = rows[starts[-back]][1]
-    i_fwd, i_cf, i_cb, i_bw = sections(seg)
-    cuts = [("front", 0, i_fwd), ("render", i_fwd, i_cf + 1), ("loss", i_cf + 1, i_cb), ("backward", i_cb, i_bw + 1), ("optimise", i_bw + 1, len(seg))]
+    names = [short(r[0]) for r in seg]
+    i_cf = max(i for i, n in enumerate(names) if n.startswith("composite_fwd"))
+    i_cb = next(i for i, n in enumerate(names) if n.startswith("composite_bwd"))
+    i_bw = max(i for i, n in enumerate(names) if n.startswith(("spline_bwd", "rays_bwd", "dw_compose", "dw_reduce")))
+    cuts = [("render", 0, i_cf + 1), ("loss", i_cf + 1, i_cb), ("backward", i_cb, i_bw + 1), ("optimise+front", i_bw + 1, len(seg))]
     summ = {"launches_per_step": per_step[-back], "launches_per_step_all": per_step, "span_ms": round((t_end - t0) / 1e6, 3), "sections": {}}
     bounds = {}
     for name, a, b in cuts:
@@ -87,7 +94,8 @@ def main():
             continue
         s0 = seg[a][1] if a else t0
         s1 = seg[b][1] if b < len(seg) else t_end
-        busy = union([(max(r[1], s0), min(r[2], s1)) for r in part if min(r[2], s1) > max(r[1], s0)])
+        # busy: every launch that overlaps the section's window counts (launches of the second stream started earlier included)
+        busy = union([(max(r[1], s0), min(r[2], s1)) for r in seg if min(r[2], s1) > max(r[1], s0)])
         k3 = sum(r[2] - r[1] for r in part if short(r[0]).startswith(K3))
         summ["sections"][name] = {"launches": len(part), "span_ms": round((s1 - s0) / 1e6, 3), "busy_ms": round(busy / 1e6, 3),
                                   "idle_ms": round((s1 - s0 - busy) / 1e6, 3), "k3_ms": round(k3 / 1e6, 3)}
