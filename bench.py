@@ -612,9 +612,8 @@ def main():
         if a.event_bins == 1:
             K.event_window_accumulate(ev_x, ev_y, ev_p, ev_t, low_t, up_t, cam["H"], cam["W"], out=accu[0])
         else:       # one K7 pass per bin over the device-resident sorted stream; bin edges = the f32 linspace the poses are evaluated at
-            edges = torch.linspace(low_t, up_t, a.event_bins + 1, dtype=torch.float32).tolist()
-            for b in range(a.event_bins):
-                K.event_window_accumulate(ev_x, ev_y, ev_p, ev_t, edges[b], edges[b + 1], cam["H"], cam["W"], out=accu[b])
+            for b, (lo_b, up_b) in enumerate(K.event_bin_windows(low_t, up_t, a.event_bins)):      # interior bins half-open: no event counted twice
+                K.event_window_accumulate(ev_x, ev_y, ev_p, ev_t, lo_b, up_b, cam["H"], cam["W"], out=accu[b])
         evt_ts = torch.full((2,), low_t, dtype=torch.float32, device=device)      # scalars by value: no host buffer to keep alive
         evt_ts[1:].fill_(up_t)
         idx_e = K.sample_pixels(HW, Re_g, a.seed + 1234, 2 * k + 2, device)
@@ -724,6 +723,30 @@ def main():
             K.TIMERS.enabled = False
             n_l, ms_l, pts_l = K.TIMERS.summary().get("mlp_fwd", (0, 0.0, 0))
             K.TIMERS.records.clear()
+            # (iii) a FRAME as the unit of inference: Graph.render_video on the workload's camera (what test.py:112-135 and
+            # train.py:404-441 call through render_image_test / render_video_test) - H x W rays in chunks of args.chunk, the four draws
+            # per chunk from torch's generator like the reference, outputs concatenated into [H, W, ...] tensors
+            frame = None
+            try:
+                Kmat = np.array([[cam["fx"], 0, cam["cx"]], [0, cam["fy"], cam["cy"]], [0, 0, 1]], dtype=np.float32)
+                g.render_video(0, pose1, cam["H"], cam["W"], Kmat, args_ns, np.array([]), type="rgb")      # warm-up frame
+                torch.cuda.synchronize()
+                n_frames = 3
+                tf0 = time.perf_counter()
+                for _ in range(n_frames):
+                    fr = g.render_video(0, pose1, cam["H"], cam["W"], Kmat, args_ns, np.array([]), type="rgb")
+                torch.cuda.synchronize()
+                dt_f = (time.perf_counter() - tf0) / n_frames
+                n_ch = (HW + chunk - 1) // chunk
+                frame = {"frame_ms": round(dt_f * 1e3, 2), "frames_per_s": round(1.0 / dt_f, 2), "frame": "%dx%d" % (cam["H"], cam["W"]),
+                         "rays_per_frame": HW, "chunks_per_frame": n_ch, "frame_rays_per_s": round(HW / dt_f, 1),
+                         "launches_per_chunk": "4 draws (torch.rand / randn, the reference's) + rays_fwd, stratified_z, mlp_fwd (coarse; split + "
+                                               "the normally empty exact-f32 fallback), composite_fwd, sample_pdf_merge, mlp_fwd (fine; "
+                                               "split + fallback), composite_fwd = 13; then one torch.cat per output map and frame",
+                         "shape_ok": list(fr["rgb_map"].shape) == [cam["H"], cam["W"], wl["channels"]]}
+                del fr
+            except Exception as e:      # noqa: BLE001 - informational
+                frame = {"error": repr(e)[:200]}
             if n_l:
                 fpp_i = WL.mlp_flops_per_point(wl["channels"])
                 pk_i = F16_MFMA_PEAK_TFLOPS if split_mode(a) else F32_MFMA_PEAK_TFLOPS
@@ -739,6 +762,8 @@ def main():
                                     "launches of a chunk (coarse %d + fine %d samples per ray), averaged; in the split mode an inference "
                                     "launch is BENERF_MLP_AUTO: the split launch + the normally empty exact-f32 fallback launch"
                                     % (wl["S"], wl["S"] + wl["Ni"])}
+                if frame is not None:
+                    roof_inf.update(frame)
 
     # ---- secondary: the same training step with exact-f32 MFMA products (the strict arithmetic mode), >= 20 timed steps,
     # its own per-kernel HIP-event durations -> `exact_f32` + `roofline_f32` in the JSON line --------------------------------

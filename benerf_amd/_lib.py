@@ -35,6 +35,7 @@ class LossCfg(Structure):
 
 
 P = c_void_p
+ABI_VERSION = 102       # include/benerf_hip.h: BENERF_ABI_VERSION
 _SIGNATURES = {
     "benerf_version": (c_int, []),
     "benerf_last_error": (c_char_p, []),
@@ -109,6 +110,9 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing: fail loudly
         fn.restype = res
         fn.argtypes = args
+    if lib.benerf_version() != ABI_VERSION:       # a stale in-tree build, or a library of another revision on the path
+        raise BenerfHipError("libbenerf_hip.so at %s reports ABI revision %d, this binding is written against %d (include/benerf_hip.h: "
+                             "BENERF_ABI_VERSION) - rebuild with `make -C benerf_amd/csrc`" % (LIB_PATH, lib.benerf_version(), ABI_VERSION))
     _lib = lib
     return lib
 

@@ -11,7 +11,7 @@ void benerf_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int benerf_version(void) { return 100; }
+extern "C" int benerf_version(void) { return BENERF_ABI_VERSION; }      // include/benerf_hip.h
 extern "C" const char* benerf_last_error(void) { return g_err; }
 
 // Range guard of the split-f16 MLP mode (include/benerf_hip.h, benerf_mlp_status_check): the only entry point that

@@ -74,7 +74,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t dw_rsrc(const void* p) {
     return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(wau), 0, 0x7fffffff, 0x00020000);
 }
 // cache policy of the operand loads: every byte of the saved activations / gradients is read by exactly ONE workgroup, once (aux 2 = nt on
-// gfx950; measured: see DWS_NT in profiles/r05_dw_nt_loads_ab.log)
+// gfx950; measured: -0.3 % of the step for these loads alone, profiles/r05_cache_policy_ab.log)
 #ifndef DWS_NT
 #define DWS_NT 2
 #endif

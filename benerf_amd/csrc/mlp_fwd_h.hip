@@ -16,6 +16,9 @@
 // arrays as SH arrays from the finished planes); BENERF_MLP_SPLIT_F16BWD (SAVE == 1) - the hi halves as SH arrays (mlp_split.h).
 #define BENERF_HSW_V2      // this kernel's planes use the round-5 slot swizzle (mlp_split.h: hsw)
 #include "mlp_split.h"
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "mlp_fwd_h.hip is written for gfx950: scalar stores (s_store_dwordx2 + s_dcache_wb), aux = 2 cache policy, v_permlane32_swap"
+#endif
 // Cache policy of the saved-operand stores (aux of raw_buffer_store on gfx950: 0 default, 1 = sc0, 2 = nt, 16 = sc1).  The activations are
 // written once and read ~2 ms later by another kernel - 2.8 GB per 522 k-point launch streaming through the 4 MiB L2 of an XCD, where the
 // weight fragments every K-loop re-reads (2.3 MB per network) live.  nt: C2 step 7.96-7.99 -> 7.66-7.72 ms with the dX kernel's stores
@@ -653,7 +656,9 @@ __global__ __launch_bounds__(FNT, 1) void mlp_fwd_split_kernel(FwdArgs a) {
         }
     }
     TRF(20);
-    if (SAVE == 2) asm volatile("s_dcache_wb" ::: "memory");      // the sign-bit words went through the scalar data cache
+    // the sign-bit words went through the scalar data cache: scalar stores are invisible to the compiler's wait-count tracking, so
+    // wait for them explicitly, then write the cache back
+    if (SAVE == 2) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb" ::: "memory");
 }
 
 }  // namespace

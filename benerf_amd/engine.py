@@ -111,8 +111,10 @@ class SplinePosesPair(torch.autograd.Function):
         return dk_a.add_(dk_b), dt_b.reshape(tr_shape), None, None, None, None, None
 
 
-def _render_forward(cam, ndc, n_samples, n_importance, draws, poses, ray_idx, net_c, net_f, save):
-    """Shared forward kernel sequence of Graph.render.  Returns (outputs dict, saved dict)."""
+def _render_forward(cam, ndc, n_samples, n_importance, draws, poses, ray_idx, net_c, net_f, save, z_fine_forced=None):
+    """Shared forward kernel sequence of Graph.render.  Returns (outputs dict, saved dict).
+    z_fine_forced [N, S + Ni]: parity runs may hand in the merged fine depths of another evaluation instead of K5's
+    (sample_pdf is ill-conditioned in the coarse weights: this isolates everything behind it)."""
     ro, rd, vd = K.rays_fwd(poses, ray_idx, cam.H, cam.W, cam.fx, cam.fy, cam.cx, cam.cy, ndc, remap=cam.remap)
     n_rays = ro.shape[0]
     t_rand, seed, off = draws.jitter_args()
@@ -125,7 +127,7 @@ def _render_forward(cam, ndc, n_samples, n_importance, draws, poses, ray_idx, ne
     saved = {"ro": ro, "rd": rd, "vd": vd, "z": z, "raw0": raw0, "acts0": acts0}
     if n_importance > 0:
         u, useed, uoff = draws.u_args()
-        z_fine = K.sample_pdf_merge(z, c0["weights"], n_importance, u, useed, uoff)
+        z_fine = K.sample_pdf_merge(z, c0["weights"], n_importance, u, useed, uoff) if z_fine_forced is None else z_fine_forced.contiguous()
         raw1, acts1 = K.mlp_fwd(net_f, ro, rd, vd, z_fine, save)
         nz1 = draws.noise_args(1)
         c1 = K.composite_fwd(raw1, z_fine, rd, nz1[0], nz1[1], nz1[2], nz1[3], want=("rgb_map", "disp", "acc", "sigma"))
@@ -651,8 +653,14 @@ class TrainStep:
         """This rank's contiguous slices of the global event / blur pixel-index vectors."""
         if not self.uneven_shards or self.world == 1:
             return dist.shard_indices(idx_evt, self.rank, self.world), dist.shard_indices(idx_rgb, self.rank, self.world)
-        (e0, e1), (r0, r1) = dist.balanced_shard_bounds(idx_evt.shape[0], idx_rgb.shape[0], self.event_bins + 1,
-                                                        self.cfg.num_interpolated_pose, self.world)[self.rank]
+        table = dist.balanced_shard_bounds(idx_evt.shape[0], idx_rgb.shape[0], self.event_bins + 1, self.cfg.num_interpolated_pose, self.world)
+        # every rank computes the whole table and refuses the SAME batches: a rank with no event or no blur pixels would fail in its
+        # own kernels (positive sizes required) and leave the others waiting in the all-reduce
+        empty = [k for k, ((a0, a1), (b0, b1)) in enumerate(table) if a1 <= a0 or b1 <= b0]
+        if empty:
+            raise ValueError("TrainStep(uneven_shards): %d event / %d blur pixels over %d ranks leave rank(s) %s without event or blur "
+                             "pixels - use a larger global batch or fewer ranks" % (idx_evt.shape[0], idx_rgb.shape[0], self.world, empty))
+        (e0, e1), (r0, r1) = table[self.rank]
         return idx_evt[e0:e1].contiguous(), idx_rgb[r0:r1].contiguous()
 
     def _ray_setup(self, evt_ts2, rgb_ts2, idx_e, idx_r, d):

@@ -498,6 +498,12 @@ def mlp_bwd_dw(net, d_raw, acts, dacts, n_rays, n_samples, grad_w, grad_b, accum
     ws = scratch("dw_ws", ws_floats, d_raw.device)
     pe_w = getattr(acts, "benerf_pe_weights", net.pe_weights)
     g = _param_struct(MlpGrads, grad_w, grad_b)
+    if code == MLP_PRECISIONS["split"] and net.version is not None and net._key() != net.version:
+        # BENERF_MLP_SPLIT composes the feature / views weight gradients from G = dhv^T h7 and the LIVE W_v, W_f, b_f, while the forward
+        # and dX passes used the W_c = W_v[:, :256] W_f snapshot of the last pack(): parameters rewritten in between (an optimiser step,
+        # a checkpoint load) would give silently inconsistent gradients
+        raise _lib.BenerfHipError("mlp_bwd_dw(split): the network's parameters changed since its weights were packed (between the forward "
+                                  "pass and this backward call): the composed feature / views gradients would mix two parameter sets")
     s = net.struct()        # BENERF_MLP_SPLIT composes the feature / views weight gradients from dhv^T h7 and these weights
     _timer("mlp_bwd_dw", M)
     _lib.check(lib.benerf_mlp_bwd_dw(ctypes.byref(s), net.channels, n_rays, n_samples, _chk(d_raw), _chk(acts), dacts.data_ptr(),
@@ -633,6 +639,17 @@ def event_window_accumulate(xs, ys, ps, ts, low_t, upper_t, H, W, out=None):
                                                   float(upper_t), H, W, out.data_ptr(), _stream()),
                "event_window_accumulate")
     return out
+
+
+def event_bin_windows(low_t, upper_t, bins):
+    """[(lo_b, up_b)] of `bins` contiguous equal bins of the window [low_t, upper_t] for event_window_accumulate, whose window is
+    CLOSED on both ends like the reference's single window (model/nerf.py:170: low_t <= ts <= upper_t).  Edges = the float32
+    linspace the trajectory kernel evaluates the bins + 1 event poses at.  Interior bins are half-open [t_b, t_b+1) - their upper
+    bound is the float64 just below the next edge - so that an event whose timestamp equals an interior edge is counted once and
+    the bins add up to the one-window sum; only the last bin is closed."""
+    import math
+    edges = torch.linspace(float(low_t), float(upper_t), int(bins) + 1, dtype=torch.float32, device="cpu").tolist()
+    return [(edges[b], edges[b + 1] if b == bins - 1 else math.nextafter(edges[b + 1], -math.inf)) for b in range(int(bins))]
 
 
 def gather_rows(src, idx):

@@ -310,10 +310,9 @@ class Graph(nn.Module):
             lo, up = float(np.asarray(low_t).reshape(-1)[0]), float(np.asarray(upper_t).reshape(-1)[0])
             if bins == 1:
                 accu = K_.event_window_accumulate(ev["x"], ev["y"], ev["p"], ev["ts"], lo, up, He, We)
-            else:   # bin boundaries = the float32 linspace the trajectory kernel evaluates the B + 1 event poses at
-                edges = torch.linspace(lo, up, bins + 1, dtype=torch.float32).tolist()
-                accu = torch.stack([K_.event_window_accumulate(ev["x"], ev["y"], ev["p"], ev["ts"], edges[b], edges[b + 1], He, We)
-                                    for b in range(bins)])
+            else:   # bin boundaries = the float32 linspace the trajectory kernel evaluates the B + 1 event poses at; interior bins half-open
+                accu = torch.stack([K_.event_window_accumulate(ev["x"], ev["y"], ev["p"], ev["ts"], lo_b, up_b, He, We)
+                                    for lo_b, up_b in K_.event_bin_windows(lo, up, bins)])
             events_ts = np.stack((low_t, upper_t)).reshape(2)
         else:
             num = len(events["pol"])

@@ -38,6 +38,11 @@ extern "C" {
 
 typedef void* benerf_stream_t; /* hipStream_t */
 
+/* ABI revision of this header: bumped whenever the signature or the argument meaning of an entry point changes (round 5's
+ * `params` argument in front of benerf_mlp_bwd_dw made it 101; round 6: 102).  benerf_version() returns the revision the LIBRARY
+ * was built from - a binding compares the two before its first call (benerf_amd/_lib.py does and refuses a mismatch): a caller
+ * compiled against another revision would pass shifted arguments. */
+#define BENERF_ABI_VERSION 102
 int benerf_version(void);
 const char* benerf_last_error(void);
 

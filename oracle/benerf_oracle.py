@@ -435,9 +435,9 @@ def sample_pdf_exact(bins, weights, u):
 def fine_depths(z, weights, u, exact=False):
     """z_mid, sample_pdf on weights[1:-1], detach, sort-merge (model/nerf.py:322-326)."""
     z_mid = 0.5 * (z[..., 1:] + z[..., :-1])
-    if exact:
-        s, _, _ = sample_pdf_exact(z_mid.detach().numpy(), weights[..., 1:-1].detach().numpy(), u.numpy())
-        z_samples = torch.from_numpy(s)
+    if exact:     # numpy on the host whatever device the tensors live on (tests may evaluate the torch parts of the oracle on a GPU)
+        s, _, _ = sample_pdf_exact(z_mid.detach().cpu().numpy(), weights[..., 1:-1].detach().cpu().numpy(), u.cpu().numpy())
+        z_samples = torch.from_numpy(s).to(z.device)
     else:
         z_samples, _ = sample_pdf_torch(z_mid, weights[..., 1:-1], u)
     z_samples = z_samples.detach()

@@ -15,6 +15,14 @@ REPORT = []
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The oracle's torch-CPU steps are chains of thousands of small ATen operators: on the GPU box's 128+ hardware threads the
+    # default intra-op pool is 3 x SLOWER than 16 threads (bench.py's cpu_baseline sweep: 8.8 s per full C2 step at 16 threads, 13.6 s
+    # at 64, 29.6 s at 128).  Round 6: the full-size oracle evaluations are 500 of the GPU suite's 815 s at the default.
+    try:
+        import torch
+        torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    except ImportError:
+        pass
 
 
 @pytest.fixture(params=["split", "f32"])

@@ -27,7 +27,9 @@ def test_header_symbols_exported(lib):
 
 
 def test_size_queries(lib):
-    assert lib.benerf_version() >= 100
+    from benerf_amd import _lib as L
+    hdr = open(os.path.join(ROOT, "include", "benerf_hip.h")).read()
+    assert lib.benerf_version() == L.ABI_VERSION == int(re.search(r"#define BENERF_ABI_VERSION (\d+)", hdr).group(1))
     # sized for every arithmetic mode.  f32: rows of 2528 / 2432 floats per point + 8 layers of ReLU sign-bit words per
     # 64-point tile; split: points padded to 128, PE rows (64 + 32 floats) + f16 arrays (9 x 256 + 128 halfs), 9 mask layers,
     # 16 info words, then the twin arrays of 8-bit residual codes (one byte per saved value: the fp32-equivalent backward)

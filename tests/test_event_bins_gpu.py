@@ -124,3 +124,27 @@ def test_four_bins_gradients_vs_float64(case):
     tab = T.error_table(o64["grads"], cands)
     for mode in ("f32", "split"):
         _assert_no_worse(tab, mode, "bins4 " + case, lottery_factor=3.0)
+
+
+def test_bins_add_up_to_the_single_window_with_events_on_the_edges():
+    """Advisor, round 5: K7's window is closed on both ends (the reference's one window), so with B > 1 an event whose timestamp
+    equals an interior bin edge was counted in two bins.  kernels.event_bin_windows makes interior bins half-open: the per-bin
+    polarity images must add up to the one-window image on a stream that has events EXACTLY on every edge."""
+    from benerf_amd import kernels as K
+    H, W, B = 24, 40, 4
+    lo, up = 0.25, 0.75
+    edges = torch.linspace(lo, up, B + 1, dtype=torch.float32).tolist()
+    rng = np.random.default_rng(3)
+    ts = np.sort(np.concatenate([rng.random(5000), np.repeat(np.asarray(edges, np.float64), 7)]))      # 7 events on each edge
+    n = ts.size
+    xs = torch.from_numpy(rng.integers(0, W, n).astype(np.int32)).to(DEV)
+    ys = torch.from_numpy(rng.integers(0, H, n).astype(np.int32)).to(DEV)
+    ps = torch.from_numpy((rng.integers(0, 2, n) * 2 - 1).astype(np.float32)).to(DEV)
+    tsd = torch.from_numpy(ts).to(DEV)
+    one = K.event_window_accumulate(xs, ys, ps, tsd, lo, up, H, W)
+    per_bin = [K.event_window_accumulate(xs, ys, ps, tsd, a, b, H, W) for a, b in K.event_bin_windows(lo, up, B)]
+    assert torch.equal(sum(per_bin), one), "bins must partition the window"
+    counts = [int(((ts >= a) & (ts <= b)).sum()) for a, b in K.event_bin_windows(lo, up, B)]
+    assert sum(counts) == int(((ts >= lo) & (ts <= up)).sum())
+    naive = [K.event_window_accumulate(xs, ys, ps, tsd, edges[b], edges[b + 1], H, W) for b in range(B)]
+    assert not torch.equal(sum(naive), one), "the stream is built so that closed bins double-count (otherwise this test shows nothing)"
