@@ -138,13 +138,18 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int64_t 
 #endif
     // Loads through buffer descriptors: the chunk part of every address is wave-uniform (one SGPR offset), the thread part a
     // constant (two VGPRs for the whole kernel) - plain pointers cost two 64-bit VGPR addresses per load and, with the SP layout's
-    // index arithmetic on top, nine spilled registers.  Offsets are 32-bit: one array < 2^31 bytes, i.e. < 4 M points per launch
-    // (checked by the launcher).
-    const __amdgpu_buffer_rsrc_t rs_y = dw_rsrc(src.y), rs_y8 = dw_rsrc(src.y8), rs_x = dw_rsrc(src.x), rs_x8 = dw_rsrc(src.x8);
+    // index arithmetic on top, nine spilled registers.  Offsets are 32-bit and RELATIVE TO THIS SPLIT'S FIRST CHUNK (round 6: the
+    // descriptors' bases are advanced by 64-bit pointer arithmetic, once): a split's share of one array must stay below 2^31 bytes,
+    // i.e. < 128 M points per launch (checked by the launcher; absolute offsets had capped a launch at 4 M points - C5 with 8 dense
+    // event bins is 5.8 M).
+    const int64_t cb0 = chunk_begin;
+    const __amdgpu_buffer_rsrc_t rs_y = dw_rsrc(src.y + cb0 * YU), rs_y8 = dw_rsrc(src.y8 + cb0 * YU), rs_x = dw_rsrc(src.x + cb0 * XU),
+                                 rs_x8 = dw_rsrc(src.x8 + cb0 * XU);
     // X, SP layout: a chunk is 512 consecutive units [slot tid >> 4][point tid & 15]
 #define DW_PREFETCH(R, CHUNK)                                                                             \
     {                                                                                                     \
-        const int cc = (int)((CHUNK) < chunk_end ? (CHUNK) : chunk_end - 1);                              \
+        const int64_t ca = (CHUNK) < chunk_end ? (CHUNK) : chunk_end - 1;                                 \
+        const int cc = (int)(ca - cb0);                                                                   \
         _Pragma("unroll") for (int j = 0; j < NY; ++j)                                                    \
             if (YFULL || tid + j * DWT < YU) {                                                            \
                 R.y[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, (tid + j * DWT) * 16, cc * (YU * 16), DWS_NT);                  \
@@ -153,7 +158,7 @@ __device__ __forceinline__ void dw_gemm(const DwArgs& a, const Src src, int64_t 
         R.x[0] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, tid * 16, cc * (XU * 16), DWS_NT);           \
         R.x8[0] = DWS_CODE_LOAD(dw_load_b64(rs_x8, tid * 8, cc * (XU * 8)));                              \
         if (ALPHA) {                                                                                      \
-            const int64_t row = (int64_t)cc * CHP + (tid & (CHP - 1));                                    \
+            const int64_t row = ca * CHP + (tid & (CHP - 1));                                             \
             R.da = a.d_raw[(row < M ? row : M - 1) * (a.C + 1) + a.C];                                    \
             if (row >= M) R.da = 0.f;                                                                     \
         }                                                                                                 \
@@ -699,7 +704,7 @@ int benerf_mlp_dw_split22_launch(const BenerfMlpParams* params, int channels, in
     a.ws = dw_ws;
     a.M = M;
     a.C = channels;
-    BENERF_REQUIRE(mlp::m_pad(M) * 512 < (1ll << 31), "mlp_bwd(dw, split): at most 4 M points per launch (32-bit buffer offsets)");
+    BENERF_REQUIRE(mlp::m_pad(M) < (1ll << 27), "mlp_bwd(dw, split): at most 128 M points per launch (32-bit buffer offsets inside a split)");
     static BenerfLdsAttr attr_big;      // once per device
     if (!benerf_lds_attr(attr_big, (const void*)mlp_dw_split_big_kernel, (int)DWS_SMEM)) {
         benerf_set_error("mlp_bwd(dw, split): cannot reserve LDS");

@@ -158,20 +158,22 @@ def test_render_video_and_image_test(tmp_path):
 
 def _oracle_frame(pc, pf, pose, n, Hh, Ww, Kt, C, S, Ni, draws, chunk, z_forced=None, device=DEV, rows=None):
     """The oracle's render of pixels `rows` (default: all n) of one frame in chunks of `chunk` rays, its torch parts evaluated on
-    `device` (float32 torch either way; sample_pdf_exact is numpy on the host).  Returns {rgb_map, acc_map, disp_map, z_fine}."""
+    `device` (float32 torch either way; sample_pdf_exact is numpy on the host).  z_forced = (z_coarse, z_fine) indexed like `rows`.
+    Returns {rgb_map, acc_map, disp_map, z_coarse, z_fine} for those rows."""
     rows = torch.arange(n) if rows is None else rows
-    out = {k: [] for k in ("rgb_map", "acc_map", "disp_map", "z_fine")}
+    out = {k: [] for k in ("rgb_map", "acc_map", "disp_map", "z_coarse", "z_fine")}
     with torch.device(device), torch.no_grad():
         qc = {k: v.to(device) for k, v in pc.items()}
         qf = {k: v.to(device) for k, v in pf.items()}
         for i in range(0, rows.numel(), chunk):
             r = rows[i:i + chunk]
             d = {k: v[r].to(device) for k, v in draws.items()}
-            zf = None if z_forced is None else tuple(t[r].to(device) for t in z_forced)
+            zf = None if z_forced is None else tuple(t[i:i + chunk].to(device) for t in z_forced)
             ret, ex = O.render(qc, qf, pose.to(device), r.to(device), Hh, Ww, Kt.to(device), C, S, Ni, d, exact_pdf=True, want_extras=True,
                                z_forced=zf)
             for k in ("rgb_map", "acc_map", "disp_map"):
                 out[k].append(ret[k].float().cpu())
+            out["z_coarse"].append(ex["z_coarse"].float().cpu())
             out["z_fine"].append(ex["z_fine"].float().cpu())
     return {k: torch.cat(v) for k, v in out.items()}
 
@@ -179,13 +181,15 @@ def _oracle_frame(pc, pf, pose, n, Hh, Ww, Kt, C, S, Ni, draws, chunk, z_forced=
 def test_full_resolution_frame_vs_oracle():
     """One full-resolution frame - 480 x 768, 64 + 128 samples, chunk = 4096: what test.py:112-135 / train.py:404-441 render through
     Graph.render_video (model/nerf.py:353-390) - against the oracle on the same draws, per pixel, at north_star's 1e-4:
-      (1) render_video with its OWN importance samples against the oracle with ITS own (sample_pdf_exact): every pixel beyond
-          1e-4 must be EXPLAINED - its merged fine depths differ from the oracle's (the two coarse passes agree to ~1e-6, and a
-          uniform draw within that of a cdf knot lands in the neighbouring bin: another sample, legitimately another colour);
-      (2) the same frame with the oracle's fine depths forced in: ZERO pixels beyond 1e-4 (rgb, acc; disparity 1e-4 relative).
+      (1) the oracle's fine depths forced in: ZERO pixels beyond 1e-4 (rgb, acc; disparity 1e-4 relative);
+      (2) render_video with its OWN importance samples against the oracle with ITS own (sample_pdf_exact): the two coarse passes
+          agree to ~1e-6, so nearly every ray merges depths that differ in their last bits, and the fine network - positional
+          encoding up to 2^9 x - turns a few ulps of depth into 1e-5 .. 1e-4 of colour.  Every pixel beyond 1e-4 must be EXPLAINED
+          by exactly that: the oracle evaluated at the HIP path's depths reproduces the HIP colour within 1e-4.
     The oracle's torch parts run on the GPU box's device for the whole frame (368 640 rays x 192 samples: minutes on the host);
-    two chunks are re-evaluated on the host and must agree with the device evaluation to 2e-6."""
+    two chunks are re-evaluated on the host at the same depths and must agree with the device evaluation to 2e-6."""
     from benerf_amd import engine, kernels as Kk, workloads as WL
+    from conftest import REPORT
     from test_path_gpu import ReplayRNG
     cam = WL.CAMERAS["unreal"]
     Hh, Ww, S, Ni, chunk, C = cam["H"], cam["W"], 64, 64, 4096, 1
@@ -206,50 +210,52 @@ def test_full_resolution_frame_vs_oracle():
     pc = {k: v.detach().cpu() for k, v in g.nerf.state_dict().items()}
     pf = {k: v.detach().cpu() for k, v in g.nerf_fine.state_dict().items()}
     ref = _oracle_frame(pc, pf, pose.cpu(), n, Hh, Ww, Kt, C, S, Ni, draws, chunk)
-    # the device evaluation of the oracle IS the oracle: two chunks (the first and one in the middle of the frame) on the host
+    # the device evaluation of the oracle IS the oracle: two chunks (the first and one in the middle of the frame) on the host, at the
+    # device evaluation's depths (left to themselves the two would draw depths that differ in their last bits, like any two evaluations)
     rows = torch.cat([torch.arange(0, chunk), torch.arange(45 * chunk, 46 * chunk)])
-    host = _oracle_frame(pc, pf, pose.cpu(), n, Hh, Ww, Kt, C, S, Ni, draws, chunk, device="cpu", rows=rows)
-    same = (host["z_fine"] == ref["z_fine"][rows]).all(1)        # rows whose importance samples agree between the two evaluations
-    report("oracle on the device vs on the host, rgb_map (rows with equal samples: %d of %d)" % (int(same.sum()), rows.numel()),
-           ref["rgb_map"][rows][same], host["rgb_map"][same], atol=2e-6)
-    assert int(same.sum()) > 0.99 * rows.numel()
+    host = _oracle_frame(pc, pf, pose.cpu(), n, Hh, Ww, Kt, C, S, Ni, draws, chunk, device="cpu", rows=rows,
+                         z_forced=(ref["z_coarse"][rows], ref["z_fine"][rows]))
+    report("oracle evaluated on the device vs on the host (same depths), rgb_map of %d rays" % rows.numel(), ref["rgb_map"][rows], host["rgb_map"], atol=2e-6)
 
-    # (1) own importance samples
     cam_o = engine.Camera.from_K(Hh, Ww, Kt)
     net_c, net_f = g.nerf.packed(), g.nerf_fine.packed()
-    hip_z = []
-    with torch.no_grad():       # the same kernel sequence as render_video's chunks, to read the depths it merged
-        for i in range(0, n, chunk):
-            d = engine.Draws(*(draws[k][i:i + chunk].to(DEV) for k in ("t_rand", "noise0", "u", "noise1")))
-            out, saved = engine._render_forward(cam_o, True, S, Ni, d, pose.contiguous(), torch.arange(i, min(i + chunk, n), device=DEV),
-                                                net_c, net_f, False)
-            assert torch.equal(out["rgb_map"], ret["rgb_map"].reshape(n, C)[i:i + chunk]), "render_video's chunk %d differs from the same launches" % (i // chunk)
-            hip_z.append(saved["z_fine"].cpu())
-    hip_z = torch.cat(hip_z)
-    d_rgb = (ret["rgb_map"].reshape(n, C).cpu() - ref["rgb_map"]).abs().max(1).values
-    beyond = d_rgb > 1e-4
-    explained = (hip_z != ref["z_fine"]).any(1)
-    from conftest import REPORT
-    REPORT.append("full frame %dx%d, %d+%d samples, own importance samples: rgb max|d| %.2e, %d of %d pixels beyond 1e-4, %d of them with "
-                  "different merged depths; pixels with different depths in all: %d"
-                  % (Hh, Ww, S, S + Ni, float(d_rgb.max()), int(beyond.sum()), n, int((beyond & explained).sum()), int(explained.sum())))
-    assert int((beyond & ~explained).sum()) == 0, "pixels beyond 1e-4 although the importance samples agree"
-    assert float(d_rgb[~explained].max()) <= 1e-4
 
-    # (2) the oracle's fine depths forced in
-    maps = {k: [] for k in ("rgb_map", "acc_map", "disp_map")}
-    with torch.no_grad():
-        for i in range(0, n, chunk):
-            d = engine.Draws(*(draws[k][i:i + chunk].to(DEV) for k in ("t_rand", "noise0", "u", "noise1")))
-            out, _ = engine._render_forward(cam_o, True, S, Ni, d, pose.contiguous(), torch.arange(i, min(i + chunk, n), device=DEV), net_c, net_f,
-                                            False, z_fine_forced=ref["z_fine"][i:i + chunk].to(DEV))
-            for k in maps:
-                maps[k].append(out[k].cpu())
-    maps = {k: torch.cat(v) for k, v in maps.items()}
-    report("full frame, forced fine depths: rgb_map per pixel", maps["rgb_map"], ref["rgb_map"], atol=1e-4)
-    report("full frame, forced fine depths: acc_map per pixel", maps["acc_map"], ref["acc_map"], atol=1e-4)
-    report("full frame, forced fine depths: disp_map per pixel", maps["disp_map"], ref["disp_map"], atol=1e-4, rtol=1e-4)
-    assert Kk.auto_fallback_max(DEV) == 0.0 or me_mode() != "split"      # no inference launch fell back to exact f32 on this frame
+    def hip_frame(z_forced=None):
+        """the kernel sequence of render_video's chunks (engine._render_forward), to read the merged depths / force them"""
+        maps = {k: [] for k in ("rgb_map", "acc_map", "disp_map", "z", "z_fine")}
+        with torch.no_grad():
+            for i in range(0, n, chunk):
+                d = engine.Draws(*(draws[k][i:i + chunk].to(DEV) for k in ("t_rand", "noise0", "u", "noise1")))
+                out, saved = engine._render_forward(cam_o, True, S, Ni, d, pose.contiguous(), torch.arange(i, min(i + chunk, n), device=DEV), net_c,
+                                                    net_f, False, z_fine_forced=None if z_forced is None else z_forced[i:i + chunk].to(DEV))
+                for k in ("rgb_map", "acc_map", "disp_map"):
+                    maps[k].append(out[k].cpu())
+                maps["z"].append(saved["z"].cpu())
+                maps["z_fine"].append(saved["z_fine"].cpu())
+        return {k: torch.cat(v) for k, v in maps.items()}
+
+    # (1) the oracle's fine depths forced in
+    forced = hip_frame(ref["z_fine"])
+    report("full frame, forced fine depths: rgb_map per pixel (%d pixels)" % n, forced["rgb_map"], ref["rgb_map"], atol=1e-4)
+    report("full frame, forced fine depths: acc_map per pixel", forced["acc_map"], ref["acc_map"], atol=1e-4)
+    report("full frame, forced fine depths: disp_map per pixel", forced["disp_map"], ref["disp_map"], atol=1e-4, rtol=1e-4)
+
+    # (2) own importance samples
+    own = hip_frame()
+    assert torch.equal(own["rgb_map"], ret["rgb_map"].reshape(n, C).cpu()), "render_video must be these very launches"
+    d_rgb = (own["rgb_map"] - ref["rgb_map"]).abs().max(1).values
+    dz = (own["z_fine"] - ref["z_fine"]).abs().max(1).values
+    beyond = torch.nonzero(d_rgb > 1e-4).reshape(-1)
+    REPORT.append("full frame %dx%d, %d+%d samples, own importance samples: rgb max|d| %.2e, %d of %d pixels beyond 1e-4; merged depths differ "
+                  "on %d pixels (median max|dz| %.1e, of the pixels beyond 1e-4: %.1e)"
+                  % (Hh, Ww, S, S + Ni, float(d_rgb.max()), beyond.numel(), n, int((dz > 0).sum()), float(dz.median()),
+                     float(dz[beyond].median()) if beyond.numel() else 0.0))
+    if beyond.numel():
+        sel = beyond[:8192]
+        at_hip = _oracle_frame(pc, pf, pose.cpu(), n, Hh, Ww, Kt, C, S, Ni, draws, chunk, rows=sel, z_forced=(own["z"][sel], own["z_fine"][sel]))
+        report("full frame, own samples: the %d pixels beyond 1e-4, oracle evaluated at the HIP path's depths" % sel.numel(),
+               own["rgb_map"][sel], at_hip["rgb_map"], atol=1e-4)
+    assert Kk.auto_fallback_max(DEV) == 0.0      # no inference launch of this frame fell back to exact f32
 
 
 def test_checkpoint_resume_equals_uninterrupted(tmp_path):

@@ -168,6 +168,18 @@ def test_shard_indices():
             assert max(rays) - min(rays) <= pe + 1 or min(e1 - e0 for (e0, e1), _ in tab) == 0, (ne, nr, world, rays)
             if cap is not None and world == 8:
                 assert max(rays) <= cap, rays
+    # dense event bins (BASELINE.json configs[4]): B + 1 event poses per event pixel - rays per event pixel = B + 1.  C5 over 8 ranks
+    # at B = 4 and 8: a partition, blur pixels as above, every rank within one event pixel's rays (B + 1) of the mean, nobody empty
+    for bins in (4, 8):
+        pe = bins + 1
+        for ne, nr, pn in ((2048, 132, 31), (1024, 107, 19)):
+            tab = dist.balanced_shard_bounds(ne, nr, pe, pn, 8)
+            assert tab[0][0][0] == 0 and tab[0][1][0] == 0 and tab[-1][0][1] == ne and tab[-1][1][1] == nr
+            assert all(tab[k][0][1] == tab[k + 1][0][0] and tab[k][1][1] == tab[k + 1][1][0] for k in range(7))
+            rays = [pe * (e1 - e0) + pn * (r1 - r0) for (e0, e1), (r0, r1) in tab]
+            assert max(rays) - min(rays) <= pe + 1, (bins, ne, nr, rays)
+            assert min(e1 - e0 for (e0, e1), _ in tab) > 0 and min(r1 - r0 for _, (r0, r1) in tab) > 0
+            assert sum(rays) == pe * ne + pn * nr
     # degenerate batches (a rank whose blur pixels alone exceed the mean share of rays; no event or no blur pixels): still a partition
     for ne, nr, pe, pn, world in ((1, 5, 2, 19, 4), (2, 20, 2, 19, 4), (0, 7, 2, 19, 3), (5, 0, 2, 19, 3)):
         tab = dist.balanced_shard_bounds(ne, nr, pe, pn, world)
