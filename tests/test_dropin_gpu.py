@@ -300,3 +300,104 @@ def test_graph_forward_tum_vie(installed, monkeypatch):
     a, b = rets["BeNeRF_Unreal"], rets["TUM_VIE"]
     assert torch.equal(a[2], b[2]), "polarity 0 must accumulate as -1"
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), "identity undistortion tables must not change the renders"
+
+
+def test_fused_graph_forward_equals_the_two_separate_renders(installed):
+    """Graph.forward's fused pair of nodes (engine.SplinePosesPair + engine.RenderPair: one batched launch sequence, per-pose block
+    outputs, parameter-independent work on a second stream) against the reference's own sequence of four calls (get_pose_evt,
+    get_pose_rgb, render, render - what Graph.forward falls back to when a caller overrides one of them) on the same seeds: the
+    rendered maps are bit-identical (a sample point's value does not depend on which other points share its launch), the loss
+    gradients agree to round-off (the weight-gradient sums run over another partition of the points)."""
+    from model import optimize
+    args, cam = _small_args()
+    H, W = cam["H"], cam["W"]
+    K = np.array([[cam["fx"], 0, cam["cx"]], [0, cam["fy"], cam["cy"]], [0, 0, 1]], dtype=np.float32)
+    events = GI.synthetic_events(np.random.default_rng(12), cam, 30000)
+    outs = {}
+    for which in ("fused", "separate"):
+        torch.manual_seed(1)
+        model = optimize.Model(args)
+        model.graph.to(DEV)
+        g = model.build_network(args)
+        with torch.no_grad():
+            g.nerf.alpha_linear.bias += 1.0
+            g.nerf_fine.alpha_linear.bias += 1.0
+        if which == "separate":
+            orig = g.get_pose_evt
+            g.get_pose_evt = lambda a, ts, seg_num=None: orig(a, ts, seg_num) if seg_num is not None else orig(a, ts)   # an instance override
+        assert g._stock_queries() == (which == "fused")
+        np.random.seed(9)
+        torch.manual_seed(2)
+        ret_e, ret_r, idx_e, idx_r, accu = g.forward(0, events, np.array([0.0, 1.0]), H, W, K, K, args, np.array([]), np.array([]))
+        n = idx_e.shape[0]
+        blur = 0
+        R = idx_r.shape[0]
+        for j in range(args.num_interpolated_pose):
+            blur = blur + ret_r["rgb_map"][j * R:(j + 1) * R] + 0.5 * ret_r["rgb0"][j * R:(j + 1) * R]
+        loss = ((ret_e["rgb_map"][n:] - ret_e["rgb_map"][:n]) ** 2).mean() + (ret_e["rgb0"] ** 2).mean() + (blur ** 2).mean() \
+            + ret_r["acc_map"].mean() + 0.1 * ret_r["rgb_map"].sum()       # blocks AND whole maps, colours and opacity
+        loss.backward()
+        outs[which] = ({k: v.detach().cpu().clone() for k, v in list(ret_e.items()) + [("r_" + k2, v2) for k2, v2 in ret_r.items()]},
+                       g.evt_knot_pose_se3.params.weight.grad.cpu().clone(), g.transform.params.weight.grad.cpu().clone(),
+                       g.nerf.pts_linears[2].weight.grad.cpu().clone(), g.nerf_fine.views_linears[0].weight.grad.cpu().clone(),
+                       idx_e.cpu(), idx_r.cpu(), float(loss))
+    a, b = outs["fused"], outs["separate"]
+    assert torch.equal(a[5], b[5]) and torch.equal(a[6], b[6]), "same pixel draws"
+    for k in a[0]:
+        assert torch.equal(a[0][k], b[0][k]), k
+    assert a[7] == b[7]
+    for i, name in ((1, "knots"), (2, "transform"), (3, "nerf.pts_linears.2.weight"), (4, "nerf_fine.views_linears.0.weight")):
+        report("fused Graph.forward vs two renders: d " + name, a[i], b[i], atol=2e-5 * float(b[i].abs().max()), rtol=1e-4)
+
+
+def test_flat_adam_is_torch_adam(installed):
+    """benerf_amd.optim.FlatAdam (what Model.setup_optimizer returns) against torch.optim.Adam on the same gradients: parameters and
+    state after 5 steps with the learning rate rewritten between them as train.py:355-394 does, a parameter that gets no gradient in
+    one step (torch leaves it and its counters alone), a gradient the caller replaced by a tensor of its own, gradients accumulated over
+    two backward passes without zero_grad, state_dict() in the reference's checkpoint format and load_state_dict() into a fresh pair."""
+    from benerf_amd.optim import FlatAdam
+    torch.manual_seed(0)
+
+    def nets():
+        torch.manual_seed(5)
+        return torch.nn.Sequential(torch.nn.Linear(9, 33), torch.nn.ReLU(), torch.nn.Linear(33, 4)).to(DEV)
+    na, nb = nets(), nets()
+    oa, ob = FlatAdam(na.parameters(), lr=5e-4), torch.optim.Adam(nb.parameters(), lr=5e-4, foreach=False)
+    x = torch.randn(64, 9, device=DEV)
+
+    def steps(na, nb, oa, ob, n0, n1):
+        for it in range(n0, n1):
+            for net, opt in ((na, oa), (nb, ob)):
+                if it != 3:
+                    opt.zero_grad()              # it == 3: accumulate on top of step 2's gradients
+                loss = (net(x) ** 2).mean() if it != 1 else (net[0](x) ** 2).mean()      # it == 1: the last layer gets no gradient
+                loss.backward()
+                if it == 2:
+                    p0 = next(net.parameters())
+                    p0.grad = p0.grad * 2.0       # a caller-owned gradient tensor
+                opt.step()
+                for gr in opt.param_groups:
+                    gr["lr"] = 5e-4 * 0.1 ** (it / 7.0)
+    steps(na, nb, oa, ob, 0, 5)
+    for (n_, pa), pb in zip(na.named_parameters(), nb.parameters()):
+        report("FlatAdam vs torch Adam: " + n_, pa, pb, atol=2e-7, rtol=1e-6)
+    import copy
+    sa, sb = copy.deepcopy(oa.state_dict()), copy.deepcopy(ob.state_dict())      # as a checkpoint file would hold them (state_dict() hands out live tensors)
+    assert sa["param_groups"][0]["params"] == sb["param_groups"][0]["params"] and sorted(sa["state"]) == sorted(sb["state"])
+    for k in sa["state"]:
+        assert sorted(sa["state"][k]) == ["exp_avg", "exp_avg_sq", "step"]
+        assert float(sa["state"][k]["step"]) == float(sb["state"][k]["step"]), k
+        report("FlatAdam state exp_avg_sq %d" % k, sa["state"][k]["exp_avg_sq"], sb["state"][k]["exp_avg_sq"], atol=1e-12, rtol=1e-5)
+    # the torch optimiser's checkpoint into a fresh FlatAdam (and vice versa), then two more steps
+    nc, nd = nets(), nets()
+    nc.load_state_dict(nb.state_dict())
+    nd.load_state_dict(na.state_dict())
+    oc, od = FlatAdam(nc.parameters(), lr=5e-4), torch.optim.Adam(nd.parameters(), lr=5e-4, foreach=False)
+    oc.load_state_dict(sb)
+    od.load_state_dict(sa)
+    steps(nc, nd, oc, od, 5, 7)
+    steps(na, nb, oa, ob, 5, 7)
+    for (n_, pc), pa_ in zip(nc.named_parameters(), na.parameters()):
+        report("FlatAdam resumed from torch's state_dict: " + n_, pc, pa_, atol=2e-7, rtol=1e-6)
+    for (n_, pd), pb_ in zip(nd.named_parameters(), nb.parameters()):
+        report("torch Adam resumed from FlatAdam's state_dict: " + n_, pd, pb_, atol=2e-7, rtol=1e-6)
