@@ -199,6 +199,13 @@ def run(workload="C2", steps=20, warmup=5, seed=0, n_events=2_000_000, timers=Fa
         drv = Driver(args, cam, events, img, seed)
         drv.iterate(warmup)
         torch.cuda.synchronize()
+        # Warm-up includes the interpreter's first FULL garbage collection: CPython runs one when the young generations have overflowed
+        # often enough (here: around iteration 45), and a full pass walks every tracked object of the process - with torch imported
+        # ~80-130 ms (profiles/r06_dropin_gc_outlier.log).  After it, full collections need the long-lived heap to grow by a quarter,
+        # which a training loop in steady state never does: a one-off of any long run, not a per-iteration cost - and not one that a
+        # 20-50-iteration sample should carry as if it recurred.
+        import gc
+        gc.collect()
         if timers:
             K.TIMERS.records.clear()
             K.TIMERS.enabled = True
@@ -212,10 +219,13 @@ def run(workload="C2", steps=20, warmup=5, seed=0, n_events=2_000_000, timers=Fa
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         K.TIMERS.enabled = False
-        per = sorted(b - a for a, b in zip([t0] + marks[:-1], marks))
+        series = [b - a for a, b in zip([t0] + marks[:-1], marks)]
+        per = sorted(series)
         rays = WL.rays_per_step(wl)
         out = {"ms_per_step": round(dt / steps * 1e3, 3), "median_ms_per_step": round(per[len(per) // 2] * 1e3, 3),
                "rays_per_s": round(rays * steps / dt, 1), "rays_per_step": rays, "steps": steps, "warmup": warmup,
+               "max_ms_per_step": round(per[-1] * 1e3, 3),
+               "slowest_steps": [(i, round(t * 1e3, 2)) for i, t in sorted(enumerate(series), key=lambda kv: -kv[1])[:4]],
                "final_loss": float(drv.last_loss.item()), "host_syncs_per_step": "6 x .item() (logger.write) + 1 image upload (torch.Tensor(img[0]))"}
         if host_times:
             out["host_ms_per_step"] = {k: round(v / steps * 1e3, 3) for k, v in drv.host_times.items()}
