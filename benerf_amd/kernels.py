@@ -435,6 +435,7 @@ def mlp_fwd(net, rays_o, rays_d, viewdirs, z, save_acts, precision=None, status=
         acts = torch.empty(lib.benerf_mlp_act_floats_for(n_rays * n_samples, MLP_PRECISIONS[mode]), dtype=torch.float32, device=z.device)
         acts.benerf_precision = mode
         acts.benerf_pe_weights = net.pe_weights       # the backward of THIS forward uses the same column weights
+        acts.benerf_pack_version = (net.version, _param_generation)      # mlp_bwd_dw: the pack this forward ran on must still be the current one
     s = net.struct()
     code = MLP_PRECISIONS[mode]
     if mode == "split" and not save_acts:
@@ -498,12 +499,15 @@ def mlp_bwd_dw(net, d_raw, acts, dacts, n_rays, n_samples, grad_w, grad_b, accum
     ws = scratch("dw_ws", ws_floats, d_raw.device)
     pe_w = getattr(acts, "benerf_pe_weights", net.pe_weights)
     g = _param_struct(MlpGrads, grad_w, grad_b)
-    if code == MLP_PRECISIONS["split"] and net.version is not None and net._key() != net.version:
+    if code == MLP_PRECISIONS["split"] and getattr(acts, "benerf_pack_version", None) not in (None, (net.version, _param_generation)):
         # BENERF_MLP_SPLIT composes the feature / views weight gradients from G = dhv^T h7 and the LIVE W_v, W_f, b_f, while the forward
-        # and dX passes used the W_c = W_v[:, :256] W_f snapshot of the last pack(): parameters rewritten in between (an optimiser step,
-        # a checkpoint load) would give silently inconsistent gradients
-        raise _lib.BenerfHipError("mlp_bwd_dw(split): the network's parameters changed since its weights were packed (between the forward "
-                                  "pass and this backward call): the composed feature / views gradients would mix two parameter sets")
+        # and dX passes used the W_c = W_v[:, :256] W_f snapshot of the pack they ran on: a fused optimiser step or a re-pack between
+        # THAT forward and this call (kernels.params_changed / PackedMlp.pack) would give silently inconsistent gradients.  (Version
+        # counters are not compared here: the parameters of a TrainStep are views of one flat buffer and share ONE counter - a
+        # write to the trajectory knots would make both networks look stale.)
+        raise _lib.BenerfHipError("mlp_bwd_dw(split): the network was re-packed or its parameters were updated between the forward pass "
+                                  "that saved these activations and this backward call: the composed feature / views gradients would "
+                                  "mix two parameter sets")
     s = net.struct()        # BENERF_MLP_SPLIT composes the feature / views weight gradients from dhv^T h7 and these weights
     _timer("mlp_bwd_dw", M)
     _lib.check(lib.benerf_mlp_bwd_dw(ctypes.byref(s), net.channels, n_rays, n_samples, _chk(d_raw), _chk(acts), dacts.data_ptr(),

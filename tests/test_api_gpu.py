@@ -618,9 +618,9 @@ def test_train_step_range_guard_skips_counts_and_raises():
     # repaired parameters: training resumes, the consecutive counter falls back to zero
     with torch.no_grad():
         step.flat_p.copy_(good)
-    step.net_c.packed.pack()
+    K.params_changed()             # storage rewritten behind the Parameters' version counters: say so BEFORE re-packing (the weight-
+    step.net_c.packed.pack()       # gradient launch refuses a network whose parameters changed since its last pack)
     step.net_f.packed.pack()
-    K.params_changed()
     step.guard.words.zero_()
     one()
     torch.cuda.synchronize()
@@ -757,8 +757,8 @@ def test_train_step_skips_a_nonfinite_loss_gradient():
         step.check_range()
     with torch.no_grad():
         bias.copy_(keep)
-    step.net_f.packed.pack()
     K.params_changed()
+    step.net_f.packed.pack()
     one()
     torch.cuda.synchronize()
     step.check_range()
