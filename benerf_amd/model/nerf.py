@@ -39,9 +39,11 @@ def _draw(fn, shape, device, scale=None, out=None):
     shape to draw into (a row range of a batch buffer) - the same values as a fresh tensor gets."""
     if out is not None:
         t = fn(shape, out=out)
+        if t is not out:            # a stand-in for torch.rand / randn that ignores `out` (tests replaying recorded draws)
+            out.copy_(t)
         if scale is not None and scale != 1.0:
-            t.mul_(scale)
-        return t
+            out.mul_(scale)
+        return out
     t = fn(shape, device=device)
     if scale is not None and scale != 1.0:
         t = t * scale
@@ -73,6 +75,9 @@ def _pose_major(t, blocks):
     return rows
 
 
+_FRONT_STREAMS = {}
+
+
 class _FrontStream:
     """A second HIP stream for the parameter-independent head of Graph.forward (see there).  Tensors made inside are registered
     with keep(): close() tells the caching allocator that the main stream uses them too (record_stream) and makes the main
@@ -83,9 +88,9 @@ class _FrontStream:
         self.open = False
         self.made = []
         if self.on:
-            side = getattr(graph, "_front_stream", None)
-            if side is None or side.device != dev:
-                side = graph._front_stream = torch.cuda.Stream(device=dev)
+            side = _FRONT_STREAMS.get(dev)      # per device, not on the module: a graph stays picklable / deep-copyable
+            if side is None:
+                side = _FRONT_STREAMS[dev] = torch.cuda.Stream(device=dev)
             self.side = side
             self.main = torch.cuda.current_stream(dev)
 
