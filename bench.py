@@ -743,6 +743,9 @@ def main():
                          "launches_per_chunk": "4 draws (torch.rand / randn, the reference's) + rays_fwd, stratified_z, mlp_fwd (coarse; split + "
                                                "the normally empty exact-f32 fallback), composite_fwd, sample_pdf_merge, mlp_fwd (fine; "
                                                "split + fallback), composite_fwd = 13; then one torch.cat per output map and frame",
+                         "sustained_note": "three whole frames back to back (0.7 s of forward launches at the board's power cap): the "
+                                           "SUSTAINED rate; `rays_per_s` / `avg_launch_ms` above come from a 60-ms burst of chunks behind an idle "
+                                           "device, which the power controller lets run ~25 % faster (profiles/r06_idle_gap_probe.log)",
                          "shape_ok": list(fr["rgb_map"].shape) == [cam["H"], cam["W"], wl["channels"]]}
                 del fr
             except Exception as e:      # noqa: BLE001 - informational
