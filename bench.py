@@ -192,10 +192,13 @@ def power_leg(one_step, device_index, seconds):
     th = threading.Thread(target=sample, daemon=True)
     th.start()
     t0 = time.perf_counter()
+    n_steps = 0
     while time.perf_counter() - t0 < seconds:
         for _ in range(10):
             one_step()
+        n_steps += 10
         torch.cuda.synchronize()
+    sustained_ms = (time.perf_counter() - t0) / n_steps * 1e3
     stop[0] = True
     th.join()
     pw = [float(r[0]) for r in rows if isinstance(r[0], (int, float))]
@@ -204,6 +207,7 @@ def power_leg(one_step, device_index, seconds):
         return None
     return {"cap_w": round(cap / 1e6, 1) if isinstance(cap, (int, float)) else None, "avg_w": round(sum(pw) / len(pw), 1), "max_w": max(pw),
             "gfx_mhz_avg": round(sum(ck) / len(ck), 1) if ck else None, "samples": len(pw),
+            "ms_per_step_sustained": round(sustained_ms, 3), "steps_sustained": n_steps,
             "note": "socket power / shader clock sampled every 10 ms over back-to-back training steps (small-kernel phases included)"}
 
 
@@ -644,7 +648,14 @@ def main():
     sync()
     t0 = time.perf_counter()
     marks[0].record()
+    # HIP-event brackets around the six K3 launches (the roofline's per-kernel durations, measured live in the timed region) on every
+    # TIMER_EVERY-th timed step: each bracket is two timestamp packets in the stream, ~0.1 ms per fully instrumented step
+    # (profiles/r06_timer_overhead.log) - instrumentation, not workload
+    timer_every = max(1, int(os.environ.get("BENERF_BENCH_TIMER_EVERY", "4")))
+    n_sampled = 0
     for i in range(a.steps):
+        K.TIMERS.enabled = i % timer_every == 0
+        n_sampled += int(K.TIMERS.enabled)
         losses = one_step()
         marks[i + 1].record()
     sync()
@@ -935,9 +946,9 @@ def main():
                 "peak_note": "dense %s MFMA peak at 2.4 GHz; the K3 kernels run at the board's power cap (`power` below, "
                              "profiles/r04_mfma_power_probe.log: a pure MFMA stream is clocked at 1.9 GHz by the 1400 W cap) and are clocked at "
                              "1.7-2.1 GHz: DESIGN.md 4" % ("f16" if split else "f32"),
-                "per_kernel_note": "HIP-event durations on the launching stream; only the step's LAST weight-gradient launch (coarse network) "
+                "per_kernel_note": "HIP-event durations on the launching stream, bracketed on every %d-th timed step (%d of %d); only the step's LAST weight-gradient launch (coarse network) "
                                    "runs on the second stream, beside the small kernels of the trajectory tail (engine.TrainStep), so the six K3 "
-                                   "launches of a step add up to its duration",
+                                   "launches of a step add up to its duration" % (timer_every, n_sampled, a.steps),
                 "per_kernel": kern}
         if pmc:
             roof["traffic_source"] = pmc_src
@@ -962,7 +973,7 @@ def main():
             if all(t is not None for t in tr):
                 hbm["k3_traffic_per_step"] = 2 * sum(tr)                  # coarse + fine launches of each kernel
             roof["hbm"] = hbm
-    mlp_ms = sum(v[1] for v in summ.values()) / a.steps if summ else None
+    mlp_ms = sum(v[1] for v in summ.values()) / max(n_sampled, 1) if summ else None
 
     out = {
         "metric": "training rays/s" if not a.oversubscribe else "training rays/s (ranks oversubscribed on one device: not a measurement)",
