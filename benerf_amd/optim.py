@@ -173,7 +173,9 @@ class FlatAdam(torch.optim.Adam):
                 if p.grad is None:          # torch's Adam leaves such a parameter (and its counters) alone
                     run = self._flush(run, lr, beta1, beta2, eps)
                     continue
-                i = self._index[id(p)]
+                i = self._index.get(id(p))
+                if i is None:
+                    raise NotImplementedError("FlatAdam: a parameter added after the first step() (add_param_group) has no slot in the arena")
                 o, k = a.slots[i]
                 if not a.grad_is_window(i):
                     a.g[o:o + k].copy_(p.grad.detach().to(torch.float32).reshape(-1))
