@@ -196,6 +196,7 @@ def test_full_resolution_frame_vs_oracle():
     args = WL.make_args("C2")
     assert args.N_samples == S and args.N_importance == Ni and args.chunk == chunk
     model, g = _graph(args, seed=5)
+    fallback_before = Kk.auto_fallback_max(DEV)      # other tests of the session overflow the f16 range on purpose
     rng = np.random.default_rng(6)
     Kt = torch.tensor([[cam["fx"], 0, cam["cx"]], [0, cam["fy"], cam["cy"]], [0, 0, 1]], dtype=torch.float32)
     pose = g.get_pose_rgb(args, [0, 1], seg_num=3).detach()[1:2]
@@ -255,7 +256,7 @@ def test_full_resolution_frame_vs_oracle():
         at_hip = _oracle_frame(pc, pf, pose.cpu(), n, Hh, Ww, Kt, C, S, Ni, draws, chunk, rows=sel, z_forced=(own["z"][sel], own["z_fine"][sel]))
         report("full frame, own samples: the %d pixels beyond 1e-4, oracle evaluated at the HIP path's depths" % sel.numel(),
                own["rgb_map"][sel], at_hip["rgb_map"], atol=1e-4)
-    assert Kk.auto_fallback_max(DEV) == 0.0      # no inference launch of this frame fell back to exact f32
+    assert Kk.auto_fallback_max(DEV) == fallback_before      # no inference launch of this frame fell back to exact f32
 
 
 def test_checkpoint_resume_equals_uninterrupted(tmp_path):
