@@ -35,7 +35,7 @@ class LossCfg(Structure):
 
 
 P = c_void_p
-ABI_VERSION = 102       # include/benerf_hip.h: BENERF_ABI_VERSION
+ABI_VERSION = 103       # include/benerf_hip.h: BENERF_ABI_VERSION
 _SIGNATURES = {
     "benerf_version": (c_int, []),
     "benerf_last_error": (c_char_p, []),
@@ -76,6 +76,10 @@ _SIGNATURES = {
     "benerf_posenc": (c_int, [P, c_int64, c_int, c_int, c_int, P, P]),
     "benerf_mse_fwd": (c_int, [P, P, c_int64, P, P]),
     "benerf_mse_bwd": (c_int, [P, P, c_int64, P, P, P, P]),
+    "benerf_bright_log_fwd": (c_int, [P, c_int64, c_int, P, P]),
+    "benerf_bright_log_bwd": (c_int, [P, P, c_int64, c_int, P, P]),
+    "benerf_rgb2gray_fwd": (c_int, [P, c_int64, P, P]),
+    "benerf_rgb2gray_bwd": (c_int, [P, c_int64, P, P]),
     "benerf_loss_stats": (c_int, [POINTER(LossCfg), P, P, P, P, P, P, P, P]),
     "benerf_loss_grads": (c_int, [POINTER(LossCfg), P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "benerf_event_accumulate": (c_int, [P, P, P, c_int64, c_int, c_int, P, P]),

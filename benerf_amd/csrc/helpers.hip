@@ -4,6 +4,8 @@
 //   benerf_ndc_rays    <- run_nerf_helpers.ndc_rays                       (run_nerf_helpers.py:46-71)
 //   benerf_posenc      <- Embedder.embed                                  (model/embedder.py:9-34)
 //   benerf_mse_fwd/bwd <- MSELoss                                         (loss/imgloss.py:3-5)
+//   benerf_bright_log_fwd/bwd <- rgb2brightlog                            (utils/math_utils.py:4-23)
+//   benerf_rgb2gray_fwd/bwd   <- RGB2Gray                                 (utils/img_utils.py:7-16)
 // Built with -ffp-contract=off (separately rounded mul/add like the torch ops).
 #include "common.h"
 
@@ -90,7 +92,74 @@ __global__ void mse_bwd_kernel(const float* __restrict__ a, const float* __restr
     if (db) db[i] = -v;
 }
 
+// rgb2brightlog / RGB2Gray of the reference's loss lines as single launches (the same curves as loss.hip's bright_log / to_gray)
+__device__ __forceinline__ float h_bright_log(float x, int linlog) {
+    if (!linlog) return logf(x + 1e-9f);
+    const float c = x * 255.0f;
+    const float slope = logf(20.0f) / 20.0f;
+    return c < 20.0f ? slope * c : logf(c + 1e-9f);
+}
+__device__ __forceinline__ float h_bright_log_grad(float x, int linlog) {
+    if (!linlog) return 1.0f / (x + 1e-9f);
+    const float c = x * 255.0f;
+    const float slope = logf(20.0f) / 20.0f;
+    return c < 20.0f ? slope * 255.0f : 255.0f / (c + 1e-9f);
+}
+__global__ void bright_log_fwd_kernel(const float* __restrict__ x, int64_t n, int linlog, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = h_bright_log(x[i], linlog);
+}
+__global__ void bright_log_bwd_kernel(const float* __restrict__ x, const float* __restrict__ g, int64_t n, int linlog, float* __restrict__ dx) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dx[i] = g[i] * h_bright_log_grad(x[i], linlog);
+}
+__global__ void rgb2gray_fwd_kernel(const float* __restrict__ rgb, int64_t n, float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (rgb[3 * i] * 0.299f + rgb[3 * i + 1] * 0.587f) + rgb[3 * i + 2] * 0.114f;
+}
+__global__ void rgb2gray_bwd_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ d_rgb) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float v = g[i];
+        d_rgb[3 * i] = v * 0.299f;
+        d_rgb[3 * i + 1] = v * 0.587f;
+        d_rgb[3 * i + 2] = v * 0.114f;
+    }
+}
+
 }  // namespace
+
+extern "C" int benerf_bright_log_fwd(const float* x, int64_t n, int linlog, float* out, benerf_stream_t stream) {
+    BENERF_REQUIRE(x && out && n >= 0, "bright_log_fwd: bad args");
+    if (n == 0) return BENERF_OK;
+    hipLaunchKernelGGL(bright_log_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), x, n, linlog, out);
+    BENERF_LAUNCH_CHECK("bright_log_fwd");
+    return BENERF_OK;
+}
+
+extern "C" int benerf_bright_log_bwd(const float* x, const float* grad, int64_t n, int linlog, float* d_x, benerf_stream_t stream) {
+    BENERF_REQUIRE(x && grad && d_x && n >= 0, "bright_log_bwd: bad args");
+    if (n == 0) return BENERF_OK;
+    hipLaunchKernelGGL(bright_log_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), x, grad, n, linlog, d_x);
+    BENERF_LAUNCH_CHECK("bright_log_bwd");
+    return BENERF_OK;
+}
+
+extern "C" int benerf_rgb2gray_fwd(const float* rgb, int64_t n, float* out, benerf_stream_t stream) {
+    BENERF_REQUIRE(rgb && out && n >= 0, "rgb2gray_fwd: bad args");
+    if (n == 0) return BENERF_OK;
+    hipLaunchKernelGGL(rgb2gray_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), rgb, n, out);
+    BENERF_LAUNCH_CHECK("rgb2gray_fwd");
+    return BENERF_OK;
+}
+
+extern "C" int benerf_rgb2gray_bwd(const float* grad, int64_t n, float* d_rgb, benerf_stream_t stream) {
+    BENERF_REQUIRE(grad && d_rgb && n >= 0, "rgb2gray_bwd: bad args");
+    if (n == 0) return BENERF_OK;
+    hipLaunchKernelGGL(rgb2gray_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), grad, n, d_rgb);
+    BENERF_LAUNCH_CHECK("rgb2gray_bwd");
+    return BENERF_OK;
+}
 
 extern "C" int benerf_pixel_rays(const float* c2w, int per_ray_pose, const int64_t* i, const int64_t* j, int64_t n,
                                  float fx, float fy, float cx, float cy, float* rays_o, float* rays_d,

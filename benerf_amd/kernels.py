@@ -725,6 +725,36 @@ def posenc(x, n_freqs, include_input=True):
     return out
 
 
+def bright_log_fwd(x, linlog):
+    lib = _lib.load()
+    out = torch.empty_like(x)
+    _lib.check(lib.benerf_bright_log_fwd(_chk(x, name="x"), x.numel(), int(bool(linlog)), out.data_ptr(), _stream()), "bright_log_fwd")
+    return out
+
+
+def bright_log_bwd(x, grad, linlog):
+    lib = _lib.load()
+    dx = torch.empty_like(x)
+    _lib.check(lib.benerf_bright_log_bwd(_chk(x, name="x"), _chk(grad, name="grad"), x.numel(), int(bool(linlog)), dx.data_ptr(), _stream()),
+               "bright_log_bwd")
+    return dx
+
+
+def rgb2gray_fwd(rgb):
+    lib = _lib.load()
+    n = rgb.shape[0]
+    out = torch.empty((n, 1), dtype=torch.float32, device=rgb.device)
+    _lib.check(lib.benerf_rgb2gray_fwd(_chk(rgb, name="rgb"), n, out.data_ptr(), _stream()), "rgb2gray_fwd")
+    return out
+
+
+def rgb2gray_bwd(grad, n):
+    lib = _lib.load()
+    d = torch.empty((n, 3), dtype=torch.float32, device=grad.device)
+    _lib.check(lib.benerf_rgb2gray_bwd(_chk(grad, name="grad"), n, d.data_ptr(), _stream()), "rgb2gray_bwd")
+    return d
+
+
 def mse_fwd(a, b):
     lib = _lib.load()
     out = _new((), a)       # 0-dim: the reference scales the loss IN PLACE (train.py:222 `event_loss_fine *= ...`) - a view out of an autograd Function forbids that

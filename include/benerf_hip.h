@@ -39,10 +39,10 @@ extern "C" {
 typedef void* benerf_stream_t; /* hipStream_t */
 
 /* ABI revision of this header: bumped whenever the signature or the argument meaning of an entry point changes (round 5's
- * `params` argument in front of benerf_mlp_bwd_dw made it 101; round 6: 102).  benerf_version() returns the revision the LIBRARY
+ * `params` argument in front of benerf_mlp_bwd_dw made it 101; round 6: 102, 103 with the loss-glue operators).  benerf_version() returns the revision the LIBRARY
  * was built from - a binding compares the two before its first call (benerf_amd/_lib.py does and refuses a mismatch): a caller
  * compiled against another revision would pass shifted arguments. */
-#define BENERF_ABI_VERSION 102
+#define BENERF_ABI_VERSION 103
 int benerf_version(void);
 const char* benerf_last_error(void);
 
@@ -312,7 +312,14 @@ int benerf_sample_pdf(const float* bins, const float* weights, const float* u, u
  *   [n,3,4] (per_ray_pose != 0) or one [3,4] pose shared by all rays; i = column, j = row.
  * benerf_ndc_rays: ndc_rays (run_nerf_helpers.py:46-71).
  * benerf_posenc: Embedder.embed (model/embedder.py:9-34): [x | sin(2^k x), cos(2^k x)]_k.
- * benerf_mse_fwd/bwd: MSELoss (loss/imgloss.py:3-5), out/grad_out are 1-element arrays. */
+ * benerf_mse_fwd/bwd: MSELoss (loss/imgloss.py:3-5), out/grad_out are 1-element arrays.
+ * benerf_bright_log_fwd/bwd: rgb2brightlog (utils/math_utils.py:4-23) on n values: linlog == 0 log(x + 1e-9) (BeNeRF_*),
+ *   linlog != 0 the lin-log curve of 8-bit brightness (E2NeRF_*: c = 255 x; c < 20 ? c log(20)/20 : log(c + 1e-9));
+ *   bwd: d_x = grad * d curve / dx.  The fused step evaluates the same curves inside K6.
+ * benerf_rgb2gray_fwd/bwd: RGB2Gray (utils/img_utils.py:7-16): [n,3] -> [n] luma (0.299 r + 0.587 g) + 0.114 b, summed in that
+ *   order; bwd: d_rgb[n,3] = grad[n] * weights.
+ * (One launch each way per call in a reference-style loop that assembles the event loss itself, train.py:207-292, instead of
+ *  2-8 element-wise torch operators and as many autograd nodes.) */
 int benerf_pixel_rays(const float* c2w, int per_ray_pose, const int64_t* i, const int64_t* j,
                       int64_t n, float fx, float fy, float cx, float cy, float* rays_o,
                       float* rays_d, benerf_stream_t stream);
@@ -324,6 +331,10 @@ int benerf_posenc(const float* x, int64_t n, int dims, int n_freqs, int include_
 int benerf_mse_fwd(const float* a, const float* b, int64_t n, float* out, benerf_stream_t stream);
 int benerf_mse_bwd(const float* a, const float* b, int64_t n, const float* grad_out, float* d_a,
                    float* d_b, benerf_stream_t stream);
+int benerf_bright_log_fwd(const float* x, int64_t n, int linlog, float* out, benerf_stream_t stream);
+int benerf_bright_log_bwd(const float* x, const float* grad, int64_t n, int linlog, float* d_x, benerf_stream_t stream);
+int benerf_rgb2gray_fwd(const float* rgb, int64_t n, float* out, benerf_stream_t stream);
+int benerf_rgb2gray_bwd(const float* grad, int64_t n, float* d_rgb, benerf_stream_t stream);
 
 /* ---------------------------------------------------------------- K6: losses ------- */
 typedef struct BenerfLossCfg {

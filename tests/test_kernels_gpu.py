@@ -985,3 +985,30 @@ def test_saved_operand_codec_known_answers(K, scale_log2):
     assert float(rel.max()) <= 2.0 ** -19 * (1 + 1 / 16) + 2.0 ** -24 and float(err[~big].max()) <= 2.0 ** -24
     assert rel_tie.size == 0 or float(rel_tie.max()) <= 2.0 ** -18
     assert codes[0] == 128 and codes[1] == 128 and dec[0] == 0.0, "zero encodes as code 128 and decodes to zero"
+
+
+@pytest.mark.parametrize("dataset", ["BeNeRF_Unreal", "E2NeRF_Real"])
+def test_loss_glue_operators_vs_torch(dataset):
+    """rgb2brightlog (utils/math_utils.py:4-23) and RGB2Gray (utils/img_utils.py:7-16) as single launches each way
+    (benerf_bright_log_fwd/bwd, benerf_rgb2gray_fwd/bwd) against the element-wise torch expressions they replace in a
+    reference-style loop: values and gradients, both brightness curves, values on both sides of the lin-log knee."""
+    from benerf_amd.utils import img_utils, math_utils
+    rng = np.random.default_rng(17)
+    x = GI.f32(np.concatenate([rng.random(4000), [0.0, 1e-6, 19.9 / 255, 20.0 / 255, 20.1 / 255, 1.0]])).reshape(-1, 1).to(DEV)
+    rgb = GI.f32(rng.random((3001, 3))).to(DEV)
+    outs = {}
+    for fused in (True, False):
+        math_utils._FUSED = img_utils._FUSED = fused
+        try:
+            xa, ra = x.clone().requires_grad_(True), rgb.clone().requires_grad_(True)
+            b = math_utils._BrightLog.apply(xa, dataset.startswith("E2NeRF")) if fused else math_utils.rgb2brightlog(xa, dataset)   # (the mirror keeps log(x + eps) on torch: two operators)
+            gr = img_utils.RGB2Gray()(ra)
+            assert gr.shape == (3001, 1) and b.shape == xa.shape
+            (b * torch.linspace(0.5, 1.5, b.numel(), device=DEV).reshape(b.shape)).sum().backward()
+            (math_utils.rgb2brightlog(gr, dataset) ** 2).sum().backward()
+            outs[fused] = (b.detach(), xa.grad.clone(), gr.detach(), ra.grad.clone())
+        finally:
+            math_utils._FUSED = img_utils._FUSED = True
+    for name, a, b_, tol in (("brightlog", outs[True][0], outs[False][0], 2e-6), ("d brightlog", outs[True][1], outs[False][1], 2e-6),
+                             ("luma", outs[True][2], outs[False][2], 1e-7), ("d rgb through luma + brightlog", outs[True][3], outs[False][3], 5e-6)):
+        report("loss glue %s, %s" % (dataset, name), a, b_, atol=tol * max(1.0, float(b_.abs().max())) if tol else 0.0, rtol=tol)
