@@ -116,7 +116,7 @@ def test_four_bins_gradients_vs_float64(case):
     norm error on the coarse network's layer-0 bias at C5 shape); the whole-tensor L2 error of every weight gradient, which bounds
     its norm error from above, is held to 1.5."""
     from benerf_amd import workloads as WL
-    from test_f64_truth_gpu import _assert_no_worse
+    from test_f64_truth_gpu import _assert_no_worse, _assert_split_vs_control
     B = 4
     if case == "C2_eighth":
         wl, seed, chunks = dict(WL.WORKLOADS["C2"], Re=128, Rr=13), 1900, 3
@@ -132,6 +132,7 @@ def test_four_bins_gradients_vs_float64(case):
     tab = T.error_table(o64["grads"], cands)
     for mode in ("f32", "split"):
         _assert_no_worse(tab, mode, "bins4 " + case, lottery_factor=3.0)
+    _assert_split_vs_control(tab, "bins4 " + case)
 
 
 def test_four_bins_full_size_c5_vs_oracle():

@@ -134,6 +134,23 @@ def _hip_step(x, mode, z_forced):
         K.set_mlp_precision(prev)
 
 
+def _assert_split_vs_control(tab, case):
+    """Round 6 (advisor): the lottery factor widens BOTH modes against the oracle; what it must not hide is a regression of the split
+    arithmetic itself.  The exact-f32 mode is the control: the same kernels' tiling, the same summation orders, exact products - on
+    every gradient the split mode's whole-tensor error against float64 may exceed the control's by the scatter of one draw at most
+    (1.5 x + a fifth of the L2 floor)."""
+    worst, bad = (0.0, ""), []
+    for name, row in tab.items():
+        e_s, e_c = row["split"][2], row["f32"][2]
+        bound = (2.0 if name in ("knots", "transform") else 1.5) * e_c + FLOOR["L2"] / 5      # 24 + 6 pose numbers: no averaging, one more draw
+        if e_s / bound > worst[0]:
+            worst = (e_s / bound, "%s: split %.2e, exact-f32 control %.2e" % (name, e_s, e_c))
+        if e_s > bound:
+            bad.append("%s: split L2 error %.3e > 1.5 x control %.3e + %.0e" % (name, e_s, e_c, FLOOR["L2"] / 5))
+    REPORT.append("f64 truth %-10s split vs exact-f32 control, L2: closest to its bound %.2f of it (%s)" % (case, worst[0], worst[1]))
+    assert not bad, "%s - split further from float64 than the exact-f32 control allows:\n%s" % (case, "\n".join(bad))
+
+
 LAST_MAPS = [None]      # per-ray outputs (rgb_map, rgb0, acc, disp of both renders) of the last _hip_step
 
 
@@ -185,6 +202,40 @@ def test_step_gradients_vs_float64(case):
     for mode in ("f32", "split"):
         # G8-sized batches (~4 k points): one flipped unit of a heavy sample IS the largest entry error - the lottery factor there
         _assert_no_worse(tab, mode, case, lottery_factor=3.0 if case.startswith("g8_") else None)
+    _assert_split_vs_control(tab, case)
+
+
+# (the e2real spec of G8 - L2-normalised loss on 16 + 2 pixels - is not here: on ~4 k points ONE flipped ReLU moves a bias gradient
+# of the fine network by 1e-2 in either HIP mode while the float32 oracle happens to flip none; test_mlp_backward_arithmetic_
+# vs_float64 takes the flips out instead)
+@pytest.mark.parametrize("case", ["g8_0", "g8_1", "g8_2", "C2_eighth", "C2"])
+def test_step_gradients_vs_float64(case):
+    x = _case(case)
+    a = _oracle_args(x)
+    o32 = T.step_grads(*a, dtype=torch.float32, z_forced=None, n_chunks=x["chunks"])
+    o64 = T.step_grads(*a, dtype=torch.float64, z_forced=o32["z"], n_chunks=x["chunks"], force_inputs=False)
+    assert abs(o32["loss"] - o64["loss"]) <= 2e-6 * max(1.0, abs(o64["loss"]))
+    cands = {"o32": o32["grads"]}
+    for mode in ("f32", "split"):
+        loss, cands[mode] = _hip_step(x, mode, o32["z"])
+        assert abs(loss - o64["loss"]) <= 2e-5 * max(1.0, abs(o64["loss"])), (mode, loss, o64["loss"])
+    tab = T.error_table(o64["grads"], cands)
+    for mode in ("f32", "split"):
+        # G8-sized batches (~4 k points): one flipped unit of a heavy sample IS the largest entry error - the lottery factor there
+        _assert_no_worse(tab, mode, case, lottery_factor=3.0 if case.startswith("g8_") else None)
+    # Round 6 (advisor): the lottery factor widens BOTH modes against the oracle; what it must not hide is a regression of the split
+    # arithmetic itself.  The exact-f32 mode is the control: same kernels' tiling, same summation orders, exact products - on every
+    # gradient the split mode's whole-tensor error against float64 may exceed the control's by the scatter of one draw at most.
+    worst, bad = (0.0, ""), []
+    for name, row in tab.items():
+        e_s, e_c = row["split"][2], row["f32"][2]
+        bound = 1.5 * e_c + FLOOR["L2"] / 5
+        if e_s / bound > worst[0]:
+            worst = (e_s / bound, "%s: split %.2e, exact-f32 control %.2e" % (name, e_s, e_c))
+        if e_s > bound:
+            bad.append("%s: split L2 error %.3e > 1.5 x control %.3e + %.0e" % (name, e_s, e_c, FLOOR["L2"] / 5))
+    REPORT.append("f64 truth %-10s split vs exact-f32 control, L2: closest to its bound %.2f of it (%s)" % (case, worst[0], worst[1]))
+    assert not bad, "%s - split further from float64 than the exact-f32 control allows:\n%s" % (case, "\n".join(bad))
 
 
 def test_full_size_step_vs_oracle():
