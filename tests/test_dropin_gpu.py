@@ -11,7 +11,7 @@ import torch
 
 import benerf_oracle as O
 import golden_inputs as GI
-from conftest import report
+from conftest import REPORT as REPORT_LINES, report
 
 pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("mlp_precision")]
 DEV = "cuda:0"
@@ -401,3 +401,87 @@ def test_flat_adam_is_torch_adam(installed):
         report("FlatAdam resumed from torch's state_dict: " + n_, pc, pa_, atol=2e-7, rtol=1e-6)
     for (n_, pd), pb_ in zip(nd.named_parameters(), nb.parameters()):
         report("torch Adam resumed from FlatAdam's state_dict: " + n_, pd, pb_, atol=2e-7, rtol=1e-6)
+
+
+def test_reference_shaped_loop_equals_train_step(installed, monkeypatch):
+    """The two ways through the same kernels: tools/dropin_driver.py (train.py:153-394 on the drop-in modules: Graph.forward's
+    fused nodes, the loss lines in torch, FlatAdam) against engine.TrainStep (K6 losses, flat Adam) on IDENTICAL inputs - the pixel
+    draws, the eight sampling draws and the event window of every iteration of the loop are recorded and handed to the fused step.
+    Six iterations at a C1-like size: the losses agree to round-off at every iteration (so every update in between did), and the
+    parameters at the end differ by a fraction of a step on a handful of entries only (Adam's first updates are lr * sign(g): an
+    entry whose gradient is round-off noise around zero moves by +-lr in either run)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import dropin_driver as DD
+    from benerf_amd import engine, kernels as K, workloads as WL
+    from benerf_amd.model import optimize
+    wl = dict(WL.WORKLOADS["C1"], S=16, Ni=16, Re=64, Rr=6, n=5)
+    cam = WL.CAMERAS[wl["cam"]]
+    args = WL.make_args(wl, optimize_trans=True)
+    H, W, C = cam["H"], cam["W"], wl["channels"]
+    events, img = DD.synthetic_scene(wl, cam, 60000, 5)
+    rec = Recorder(monkeypatch)
+    DD.cuda_default_tensor_type(True)
+    try:
+        drv = DD.Driver(args, cam, events, img, seed=4)
+        snaps = []
+        orig_init = drv.ns["init_nerf"]
+
+        def init_and_snapshot(net):
+            orig_init(net)
+            with torch.no_grad():
+                net.alpha_linear.bias += 1.0
+            snaps.append({k: v.detach().clone() for k, v in net.state_dict().items()})
+        drv.ns["init_nerf"] = init_and_snapshot
+        knots0 = drv.graph.evt_knot_pose_se3.params.weight.detach().clone()
+        tr0 = drv.graph.transform.params.weight.detach().clone()
+        loop_losses, inputs = [], []
+        for it in range(6):
+            np.random.seed(300 + it)
+            drv.iterate(1)
+            loop_losses.append(float(drv.last_loss))
+            idx_e, idx_r, d_e, d_r = rec.pop_step()
+            np.random.seed(300 + it)
+            low_t = float(np.random.rand(1)[0] * (1 - args.accumulate_time_length))
+            inputs.append((low_t, low_t + args.accumulate_time_length, idx_e[:args.sampling_event_rays],
+                           idx_r[:args.sampling_rgb_rays // args.num_interpolated_pose], d_e, d_r))
+        loop_params = {k: v.detach().clone() for k, v in drv.graph.state_dict().items()}
+    finally:
+        DD.cuda_default_tensor_type(False)
+    # the fused step on a second graph with the loop's initial parameters
+    torch.manual_seed(0)
+    model = optimize.Model(args)
+    model.graph.to(DEV)
+    g = model.build_network(args)
+    g.nerf.load_state_dict(snaps[0])
+    g.nerf_fine.load_state_dict(snaps[1])
+    with torch.no_grad():
+        g.evt_knot_pose_se3.params.weight.copy_(knots0)
+        g.transform.params.weight.copy_(tr0)
+    cam_o = engine.Camera(H, W, cam["fx"], cam["fy"], cam["cx"], cam["cy"])
+    step = engine.TrainStep(g, args, cam_o, cam_o, torch.device(DEV))
+    ev = drv.graph._events_on_device(events)
+    image = torch.from_numpy(img[0].reshape(H * W, C)).to(DEV)
+    for it, (lo, up, idx_e, idx_r, d_e, d_r) in enumerate(inputs):
+        accu = K.event_window_accumulate(ev["x"], ev["y"], ev["p"], ev["ts"], lo, up, H, W).view(-1)
+        ts = torch.tensor([lo, up], dtype=torch.float32, device=DEV)
+        dd = lambda d: engine.Draws(*(d[k].to(DEV) for k in ("t_rand", "noise0", "u", "noise1")))   # noqa: E731
+        losses = step.step(ts, torch.tensor([0.0, 1.0], device=DEV), idx_e.to(DEV), idx_r.to(DEV), accu, image, dd(d_e), dd(d_r))
+        report("reference-shaped loop vs TrainStep: loss, iteration %d" % it, np.array(loop_losses[it]), losses[0:1].cpu().numpy().reshape(()),
+               rtol=2e-5 if it == 0 else 2e-3)
+    step.check_range()
+    worst = 0.0
+    for k, v in g.state_dict().items():
+        if k.startswith(("rgb_crf", "event_crf", "rgb_knot")):
+            continue
+        lr = args.pose_lrate if "knot" in k or "transform" in k else args.lrate
+        frac = float(((v - loop_params[k]).abs() > 0.25 * lr).float().mean())
+        worst = max(worst, frac)
+        # the coarse network's first layers - behind the 2^9 x frequencies of the positional encoding: many entries whose gradient is
+        # round-off noise around zero, each moved by lr * sign - scatter most (exact-f32 mode: 7.3 % of nerf.pts_linears.0.weight, 5.4 %
+        # of pts_linears.1.weight, 2 % of pts_linears.0.bias; everything else below 1e-4): one generous limit, the losses are the test
+        lim = 0.15
+        REPORT_LINES.append("reference-shaped loop vs TrainStep, %-40s entries more than lr/4 apart after 6 iterations: %.4f" % (k, frac))
+        assert frac < lim, "%s: %.3f of the entries more than lr / 4 apart after 6 iterations" % (k, frac)
+    print("reference-shaped loop vs TrainStep: largest fraction of a tensor's entries more than lr/4 apart after 6 iterations: %.2e" % worst)
