@@ -232,7 +232,11 @@ class RenderRays(torch.autograd.Function):
     def forward(ctx, poses, ray_idx, cam, ndc, n_samples, n_importance, draws, net_c, net_f, *params):
         poses_c = poses.detach().contiguous()
         ctx.set_materialize_grads(False)
-        need_grad = any(ctx.needs_input_grad)
+        # ctx.needs_input_grad says which inputs REQUIRE grad, also under torch.no_grad() (where forward still runs with grad mode
+        # off and no backward can follow): the caller's grad mode travels on the Draws object.  Without it render_video / render_*_test
+        # (torch.no_grad) ran TRAINING launches - activations saved for nobody, 25 % slower, and not the BENERF_MLP_AUTO inference
+        # launch with its exact-f32 fallback (round 6: found in the kernel trace of a frame)
+        need_grad = any(ctx.needs_input_grad) and getattr(draws, "grad_enabled", True)
         if need_grad and K.is_split():
             # range guard of the autograd path: the previous backward posted the device's status words to pinned host memory;
             # gradients that left the f16 range (inf / NaN into torch.optim) are reported here, without a synchronisation
@@ -292,7 +296,7 @@ class RenderPair(torch.autograd.Function):
         pe, pr = poses_e.detach().contiguous(), poses_r.detach().contiguous()
         dev = pe.device
         ctx.set_materialize_grads(False)       # outputs no loss uses (disp, acc, unused blocks) arrive as None, not as zero-filled tensors
-        need_grad = any(ctx.needs_input_grad)
+        need_grad = any(ctx.needs_input_grad) and getattr(draws, "grad_enabled", True)      # the caller's grad mode: see RenderRays.forward
         if need_grad and K.is_split():
             K.range_guard(dev).poll()          # what the previous backward posted (see RenderRays.forward)
         if net_c._key() != net_c.version or net_f._key() != net_f.version:

@@ -120,13 +120,13 @@ class _MlpPoints(torch.autograd.Function):
     """NeRF.forward on explicit points: pts [N,S,3], viewdirs [N,3] -> raw [N,S,C+1]  (K3)."""
 
     @staticmethod
-    def forward(ctx, pts, viewdirs, net, *params):
+    def forward(ctx, pts, viewdirs, net, grad_enabled, *params):
         N, S = pts.shape[0], pts.shape[1]
         M = N * S
         dev = pts.device
         pts_c = pts.detach().reshape(M, 3).float().contiguous()
         vd = viewdirs.detach().float()[:, None].expand(N, S, 3).reshape(M, 3).contiguous()
-        need = any(ctx.needs_input_grad)
+        need = any(ctx.needs_input_grad) and grad_enabled      # needs_input_grad ignores torch.no_grad(): the caller's grad mode is an argument
         net.pack_if_stale()
         # pts = 0 + pts * 1: feed each point as a one-sample ray
         raw, acts = K.mlp_fwd(net, torch.zeros((M, 3), device=dev), pts_c, vd, torch.ones((M, 1), device=dev), need)
@@ -140,7 +140,7 @@ class _MlpPoints(torch.autograd.Function):
         gb = [torch.empty_like(b) for b in net.biases]
         d_pts, d_vd = K.mlp_bwd(net, d_raw.contiguous().view(N * S, -1), ctx.acts, N * S, 1, gw, gb, False)
         ctx.acts = None
-        return (d_pts.view(N, S, 3), d_vd.view(N, S, 3).sum(1), None) + tuple(gw) + tuple(gb)
+        return (d_pts.view(N, S, 3), d_vd.view(N, S, 3).sum(1), None, None) + tuple(gw) + tuple(gb)
 
 
 class _Composite(torch.autograd.Function):
@@ -213,7 +213,7 @@ class NeRF(nn.Module):
             raise NotImplementedError("use_viewdirs=False is not supported")
         net = self.packed()
         net.pe_weights = barf_weights(iter_step, args, pts.device)
-        return _MlpPoints.apply(pts, viewdirs, net, *net.weights, *net.biases)
+        return _MlpPoints.apply(pts, viewdirs, net, torch.is_grad_enabled(), *net.weights, *net.biases)
 
     def raw2output(self, crf_func, enable_crf: bool, sensor_type, raw, z_vals, rays_d, raw_noise_std=1.0):
         """(model/nerf.py:118-148); crf_func / enable_crf / sensor_type are accepted and unused,
@@ -391,7 +391,8 @@ class Graph(nn.Module):
                                                                         ts_e, ts_r, Pe, Pr, traj)
         net_c, net_f = self.nerf.packed(), self.nerf_fine.packed()
         net_c.pe_weights = net_f.pe_weights = barf_weights(iter_step, args, dev)
-        chunks = os.environ.get("BENERF_POSE_BLOCKS", "1") != "0" and torch.is_grad_enabled()
+        draws.grad_enabled = torch.is_grad_enabled()
+        chunks = os.environ.get("BENERF_POSE_BLOCKS", "1") != "0" and draws.grad_enabled
         outs = engine.RenderPair.apply(spline_evt_poses, spline_rgb_poses, ray_idx_event, ray_idx_rgb, cam_e, cam_r,
                                        bool(args.ndc), S, Ni, draws, net_c, net_f, chunks, *net_c.weights, *net_c.biases, *net_f.weights, *net_f.biases)
         keys = ("rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "sigma")
@@ -460,6 +461,7 @@ class Graph(nn.Module):
         params = list(net_c.weights) + list(net_c.biases)
         if net_f is not None:
             params += list(net_f.weights) + list(net_f.biases)
+        draws.grad_enabled = torch.is_grad_enabled()      # inside an autograd Function's forward grad mode is always off
         outs = engine.RenderRays.apply(poses.float(), ray_idx, cam, bool(args.ndc), S, Ni, draws, net_c, net_f, *params)
         if Ni > 0:
             keys = ("rgb_map", "disp_map", "acc_map", "rgb0", "disp0", "acc0", "sigma")

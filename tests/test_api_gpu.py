@@ -910,3 +910,41 @@ def test_bench_two_ranks_end_to_end():
     assert one["n_gpus"] == 1 and np.isfinite(one["config"]["final_loss"])
     assert abs(two["config"]["final_loss"] - one["config"]["final_loss"]) <= 2e-2 * abs(one["config"]["final_loss"]), \
         (two["config"]["final_loss"], one["config"]["final_loss"])
+
+
+def test_no_grad_renders_run_inference_launches(monkeypatch):
+    """torch.no_grad() renders (render_video, render_*_test: model/nerf.py:353, run_nerf_helpers.py:117-171) must run INFERENCE
+    launches - no saved activations, BENERF_MLP_AUTO with its exact-f32 fallback in the split mode.  An autograd Function's
+    ctx.needs_input_grad says True for parameters under no_grad too: round 6 found render_video saving 7 KB per sample point for
+    nobody (25 % slower).  Values must not depend on the launch kind."""
+    from benerf_amd import kernels as K, workloads as WL
+    args = WL.make_args("C2", N_samples=16, N_importance=16, chunk=64)
+    model, g = _graph(args)
+    Kt = torch.tensor([[30.0, 0, 10.0], [0, 30.0, 6.0], [0, 0, 1]])
+    pose = g.get_pose_rgb(args, [0, 1], seg_num=3).detach()[1:2]
+    seen = []
+    orig = K.mlp_fwd
+
+    def spy(net, ro, rd, vd, z, save_acts, *a, **k):
+        seen.append(bool(save_acts))
+        return orig(net, ro, rd, vd, z, save_acts, *a, **k)
+    monkeypatch.setattr(K, "mlp_fwd", spy)
+    idx = torch.arange(64, device=DEV)
+    torch.manual_seed(3)
+    with torch.no_grad():
+        a = g.render(0, pose, idx, 12, 20, Kt, args, enable_crf=False, sensor_type=None, remap=np.array([]))
+    assert seen == [False, False], seen
+    seen.clear()
+    torch.manual_seed(3)
+    b = g.render(0, pose, idx, 12, 20, Kt, args, enable_crf=False, sensor_type=None, remap=np.array([]))
+    assert seen == [True, True] and b["rgb_map"].requires_grad and not a["rgb_map"].requires_grad
+    report("render under no_grad (inference launch) vs with grad (training launch)", a["rgb_map"], b["rgb_map"].detach(), atol=1e-6)
+    seen.clear()
+    g.render_video(0, pose, 12, 20, Kt, args, np.array([]), type="rgb")
+    assert seen and not any(seen)
+    seen.clear()
+    with torch.no_grad():
+        pts = torch.rand(8, 4, 3, device=DEV)
+        vd = torch.nn.functional.normalize(torch.rand(8, 3, device=DEV), dim=-1)
+        g.nerf(0, pts, vd, args)
+    assert seen == [False]
